@@ -1,0 +1,537 @@
+// bbai_gen.hpp -- level generator: RoomGrid layout + LevelGen / GoTo-family missions,
+// consuming the env's persistent numpy-RandomState (MT19937) stream draw-for-draw.
+//
+// Follows (reference file:line, /root/reference):
+//   RoomGridLevel._gen_grid rejection loop        babyai/levels/levelgen.py:77-102
+//   validate_instrs                               babyai/levels/levelgen.py:104-155
+//   check_objs_reachable                          babyai/levels/levelgen.py:201-253
+//   LevelGen.gen_mission / add_locked_room        babyai/levels/levelgen.py:293-352
+//   LevelGen.rand_obj / rand_instr                babyai/levels/levelgen.py:354-460
+//   ObjDesc.find_matching_objs (use_location)     babyai/levels/verifier.py:96-161
+//   GoToRedBall / GoToObj / GoToLocal / GoTo      babyai/levels/iclr19_levels.py:40-124,224-257
+//   RoomGrid / MiniGridEnv placement helpers      gym_minigrid (absent dependency), restated
+//                                                 per SURVEY.md Appendix B3-B7
+//
+// Execution model: ONE WAVEFRONT = ONE ENV.  Control flow is wave-uniform (every lane
+// runs the same scalar program on the same RNG draws); the working set (MT state, both
+// grid planes, room / object tables) sits in LDS; lanes split the data-parallel parts
+// (MT twist, grid fill, reachability rows, record write-out).  The same code compiles
+// for the host with nlanes == 1 (unit tests only, never a product path).
+#pragma once
+#include "bbai_types.hpp"
+
+namespace bbai {
+
+constexpr int GEN_ES = 36;                       // >= round_up(MAX_W + 2*MARGIN, 4)
+constexpr int GEN_EH = MAX_W + 2 * MARGIN;       // 35
+
+struct GenWork {                                 // lives in LDS on the device
+    uint32_t mt[MT_N];
+    uint8_t E[GEN_ES * GEN_EH];
+    uint8_t I[MAX_W * MAX_W + 3];
+    uint8_t app[MAX_OBJ], px[MAX_OBJ], py[MAX_OBJ];
+    uint8_t door_x[MAX_ROOMS][4], door_y[MAX_ROOMS][4], door_obj[MAX_ROOMS][4];
+    uint8_t locked[MAX_ROOMS];
+    uint32_t rowbuf[2][MAX_W + 2];               // reachability rows
+    Prog prog;
+};
+
+// Ctx contract: lane(), nlanes(), sync().  Host: 0,1,no-op.  Device: lane id in the
+// wave, 64, workgroup barrier (one wave per workgroup).
+template <class Ctx>
+struct Gen {
+    Ctx ctx;
+    const LevelCfg& cfg;
+    GenWork& w;
+    int mti;                 // MT19937 output index (wave-uniform)
+    int nobj;
+    int ax, ay, adir;
+    bool agent_set;
+    int locked_room;         // room index or -1: the locked room created in THIS attempt
+    int last_locked;         // room index or -1: `self.locked_room` as the reference keeps it -- it is
+                             // only ever assigned in add_locked_room, so it survives attempts and
+                             // episodes; a stale value never `is` a current room (levelgen.py:305-307)
+                             // but still feeds rand_obj's implicit_unlock filter (levelgen.py:384-392)
+    int S, rows, cols;
+
+    BB_HD Gen(Ctx c, const LevelCfg& cf, GenWork& wk, int mti_, int last_locked_)
+        : ctx(c), cfg(cf), w(wk), mti(mti_), nobj(0), ax(0), ay(0), adir(0), agent_set(false),
+          locked_room(-1), last_locked(last_locked_), S(cf.room_size), rows(cf.num_rows), cols(cf.num_cols) {}
+
+    // ---------------- MT19937 (numpy legacy RandomState bit stream) ----------------
+    BB_HD static uint32_t mix(uint32_t u, uint32_t v) {
+        uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
+        return (y >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
+    }
+    BB_HD void twist_chunk(int lo, int hi) {
+        // new[k] = src[k+397 mod] ^ mix(old[k], old[k+1]) for k in [lo,hi); reads complete
+        // before any write of the chunk (sync), so lanes never see half-updated inputs.
+        // (chunks are <= 227 long: 4 strided elements per lane cover them with 64 lanes)
+        uint32_t tmp[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int k = lo + ctx.lane() + q * ctx.nlanes();
+            if (k < hi) {
+                int m = k + 397; if (m >= MT_N) m -= MT_N;
+                tmp[q] = w.mt[m] ^ mix(w.mt[k], w.mt[k + 1 < MT_N ? k + 1 : 0]);
+            }
+        }
+        ctx.sync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int k = lo + ctx.lane() + q * ctx.nlanes();
+            if (k < hi) w.mt[k] = tmp[q];
+        }
+        ctx.sync();
+    }
+    BB_HD void twist() {
+        if (ctx.nlanes() == 1) {           // host: plain sequential generation
+            for (int k = 0; k < MT_N; ++k) {
+                int m = k + 397; if (m >= MT_N) m -= MT_N;
+                w.mt[k] = w.mt[m] ^ mix(w.mt[k], w.mt[k + 1 < MT_N ? k + 1 : 0]);
+            }
+            return;
+        }
+        ctx.sync();
+        twist_chunk(0, 227);      // uses old[k+397]
+        twist_chunk(227, 454);    // uses new[k-227] from the first chunk
+        twist_chunk(454, 623);    // uses new[k-227] from the second chunk
+        twist_chunk(623, 624);    // uses new[396] and new[0]
+    }
+    BB_HD uint32_t next_u32() {
+        if (mti >= MT_N) { twist(); mti = 0; }
+        uint32_t y = w.mt[mti++];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        return y;
+    }
+    // RandomState.randint(lo, hi): masked rejection on 32-bit outputs; range 1 => no draw.
+    BB_HD int rand_int(int lo, int hi) {
+        uint32_t rng = (uint32_t)(hi - lo - 1);
+        if (rng == 0) return lo;
+        uint32_t mask = rng;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        uint32_t v;
+        do { v = next_u32() & mask; } while (v > rng);
+        return lo + (int)v;
+    }
+    BB_HD bool rand_bool() { return rand_int(0, 2) == 0; }
+    BB_HD double rand_float01() {   // RandomState.uniform(0,1): 53-bit double from two draws
+        uint32_t a = next_u32() >> 5, b = next_u32() >> 6;
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+    BB_HD int rand_color() { return color_name_to_idx(rand_int(0, 6)); }
+
+    // ---------------- grid helpers ----------------
+    BB_HD int eidx(int x, int y) const { return (y + MARGIN) * cfg.ES + (x + MARGIN); }
+    BB_HD int iidx(int x, int y) const { return y * cfg.W + x; }
+    BB_HD void set_cell(int x, int y, int e, int id) { w.E[eidx(x, y)] = (uint8_t)e; w.I[iidx(x, y)] = (uint8_t)id; }
+    BB_HD int room_of(int x, int y) const { return (y / (S - 1)) * cols + (x / (S - 1)); }
+    BB_HD bool has_neighbor(int r, int k) const {
+        int i = r % cols, j = r / cols;
+        return k == 0 ? i < cols - 1 : k == 1 ? j < rows - 1 : k == 2 ? i > 0 : j > 0;
+    }
+    BB_HD int neighbor(int r, int k) const { return k == 0 ? r + 1 : k == 1 ? r + cols : k == 2 ? r - 1 : r - cols; }
+    BB_HD void front_of(int& fx, int& fy) const {
+        fx = ax + (adir == 0) - (adir == 2);
+        fy = ay + (adir == 1) - (adir == 3);
+    }
+
+    // RoomGrid._gen_grid: walls on every multiple of (S-1), door slots drawn per room.
+    BB_HD void build_rooms() {
+        ctx.sync();
+        const int ncell = cfg.ES * cfg.EH;
+        for (int idx = ctx.lane(); idx < ncell; idx += ctx.nlanes()) {
+            int x = idx % cfg.ES - MARGIN, y = idx / cfg.ES - MARGIN;
+            bool inside = x >= 0 && x < cfg.W && y >= 0 && y < cfg.H;
+            bool wall = !inside || x % (S - 1) == 0 || y % (S - 1) == 0;
+            w.E[idx] = wall ? E_WALL : E_EMPTY;
+            if (inside) w.I[iidx(x, y)] = wall ? 1 : 0;
+        }
+        for (int idx = ctx.lane(); idx < MAX_ROOMS * 4; idx += ctx.nlanes()) (&w.door_obj[0][0])[idx] = NONE8;
+        for (int idx = ctx.lane(); idx < MAX_ROOMS; idx += ctx.nlanes()) w.locked[idx] = 0;
+        ctx.sync();
+        for (int j = 0; j < rows; ++j)
+            for (int i = 0; i < cols; ++i) {
+                int r = j * cols + i;
+                int tx = i * (S - 1), ty = j * (S - 1);
+                int x_l = tx + 1, y_l = ty + 1, x_m = tx + S - 1, y_m = ty + S - 1;
+                if (i < cols - 1) {
+                    int y = rand_int(y_l, y_m);
+                    w.door_x[r][0] = x_m; w.door_y[r][0] = y;
+                    w.door_x[r + 1][2] = x_m; w.door_y[r + 1][2] = y;
+                }
+                if (j < rows - 1) {
+                    int x = rand_int(x_l, x_m);
+                    w.door_x[r][1] = x; w.door_y[r][1] = y_m;
+                    w.door_x[r + cols][3] = x; w.door_y[r + cols][3] = y_m;
+                }
+            }
+        ax = (cols / 2) * (S - 1) + S / 2;
+        ay = (rows / 2) * (S - 1) + S / 2;
+        adir = 0;
+        agent_set = true;
+        nobj = 0;
+        locked_room = -1;
+        ctx.sync();
+    }
+
+    // MiniGridEnv.place_obj restricted to a room rectangle, max_tries = 1000.
+    BB_HD bool place_pos(int r, bool reject_next, int& ox, int& oy) {
+        int tx = (r % cols) * (S - 1), ty = (r / cols) * (S - 1);
+        int xh = tx + S < cfg.W ? tx + S : cfg.W, yh = ty + S < cfg.H ? ty + S : cfg.H;
+        int tries = 0;
+        for (;;) {
+            if (tries > 1000) return false;          // RecursionError('rejection sampling failed')
+            ++tries;
+            int x = rand_int(tx, xh);
+            int y = rand_int(ty, yh);
+            if (w.I[iidx(x, y)] != 0) continue;
+            if (agent_set && x == ax && y == ay) continue;
+            if (reject_next) {
+                int d = (x > ax ? x - ax : ax - x) + (y > ay ? y - ay : ay - y);
+                if (d < 2) continue;
+            }
+            ox = x; oy = y;
+            return true;
+        }
+    }
+    // RoomGrid.add_object -> place_in_room (kind and colour always given on this path).
+    BB_HD int add_object(int r, int type, int color) {
+        int x, y;
+        if (!place_pos(r, true, x, y)) return -1;
+        if (nobj >= cfg.maxo) return -1;
+        int id = nobj++;
+        int e = e_make(type, color, 0);
+        w.app[id] = e; w.px[id] = x; w.py[id] = y;
+        set_cell(x, y, e, id + 2);
+        return id;
+    }
+    // RoomGrid.add_door with explicit index / colour / locked flag.
+    BB_HD int add_door(int r, int k, int color, bool is_locked) {
+        if (nobj >= cfg.maxo) return -1;
+        int id = nobj++;
+        int x = w.door_x[r][k], y = w.door_y[r][k];
+        int e = e_make(T_DOOR, color, is_locked ? S_LOCKED : S_CLOSED);
+        w.locked[r] = is_locked ? 1 : 0;
+        w.app[id] = e; w.px[id] = x; w.py[id] = y;
+        set_cell(x, y, e, id + 2);
+        w.door_obj[r][k] = id;
+        w.door_obj[neighbor(r, k)][(k + 2) & 3] = id;
+        return id;
+    }
+    // RoomGrid.place_agent(i=None, j=None): room drawn, then pose re-drawn until the
+    // front cell is empty or a wall.
+    BB_HD bool place_agent() {
+        int i = rand_int(0, cols);
+        int j = rand_int(0, rows);
+        int r = j * cols + i;
+        for (;;) {
+            agent_set = false;
+            int x, y;
+            if (!place_pos(r, false, x, y)) return false;
+            ax = x; ay = y; agent_set = true;
+            adir = rand_int(0, 4);
+            int fx, fy; front_of(fx, fy);
+            int id = w.I[iidx(fx, fy)];
+            if (id == 0 || id == 1) return true;
+        }
+    }
+    // RoomGrid.connect_all: random doors until every room is reachable from the agent's.
+    BB_HD bool connect_all() {
+        int start = room_of(ax, ay);
+        int nrooms = rows * cols;
+        int itrs = 0;
+        for (;;) {
+            if (itrs > 5000) return false;            // RecursionError('connect_all failed')
+            ++itrs;
+            uint32_t reach = 1u << start;
+            for (int pass = 0; pass < nrooms; ++pass) {
+                uint32_t nr = reach;
+                for (int r = 0; r < nrooms; ++r)
+                    if (reach >> r & 1)
+                        for (int k = 0; k < 4; ++k)
+                            if (w.door_obj[r][k] != NONE8) nr |= 1u << neighbor(r, k);
+                if (nr == reach) break;
+                reach = nr;
+            }
+            if (__builtin_popcount(reach) == nrooms) return true;
+            int i = rand_int(0, cols);
+            int j = rand_int(0, rows);
+            int k = rand_int(0, 4);
+            int r = j * cols + i;
+            if (!has_neighbor(r, k) || w.door_obj[r][k] != NONE8) continue;
+            if (w.locked[r] || w.locked[neighbor(r, k)]) continue;
+            int color = rand_color();
+            if (add_door(r, k, color, false) < 0) return false;
+        }
+    }
+    // RoomGrid.add_distractors(i=None, j=None).  first_id receives the first new id.
+    BB_HD bool add_distractors(int num, bool all_unique) {
+        int count = 0;
+        while (count < num) {
+            int color = rand_color();
+            int type = T_KEY + rand_int(0, 3);        // ['key','ball','box']
+            if (all_unique) {
+                bool dup = false;
+                for (int o = 0; o < nobj; ++o)
+                    if (e_type(w.app[o]) != T_DOOR && e_type(w.app[o]) == type && e_color(w.app[o]) == color) dup = true;
+                if (dup) continue;
+            }
+            int ri = rand_int(0, cols);
+            int rj = rand_int(0, rows);
+            if (add_object(rj * cols + ri, type, color) < 0) return false;
+            ++count;
+        }
+        return true;
+    }
+
+    // check_objs_reachable (levelgen.py:201-253) as a row-bitmask flood fill: spread through
+    // passable cells (empty or door); an object is reached if it lies in, or 4-adjacent to,
+    // the flooded region.
+    BB_HD bool objs_reachable() {
+        const int W = cfg.W, H = cfg.H;
+        uint32_t* pass = w.rowbuf[0];
+        uint32_t* fl = w.rowbuf[1];
+        ctx.sync();
+        for (int y = ctx.lane(); y < H; y += ctx.nlanes()) {
+            uint32_t p = 0;
+            for (int x = 0; x < W; ++x) {
+                int e = w.E[eidx(x, y)];
+                if (e == E_EMPTY || e_type(e) == T_DOOR) p |= 1u << x;
+            }
+            pass[y] = p;
+            fl[y] = (y == ay) ? (1u << ax) : 0u;
+        }
+        ctx.sync();
+        for (;;) {
+            bool changed = false;
+            for (int y = 0; y < H; ++y) {
+                uint32_t f = fl[y];
+                uint32_t g = f | (y > 0 ? fl[y - 1] : 0u) | (y + 1 < H ? fl[y + 1] : 0u);
+                g &= pass[y];
+                // horizontal closure inside the row
+                for (;;) {
+                    uint32_t g2 = (g | (g << 1) | (g >> 1)) & pass[y];
+                    if (g2 == g) break;
+                    g = g2;
+                }
+                if (g != f) { fl[y] = g; changed = true; }
+            }
+            if (!changed) break;
+        }
+        for (int o = 0; o < nobj; ++o) {
+            int x = w.px[o], y = w.py[o];
+            uint32_t near = fl[y] | (fl[y] << 1) | (fl[y] >> 1) | (y > 0 ? fl[y - 1] : 0u) | (y + 1 < H ? fl[y + 1] : 0u);
+            if (!(near >> x & 1)) return false;
+        }
+        return true;
+    }
+
+    // ObjDesc.find_matching_objs(env, use_location=True) over the object table (every
+    // object is in the grid during generation).  type is never None on this path.
+    BB_HD uint64_t find_matching(int type, int color, int loc) const {
+        uint64_t m = 0;
+        int r = room_of(ax, ay);
+        int tx = (r % cols) * (S - 1), ty = (r / cols) * (S - 1);
+        int d1x = (adir == 0) - (adir == 2), d1y = (adir == 1) - (adir == 3);
+        int d2x = -d1y, d2y = d1x;
+        for (int o = 0; o < nobj; ++o) {
+            int e = w.app[o];
+            if (e_type(e) != type) continue;
+            if (color != 7 && e_color(e) != color) continue;
+            if (loc != LOC_NONE) {
+                int x = w.px[o], y = w.py[o];
+                if (x < tx || y < ty || x >= tx + S || y >= ty + S) continue;
+                int vx = x - ax, vy = y - ay;
+                int p2 = vx * d2x + vy * d2y, p1 = vx * d1x + vy * d1y;
+                bool ok = loc == LOC_LEFT ? p2 < 0 : loc == LOC_RIGHT ? p2 > 0 : loc == LOC_FRONT ? p1 > 0 : p1 < 0;
+                if (!ok) continue;
+            }
+            m |= 1ull << o;
+        }
+        return m;
+    }
+
+    // LevelGen.rand_obj.  types_mode: 0 = OBJ_TYPES, 1 = OBJ_TYPES_NOT_DOOR, 2 = ['door'].
+    BB_HD bool rand_obj(int types_mode, int leaf, int slot) {
+        int tries = 0;
+        for (;;) {
+            if (tries > 100) return false;            // RecursionError('failed to find suitable object')
+            ++tries;
+            int cv = rand_int(0, 7);
+            int color = cv == 0 ? 7 : color_name_to_idx(cv - 1);
+            int type = types_mode == 0 ? T_BOX - rand_int(0, 4) : types_mode == 1 ? T_BOX - rand_int(0, 3) : T_DOOR;
+            int loc = LOC_NONE;
+            if (cfg.locations && rand_bool()) loc = 1 + rand_int(0, 4);
+            uint64_t m = find_matching(type, color, loc);
+            if (m == 0) continue;
+            if (!cfg.implicit_unlock && last_locked >= 0) {
+                int tx = (last_locked % cols) * (S - 1), ty = (last_locked / cols) * (S - 1);
+                bool any_out = false;
+                for (int o = 0; o < nobj; ++o)
+                    if (m >> o & 1) {
+                        int x = w.px[o], y = w.py[o];
+                        if (x < tx || y < ty || x >= tx + S || y >= ty + S) any_out = true;
+                    }
+                if (!any_out) continue;
+            }
+            w.prog.set[leaf][slot] = m;
+            DescInfo d; d.type = type; d.color = color; d.loc = loc; d.count = (uint8_t)__builtin_popcountll(m);
+            w.prog.desc[leaf][slot] = d;
+            return true;
+        }
+    }
+    BB_HD bool rand_action(int leaf) {
+        int a = cfg.action_kinds[rand_int(0, cfg.n_action_kinds)];
+        if (a == AK_GOTO) { w.prog.kind[leaf] = L_GOTO; return rand_obj(0, leaf, 0); }
+        if (a == AK_PICKUP) { w.prog.kind[leaf] = L_PICKUP; return rand_obj(1, leaf, 0); }
+        if (a == AK_OPEN) { w.prog.kind[leaf] = L_OPEN; return rand_obj(2, leaf, 0); }
+        w.prog.kind[leaf] = L_PUTNEXT;
+        return rand_obj(1, leaf, 0) && rand_obj(0, leaf, 1);
+    }
+    BB_HD void clear_prog() {
+        ctx.sync();
+        uint32_t* p = (uint32_t*)&w.prog;
+        for (int k = ctx.lane(); k < (int)(sizeof(Prog) / 4); k += ctx.nlanes()) p[k] = 0;
+        ctx.sync();
+    }
+    // LevelGen.rand_instr (depth <= 2: seq -> and -> action).
+    BB_HD bool rand_instr() {
+        clear_prog();
+        int kind = cfg.instr_kinds[rand_int(0, cfg.n_instr_kinds)];
+        if (kind == IK_ACTION) {
+            w.prog.root = R_ACTION; w.prog.n_a = 1;
+            return rand_action(0);
+        }
+        if (kind == IK_AND) {
+            w.prog.root = R_AND; w.prog.n_a = 2;
+            return rand_action(0) && rand_action(1);
+        }
+        for (int side = 0; side < 2; ++side) {
+            int base = side * 2;
+            int k2 = rand_int(0, 2);                  // ['action', 'and']
+            int n = k2 == 0 ? 1 : 2;
+            if (side == 0) w.prog.n_a = n; else w.prog.n_b = n;
+            for (int q = 0; q < n; ++q)
+                if (!rand_action(base + q)) return false;
+        }
+        w.prog.root = rand_int(0, 2) == 0 ? R_BEFORE : R_AFTER;
+        return true;
+    }
+
+    // validate_instrs (levelgen.py:104-155); false => RejectSampling.
+    BB_HD bool validate() {
+        uint32_t locked_colors = 0;
+        bool unb = cfg.kind == K_LEVELGEN && cfg.unblocking;
+        if (unb)
+            for (int o = 0; o < nobj; ++o)
+                if (e_type(w.app[o]) == T_DOOR && e_state(w.E[eidx(w.px[o], w.py[o])]) == S_LOCKED)
+                    locked_colors |= 1u << e_color(w.app[o]);
+        for (int leaf = 0; leaf < 4; ++leaf) {
+            int k = w.prog.kind[leaf];
+            if (k == L_NONE) continue;
+            if (k == L_PUTNEXT) {
+                uint64_t mv = w.prog.set[leaf][0], fx = w.prog.set[leaf][1];
+                if (mv & fx) return false;
+                for (int o = 0; o < nobj; ++o)
+                    if (mv >> o & 1) {
+                        int x = w.px[o], y = w.py[o];
+                        const int nx[4] = {x + 1, x - 1, x, x}, ny[4] = {y, y, y + 1, y - 1};
+                        for (int q = 0; q < 4; ++q) {
+                            int id = w.I[iidx(nx[q], ny[q])];
+                            if (id >= 2 && (fx >> (id - 2) & 1)) return false;
+                        }
+                    }
+            }
+            if (unb)
+                for (int s = 0; s < 2; ++s) {
+                    DescInfo d = w.prog.desc[leaf][s];
+                    if ((s == 0 || k == L_PUTNEXT) && d.type == T_KEY && d.color != 7 && (locked_colors >> d.color & 1)) return false;
+                }
+        }
+        return true;
+    }
+
+    // LevelGen.gen_mission
+    BB_HD bool mission_levelgen() {
+        if (rand_float01() < cfg.locked_room_prob) {
+            // add_locked_room
+            int door_color;
+            for (;;) {
+                int i = rand_int(0, cols);
+                int j = rand_int(0, rows);
+                int k = rand_int(0, 4);
+                locked_room = last_locked = j * cols + i;
+                if (!has_neighbor(locked_room, k)) continue;
+                door_color = rand_color();
+                if (add_door(locked_room, k, door_color, true) < 0) return false;
+                break;
+            }
+            for (;;) {
+                int i = rand_int(0, cols);
+                int j = rand_int(0, rows);
+                if (j * cols + i == locked_room) continue;
+                if (add_object(j * cols + i, T_KEY, door_color) < 0) return false;
+                break;
+            }
+        }
+        if (!connect_all()) return false;
+        if (!add_distractors(cfg.num_dists, false)) return false;
+        for (;;) {
+            if (!place_agent()) return false;
+            if (room_of(ax, ay) == locked_room) continue;
+            break;
+        }
+        if (!cfg.unblocking && !objs_reachable()) return false;
+        return rand_instr();
+    }
+
+    // GoToRedBall / GoToObj / GoToLocal / GoTo gen_mission
+    BB_HD bool mission_goto() {
+        if (!place_agent()) return false;
+        int target = -1;
+        if (cfg.redball) {
+            target = add_object(0, T_BALL, C_RED);
+            if (target < 0) return false;
+        }
+        if (cfg.connect && !connect_all()) return false;
+        int first = nobj;
+        if (!add_distractors(cfg.num_dists, cfg.all_unique != 0)) return false;
+        if (cfg.check_reach && !objs_reachable()) return false;
+        if (!cfg.redball) target = first + rand_int(0, cfg.num_dists);   // distractors are the last ids
+        clear_prog();
+        int type = e_type(w.app[target]), color = e_color(w.app[target]);
+        w.prog.root = R_ACTION; w.prog.n_a = 1; w.prog.kind[0] = L_GOTO;
+        uint64_t m = find_matching(type, color, LOC_NONE);
+        w.prog.set[0][0] = m;
+        DescInfo d; d.type = type; d.color = color; d.loc = LOC_NONE; d.count = (uint8_t)__builtin_popcountll(m);
+        w.prog.desc[0][0] = d;
+        if (cfg.doors_open)
+            for (int o = 0; o < nobj; ++o)
+                if (e_type(w.app[o]) == T_DOOR) {
+                    int e = e_make(T_DOOR, e_color(w.app[o]), S_OPEN);
+                    w.E[eidx(w.px[o], w.py[o])] = e;
+                }
+        return true;
+    }
+
+    // RoomGridLevel._gen_grid: retry until a mission is generated and validated.
+    // Returns max_steps (levelgen.py:42-45).
+    BB_HD int generate() {
+        for (;;) {
+            build_rooms();
+            bool ok = cfg.kind == K_LEVELGEN ? mission_levelgen() : mission_goto();
+            if (ok && validate()) break;
+        }
+        ctx.sync();
+        int navs = 0;
+        for (int leaf = 0; leaf < 4; ++leaf)
+            navs += w.prog.kind[leaf] == L_PUTNEXT ? 2 : w.prog.kind[leaf] != L_NONE ? 1 : 0;
+        return navs * S * S * rows * cols;
+    }
+};
+
+}  // namespace bbai

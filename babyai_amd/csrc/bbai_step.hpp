@@ -1,0 +1,231 @@
+// bbai_step.hpp -- per-env transition + instruction verifier + egocentric observation.
+// One lane = one env (scalar code per lane; the kernels in bbai_engine.hip wrap it with
+// coalesced SoA loads / LDS staging).
+//
+// Follows (reference file:line, /root/reference):
+//   RoomGridLevel.step                  babyai/levels/levelgen.py:49-66
+//   update_objs_poss on every drop      babyai/levels/levelgen.py:53-54,68-75
+//   GoToInstr / OpenInstr / PickupInstr / PutNextInstr .verify_action
+//                                       babyai/levels/verifier.py:257-274,296-303,330-350,393-417
+//   BeforeInstr / AfterInstr / AndInstr .verify
+//                                       babyai/levels/verifier.py:449-471,490-512,536-550
+//   MiniGridEnv.step / _reward / gen_obs_grid / Grid.process_vis / Grid.encode
+//                                       gym_minigrid (absent dependency) restated per
+//                                       SURVEY.md section 8a rows 1,2,4; geometry pinned by
+//                                       babyai/bot.py:658-687
+#pragma once
+#include "bbai_types.hpp"
+
+namespace bbai {
+
+struct EnvRef {             // views into one env's record
+    uint8_t* E; uint8_t* I; uint8_t* app; uint8_t* pos; const Prog* prog;
+};
+BB_HD EnvRef env_ref(const LevelCfg& c, uint8_t* rec) {
+    EnvRef r;
+    r.E = rec; r.I = rec + c.off_I; r.app = rec + c.off_app; r.pos = rec + c.off_pos;
+    r.prog = (const Prog*)(rec + c.off_prog);
+    return r;
+}
+
+BB_HD int dir_dx(int d) { return (d == 0) - (d == 2); }
+BB_HD int dir_dy(int d) { return (d == 1) - (d == 3); }
+
+// One ActionInstr.verify_action.  `visited` semantics: preCarrying is only updated when the
+// leaf is actually evaluated (verifier.py:331-334,394-396).
+BB_HD bool verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int leaf, int action) {
+    const int kind = r.prog->kind[leaf];
+    const uint64_t set0 = r.prog->set[leaf][0];
+    if (kind == L_GOTO) {
+        // success iff front_pos is one of the recorded positions (obj_poss): live tracked
+        // object in the front cell, or the remembered cell of one that left the grid since
+        // the last refresh.
+        int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
+        int id = r.I[i_index(c, fx, fy)];
+        if (id >= 2 && (set0 >> (id - 2) & 1)) return true;
+        uint64_t m = set0 & stale;
+        while (m) {
+            int o = __builtin_ctzll(m);
+            m &= m - 1;
+            if (r.pos[2 * o] == fx && r.pos[2 * o + 1] == fy) return true;
+        }
+        return false;
+    }
+    if (kind == L_OPEN) {
+        if (action != A_TOGGLE) return false;
+        int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
+        int id = r.I[i_index(c, fx, fy)];
+        if (id < 2 || !(set0 >> (id - 2) & 1)) return false;
+        return e_state(r.E[e_index(c, fx, fy)]) == S_OPEN;
+    }
+    // Pickup / PutNext share the preCarrying protocol.
+    int pre = h.pre[leaf];
+    h.pre[leaf] = h.carry;
+    if (kind == L_PICKUP) {
+        if (action != A_PICKUP) return false;
+        return pre == NONE8 && h.carry != NONE8 && (set0 >> h.carry & 1);
+    }
+    // L_PUTNEXT
+    if (action != A_DROP) return false;
+    if (pre == NONE8 || !(set0 >> pre & 1)) return false;
+    if (h.carry == pre) return false;               // drop failed: cur_pos == (-1,-1)
+    const uint64_t set1 = r.prog->set[leaf][1];
+    int x = r.pos[2 * pre], y = r.pos[2 * pre + 1];
+    const int nx[4] = {x + 1, x - 1, x, x}, ny[4] = {y, y, y + 1, y - 1};
+    for (int q = 0; q < 4; ++q) {
+        int id = r.I[i_index(c, nx[q], ny[q])];
+        if (id >= 2 && (set1 >> (id - 2) & 1)) return true;
+    }
+    return false;
+}
+
+// One side of a Seq (an ActionInstr, or an AndInstr of two).  bit_a/bit_b: And progress bits.
+BB_HD bool verify_side(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int base, int n, int bit_a, int action) {
+    if (n == 1) return verify_leaf(c, r, h, stale, base, action);
+    if (!(h.vstate >> bit_a & 1))
+        if (verify_leaf(c, r, h, stale, base, action)) h.vstate |= 1 << bit_a;
+    if (!(h.vstate >> (bit_a + 1) & 1))
+        if (verify_leaf(c, r, h, stale, base + 1, action)) h.vstate |= 1 << (bit_a + 1);
+    return (h.vstate >> bit_a & 3) == 3;
+}
+
+BB_HD bool verify_root(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action) {
+    const Prog* p = r.prog;
+    if (p->root == R_ACTION || p->root == R_AND) return verify_side(c, r, h, stale, 0, p->n_a, 1, action);
+    // Before: a then b; After: b then a.  The second part is verified with the SAME action in
+    // the step the first part completes (verifier.py:463-464,504-505).
+    const bool before = p->root == R_BEFORE;
+    const int b1 = before ? 0 : 2, n1 = before ? p->n_a : p->n_b, s1 = before ? 1 : 3;
+    const int b2 = before ? 2 : 0, n2 = before ? p->n_b : p->n_a, s2 = before ? 3 : 1;
+    if (!(h.vstate & 1)) {
+        if (!verify_side(c, r, h, stale, b1, n1, s1, action)) return false;
+        h.vstate |= 1;
+    }
+    return verify_side(c, r, h, stale, b2, n2, s2, action);
+}
+
+// reward = 1 - 0.9 * (step_count / max_steps) in float64, no FMA contraction, then f32.
+BB_HD float success_reward(int step, int max_steps) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double q = __ddiv_rn((double)step, (double)max_steps);
+    return (float)__dsub_rn(1.0, __dmul_rn(0.9, q));
+#else
+    volatile double q = (double)step / (double)max_steps;
+    volatile double m = 0.9 * q;
+    return (float)(1.0 - m);
+#endif
+}
+
+// MiniGridEnv.step + RoomGridLevel.step for one env.  Returns done; reward by reference.
+BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, Hot& h, uint64_t& stale, int action, float& reward) {
+    EnvRef r = env_ref(c, rec);
+    h.step = (uint16_t)(h.step + 1);
+    const int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
+    const int ei = e_index(c, fx, fy), ii = i_index(c, fx, fy);
+    const int fe = r.E[ei];
+    switch (action) {
+    case A_LEFT: h.dir = (h.dir + 3) & 3; break;
+    case A_RIGHT: h.dir = (h.dir + 1) & 3; break;
+    case A_FORWARD:
+        if (fe == E_EMPTY || (e_type(fe) == T_DOOR && e_state(fe) == S_OPEN)) { h.ax = fx; h.ay = fy; }
+        break;
+    case A_PICKUP:
+        if (e_type(fe) >= T_KEY && h.carry == NONE8) {
+            int o = r.I[ii] - 2;
+            h.carry = (uint8_t)o;
+            r.E[ei] = E_EMPTY; r.I[ii] = 0;
+            stale |= 1ull << o;                      // its recorded position is now stale
+        }
+        break;
+    case A_DROP:
+        if (fe == E_EMPTY && h.carry != NONE8) {
+            int o = h.carry;
+            r.E[ei] = r.app[o]; r.I[ii] = (uint8_t)(o + 2);
+            r.pos[2 * o] = (uint8_t)fx; r.pos[2 * o + 1] = (uint8_t)fy;
+            h.carry = NONE8;
+        }
+        break;
+    case A_TOGGLE:
+        if (e_type(fe) == T_DOOR) {
+            if (e_state(fe) == S_LOCKED) {
+                if (h.carry != NONE8) {
+                    int ce = r.app[h.carry];
+                    if (e_type(ce) == T_KEY && e_color(ce) == e_color(fe)) r.E[ei] = (uint8_t)e_make(T_DOOR, e_color(fe), S_OPEN);
+                }
+            } else {
+                r.E[ei] = (uint8_t)e_make(T_DOOR, e_color(fe), e_state(fe) == S_OPEN ? S_CLOSED : S_OPEN);
+            }
+        } else if (e_type(fe) == T_BOX) {            // box is replaced by its (empty) contents
+            int o = r.I[ii] - 2;
+            r.E[ei] = E_EMPTY; r.I[ii] = 0;
+            stale |= 1ull << o;
+        }
+        break;
+    default: break;                                   // done
+    }
+    // every drop ACTION refreshes the tracked positions (levelgen.py:53-54)
+    if (action == A_DROP) stale = 0;
+    bool success = verify_root(c, r, h, stale, action);
+    bool done = h.step >= h.max_steps;
+    reward = 0.0f;
+    if (success) { done = true; reward = success_reward(h.step, h.max_steps); }
+    return done;
+}
+
+// Grid.process_vis on 7-bit row masks.  opq[vj] bit vi = cell (vi,vj) blocks sight.
+// Returns vis[vj] rows.  Agent at (3,6).
+BB_HD void process_vis_rows(const uint32_t opq[VIEW], uint32_t vis[VIEW]) {
+    uint32_t m = 1u << 3;
+    for (int vj = VIEW - 1; vj >= 0; --vj) {
+        const uint32_t t = ~opq[vj] & 0x7Fu;
+        // left-to-right sweep (i = 0..5): closure of  m[i+1] |= m[i] & t[i]
+        for (int k = 0; k < 6; ++k) m |= ((m & t & 0x3Fu) << 1);
+        uint32_t a1 = m & t & 0x3Fu;
+        uint32_t up = a1 | (a1 << 1);
+        // right-to-left sweep (i = 6..1)
+        for (int k = 0; k < 6; ++k) m |= ((m & t & 0x7Eu) >> 1);
+        uint32_t a2 = m & t & 0x7Eu;
+        up |= a2 | (a2 >> 1);
+        vis[vj] = m & 0x7Fu;
+        m = up & 0x7Fu;
+    }
+}
+
+// World cell shown at view cell (vi, vj): pos + f*(6-vj) + r*(vi-3), r = (-f.y, f.x).
+BB_HD void view_to_world(int ax, int ay, int dir, int vi, int vj, int& x, int& y) {
+    int fx = dir_dx(dir), fy = dir_dy(dir);
+    int rx = -fy, ry = fx;
+    x = ax + fx * (6 - vj) + rx * (vi - 3);
+    y = ay + fy * (6 - vj) + ry * (vi - 3);
+}
+
+// gen_obs_grid + encode for one env: writes 147 bytes, image[vi][vj][ch].
+// (straightforward per-lane form; the step kernel uses an LDS-staged equivalent)
+BB_HD void observe_env(const LevelCfg& c, const uint8_t* rec, const Hot& h, uint8_t* out) {
+    const uint8_t* E = rec;
+    const uint8_t* app = rec + c.off_app;
+    uint8_t cell[VIEW][VIEW];
+    uint32_t opq[VIEW], vis[VIEW];
+    for (int vj = 0; vj < VIEW; ++vj) {
+        uint32_t o = 0;
+        for (int vi = 0; vi < VIEW; ++vi) {
+            int x, y; view_to_world(h.ax, h.ay, h.dir, vi, vj, x, y);
+            int e = E[e_index(c, x, y)];
+            cell[vj][vi] = (uint8_t)e;
+            if (e_opaque(e)) o |= 1u << vi;
+        }
+        opq[vj] = o;
+    }
+    process_vis_rows(opq, vis);
+    // the agent's own cell shows what it carries
+    cell[6][3] = h.carry != NONE8 ? app[h.carry] : (uint8_t)E_EMPTY;
+    for (int vi = 0; vi < VIEW; ++vi)
+        for (int vj = 0; vj < VIEW; ++vj) {
+            int e = cell[vj][vi];
+            bool v = vis[vj] >> vi & 1;
+            uint8_t* o = out + (vi * VIEW + vj) * 3;
+            o[0] = v ? e_type(e) : 0; o[1] = v ? e_color(e) : 0; o[2] = v ? e_state(e) : 0;
+        }
+}
+
+}  // namespace bbai

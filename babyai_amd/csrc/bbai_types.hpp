@@ -1,0 +1,153 @@
+// bbai_types.hpp -- data layout of the batched BabyAI engine (MI355X / gfx950).
+//
+// One environment ("env") = one RoomGridLevel instance of the reference
+// (babyai/levels/levelgen.py:17-66).  State lives in HBM as
+//   * a fixed-size per-env RECORD (cold-ish, gathered per lane / streamed per wave):
+//       E plane : appearance byte per cell, 5-cell wall margin on every side so the
+//                 7x7 egocentric window never needs a bounds check
+//       I plane : object id per cell (0 empty, 1 wall, 2+k = object k)
+//       app[k]  : appearance byte of object k (type | colour<<3 | door-state<<6)
+//       pos[k]  : last grid position of object k (x,y)
+//       Prog    : compiled instruction tree (verifier program + mission descriptor)
+//   * struct-of-arrays HOT state, one element per env, lane == env, fully coalesced:
+//       Hot (16 B): agent x,y,dir, carried object, step_count, max_steps,
+//                   per-leaf preCarrying, Seq/And progress bits
+//       stale (8 B): objects that left the grid since the verifier's positions were
+//                   last refreshed (reference: ObjDesc.obj_poss staleness,
+//                   babyai/levels/verifier.py:96-161, levelgen.py:53-54)
+//   * MT19937 state per env (624 words + index) -- numpy RandomState bit stream.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define BB_HD __host__ __device__ __forceinline__
+#else
+#define BB_HD inline
+#endif
+
+namespace bbai {
+
+// ---- appearance byte ------------------------------------------------------
+// bits 2:0 = OBJECT_TO_IDX (1 empty, 2 wall, 4 door, 5 key, 6 ball, 7 box)
+// bits 5:3 = COLOR_TO_IDX (red0 green1 blue2 purple3 yellow4 grey5)
+// bits 7:6 = door state (0 open, 1 closed, 2 locked)
+// => the 3 observation channels of a visible cell are plain bit fields of E.
+enum : int {
+    T_UNSEEN = 0, T_EMPTY = 1, T_WALL = 2, T_DOOR = 4, T_KEY = 5, T_BALL = 6, T_BOX = 7,
+};
+enum : int { C_RED = 0, C_GREEN = 1, C_BLUE = 2, C_PURPLE = 3, C_YELLOW = 4, C_GREY = 5 };
+enum : int { S_OPEN = 0, S_CLOSED = 1, S_LOCKED = 2 };
+enum : int { E_EMPTY = T_EMPTY, E_WALL = T_WALL | (C_GREY << 3) };
+enum : int { A_LEFT = 0, A_RIGHT = 1, A_FORWARD = 2, A_PICKUP = 3, A_DROP = 4, A_TOGGLE = 5, A_DONE = 6 };
+
+BB_HD int e_type(int e) { return e & 7; }
+BB_HD int e_color(int e) { return (e >> 3) & 7; }
+BB_HD int e_state(int e) { return (e >> 6) & 3; }
+BB_HD int e_make(int t, int c, int s) { return t | (c << 3) | (s << 6); }
+// Wall, or a door that is not open, blocks sight (WorldObj.see_behind).
+BB_HD bool e_opaque(int e) { return e_type(e) == T_WALL || (e_type(e) == T_DOOR && e_state(e) != S_OPEN); }
+
+constexpr int MARGIN = 5;        // agent x>=1 and the view reaches 6 cells ahead
+constexpr int VIEW = 7;
+constexpr int OBS_BYTES = VIEW * VIEW * 3;   // 147
+constexpr int NONE8 = 0xFF;      // "no object" (carrying / preCarrying)
+constexpr int MAX_ROOMS = 9;
+constexpr int MAX_W = 25;
+constexpr int MAX_OBJ = 48;      // ids fit a 64-bit set
+constexpr int MT_N = 624;
+constexpr int TILE = 8;          // RGBImgPartialObsWrapper tile size
+constexpr int PIX = VIEW * TILE; // 56
+constexpr int PIX_BYTES = PIX * PIX * 3;     // 9408
+constexpr int TILE_BYTES = TILE * TILE * 3;  // 192
+constexpr int MAX_TILES = 96;
+
+// COLOR_NAMES = sorted(COLORS) = blue, green, grey, purple, red, yellow
+// (gym_minigrid.minigrid; used through _rand_elem so ORDER is part of the RNG contract)
+BB_HD int color_name_to_idx(int k) {
+    // index into sorted names -> COLOR_TO_IDX
+    return (0x403512 >> (4 * k)) & 0xF;   // nibble k: blue2 green1 grey5 purple3 red0 yellow4
+}
+
+// ---- instruction program --------------------------------------------------
+enum : int { L_NONE = 0, L_GOTO = 1, L_PICKUP = 2, L_OPEN = 3, L_PUTNEXT = 4 };
+enum : int { R_ACTION = 0, R_AND = 1, R_BEFORE = 2, R_AFTER = 3 };
+enum : int { LOC_NONE = 0, LOC_LEFT = 1, LOC_RIGHT = 2, LOC_FRONT = 3, LOC_BEHIND = 4 };
+// verifier.py:7  OBJ_TYPES = ['box', 'ball', 'key', 'door']  (index -> OBJECT_TO_IDX = 7 - index)
+
+struct DescInfo {           // mission-surface descriptor (verifier.py:64-94)
+    uint8_t type;           // OBJECT_TO_IDX of the described type
+    uint8_t color;          // COLOR_TO_IDX, or 7 = no colour given
+    uint8_t loc;            // LOC_*
+    uint8_t count;          // number of matching objects at generation (article: >1 => "a")
+};
+
+struct Prog {               // 112 bytes
+    uint64_t set[4][2];     // [leaf][0]=desc / desc_move, [leaf][1]=desc_fixed : obj_set as id bitmask
+    DescInfo desc[4][2];
+    uint8_t kind[4];        // L_* ; leaves 0,1 = side A (two => And), leaves 2,3 = side B
+    uint8_t root;           // R_*
+    uint8_t n_a, n_b;       // leaves on each side
+    uint8_t pad[9];
+};
+static_assert(sizeof(Prog) == 112, "Prog layout");
+
+struct Hot {                // 16 bytes, one per env, SoA array => one dwordx4 per lane
+    uint8_t ax, ay, dir, carry;
+    uint16_t step, max_steps;
+    uint8_t pre[4];         // preCarrying per leaf (verifier.py:321-334,373-395)
+    uint8_t vstate;         // bit0 Seq first part done; bits1,2 side-A And a/b; bits3,4 side-B And a/b
+    uint8_t frozen;         // ManyEnvs semantics: finished, waiting for an explicit reset
+    uint8_t last_locked;    // LevelGen.locked_room survives episodes (levelgen.py:284,325,384): room idx or NONE8
+    uint8_t pad;
+};
+static_assert(sizeof(Hot) == 16, "Hot layout");
+
+// ---- level configuration ---------------------------------------------------
+enum : int { K_GOTO = 0, K_LEVELGEN = 1 };
+enum : int { AK_GOTO = 0, AK_PICKUP = 1, AK_OPEN = 2, AK_PUTNEXT = 3 };
+enum : int { IK_ACTION = 0, IK_AND = 1, IK_SEQ = 2 };
+
+struct LevelCfg {
+    int32_t kind;
+    int32_t room_size, num_rows, num_cols, num_dists;
+    // K_GOTO family (iclr19_levels.py:40-63,66-124,224-257)
+    int32_t redball;        // place a red ball first and make it the target
+    int32_t connect;        // connect_all() after placing the agent
+    int32_t check_reach;    // check_objs_reachable()
+    int32_t doors_open;     // open_all_doors() at the end
+    int32_t all_unique;     // add_distractors(all_unique=...)
+    // K_LEVELGEN (levelgen.py:256-460)
+    int32_t locations, unblocking, implicit_unlock;
+    int32_t n_action_kinds, action_kinds[4];
+    int32_t n_instr_kinds, instr_kinds[3];
+    double locked_room_prob;
+    // derived layout (fill_layout)
+    int32_t W, H, ES, EH, maxo;
+    int32_t off_I, off_app, off_pos, off_prog, rec_bytes;
+};
+
+BB_HD int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+inline int fill_layout(LevelCfg& c) {
+    if (c.room_size < 3 || c.num_rows < 1 || c.num_cols < 1) return -1;
+    if (c.num_rows * c.num_cols > MAX_ROOMS) return -1;
+    c.W = (c.room_size - 1) * c.num_cols + 1;
+    c.H = (c.room_size - 1) * c.num_rows + 1;
+    if (c.W > MAX_W || c.H > MAX_W) return -1;
+    c.ES = round_up(c.W + 2 * MARGIN, 4);
+    c.EH = c.H + 2 * MARGIN;
+    int ndoors = c.num_rows * (c.num_cols - 1) + c.num_cols * (c.num_rows - 1);
+    c.maxo = round_up(c.num_dists + 2 + ndoors, 8);
+    if (c.maxo > MAX_OBJ) return -1;
+    c.off_I = c.ES * c.EH;
+    c.off_app = round_up(c.off_I + c.W * c.H, 4);
+    c.off_pos = c.off_app + c.maxo;
+    c.off_prog = round_up(c.off_pos + 2 * c.maxo, 16);
+    c.rec_bytes = round_up(c.off_prog + (int)sizeof(Prog), 64);
+    return 0;
+}
+
+BB_HD int e_index(const LevelCfg& c, int x, int y) { return (y + MARGIN) * c.ES + (x + MARGIN); }
+BB_HD int i_index(const LevelCfg& c, int x, int y) { return y * c.W + x; }
+
+}  // namespace bbai

@@ -1,0 +1,154 @@
+"""Level table: BabyAI level ids -> generator configuration (`LevelCfg`).
+
+Each entry restates the constructor arguments of the reference level class
+(file:line under /root/reference/babyai/levels/iclr19_levels.py) as plain data for
+the device-side generator (babyai_amd/csrc/bbai_gen.hpp).  Levels are grouped in two
+generator families:
+
+  * K_GOTO      GoToRedBall :40-63, GoToObj :75-102, GoToLocal :105-184, GoTo :224-301
+  * K_LEVELGEN  every `LevelGen` parameterisation (levelgen.py:256-460): PickupLoc :494-515,
+                GoToSeq :518-551, Synth :554-594, SynthLoc :597-614, SynthSeq :617-633,
+                MiniBossLevel :636-645, BossLevel :648-652, BossLevelNoUnlock :655-661
+
+Hand-written levels (Unlock, PutNext, GoToImpUnlock, ...) and the bonus levels are not
+covered yet; `make_cfg` raises KeyError for them.
+"""
+import ctypes
+
+K_GOTO, K_LEVELGEN = 0, 1
+AK = {"goto": 0, "pickup": 1, "open": 2, "putnext": 3}
+IK = {"action": 0, "and": 1, "seq": 2}
+
+
+class LevelCfg(ctypes.Structure):
+    """Mirror of `bbai::LevelCfg` (babyai_amd/csrc/bbai_types.hpp) == `bbai_level_cfg` (include/bbai.h)."""
+    _fields_ = [
+        ("kind", ctypes.c_int32),
+        ("room_size", ctypes.c_int32), ("num_rows", ctypes.c_int32), ("num_cols", ctypes.c_int32),
+        ("num_dists", ctypes.c_int32),
+        ("redball", ctypes.c_int32), ("connect", ctypes.c_int32), ("check_reach", ctypes.c_int32),
+        ("doors_open", ctypes.c_int32), ("all_unique", ctypes.c_int32),
+        ("locations", ctypes.c_int32), ("unblocking", ctypes.c_int32), ("implicit_unlock", ctypes.c_int32),
+        ("n_action_kinds", ctypes.c_int32), ("action_kinds", ctypes.c_int32 * 4),
+        ("n_instr_kinds", ctypes.c_int32), ("instr_kinds", ctypes.c_int32 * 3),
+        ("locked_room_prob", ctypes.c_double),
+        ("W", ctypes.c_int32), ("H", ctypes.c_int32), ("ES", ctypes.c_int32), ("EH", ctypes.c_int32),
+        ("maxo", ctypes.c_int32),
+        ("off_I", ctypes.c_int32), ("off_app", ctypes.c_int32), ("off_pos", ctypes.c_int32),
+        ("off_prog", ctypes.c_int32), ("rec_bytes", ctypes.c_int32),
+    ]
+
+
+def _goto(room_size=8, num_rows=1, num_cols=1, num_dists=8, redball=0, connect=0,
+          check_reach=1, doors_open=0, all_unique=0):
+    return dict(kind=K_GOTO, room_size=room_size, num_rows=num_rows, num_cols=num_cols,
+                num_dists=num_dists, redball=redball, connect=connect, check_reach=check_reach,
+                doors_open=doors_open, all_unique=all_unique)
+
+
+def _levelgen(room_size=8, num_rows=3, num_cols=3, num_dists=18, locked_room_prob=0.5,
+              locations=True, unblocking=True, implicit_unlock=True,
+              action_kinds=("goto", "pickup", "open", "putnext"),
+              instr_kinds=("action", "and", "seq")):
+    return dict(kind=K_LEVELGEN, room_size=room_size, num_rows=num_rows, num_cols=num_cols,
+                num_dists=num_dists, locked_room_prob=float(locked_room_prob),
+                locations=int(locations), unblocking=int(unblocking),
+                implicit_unlock=int(implicit_unlock),
+                action_kinds=tuple(action_kinds), instr_kinds=tuple(instr_kinds))
+
+
+LEVELS = {
+    # --- K_GOTO family -----------------------------------------------------------------
+    "GoToRedBall": _goto(num_dists=7, redball=1),
+    "GoToRedBallNoDists": _goto(num_dists=0, redball=1),
+    "GoToObj": _goto(num_dists=1, all_unique=1, check_reach=0),
+    "GoToObjS4": _goto(room_size=4, num_dists=1, all_unique=1, check_reach=0),
+    "GoToObjS6": _goto(room_size=6, num_dists=1, all_unique=1, check_reach=0),
+    "GoToLocal": _goto(num_dists=8),
+    "GoToLocalS5N2": _goto(room_size=5, num_dists=2),
+    "GoToLocalS6N2": _goto(room_size=6, num_dists=2),
+    "GoToLocalS6N3": _goto(room_size=6, num_dists=3),
+    "GoToLocalS6N4": _goto(room_size=6, num_dists=4),
+    "GoToLocalS7N4": _goto(room_size=7, num_dists=4),
+    "GoToLocalS7N5": _goto(room_size=7, num_dists=5),
+    "GoToLocalS8N2": _goto(num_dists=2),
+    "GoToLocalS8N3": _goto(num_dists=3),
+    "GoToLocalS8N4": _goto(num_dists=4),
+    "GoToLocalS8N5": _goto(num_dists=5),
+    "GoToLocalS8N6": _goto(num_dists=6),
+    "GoToLocalS8N7": _goto(num_dists=7),
+    "GoTo": _goto(num_rows=3, num_cols=3, num_dists=18, connect=1),
+    "GoToOpen": _goto(num_rows=3, num_cols=3, num_dists=18, connect=1, doors_open=1),
+    "GoToObjMaze": _goto(num_rows=3, num_cols=3, num_dists=1, connect=1),
+    "GoToObjMazeOpen": _goto(num_rows=3, num_cols=3, num_dists=1, connect=1, doors_open=1),
+    "GoToObjMazeS4R2": _goto(room_size=4, num_rows=2, num_cols=2, num_dists=1, connect=1),
+    "GoToObjMazeS4": _goto(room_size=4, num_rows=3, num_cols=3, num_dists=1, connect=1),
+    "GoToObjMazeS5": _goto(room_size=5, num_rows=3, num_cols=3, num_dists=1, connect=1),
+    "GoToObjMazeS6": _goto(room_size=6, num_rows=3, num_cols=3, num_dists=1, connect=1),
+    "GoToObjMazeS7": _goto(room_size=7, num_rows=3, num_cols=3, num_dists=1, connect=1),
+    # --- K_LEVELGEN family ---------------------------------------------------------------
+    "PickupLoc": _levelgen(action_kinds=("pickup",), instr_kinds=("action",), num_rows=1, num_cols=1,
+                           num_dists=8, locked_room_prob=0, locations=True, unblocking=False),
+    "GoToSeq": _levelgen(action_kinds=("goto",), locked_room_prob=0, locations=False, unblocking=False),
+    "GoToSeqS5R2": _levelgen(room_size=5, num_rows=2, num_cols=2, num_dists=4, action_kinds=("goto",),
+                             locked_room_prob=0, locations=False, unblocking=False),
+    "Synth": _levelgen(instr_kinds=("action",), locations=False, unblocking=True, implicit_unlock=False),
+    "SynthS5R2": _levelgen(room_size=5, num_rows=2, num_cols=2, num_dists=7, instr_kinds=("action",),
+                           locations=False, unblocking=True, implicit_unlock=False),
+    "SynthLoc": _levelgen(instr_kinds=("action",), locations=True, unblocking=True, implicit_unlock=False),
+    "SynthSeq": _levelgen(locations=True, unblocking=True, implicit_unlock=False),
+    "MiniBossLevel": _levelgen(num_cols=2, num_rows=2, room_size=5, num_dists=7, locked_room_prob=0.25),
+    "BossLevel": _levelgen(),
+    "BossLevelNoUnlock": _levelgen(locked_room_prob=0, implicit_unlock=False),
+}
+
+
+def level_name(env_id):
+    """'BabyAI-GoToLocal-v0' or 'GoToLocal' -> 'GoToLocal' (levelgen.py:480 id scheme)."""
+    name = env_id
+    if name.startswith("BabyAI-"):
+        name = name[len("BabyAI-"):]
+        if name.endswith("-v0"):
+            name = name[:-3]
+    return name
+
+
+def fill_layout(cfg):
+    """Python twin of bbai::fill_layout (bbai_types.hpp); the C library recomputes and checks it."""
+    def rup(v, m):
+        return (v + m - 1) // m * m
+    MARGIN, PROG = 5, 112
+    cfg.W = (cfg.room_size - 1) * cfg.num_cols + 1
+    cfg.H = (cfg.room_size - 1) * cfg.num_rows + 1
+    cfg.ES = rup(cfg.W + 2 * MARGIN, 4)
+    cfg.EH = cfg.H + 2 * MARGIN
+    ndoors = cfg.num_rows * (cfg.num_cols - 1) + cfg.num_cols * (cfg.num_rows - 1)
+    cfg.maxo = rup(cfg.num_dists + 2 + ndoors, 8)
+    cfg.off_I = cfg.ES * cfg.EH
+    cfg.off_app = rup(cfg.off_I + cfg.W * cfg.H, 4)
+    cfg.off_pos = cfg.off_app + cfg.maxo
+    cfg.off_prog = rup(cfg.off_pos + 2 * cfg.maxo, 16)
+    cfg.rec_bytes = rup(cfg.off_prog + PROG, 64)
+    return cfg
+
+
+def make_cfg(env_id):
+    """Build the `LevelCfg` for a level id; KeyError if the level is not covered."""
+    name = level_name(env_id)
+    if name not in LEVELS:
+        raise KeyError("level %r is not supported by the batched engine (supported: %s)"
+                       % (env_id, ", ".join(sorted(LEVELS))))
+    p = LEVELS[name]
+    cfg = LevelCfg()
+    for k, v in p.items():
+        if k == "action_kinds":
+            cfg.n_action_kinds = len(v)
+            for i, a in enumerate(v):
+                cfg.action_kinds[i] = AK[a]
+        elif k == "instr_kinds":
+            cfg.n_instr_kinds = len(v)
+            for i, a in enumerate(v):
+                cfg.instr_kinds[i] = IK[a]
+        else:
+            setattr(cfg, k, v)
+    return fill_layout(cfg)

@@ -1,0 +1,58 @@
+// hostsim.cpp -- TEST HARNESS ONLY: compiles the engine's per-env core (generator, step,
+// verifier, observation) for the host CPU with one "lane", so the logic can be checked
+// against the Python oracle in a container without a GPU.  Never loaded by the product
+// package (babyai_amd loads only the HIP library and fails without it).
+#include <string.h>
+#include "../../babyai_amd/csrc/bbai_types.hpp"
+#include "../../babyai_amd/csrc/bbai_gen.hpp"
+#include "../../babyai_amd/csrc/bbai_step.hpp"
+#include "../../babyai_amd/csrc/bbai_seed.hpp"
+
+using namespace bbai;
+
+struct HostCtx {
+    int lane() const { return 0; }
+    int nlanes() const { return 1; }
+    void sync() const {}
+};
+
+extern "C" {
+
+int hs_fill_layout(LevelCfg* cfg) { return fill_layout(*cfg); }
+
+void hs_seed(uint64_t seed, uint32_t* mt) { seed_env(seed, mt); }
+
+// Generate the next level of the stream (mt, *mti) into rec / hot; stale := 0.
+int hs_generate(const LevelCfg* cfg, uint32_t* mt, int32_t* mti, uint8_t* rec, Hot* hot) {
+    int last_locked = hot->last_locked == NONE8 ? -1 : hot->last_locked;
+    static thread_local GenWork w;
+    memcpy(w.mt, mt, sizeof(w.mt));
+    Gen<HostCtx> g(HostCtx(), *cfg, w, *mti, last_locked);
+    int max_steps = g.generate();
+    memcpy(mt, w.mt, sizeof(w.mt));
+    *mti = g.mti;
+    memset(rec, 0, cfg->rec_bytes);
+    memcpy(rec, w.E, cfg->ES * cfg->EH);
+    memcpy(rec + cfg->off_I, w.I, cfg->W * cfg->H);
+    memcpy(rec + cfg->off_app, w.app, cfg->maxo);
+    for (int o = 0; o < cfg->maxo; ++o) { rec[cfg->off_pos + 2 * o] = w.px[o]; rec[cfg->off_pos + 2 * o + 1] = w.py[o]; }
+    memcpy(rec + cfg->off_prog, &w.prog, sizeof(Prog));
+    Hot h;
+    memset(&h, 0, sizeof(h));
+    h.ax = g.ax; h.ay = g.ay; h.dir = g.adir; h.carry = NONE8;
+    h.step = 0; h.max_steps = (uint16_t)max_steps;
+    for (int k = 0; k < 4; ++k) h.pre[k] = NONE8;
+    h.last_locked = g.last_locked < 0 ? NONE8 : (uint8_t)g.last_locked;
+    *hot = h;
+    return g.nobj;
+}
+
+int hs_step(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int action, float* reward) {
+    return step_env(*cfg, rec, *hot, *stale, action, *reward) ? 1 : 0;
+}
+
+void hs_observe(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, uint8_t* out) {
+    observe_env(*cfg, rec, *hot, out);
+}
+
+}  // extern "C"
