@@ -1,0 +1,500 @@
+// bbai_engine.hip -- HIP kernels + C ABI of the batched BabyAI engine (gfx950 / MI355X).
+//
+// Kernels (all integer / byte work, HBM- and latency-bound; no MFMA by design):
+//   k_step         lane = env.  Coalesced SoA loads of the 16-byte hot state, action and stale
+//                  set; per-lane transition + verifier on the env's record; 7x7 egocentric
+//                  observation; the 147-byte encodings of a block's 256 envs are staged in LDS
+//                  and written back as one contiguous, dword-coalesced span.  Finished envs are
+//                  compacted into the reset list with one wave-aggregated atomic per wave.
+//   k_reset        wave = env over the reset list: the next level of the env's MT19937 stream is
+//                  generated wave-uniformly with the whole working set in LDS (bbai_gen.hpp).
+//   k_observe_list lane = env over the reset list: first observation of the new episodes.
+//   k_render       RGBImgPartialObsWrapper as a pure tile-atlas gather: the atlas lives in LDS,
+//                  each lane emits 8-byte pixel chunks, a wave writes 512 contiguous bytes.
+//
+// Reference semantics: see bbai_step.hpp / bbai_gen.hpp headers for file:line citations.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include <thread>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/bbai.h"
+#include "bbai_types.hpp"
+#include "bbai_gen.hpp"
+#include "bbai_step.hpp"
+#include "bbai_seed.hpp"
+
+using namespace bbai;
+
+static_assert(sizeof(bbai_level_cfg) == sizeof(LevelCfg), "C ABI cfg mirrors bbai::LevelCfg");
+
+static thread_local char g_err[512] = "";
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            snprintf(g_err, sizeof(g_err), "%s:%d %s -> %s", __FILE__, __LINE__, #expr,       \
+                     hipGetErrorString(e_));                                                  \
+            return BBAI_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+struct bbai_env {
+    LevelCfg cfg;
+    int64_t n;
+    int device;
+    uint8_t* rec;         // [n][rec_bytes]
+    Hot* hot;             // [n]
+    uint64_t* stale;      // [n]
+    uint32_t* mt;         // [n][624]
+    int32_t* mti;         // [n]
+    int32_t* reset_list;  // [n]
+    uint32_t* counters;   // [0] reset list length, [1] generator guard trips
+    unsigned long long* total_resets;
+    uint8_t* atlas;       // [n_tiles][192]
+    uint8_t* lut;         // [2][256]
+    int n_tiles;
+    bool seeded, live;
+};
+
+// ------------------------------------------------------------------------------------------
+// k_step
+// ------------------------------------------------------------------------------------------
+constexpr int STEP_BLOCK = 256;
+constexpr int OBS_PAD = 148;           // LDS row per env (bytes), dword multiple
+
+__device__ __forceinline__ void observe_lane(const LevelCfg& c, const uint8_t* __restrict__ rec, const Hot& h,
+                                             uint8_t* __restrict__ dst /* LDS or global, byte addressed */) {
+    const uint8_t* E = rec;
+    const int fx = dir_dx(h.dir), fy = dir_dy(h.dir);
+    const int rx = -fy, ry = fx;
+    // world cell of view (0,0): pos + f*6 + r*(-3); stepping vi adds r, stepping vj subtracts f
+    const int x00 = h.ax + fx * 6 - rx * 3, y00 = h.ay + fy * 6 - ry * 3;
+    const int base = (y00 + MARGIN) * c.ES + (x00 + MARGIN);
+    const int dvi = ry * c.ES + rx;      // address step for vi+1
+    const int dvj = -(fy * c.ES + fx);   // address step for vj+1
+    uint8_t cell[VIEW][VIEW];
+    uint32_t opq[VIEW], vis[VIEW];
+#pragma unroll
+    for (int vj = 0; vj < VIEW; ++vj) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int vi = 0; vi < VIEW; ++vi) {
+            int e = E[base + vi * dvi + vj * dvj];
+            cell[vj][vi] = (uint8_t)e;
+            o |= (e_opaque(e) ? 1u : 0u) << vi;
+        }
+        opq[vj] = o;
+    }
+    process_vis_rows(opq, vis);
+    cell[6][3] = h.carry != NONE8 ? rec[c.off_app + h.carry] : (uint8_t)E_EMPTY;
+#pragma unroll
+    for (int vi = 0; vi < VIEW; ++vi)
+#pragma unroll
+        for (int vj = 0; vj < VIEW; ++vj) {
+            int e = cell[vj][vi];
+            bool v = vis[vj] >> vi & 1;
+            uint8_t* o = dst + (vi * VIEW + vj) * 3;
+            o[0] = v ? e_type(e) : 0; o[1] = v ? e_color(e) : 0; o[2] = v ? e_state(e) : 0;
+        }
+}
+
+__global__ __launch_bounds__(STEP_BLOCK) void k_step(LevelCfg c, int64_t n, uint8_t* __restrict__ recs,
+                                                     Hot* __restrict__ hots, uint64_t* __restrict__ stales,
+                                                     const uint8_t* __restrict__ actions, uint8_t* __restrict__ image,
+                                                     uint8_t* __restrict__ dirs, float* __restrict__ rewards,
+                                                     uint8_t* __restrict__ dones, int auto_reset,
+                                                     int32_t* __restrict__ reset_list, uint32_t* __restrict__ counters) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_obs[STEP_BLOCK * OBS_PAD];
+    const int64_t env0 = (int64_t)blockIdx.x * STEP_BLOCK;
+    const int64_t env = env0 + threadIdx.x;
+    const bool active = env < n;
+    bool want_reset = false;
+    if (active) {
+        Hot h = hots[env];
+        uint8_t* rec = recs + env * (int64_t)c.rec_bytes;
+        if (!h.frozen) {
+            uint64_t stale = stales[env];
+            float reward;
+            bool done = step_env(c, rec, h, stale, actions[env], reward);
+            if (done && !auto_reset) h.frozen = 1;
+            want_reset = done && auto_reset;
+            hots[env] = h;
+            stales[env] = stale;
+            rewards[env] = reward;
+            dones[env] = done ? 1 : 0;
+            dirs[env] = h.dir;
+            observe_lane(c, rec, h, s_obs + threadIdx.x * OBS_PAD);
+        }
+        // frozen envs keep re-emitting their last outputs: copy them through LDS unchanged
+        else {
+            const uint8_t* src = image + env * OBS_BYTES;
+            for (int b = 0; b < OBS_BYTES; ++b) s_obs[threadIdx.x * OBS_PAD + b] = src[b];
+        }
+    }
+    // compact finished envs into the reset list: one atomic per wave
+    {
+        unsigned long long bal = __ballot(want_reset);
+        if (bal) {
+            int lane = threadIdx.x & 63;
+            int leader = __ffsll((long long)bal) - 1;
+            uint32_t basei = 0;
+            if (lane == leader) basei = atomicAdd(&counters[0], (uint32_t)__popcll(bal));
+            basei = __shfl(basei, leader);
+            if (want_reset) reset_list[basei + __popcll(bal & ((1ull << lane) - 1))] = (int32_t)env;
+        }
+    }
+    __syncthreads();
+    // cooperative, dword-coalesced write of the block's contiguous obs span
+    const int64_t nb = n - env0 < STEP_BLOCK ? n - env0 : STEP_BLOCK;      // envs in this block
+    const int total = (int)nb * OBS_BYTES;
+    uint8_t* out = image + env0 * OBS_BYTES;                              // 256*147 is a dword multiple
+    const int ndw = total >> 2;
+    for (int d = threadIdx.x; d < ndw; d += STEP_BLOCK) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int b = 4 * d + k;
+            int e = b / OBS_BYTES, off = b - e * OBS_BYTES;
+            v |= (uint32_t)s_obs[e * OBS_PAD + off] << (8 * k);
+        }
+        ((uint32_t*)out)[d] = v;
+    }
+    for (int b = (ndw << 2) + threadIdx.x; b < total; b += STEP_BLOCK) {
+        int e = b / OBS_BYTES, off = b - e * OBS_BYTES;
+        out[b] = s_obs[e * OBS_PAD + off];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_reset : one wavefront generates one env's next level
+// ------------------------------------------------------------------------------------------
+struct WaveCtx {
+    __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
+    __device__ __forceinline__ int nlanes() const { return 64; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+};
+
+__global__ __launch_bounds__(64) void k_reset(LevelCfg c, int64_t n, uint8_t* __restrict__ recs, Hot* __restrict__ hots,
+                                              uint64_t* __restrict__ stales, uint32_t* __restrict__ mts,
+                                              int32_t* __restrict__ mtis, const int32_t* __restrict__ reset_list,
+                                              const uint32_t* __restrict__ counters, int all,
+                                              unsigned long long* __restrict__ total_resets) {
+    __shared__ GenWork w;
+    const int64_t count = all ? n : (int64_t)counters[0];
+    const int lane = threadIdx.x;
+    for (int64_t it = blockIdx.x; it < count; it += gridDim.x) {
+        const int64_t env = all ? it : (int64_t)reset_list[it];
+        uint32_t* mt = mts + env * MT_N;
+        __syncthreads();
+        for (int k = lane; k < MT_N; k += 64) w.mt[k] = mt[k];
+        const int mti0 = mtis[env];
+        const Hot old = hots[env];
+        __syncthreads();
+        Gen<WaveCtx> g(WaveCtx(), c, w, mti0, old.last_locked == NONE8 ? -1 : (int)old.last_locked);
+        const int max_steps = g.generate();
+        __syncthreads();
+        // write-out: MT state, record planes, tables, program
+        for (int k = lane; k < MT_N; k += 64) mt[k] = w.mt[k];
+        uint8_t* rec = recs + env * (int64_t)c.rec_bytes;
+        {
+            const uint32_t* src = (const uint32_t*)w.E;
+            uint32_t* dst = (uint32_t*)rec;
+            const int ndw = (c.ES * c.EH) >> 2;
+            for (int k = lane; k < ndw; k += 64) dst[k] = src[k];
+        }
+        for (int k = lane; k < c.W * c.H; k += 64) rec[c.off_I + k] = w.I[k];
+        for (int k = lane; k < c.maxo; k += 64) {
+            bool used = k < g.nobj;
+            rec[c.off_app + k] = used ? w.app[k] : 0;
+            rec[c.off_pos + 2 * k] = used ? w.px[k] : 0;
+            rec[c.off_pos + 2 * k + 1] = used ? w.py[k] : 0;
+        }
+        {
+            const uint32_t* src = (const uint32_t*)&w.prog;
+            uint32_t* dst = (uint32_t*)(rec + c.off_prog);
+            for (int k = lane; k < (int)(sizeof(Prog) / 4); k += 64) dst[k] = src[k];
+        }
+        if (lane == 0) {
+            Hot h;
+            h.ax = (uint8_t)g.ax; h.ay = (uint8_t)g.ay; h.dir = (uint8_t)g.adir; h.carry = NONE8;
+            h.step = 0; h.max_steps = (uint16_t)max_steps;
+            h.pre[0] = h.pre[1] = h.pre[2] = h.pre[3] = NONE8;
+            h.vstate = 0; h.frozen = 0;
+            h.last_locked = g.last_locked < 0 ? NONE8 : (uint8_t)g.last_locked;
+            h.pad = 0;
+            hots[env] = h;
+            stales[env] = 0;
+            mtis[env] = g.mti;
+        }
+    }
+    if (blockIdx.x == 0 && lane == 0) atomicAdd(total_resets, (unsigned long long)count);
+}
+
+// first observation of freshly generated episodes (lane = env over the reset list)
+__global__ __launch_bounds__(64) void k_observe_list(LevelCfg c, int64_t n, const uint8_t* __restrict__ recs,
+                                                     const Hot* __restrict__ hots, uint8_t* __restrict__ image,
+                                                     uint8_t* __restrict__ dirs, const int32_t* __restrict__ reset_list,
+                                                     const uint32_t* __restrict__ counters, int all) {
+    const int64_t count = all ? n : (int64_t)counters[0];
+    for (int64_t it = (int64_t)blockIdx.x * 64 + threadIdx.x; it < count; it += (int64_t)gridDim.x * 64) {
+        const int64_t env = all ? it : (int64_t)reset_list[it];
+        const Hot h = hots[env];
+        observe_lane(c, recs + env * (int64_t)c.rec_bytes, h, image + env * OBS_BYTES);
+        dirs[env] = h.dir;
+    }
+}
+
+__global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, uint64_t* __restrict__ stales) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        Hot h;
+        memset(&h, 0, sizeof(h));
+        h.carry = NONE8; h.frozen = 1; h.last_locked = NONE8;
+        h.pre[0] = h.pre[1] = h.pre[2] = h.pre[3] = NONE8;
+        hots[i] = h;
+        stales[i] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_render : encoded obs -> 56x56x3 pixels through the tile atlas
+// ------------------------------------------------------------------------------------------
+constexpr int RENDER_BLOCK = 256;
+constexpr int CHUNKS_PER_ENV = PIX_BYTES / 8;     // 1176 eight-byte chunks
+constexpr int CHUNKS_PER_ROW = PIX * 3 / 8;       // 21
+
+__global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_t* __restrict__ image,
+                                                         uint8_t* __restrict__ pixels, const uint8_t* __restrict__ atlas,
+                                                         const uint8_t* __restrict__ lut, int n_tiles) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_atlas[MAX_TILES * TILE_BYTES];
+    __shared__ uint8_t s_lut[512];
+    for (int k = threadIdx.x; k < n_tiles * TILE_BYTES / 8; k += RENDER_BLOCK)
+        ((uint64_t*)s_atlas)[k] = ((const uint64_t*)atlas)[k];
+    for (int k = threadIdx.x; k < 512; k += RENDER_BLOCK) s_lut[k] = lut[k];
+    __syncthreads();
+    const int64_t total = n * CHUNKS_PER_ENV;
+    for (int64_t g = (int64_t)blockIdx.x * RENDER_BLOCK + threadIdx.x; g < total; g += (int64_t)gridDim.x * RENDER_BLOCK) {
+        const int64_t env = g / CHUNKS_PER_ENV;
+        const int ch = (int)(g - env * CHUNKS_PER_ENV);
+        const int py = ch / CHUNKS_PER_ROW, cx = ch - py * CHUNKS_PER_ROW;
+        const int ti = cx / 3, part = cx - ti * 3;        // tile column (view x), 8-byte third of the tile row
+        const int tj = py >> 3, ty = py & 7;              // tile row (view y), row inside the tile
+        const uint8_t* o = image + env * OBS_BYTES + (ti * VIEW + tj) * 3;
+        const int key = o[0] | (o[1] << 3) | (o[2] << 6);
+        const int agent = (ti == 3 && tj == 6) ? 256 : 0;
+        const int tile = s_lut[agent + key];
+        const uint64_t v = *(const uint64_t*)(s_atlas + tile * TILE_BYTES + ty * 24 + part * 8);
+        ((uint64_t*)pixels)[g] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int bbai_version(void) { return 100; }
+const char* bbai_last_error(void) { return g_err; }
+
+int bbai_fill_layout(bbai_level_cfg* cfg) {
+    if (!cfg) return BBAI_ERR_ARG;
+    LevelCfg c;
+    memcpy(&c, cfg, sizeof(c));
+    if (fill_layout(c) != 0) { snprintf(g_err, sizeof(g_err), "unsupported level geometry"); return BBAI_ERR_ARG; }
+    memcpy(cfg, &c, sizeof(c));
+    return BBAI_OK;
+}
+
+static int validate_cfg(const LevelCfg& c) {
+    if (c.kind != K_GOTO && c.kind != K_LEVELGEN) return -1;
+    if (c.num_dists < 0) return -1;
+    if (c.kind == K_GOTO && !c.redball && c.num_dists < 1) return -1;
+    if (c.kind == K_LEVELGEN) {
+        if (c.n_action_kinds < 1 || c.n_action_kinds > 4 || c.n_instr_kinds < 1 || c.n_instr_kinds > 3) return -1;
+        for (int i = 0; i < c.n_action_kinds; ++i) if (c.action_kinds[i] < 0 || c.action_kinds[i] > 3) return -1;
+        for (int i = 0; i < c.n_instr_kinds; ++i) if (c.instr_kinds[i] < 0 || c.instr_kinds[i] > 2) return -1;
+    }
+    // max_steps must fit uint16: 8 navigations * S^2 * rows * cols
+    if (8 * c.room_size * c.room_size * c.num_rows * c.num_cols > 65535) return -1;
+    return 0;
+}
+
+int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env** out) {
+    if (!cfg || !out || n_envs <= 0 || n_envs > (1ll << 30)) { snprintf(g_err, sizeof(g_err), "bad argument"); return BBAI_ERR_ARG; }
+    LevelCfg c;
+    memcpy(&c, cfg, sizeof(c));
+    LevelCfg chk = c;
+    if (fill_layout(chk) != 0 || memcmp(&chk, &c, sizeof(c)) != 0 || validate_cfg(c) != 0) {
+        snprintf(g_err, sizeof(g_err), "level configuration rejected (layout not filled or out of range)");
+        return BBAI_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(device));
+    bbai_env* e = new bbai_env();
+    memset(e, 0, sizeof(*e));
+    e->cfg = c; e->n = n_envs; e->device = device;
+    hipError_t err = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) { if (err == hipSuccess) err = hipMalloc(p, bytes); };
+    alloc((void**)&e->rec, (size_t)n_envs * c.rec_bytes);
+    alloc((void**)&e->hot, (size_t)n_envs * sizeof(Hot));
+    alloc((void**)&e->stale, (size_t)n_envs * 8);
+    alloc((void**)&e->mt, (size_t)n_envs * MT_N * 4);
+    alloc((void**)&e->mti, (size_t)n_envs * 4);
+    alloc((void**)&e->reset_list, (size_t)n_envs * 4);
+    alloc((void**)&e->counters, 64);
+    alloc((void**)&e->total_resets, 8);
+    alloc((void**)&e->atlas, MAX_TILES * TILE_BYTES);
+    alloc((void**)&e->lut, 512);
+    if (err != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "hipMalloc failed: %s", hipGetErrorString(err));
+        bbai_destroy(e);
+        return BBAI_ERR_NOMEM;
+    }
+    HIP_TRY(hipMemset(e->rec, 0, (size_t)n_envs * c.rec_bytes));
+    HIP_TRY(hipMemset(e->counters, 0, 64));
+    HIP_TRY(hipMemset(e->total_resets, 0, 8));
+    *out = e;
+    return BBAI_OK;
+}
+
+void bbai_destroy(bbai_env* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->reset_list, e->counters, e->total_resets, e->atlas, e->lut};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete e;
+}
+
+int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
+    if (!e || !seeds || n != e->n) { snprintf(g_err, sizeof(g_err), "seed: need exactly n_envs seeds"); return BBAI_ERR_ARG; }
+    HIP_TRY(hipSetDevice(e->device));
+    const int64_t chunk = 65536;
+    std::vector<uint32_t> buf((size_t)std::min<int64_t>(chunk, n) * MT_N);
+    unsigned hw = std::thread::hardware_concurrency();
+    int nthreads = (int)std::max(1u, std::min(hw ? hw : 1u, 64u));
+    for (int64_t base = 0; base < n; base += chunk) {
+        int64_t cnt = std::min<int64_t>(chunk, n - base);
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t)
+            th.emplace_back([&, t]() {
+                for (int64_t i = t; i < cnt; i += nthreads) seed_env(seeds[base + i], buf.data() + (size_t)i * MT_N);
+            });
+        for (auto& x : th) x.join();
+        HIP_TRY(hipMemcpy(e->mt + base * MT_N, buf.data(), (size_t)cnt * MT_N * 4, hipMemcpyHostToDevice));
+    }
+    // output index 624: the first draw twists (RandomState.seed leaves pos = N)
+    std::vector<int32_t> idx((size_t)n, MT_N);
+    HIP_TRY(hipMemcpy(e->mti, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_init_hot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, e->hot, e->stale);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    e->seeded = true;
+    e->live = false;
+    return BBAI_OK;
+}
+
+static unsigned reset_grid(int64_t count_hint) {
+    // wave-per-env persistent-style grid: enough single-wave blocks to fill 256 CUs x 8 waves/SIMD
+    int64_t g = std::min<int64_t>(count_hint, 256 * 32);
+    return (unsigned)std::max<int64_t>(g, 1);
+}
+
+int bbai_reset(bbai_env* e, uint8_t* image, uint8_t* dirs, void* stream) {
+    if (!e || !image || !dirs) return BBAI_ERR_ARG;
+    if (!e->seeded) { snprintf(g_err, sizeof(g_err), "reset before seed"); return BBAI_ERR_STATE; }
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_reset, dim3(reset_grid(e->n)), dim3(64), 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->mt,
+                       e->mti, e->reset_list, e->counters, 1, e->total_resets);
+    hipLaunchKernelGGL(k_observe_list, dim3((unsigned)std::min<int64_t>((e->n + 63) / 64, 65536)), dim3(64), 0, s, e->cfg,
+                       e->n, e->rec, e->hot, image, dirs, e->reset_list, e->counters, 1);
+    HIP_TRY(hipGetLastError());
+    e->live = true;
+    return BBAI_OK;
+}
+
+int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, uint8_t* dones,
+              int auto_reset, void* stream) {
+    if (!e || !actions || !image || !dirs || !rewards || !dones) return BBAI_ERR_ARG;
+    if (!e->live) { snprintf(g_err, sizeof(g_err), "step before reset"); return BBAI_ERR_STATE; }
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(e->counters, 0, 4, s));
+    hipLaunchKernelGGL(k_step, dim3((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), dim3(STEP_BLOCK), 0, s, e->cfg, e->n,
+                       e->rec, e->hot, e->stale, actions, image, dirs, rewards, dones, auto_reset, e->reset_list, e->counters);
+    if (auto_reset) {
+        // the number of finished envs is only known on the device: fixed grids, device-side count
+        hipLaunchKernelGGL(k_reset, dim3(reset_grid(std::max<int64_t>(e->n / 64, 64))), dim3(64), 0, s, e->cfg, e->n, e->rec,
+                           e->hot, e->stale, e->mt, e->mti, e->reset_list, e->counters, 0, e->total_resets);
+        hipLaunchKernelGGL(k_observe_list, dim3((unsigned)std::min<int64_t>((e->n + 4095) / 4096, 1024)), dim3(64), 0, s,
+                           e->cfg, e->n, e->rec, e->hot, image, dirs, e->reset_list, e->counters, 0);
+    }
+    HIP_TRY(hipGetLastError());
+    return BBAI_OK;
+}
+
+int bbai_set_atlas(bbai_env* e, const uint8_t* tiles, int n_tiles, const uint8_t* lut) {
+    if (!e || !tiles || !lut || n_tiles < 1 || n_tiles > MAX_TILES) return BBAI_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpy(e->atlas, tiles, (size_t)n_tiles * TILE_BYTES, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->lut, lut, 512, hipMemcpyHostToDevice));
+    e->n_tiles = n_tiles;
+    return BBAI_OK;
+}
+
+int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream) {
+    if (!e || !image || !pixels) return BBAI_ERR_ARG;
+    if (e->n_tiles <= 0) { snprintf(g_err, sizeof(g_err), "render before set_atlas"); return BBAI_ERR_STATE; }
+    HIP_TRY(hipSetDevice(e->device));
+    int64_t total = e->n * CHUNKS_PER_ENV;
+    unsigned grid = (unsigned)std::min<int64_t>((total + RENDER_BLOCK - 1) / RENDER_BLOCK, 256 * 16);
+    hipLaunchKernelGGL(k_render, dim3(grid), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut,
+                       e->n_tiles);
+    HIP_TRY(hipGetLastError());
+    return BBAI_OK;
+}
+
+int bbai_export_state(bbai_env* e, int64_t first, int64_t count, uint8_t* rec, uint8_t* hot, uint64_t* stale) {
+    if (!e || first < 0 || count < 0 || first + count > e->n) return BBAI_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (rec) HIP_TRY(hipMemcpy(rec, e->rec + first * e->cfg.rec_bytes, (size_t)count * e->cfg.rec_bytes, hipMemcpyDeviceToHost));
+    if (hot) HIP_TRY(hipMemcpy(hot, e->hot + first, (size_t)count * sizeof(Hot), hipMemcpyDeviceToHost));
+    if (stale) HIP_TRY(hipMemcpy(stale, e->stale + first, (size_t)count * 8, hipMemcpyDeviceToHost));
+    return BBAI_OK;
+}
+
+int bbai_import_state(bbai_env* e, int64_t first, int64_t count, const uint8_t* rec, const uint8_t* hot, const uint64_t* stale) {
+    if (!e || first < 0 || count < 0 || first + count > e->n) return BBAI_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (rec) HIP_TRY(hipMemcpy(e->rec + first * e->cfg.rec_bytes, rec, (size_t)count * e->cfg.rec_bytes, hipMemcpyHostToDevice));
+    if (hot) HIP_TRY(hipMemcpy(e->hot + first, hot, (size_t)count * sizeof(Hot), hipMemcpyHostToDevice));
+    if (stale) HIP_TRY(hipMemcpy(e->stale + first, stale, (size_t)count * 8, hipMemcpyHostToDevice));
+    e->live = true;
+    return BBAI_OK;
+}
+
+int bbai_get_programs(bbai_env* e, int64_t first, int64_t count, uint8_t* prog) {
+    if (!e || !prog || first < 0 || count < 0 || first + count > e->n) return BBAI_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy2D(prog, sizeof(Prog), e->rec + first * e->cfg.rec_bytes + e->cfg.off_prog, (size_t)e->cfg.rec_bytes,
+                        sizeof(Prog), (size_t)count, hipMemcpyDeviceToHost));
+    return BBAI_OK;
+}
+
+int bbai_reset_count(bbai_env* e, uint64_t* out) {
+    if (!e || !out) return BBAI_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpy(&v, e->total_resets, 8, hipMemcpyDeviceToHost));
+    *out = (uint64_t)v;
+    return BBAI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,271 @@
+"""Host side of the batched BabyAI engine: ctypes binding of the C ABI (include/bbai.h)
+over torch device tensors.
+
+`BatchedBabyAIEnv` exposes the reference's env protocol in batched / tensor form:
+`seed(seeds)`, `reset() -> obs`, `step(actions) -> (obs, reward, done, info)` with the same
+`{image, direction, mission}` observation dict (reference: babyai/levels/levelgen.py:35-66,
+obs keys babyai/utils/demos.py:57-59).  The list-of-dicts adapters that plug into the
+reference's `ParallelEnv` / `ManyEnvs` call sites live in babyai_amd/vec_env.py.
+
+PyTorch is used only for device memory, streams and (in bench.py) torch.distributed.
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible, construction
+raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .levels import LevelCfg, make_cfg
+from . import missions
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbbai_hip.so")
+ATLAS_PATH = os.path.join(_HERE, "data", "tile_atlas_ts8.npz")
+
+OBS_BYTES = 147
+PIX = 56
+PROG_BYTES = 112
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen the HIP engine; raises EngineError (never falls back to a CPU path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise EngineError("HIP engine %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    P, I64, I32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    lib.bbai_version.restype = ctypes.c_int
+    lib.bbai_last_error.restype = ctypes.c_char_p
+    lib.bbai_fill_layout.argtypes = [P]
+    lib.bbai_create.argtypes = [P, I64, I32, ctypes.POINTER(P)]
+    lib.bbai_destroy.argtypes = [P]
+    lib.bbai_destroy.restype = None
+    lib.bbai_seed.argtypes = [P, P, I64]
+    lib.bbai_reset.argtypes = [P, P, P, P]
+    lib.bbai_step.argtypes = [P, P, P, P, P, P, I32, P]
+    lib.bbai_set_atlas.argtypes = [P, P, I32, P]
+    lib.bbai_render.argtypes = [P, P, P, P]
+    lib.bbai_export_state.argtypes = [P, I64, I64, P, P, P]
+    lib.bbai_import_state.argtypes = [P, I64, I64, P, P, P]
+    lib.bbai_get_programs.argtypes = [P, I64, I64, P]
+    lib.bbai_reset_count.argtypes = [P, P]
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = (
+    "bbai_version", "bbai_last_error", "bbai_fill_layout", "bbai_create", "bbai_destroy", "bbai_seed",
+    "bbai_reset", "bbai_step", "bbai_set_atlas", "bbai_render", "bbai_export_state", "bbai_import_state",
+    "bbai_get_programs", "bbai_reset_count",
+)
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        raise EngineError("%s failed (%d): %s" % (what, rc, lib.bbai_last_error().decode()))
+
+
+class Missions(object):
+    """Lazy per-env mission strings: compiled programs are fetched from HBM and rendered to
+    text only when a consumer indexes them."""
+
+    def __init__(self, env):
+        self._env = env
+        self._progs = None
+        self._cache = {}
+
+    def _fetch(self):
+        if self._progs is None:
+            self._progs = self._env.programs()
+        return self._progs
+
+    def __len__(self):
+        return self._env.num_envs
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        i = int(i)
+        if i < 0:
+            i += len(self)
+        s = self._cache.get(i)
+        if s is None:
+            s = missions.prog_surface(self._fetch()[i])
+            self._cache[i] = s
+        return s
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+class BatchedBabyAIEnv(object):
+    """N environments of one BabyAI level on one MI355X.
+
+    Parameters
+    ----------
+    env_id : 'BabyAI-<Level>-v0' or '<Level>' (babyai/levels/levelgen.py:480)
+    num_envs : number of parallel envs on this device
+    device : torch device string / index (a ROCm GPU)
+    pixel : apply RGBImgPartialObsWrapper semantics (obs image uint8[N,56,56,3])
+    auto_reset : True = ParallelEnv protocol (penv.py:8-11); False = ManyEnvs protocol
+                 (evaluate.py:73-81: finished envs freeze until reset())
+    """
+
+    def __init__(self, env_id, num_envs, device="cuda:0", seeds=None, pixel=False, auto_reset=True):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise EngineError("no ROCm GPU visible: the batched engine has no CPU path")
+        self.lib = load_library()
+        self.env_id = env_id
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise EngineError("device must be a ROCm GPU, got %r" % (device,))
+        self.dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.pixel = bool(pixel)
+        self.auto_reset = bool(auto_reset)
+        self.cfg = make_cfg(env_id)
+        self.handle = ctypes.c_void_p()
+        _check(self.lib, self.lib.bbai_create(ctypes.byref(self.cfg), self.num_envs, self.dev_index,
+                                               ctypes.byref(self.handle)), "bbai_create")
+        n = self.num_envs
+        with torch.cuda.device(self.dev_index):
+            self.image = torch.zeros((n, 7, 7, 3), dtype=torch.uint8, device=self.device)
+            self.direction = torch.zeros((n,), dtype=torch.uint8, device=self.device)
+            self.reward = torch.zeros((n,), dtype=torch.float32, device=self.device)
+            self.done = torch.zeros((n,), dtype=torch.uint8, device=self.device)
+            self.pixels = None
+            if self.pixel:
+                self.pixels = torch.zeros((n, PIX, PIX, 3), dtype=torch.uint8, device=self.device)
+                atlas = np.load(ATLAS_PATH)
+                tiles = np.ascontiguousarray(atlas["tiles"], dtype=np.uint8)
+                lut = np.ascontiguousarray(atlas["lut"], dtype=np.uint8)
+                _check(self.lib, self.lib.bbai_set_atlas(self.handle, tiles.ctypes.data, tiles.shape[0],
+                                                          lut.ctypes.data), "bbai_set_atlas")
+        self._missions = None
+        self.kernel_events = None      # bench.py: list of (tag, start_event, end_event) when enabled
+        self.num_actions = 7
+        self.max_steps_bound = 8 * self.cfg.room_size ** 2 * self.cfg.num_rows * self.cfg.num_cols
+        if seeds is not None:
+            self.seed(seeds)
+
+    # ---- protocol ---------------------------------------------------------------------
+    def seed(self, seeds):
+        """env.seed(s) for every env: an int base (env i gets base + i) or a sequence."""
+        if isinstance(seeds, (int, np.integer)):
+            seeds = np.arange(self.num_envs, dtype=np.uint64) + np.uint64(seeds)
+        seeds = np.ascontiguousarray(np.asarray(list(seeds) if not isinstance(seeds, np.ndarray) else seeds,
+                                                dtype=np.uint64))
+        if seeds.shape != (self.num_envs,):
+            raise ValueError("need %d seeds, got shape %s" % (self.num_envs, seeds.shape))
+        _check(self.lib, self.lib.bbai_seed(self.handle, seeds.ctypes.data, self.num_envs), "bbai_seed")
+        self.seeds = seeds
+        return list(int(s) for s in seeds[:8])
+
+    def _ev_begin(self):
+        if self.kernel_events is None:
+            return None
+        ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record(self.torch.cuda.current_stream(self.dev_index))   # same stream the kernels launch on
+        return ev
+
+    def _ev_end(self, tag, start):
+        if start is None:
+            return
+        end = self.torch.cuda.Event(enable_timing=True)
+        end.record(self.torch.cuda.current_stream(self.dev_index))
+        self.kernel_events.append((tag, start, end))
+
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.dev_index).cuda_stream)
+
+    def _obs(self):
+        img = self.image
+        if self.pixel:
+            ev = self._ev_begin()
+            _check(self.lib, self.lib.bbai_render(self.handle, self.image.data_ptr(), self.pixels.data_ptr(),
+                                                   self._stream()), "bbai_render")
+            self._ev_end("render", ev)
+            img = self.pixels
+        self._missions = Missions(self)
+        return {"image": img, "direction": self.direction, "mission": self._missions}
+
+    def reset(self):
+        _check(self.lib, self.lib.bbai_reset(self.handle, self.image.data_ptr(), self.direction.data_ptr(),
+                                              self._stream()), "bbai_reset")
+        return self._obs()
+
+    def step(self, actions):
+        torch = self.torch
+        if not isinstance(actions, torch.Tensor):
+            actions = torch.as_tensor(np.asarray(actions), device=self.device)
+        if actions.dtype != torch.uint8 or actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
+        if actions.numel() != self.num_envs:
+            raise ValueError("need %d actions" % self.num_envs)
+        self._actions = actions     # keep alive until the launch is consumed
+        ev = self._ev_begin()
+        _check(self.lib, self.lib.bbai_step(self.handle, actions.data_ptr(), self.image.data_ptr(),
+                                             self.direction.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
+                                             1 if self.auto_reset else 0, self._stream()), "bbai_step")
+        self._ev_end("step", ev)
+        return self._obs(), self.reward, self.done, {}
+
+    # ---- state access -------------------------------------------------------------------
+    def programs(self, first=0, count=None):
+        count = self.num_envs - first if count is None else count
+        out = np.zeros((count, PROG_BYTES), dtype=np.uint8)
+        _check(self.lib, self.lib.bbai_get_programs(self.handle, first, count, out.ctypes.data), "bbai_get_programs")
+        return out
+
+    def missions(self):
+        return list(Missions(self))
+
+    def export_state(self, first=0, count=None):
+        count = self.num_envs - first if count is None else count
+        rec = np.zeros((count, self.cfg.rec_bytes), dtype=np.uint8)
+        hot = np.zeros((count, 16), dtype=np.uint8)
+        stale = np.zeros((count,), dtype=np.uint64)
+        _check(self.lib, self.lib.bbai_export_state(self.handle, first, count, rec.ctypes.data, hot.ctypes.data,
+                                                     stale.ctypes.data), "bbai_export_state")
+        return rec, hot, stale
+
+    def import_state(self, rec, hot, stale, first=0):
+        rec = np.ascontiguousarray(rec, dtype=np.uint8)
+        hot = np.ascontiguousarray(hot, dtype=np.uint8)
+        stale = np.ascontiguousarray(stale, dtype=np.uint64)
+        count = rec.shape[0]
+        assert rec.shape == (count, self.cfg.rec_bytes) and hot.shape == (count, 16) and stale.shape == (count,)
+        _check(self.lib, self.lib.bbai_import_state(self.handle, first, count, rec.ctypes.data, hot.ctypes.data,
+                                                     stale.ctypes.data), "bbai_import_state")
+
+    def reset_count(self):
+        v = ctypes.c_uint64(0)
+        _check(self.lib, self.lib.bbai_reset_count(self.handle, ctypes.byref(v)), "bbai_reset_count")
+        return int(v.value)
+
+    def max_steps(self):
+        """Per-env max_steps of the current episodes (levelgen.py:42-45)."""
+        _, hot, _ = self.export_state()
+        return hot[:, 6].astype(np.int32) | (hot[:, 7].astype(np.int32) << 8)
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle:
+            self.lib.bbai_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

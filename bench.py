@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched BabyAI hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch: every env of the shard applies one
+action (transition + verifier), finished envs are regenerated on the device (auto-reset) and
+the observation is written (7x7x3 encoding, plus the 56x56x3 pixel render for the default
+BossLevel workload = BASELINE.json configs[4] on one GPU).  Actions are synthetic i.i.d.
+uniform over the 7 actions, resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Envs shard embarrassingly: rank r owns envs [r*E, (r+1)*E) with seeds base + global index; no
+collective on the step path (only the timing barrier / max-reduce).  scaling = weak
+(E envs per GPU fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--envs", type=int, default=1048576, help="envs per GPU")
+    ap.add_argument("--level", default="BossLevel")
+    ap.add_argument("--no-pixel", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (no CPU path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if dist is not None:
+        dist.barrier()
+    from babyai_amd.engine import BatchedBabyAIEnv
+
+    pixel = not args.no_pixel
+    E = args.envs
+    env = BatchedBabyAIEnv("BabyAI-%s-v0" % args.level, E, device=dev, pixel=pixel)
+    env.seed(args.seed + rank * E)
+    env.reset()
+    K, W = args.steps, args.warmup
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    actions = torch.randint(0, 7, (K + W, E), dtype=torch.uint8, device=dev, generator=gen)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for t in range(W):
+        env.step(actions[t])
+    resets0 = env.reset_count()
+    env.kernel_events = []
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(W, W + K):
+        env.step(actions[t])
+    barrier()
+    dt = time.perf_counter() - t0
+    resets = env.reset_count() - resets0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        rr = torch.tensor([resets], device=dev, dtype=torch.int64)
+        dist.all_reduce(rr)
+        resets = int(rr.item())
+
+    # per-kernel-group durations from HIP events recorded on the launch stream
+    sums = {}
+    for tag, a, b in env.kernel_events:
+        sums.setdefault(tag, []).append(a.elapsed_time(b))
+    avg_ms = {k: sum(v) / len(v) for k, v in sums.items()}
+
+    total_steps = K * E * world
+    value = total_steps / dt
+    if pixel:
+        dom, alg_bytes = "k_render", E * (147 + 9408)          # reads the encoding, writes the pixels
+        dom_ms = avg_ms["render"]
+        bytes_per_step = 9496
+    else:
+        dom, alg_bytes = "k_step", E * 235
+        dom_ms = avg_ms["step"]
+        bytes_per_step = 235
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    out = {
+        "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "BabyAI-%s-v0 %s obs, %d envs/GPU, random actions, auto-reset" % (
+            args.level, "56x56x3 pixel (RGBImgPartialObsWrapper)" if pixel else "7x7x3 encoded", E),
+            "envs_per_gpu": E, "total_envs": E * world, "resets_in_timed_region": resets,
+            "parallelism": "env-shards x%d, no collective" % world},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
+                     "whole_step_alg_GBs": value / world * bytes_per_step / 1e9,
+                     "avg_ms": avg_ms},
+        "cpu_baseline": None,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            from oracle import cpu_baseline
+            out["cpu_baseline"] = cpu_baseline.run(args.level, pixel, args.cpu_baseline_seconds)
+        except Exception as exc:      # the baseline is a reported number, never the product path
+            out["cpu_baseline"] = {"error": repr(exc)}
+    if rank == 0:
+        print(json.dumps(out))
+    env.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,97 @@
+/* bbai.h -- C ABI of the MI355X batched BabyAI environment engine (libbbai_hip.so).
+ *
+ * The reference (mila-iqia/babyai) is pure Python and has no FFI; this ABI is the
+ * native boundary UNDER the Python adapter that mirrors the reference's env protocol.
+ * Each entry point names the reference interface it replaces (file:line under
+ * /root/reference).  All device pointers are caller-owned HBM buffers (e.g. the
+ * data_ptr() of torch tensors on the handle's device); launches are asynchronous on
+ * the caller's hipStream_t (passed as void*; NULL = default stream).  No exceptions
+ * cross the boundary: every call returns 0 or a negative bbai_status.  One handle per
+ * device; a handle is not thread-safe.
+ */
+#ifndef BBAI_H
+#define BBAI_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum bbai_status {
+    BBAI_OK = 0,
+    BBAI_ERR_ARG = -1,        /* bad argument / unsupported level configuration */
+    BBAI_ERR_HIP = -2,        /* HIP runtime error (see bbai_last_error) */
+    BBAI_ERR_STATE = -3,      /* call order violated (e.g. step before seed+reset) */
+    BBAI_ERR_NOMEM = -4
+};
+
+/* Level description: the constructor arguments of a reference level class
+ * (babyai/levels/iclr19_levels.py; LevelGen babyai/levels/levelgen.py:262-291) as data.
+ * Layout fields (W..rec_bytes) are derived by bbai_fill_layout. */
+typedef struct bbai_level_cfg {
+    int32_t kind;                       /* 0 = GoTo family, 1 = LevelGen family */
+    int32_t room_size, num_rows, num_cols, num_dists;
+    int32_t redball, connect, check_reach, doors_open, all_unique;     /* GoTo family */
+    int32_t locations, unblocking, implicit_unlock;                    /* LevelGen */
+    int32_t n_action_kinds, action_kinds[4];    /* 0 goto 1 pickup 2 open 3 putnext, in list order */
+    int32_t n_instr_kinds, instr_kinds[3];      /* 0 action 1 and 2 seq, in list order */
+    double locked_room_prob;
+    int32_t W, H, ES, EH, maxo;
+    int32_t off_I, off_app, off_pos, off_prog, rec_bytes;
+} bbai_level_cfg;
+
+typedef struct bbai_env bbai_env;       /* opaque: N envs of one level on one device */
+
+#define BBAI_OBS_BYTES 147              /* uint8[7][7][3], image[view_x][view_y][channel] */
+#define BBAI_PIX_BYTES 9408             /* uint8[56][56][3], RGBImgPartialObsWrapper, tile 8 */
+#define BBAI_PROG_BYTES 112             /* compiled instruction tree (mission descriptor) */
+#define BBAI_TILE_BYTES 192
+
+int bbai_version(void);
+const char* bbai_last_error(void);
+
+/* Derive the record layout for a level configuration. */
+int bbai_fill_layout(bbai_level_cfg* cfg);
+
+/* gym.make(id) x n_envs (babyai/levels/levelgen.py:467-493 registration; scripts/train_rl.py:53-60
+ * builds the env list).  Allocates all per-env state in HBM on `device`. */
+int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env** out);
+void bbai_destroy(bbai_env* env);
+
+/* env.seed(s) for every env (scripts/train_rl.py:59, babyai/evaluate.py:67-68,105-106):
+ * seeds_host[i] -> gym-style sha512 -> MT19937 init_by_array, uploaded to HBM. */
+int bbai_seed(bbai_env* env, const uint64_t* seeds_host, int64_t n);
+
+/* env.reset() for every env (babyai/levels/levelgen.py:35-47; ParallelEnv.reset
+ * babyai/rl/utils/penv.py:39-43; ManyEnvs.reset babyai/evaluate.py:68-71): generates the next
+ * level of each env's RNG stream on the device and writes the first observation. */
+int bbai_reset(bbai_env* env, uint8_t* image_dev, uint8_t* dir_dev, void* stream);
+
+/* env.step(action) for every env (babyai/levels/levelgen.py:49-66).
+ *   auto_reset != 0 : ParallelEnv semantics (babyai/rl/utils/penv.py:8-11,45-52): a finished env
+ *                     is reset in the same call and image/dir hold the NEXT episode's first obs,
+ *                     while reward/done are the terminal step's.
+ *   auto_reset == 0 : ManyEnvs semantics (babyai/evaluate.py:73-81): a finished env is frozen and
+ *                     keeps re-emitting its last (obs, reward, done) until bbai_reset. */
+int bbai_step(bbai_env* env, const uint8_t* actions_dev, uint8_t* image_dev, uint8_t* dir_dev,
+              float* reward_dev, uint8_t* done_dev, int auto_reset, void* stream);
+
+/* RGBImgPartialObsWrapper.observation (gym_minigrid.wrappers; used at babyai/evaluate.py:91-92,
+ * scripts/train_rl.py:57-58): encoded obs uint8[N][147] -> pixels uint8[N][56][56][3].
+ * The tile atlas must have been installed with bbai_set_atlas. */
+int bbai_set_atlas(bbai_env* env, const uint8_t* tiles_host, int n_tiles, const uint8_t* lut_host /* [2][256] */);
+int bbai_render(bbai_env* env, const uint8_t* image_dev, uint8_t* pixels_dev, void* stream);
+
+/* State access (host buffers; synchronous): parity tests, checkpoints, mission strings. */
+int bbai_export_state(bbai_env* env, int64_t first, int64_t count, uint8_t* rec_host,
+                      uint8_t* hot_host /* 16 B each */, uint64_t* stale_host);
+int bbai_import_state(bbai_env* env, int64_t first, int64_t count, const uint8_t* rec_host,
+                      const uint8_t* hot_host, const uint64_t* stale_host);
+int bbai_get_programs(bbai_env* env, int64_t first, int64_t count, uint8_t* prog_host /* 112 B each */);
+
+/* Number of level generations (resets) performed so far, all envs. */
+int bbai_reset_count(bbai_env* env, uint64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

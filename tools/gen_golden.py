@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Generate golden traces from the REFERENCE ITSELF (/root/reference/babyai, imported
+unmodified on top of the restated gym/gym_minigrid shim in oracle/shim).
+
+Runs only in the build container (the reference tree cannot travel to the GPU box); the
+resulting small fixtures under tests/golden/ are committed and pin
+  * the stand-alone oracle (oracle/levels.py)            -> tests/test_oracle_golden.py
+  * the HIP engine through the C ABI                     -> tests/test_gpu_parity.py
+Re-run:  PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+
+Protocol recorded = the reference's ParallelEnv worker (babyai/rl/utils/penv.py:4-16):
+  env = Level(); env.seed(s); obs = env.reset();  then for each action:
+  obs, reward, done, info = env.step(a); if done: obs = env.reset()
+`pre_resets` extra reset() calls are recorded first (they exercise the persistent RNG stream).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import refenv  # noqa: E402
+
+refenv.import_reference()
+from babyai.levels import level_dict  # noqa: E402
+from gym_minigrid.wrappers import RGBImgPartialObsWrapper  # noqa: E402
+
+# level, n_envs, n_steps, pre_resets, n_pixel_envs
+PLAN = [
+    ("GoToRedBall", 8, 160, 2, 0),
+    ("GoToLocal", 16, 256, 2, 2),
+    ("PickupLoc", 16, 256, 2, 0),
+    ("GoTo", 8, 320, 2, 0),
+    ("GoToSeq", 6, 200, 1, 0),
+    ("SynthSeq", 8, 200, 3, 0),
+    ("MiniBossLevel", 8, 320, 3, 0),
+    ("BossLevel", 16, 384, 3, 2),
+]
+SEED_BASE = 1000
+
+
+def trace(name, n_envs, n_steps, pre_resets, n_pix):
+    rng = np.random.RandomState(abs(hash(name)) % (2 ** 31) if False else sum(map(ord, name)))
+    actions = rng.randint(0, 7, size=(n_steps, n_envs)).astype(np.uint8)
+    seeds = np.arange(n_envs, dtype=np.uint64) + SEED_BASE
+    envs = []
+    for s in seeds:
+        env = level_dict[name]()
+        env.seed(int(s))
+        envs.append(env)
+    pix = [RGBImgPartialObsWrapper(e) for e in envs[:n_pix]]
+    pre_image = np.zeros((pre_resets, n_envs, 7, 7, 3), np.uint8)
+    pre_mission = []
+    for r in range(pre_resets):
+        row = []
+        for i, e in enumerate(envs):
+            o = e.reset()
+            pre_image[r, i] = o['image']
+            row.append(o['mission'])
+        pre_mission.append(row)
+    image = np.zeros((n_steps + 1, n_envs, 7, 7, 3), np.uint8)
+    direction = np.zeros((n_steps + 1, n_envs), np.uint8)
+    reward = np.zeros((n_steps, n_envs), np.float32)
+    done = np.zeros((n_steps, n_envs), np.uint8)
+    max_steps = np.zeros((n_steps + 1, n_envs), np.int32)
+    pixels = np.zeros((n_steps + 1, n_pix, 56, 56, 3), np.uint8)
+    events = []          # (t, env, mission) at every episode start; t = index into image[]
+    for i, e in enumerate(envs):
+        o = e.reset()
+        image[0, i] = o['image']; direction[0, i] = o['direction']; max_steps[0, i] = e.max_steps
+        events.append((0, i, o['mission']))
+        if i < n_pix:
+            pixels[0, i] = pix[i].observation(o)['image']
+    n_done = 0
+    for t in range(n_steps):
+        for i, e in enumerate(envs):
+            o, r, d, _ = e.step(int(actions[t, i]))
+            reward[t, i] = np.float32(r)
+            done[t, i] = d
+            if d:
+                o = e.reset()
+                events.append((t + 1, i, o['mission']))
+                n_done += 1
+            image[t + 1, i] = o['image']; direction[t + 1, i] = o['direction']; max_steps[t + 1, i] = e.max_steps
+            if i < n_pix:
+                pixels[t + 1, i] = pix[i].observation(o)['image']
+    out = os.path.join(ROOT, 'tests', 'golden', name + '.npz')
+    np.savez_compressed(
+        out, level=name, seeds=seeds, actions=actions, pre_image=pre_image,
+        pre_mission=np.array(pre_mission, dtype=object).astype(str) if pre_resets else np.zeros((0, n_envs), dtype=str),
+        image=image, direction=direction, reward=reward, done=done, max_steps=max_steps, pixels=pixels,
+        event_t=np.array([e[0] for e in events], np.int32), event_env=np.array([e[1] for e in events], np.int32),
+        event_mission=np.array([e[2] for e in events]).astype(str))
+    print('%-14s envs=%d steps=%d episodes_finished=%d success=%d -> %d KB' % (
+        name, n_envs, n_steps, n_done, int((reward > 0).sum()), os.path.getsize(out) // 1024))
+
+
+if __name__ == '__main__':
+    for p in PLAN:
+        trace(*p)
