@@ -1,0 +1,60 @@
+"""CPU baseline leg of bench.py: the stand-alone oracle (oracle/levels.py, one Python env object per
+environment -- the reference's own execution model, babyai/rl/utils/penv.py:4-16) stepping the same
+workload (same level, random actions over all 7 actions, auto-reset, optional pixel wrapper) on the
+host cores of the box the bench runs on.  TEST/REPORTING INFRASTRUCTURE: a reported baseline
+(kind = "port"), never a product path."""
+import multiprocessing as mp
+import os
+import sys
+import time
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+
+
+def _worker(args):
+    level, pixel, seconds, seed = args
+    if _ROOT not in sys.path:
+        sys.path.insert(0, _ROOT)
+    import numpy as np
+    from oracle import levels as olevels
+    from gym_minigrid.wrappers import RGBImgPartialObsWrapper
+    env = olevels.make_env(level)
+    env.seed(seed)
+    wrapped = RGBImgPartialObsWrapper(env) if pixel else env
+    wrapped.reset()
+    rng = np.random.RandomState(seed)
+    acts = rng.randint(0, 7, size=4096)
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        for a in acts:
+            _, _, done, _ = wrapped.step(int(a))
+            if done:
+                wrapped.reset()
+        steps += len(acts)
+        if time.perf_counter() - t0 >= seconds:
+            break
+    return steps, time.perf_counter() - t0
+
+
+def run(level="BossLevel", pixel=True, seconds=12.0):
+    cores = os.cpu_count() or 1
+    # one env-per-process on every host core (ParallelEnv's model), plus the single-core figure
+    one_steps, one_dt = _worker((level, pixel, min(4.0, seconds / 3), 0))
+    ctx = mp.get_context("fork")
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_worker, [(level, pixel, seconds, 1000 + i) for i in range(cores)])
+    total = sum(r[0] for r in res)
+    wall = max(r[1] for r in res)
+    return {
+        "value": total / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "sample": "oracle/levels.py BabyAI-%s-v0%s, %d procs x %.0f s random-action rollouts with auto-reset (%d steps)"
+                  % (level, " + RGBImgPartialObsWrapper" if pixel else "", cores, seconds, total),
+        "single_core_value": one_steps / one_dt,
+    }
+
+
+if __name__ == "__main__":
+    import json
+    print(json.dumps(run(*(sys.argv[1:2] or ["BossLevel"]), pixel="--no-pixel" not in sys.argv, seconds=4.0)))

@@ -1,0 +1,486 @@
+"""Stand-alone CPU oracle for the BabyAI hot path.  TEST INFRASTRUCTURE ONLY.
+
+A plain-Python restatement of the reference's level layer, written so that it can travel to
+the GPU box (where /root/reference does not exist) and serve as the checker in tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg.  It runs on the restated
+gym_minigrid core in oracle/shim (see that package's docstring: the real gym_minigrid is an
+absent third-party dependency => PARITY UNPINNED against it).
+
+PINNED against the reference itself: tests/test_oracle_golden.py replays the committed
+traces in tests/golden/ (recorded by tools/gen_golden.py from the unmodified
+/root/reference/babyai running on the same shim) and, in the build container,
+tests/test_oracle_reference.py steps this oracle side by side with the reference.
+
+What follows which reference code (all under /root/reference/babyai/levels/):
+  Desc.match / Desc.surface        verifier.py:96-161, :64-94   (ObjDesc)
+  Clause.verify                    verifier.py:257-274 (open), :296-303 (go to),
+                                   :330-350 (pick up), :393-417 (put next), objs_next :379-391
+  Combo.verify                     verifier.py:449-471 (before), :490-512 (after), :536-550 (and)
+  OracleLevel.reset / step         levelgen.py:35-47, :49-66, refresh-on-drop :68-75
+  OracleLevel._gen_grid            levelgen.py:77-102 (rejection loop)
+  OracleLevel.validate             levelgen.py:104-155
+  OracleLevel.all_reachable        levelgen.py:201-253
+  LevelGenOracle.gen_mission etc.  levelgen.py:293-460
+  GoToOracle.gen_mission           iclr19_levels.py:40-63, 75-124, 224-257
+`strict` modes and BABYAI_DONE_ACTIONS (verifier.py:17) are outside the hot path scope.
+"""
+import os
+import sys
+
+_SHIM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shim")
+if _SHIM not in sys.path:
+    sys.path.insert(0, _SHIM)
+
+from gym_minigrid.minigrid import COLOR_NAMES, DIR_TO_VEC  # noqa: E402
+from gym_minigrid.roomgrid import RoomGrid  # noqa: E402
+
+TYPES_ALL = ['box', 'ball', 'key', 'door']
+TYPES_MOVABLE = ['box', 'ball', 'key']
+LOCS = ['left', 'right', 'front', 'behind']
+
+
+class Reject(Exception):
+    """Rejection-sampling signal (reference: RejectSampling)."""
+
+
+def _manhattan1(p, q):
+    return abs(int(p[0]) - int(q[0])) + abs(int(p[1]) - int(q[1])) == 1
+
+
+class Desc(object):
+    """A set of objects picked out by (type, colour, location-relative-to-start-pose)."""
+
+    def __init__(self, type, color=None, loc=None):
+        self.type, self.color, self.loc = type, color, loc
+        self.objs, self.poss = [], []
+
+    def match(self, env, use_loc=True):
+        if use_loc:
+            self.objs = []
+        self.poss = []
+        ax, ay = env.agent_pos
+        room = env.room_from_pos(ax, ay)
+        f = DIR_TO_VEC[env.agent_dir]
+        r = (-f[1], f[0])
+        grid = env.grid
+        for x in range(grid.width):
+            for y in range(grid.height):
+                c = grid.get(x, y)
+                if c is None:
+                    continue
+                if not use_loc and not any(c is o for o in self.objs):
+                    continue
+                if self.type is not None and c.type != self.type:
+                    continue
+                if self.color is not None and c.color != self.color:
+                    continue
+                if use_loc and self.loc is not None:
+                    if not room.pos_inside(x, y):
+                        continue
+                    vx, vy = x - ax, y - ay
+                    side = vx * r[0] + vy * r[1]
+                    ahead = vx * f[0] + vy * f[1]
+                    ok = {'left': side < 0, 'right': side > 0, 'front': ahead > 0, 'behind': ahead < 0}[self.loc]
+                    if not ok:
+                        continue
+                if use_loc:
+                    self.objs.append(c)
+                self.poss.append((x, y))
+        return self.objs, self.poss
+
+    def surface(self, env):
+        self.match(env)
+        assert len(self.objs) > 0
+        words = self.type if self.type else 'object'
+        if self.color:
+            words = self.color + ' ' + words
+        if self.loc == 'front':
+            words += ' in front of you'
+        elif self.loc == 'behind':
+            words += ' behind you'
+        elif self.loc:
+            words += ' on your ' + self.loc
+        return ('a ' if len(self.objs) > 1 else 'the ') + words
+
+
+class Clause(object):
+    """One action instruction: kind in goto / pickup / open / putnext."""
+    VERB = {'goto': 'go to ', 'pickup': 'pick up ', 'open': 'open ', 'putnext': 'put '}
+
+    def __init__(self, kind, d1, d2=None):
+        self.kind, self.d1, self.d2 = kind, d1, d2
+        self.held_before = None
+
+    def descs(self):
+        return [self.d1] if self.d2 is None else [self.d1, self.d2]
+
+    def navs(self):
+        return 2 if self.kind == 'putnext' else 1
+
+    def surface(self, env):
+        s = self.VERB[self.kind] + self.d1.surface(env)
+        if self.kind == 'putnext':
+            s += ' next to ' + self.d2.surface(env)
+        return s
+
+    def start(self, env):
+        self.env = env
+        self.held_before = None
+        for d in self.descs():
+            d.match(env)
+
+    def refresh(self):
+        for d in self.descs():
+            d.match(self.env, use_loc=False)
+
+    def already_adjacent(self):
+        return any(_manhattan1(a.cur_pos, p) for a in self.d1.objs for p in self.d2.poss)
+
+    def verify(self, action):
+        env = self.env
+        A = env.actions
+        if self.kind == 'goto':
+            fx, fy = env.front_pos
+            return 'success' if any(p[0] == fx and p[1] == fy for p in self.d1.poss) else 'continue'
+        if self.kind == 'open':
+            if action != A.toggle:
+                return 'continue'
+            cell = env.grid.get(*env.front_pos)
+            if cell is not None and any(cell is d for d in self.d1.objs) and cell.is_open:
+                return 'success'
+            return 'continue'
+        before, self.held_before = self.held_before, env.carrying
+        if self.kind == 'pickup':
+            if action == A.pickup and before is None and any(env.carrying is o for o in self.d1.objs):
+                return 'success'
+            return 'continue'
+        # putnext
+        if action != A.drop:
+            return 'continue'
+        for o in self.d1.objs:
+            if before is o and any(_manhattan1(o.cur_pos, p) for p in self.d2.poss):
+                return 'success'
+        return 'continue'
+
+
+class Combo(object):
+    """Two sub-instructions joined by 'and' / 'before' / 'after'."""
+    JOIN = {'and': ' and ', 'before': ', then ', 'after': ' after you '}
+
+    def __init__(self, how, a, b):
+        self.how, self.a, self.b = how, a, b
+
+    def navs(self):
+        return self.a.navs() + self.b.navs()
+
+    def surface(self, env):
+        return self.a.surface(env) + self.JOIN[self.how] + self.b.surface(env)
+
+    def start(self, env):
+        self.a.start(env)
+        self.b.start(env)
+        self.sa = self.sb = False
+
+    def refresh(self):
+        self.a.refresh()
+        self.b.refresh()
+
+    def leaves(self):
+        out = []
+        for s in (self.a, self.b):
+            out += s.leaves() if isinstance(s, Combo) else [s]
+        return out
+
+    def verify(self, action):
+        if self.how == 'and':
+            if self.sa != 'success':
+                self.sa = self.a.verify(action)
+            if self.sb != 'success':
+                self.sb = self.b.verify(action)
+            return 'success' if self.sa == 'success' and self.sb == 'success' else 'continue'
+        first, second = (self.a, self.b) if self.how == 'before' else (self.b, self.a)
+        if not getattr(self, '_first_done', False):
+            if first.verify(action) != 'success':
+                return 'continue'
+            self._first_done = True
+        return 'success' if second.verify(action) == 'success' else 'continue'
+
+    def start_seq(self):
+        self._first_done = False
+
+
+def _leaves(instr):
+    return instr.leaves() if isinstance(instr, Combo) else [instr]
+
+
+class OracleLevel(RoomGrid):
+    """RoomGridLevel restated: reset/step glue, rejection-sampled generation, validation."""
+
+    unblocking = None      # only LevelGen-style levels define it
+
+    def __init__(self, room_size=8, **kw):
+        super().__init__(room_size=room_size, **kw)
+
+    def reset(self, **kw):
+        obs = super().reset(**kw)
+        self.instrs.start(self)
+        for node in self._combos(self.instrs):
+            node.start_seq()
+        self.max_steps = self.instrs.navs() * self.room_size ** 2 * self.num_rows * self.num_cols
+        return obs
+
+    def _combos(self, instr):
+        if isinstance(instr, Combo):
+            return [instr] + self._combos(instr.a) + self._combos(instr.b)
+        return []
+
+    def step(self, action):
+        obs, reward, done, info = super().step(action)
+        if action == self.actions.drop:
+            self.instrs.refresh()
+        if self.instrs.verify(action) == 'success':
+            done = True
+            reward = self._reward()
+        return obs, reward, done, info
+
+    def _gen_grid(self, width, height):
+        while True:
+            try:
+                super()._gen_grid(width, height)
+                self.gen_mission()
+                self.validate(self.instrs)
+            except (RecursionError, Reject):
+                continue
+            break
+        self.surface = self.instrs.surface(self)
+        self.mission = self.surface
+
+    def validate(self, instr):
+        locked_colors = []
+        if self.unblocking:
+            for i in range(self.num_cols):
+                for j in range(self.num_rows):
+                    for door in self.get_room(i, j).doors:
+                        if door and door.is_locked:
+                            locked_colors.append(door.color)
+        for leaf in _leaves(instr):
+            if leaf.kind == 'putnext':
+                leaf.start(self)
+                if any(a is b for a in leaf.d1.objs for b in leaf.d2.objs):
+                    raise Reject('same object on both sides of put-next')
+                if leaf.already_adjacent():
+                    raise Reject('objects already adjacent')
+            if self.unblocking:
+                for d in leaf.descs():
+                    if d.type == 'key' and d.color in locked_colors:
+                        raise Reject('key of a locked door')
+
+    def all_reachable(self):
+        """Flood from the agent through empty cells and doors; every object must be touched."""
+        seen = set()
+        todo = [tuple(int(v) for v in self.agent_pos)]
+        W, H = self.grid.width, self.grid.height
+        while todo:
+            x, y = todo.pop()
+            if x < 0 or y < 0 or x >= W or y >= H or (x, y) in seen:
+                continue
+            seen.add((x, y))
+            c = self.grid.get(x, y)
+            if c is not None and c.type != 'door':
+                continue
+            todo += [(x + 1, y), (x - 1, y), (x, y + 1), (x, y - 1)]
+        for x in range(W):
+            for y in range(H):
+                c = self.grid.get(x, y)
+                if c is not None and c.type != 'wall' and (x, y) not in seen:
+                    raise Reject('unreachable object')
+
+
+class GoToOracle(OracleLevel):
+    """GoToRedBall / GoToObj / GoToLocal / GoTo families."""
+
+    def __init__(self, room_size=8, num_rows=1, num_cols=1, num_dists=8, redball=False, connect=False,
+                 check_reach=True, doors_open=False, all_unique=False, seed=None):
+        self.p = dict(num_dists=num_dists, redball=redball, connect=connect, check_reach=check_reach,
+                      doors_open=doors_open, all_unique=all_unique)
+        super().__init__(room_size=room_size, num_rows=num_rows, num_cols=num_cols, seed=seed)
+
+    def gen_mission(self):
+        p = self.p
+        self.place_agent()
+        target = None
+        if p['redball']:
+            target, _ = self.add_object(0, 0, 'ball', 'red')
+        if p['connect']:
+            self.connect_all()
+        dists = self.add_distractors(num_distractors=p['num_dists'], all_unique=p['all_unique'])
+        if p['check_reach']:
+            self.all_reachable()
+        if target is None:
+            target = self._rand_elem(dists)
+        self.instrs = Clause('goto', Desc(target.type, target.color))
+        if p['doors_open']:
+            for i in range(self.num_cols):
+                for j in range(self.num_rows):
+                    for door in self.get_room(i, j).doors:
+                        if door:
+                            door.is_open = True
+
+
+class LevelGenOracle(OracleLevel):
+    """The general mission sampler (LevelGen) and all its parameterisations."""
+
+    def __init__(self, room_size=8, num_rows=3, num_cols=3, num_dists=18, locked_room_prob=0.5,
+                 locations=True, unblocking=True, implicit_unlock=True,
+                 action_kinds=('goto', 'pickup', 'open', 'putnext'),
+                 instr_kinds=('action', 'and', 'seq'), seed=None):
+        self.num_dists = num_dists
+        self.locked_room_prob = locked_room_prob
+        self.locations = locations
+        self.unblocking = unblocking
+        self.implicit_unlock = implicit_unlock
+        self.action_kinds = list(action_kinds)
+        self.instr_kinds = list(instr_kinds)
+        self.locked_room = None          # survives episodes, exactly like the reference attribute
+        super().__init__(room_size=room_size, num_rows=num_rows, num_cols=num_cols, seed=seed)
+
+    def gen_mission(self):
+        if self._rand_float(0, 1) < self.locked_room_prob:
+            self._locked_room()
+        self.connect_all()
+        self.add_distractors(num_distractors=self.num_dists, all_unique=False)
+        while True:
+            self.place_agent()
+            if self.room_from_pos(*self.agent_pos) is not self.locked_room:
+                break
+        if not self.unblocking:
+            self.all_reachable()
+        self.instrs = self._instr(self.instr_kinds)
+
+    def _locked_room(self):
+        while True:
+            i = self._rand_int(0, self.num_cols)
+            j = self._rand_int(0, self.num_rows)
+            k = self._rand_int(0, 4)
+            self.locked_room = self.get_room(i, j)
+            if self.locked_room.neighbors[k] is None:
+                continue
+            door, _ = self.add_door(i, j, k, locked=True)
+            break
+        while True:
+            i = self._rand_int(0, self.num_cols)
+            j = self._rand_int(0, self.num_rows)
+            if self.get_room(i, j) is self.locked_room:
+                continue
+            self.add_object(i, j, 'key', door.color)
+            break
+
+    def _desc(self, types=TYPES_ALL):
+        tries = 0
+        while True:
+            if tries > 100:
+                raise RecursionError('no describable object')
+            tries += 1
+            color = self._rand_elem([None] + COLOR_NAMES)
+            type_ = self._rand_elem(types)
+            loc = None
+            if self.locations and self._rand_bool():
+                loc = self._rand_elem(LOCS)
+            d = Desc(type_, color, loc)
+            objs, poss = d.match(self)
+            if not objs:
+                continue
+            if not self.implicit_unlock and self.locked_room:
+                if all(self.locked_room.pos_inside(*p) for p in poss):
+                    continue
+            return d
+
+    def _clause(self):
+        kind = self._rand_elem(self.action_kinds)
+        if kind == 'goto':
+            return Clause('goto', self._desc())
+        if kind == 'pickup':
+            return Clause('pickup', self._desc(TYPES_MOVABLE))
+        if kind == 'open':
+            return Clause('open', self._desc(['door']))
+        first = self._desc(TYPES_MOVABLE)
+        return Clause('putnext', first, self._desc())
+
+    def _instr(self, kinds):
+        kind = self._rand_elem(kinds)
+        if kind == 'action':
+            return self._clause()
+        if kind == 'and':
+            a = self._instr(['action'])
+            return Combo('and', a, self._instr(['action']))
+        a = self._instr(['action', 'and'])
+        b = self._instr(['action', 'and'])
+        return Combo(self._rand_elem(['before', 'after']), a, b)
+
+
+def _g(**kw):
+    return ('goto', kw)
+
+
+def _l(**kw):
+    return ('levelgen', kw)
+
+
+# Constructor arguments per level (iclr19_levels.py; written out independently of babyai_amd/levels.py,
+# tests/test_levels_table.py checks the two tables agree).
+SPECS = {
+    'GoToRedBall': _g(num_dists=7, redball=True),
+    'GoToRedBallNoDists': _g(num_dists=0, redball=True),
+    'GoToObj': _g(num_dists=1, all_unique=True, check_reach=False),
+    'GoToObjS4': _g(room_size=4, num_dists=1, all_unique=True, check_reach=False),
+    'GoToObjS6': _g(room_size=6, num_dists=1, all_unique=True, check_reach=False),
+    'GoToLocal': _g(num_dists=8),
+    'GoToLocalS5N2': _g(room_size=5, num_dists=2), 'GoToLocalS6N2': _g(room_size=6, num_dists=2),
+    'GoToLocalS6N3': _g(room_size=6, num_dists=3), 'GoToLocalS6N4': _g(room_size=6, num_dists=4),
+    'GoToLocalS7N4': _g(room_size=7, num_dists=4), 'GoToLocalS7N5': _g(room_size=7, num_dists=5),
+    'GoToLocalS8N2': _g(num_dists=2), 'GoToLocalS8N3': _g(num_dists=3), 'GoToLocalS8N4': _g(num_dists=4),
+    'GoToLocalS8N5': _g(num_dists=5), 'GoToLocalS8N6': _g(num_dists=6), 'GoToLocalS8N7': _g(num_dists=7),
+    'GoTo': _g(num_rows=3, num_cols=3, num_dists=18, connect=True),
+    'GoToOpen': _g(num_rows=3, num_cols=3, num_dists=18, connect=True, doors_open=True),
+    'GoToObjMaze': _g(num_rows=3, num_cols=3, num_dists=1, connect=True),
+    'GoToObjMazeOpen': _g(num_rows=3, num_cols=3, num_dists=1, connect=True, doors_open=True),
+    'GoToObjMazeS4R2': _g(room_size=4, num_rows=2, num_cols=2, num_dists=1, connect=True),
+    'GoToObjMazeS4': _g(room_size=4, num_rows=3, num_cols=3, num_dists=1, connect=True),
+    'GoToObjMazeS5': _g(room_size=5, num_rows=3, num_cols=3, num_dists=1, connect=True),
+    'GoToObjMazeS6': _g(room_size=6, num_rows=3, num_cols=3, num_dists=1, connect=True),
+    'GoToObjMazeS7': _g(room_size=7, num_rows=3, num_cols=3, num_dists=1, connect=True),
+    'PickupLoc': _l(action_kinds=('pickup',), instr_kinds=('action',), num_rows=1, num_cols=1, num_dists=8,
+                    locked_room_prob=0, locations=True, unblocking=False),
+    'GoToSeq': _l(action_kinds=('goto',), locked_room_prob=0, locations=False, unblocking=False),
+    'GoToSeqS5R2': _l(room_size=5, num_rows=2, num_cols=2, num_dists=4, action_kinds=('goto',),
+                      locked_room_prob=0, locations=False, unblocking=False),
+    'Synth': _l(instr_kinds=('action',), locations=False, unblocking=True, implicit_unlock=False),
+    'SynthS5R2': _l(room_size=5, num_rows=2, num_cols=2, num_dists=7, instr_kinds=('action',),
+                    locations=False, unblocking=True, implicit_unlock=False),
+    'SynthLoc': _l(instr_kinds=('action',), locations=True, unblocking=True, implicit_unlock=False),
+    'SynthSeq': _l(locations=True, unblocking=True, implicit_unlock=False),
+    'MiniBossLevel': _l(num_cols=2, num_rows=2, room_size=5, num_dists=7, locked_room_prob=0.25),
+    'BossLevel': _l(),
+    'BossLevelNoUnlock': _l(locked_room_prob=0, implicit_unlock=False),
+}
+
+
+def level_name(env_id):
+    name = env_id
+    if name.startswith('BabyAI-'):
+        name = name[len('BabyAI-'):]
+        if name.endswith('-v0'):
+            name = name[:-3]
+    return name
+
+
+def make_env(env_id, seed=None):
+    """Oracle twin of gym.make('BabyAI-<Level>-v0'); `seed` is the constructor seed."""
+    fam, kw = SPECS[level_name(env_id)]
+    cls = GoToOracle if fam == 'goto' else LevelGenOracle
+    env = cls(seed=seed, **kw)
+    if seed is None and fam == 'levelgen':
+        # the constructor's entropy-seeded reset must not leak a stale locked_room into the seeded
+        # stream (the reference has this leak: levelgen.py:284,325,384); seed() starts from None.
+        env.locked_room = None
+    return env

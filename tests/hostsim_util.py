@@ -1,0 +1,79 @@
+"""ctypes access to tests/hostsim/libhostsim.so -- the engine's per-env core (generator, step,
+verifier, observation) compiled for the host CPU with a single lane.  Test harness only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "hostsim", "hostsim.cpp")
+LIB = os.path.join(HERE, "hostsim", "libhostsim.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        csrc = os.path.join(os.path.dirname(HERE), "babyai_amd", "csrc")
+        deps = [SRC] + [os.path.join(csrc, f) for f in os.listdir(csrc)]
+        if not os.path.isfile(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unknown-pragmas", "-o", LIB, SRC])
+        L = ctypes.CDLL(LIB)
+        P = ctypes.c_void_p
+        L.hs_seed.argtypes = [ctypes.c_uint64, P]
+        L.hs_generate.argtypes = [P, P, P, P, P]
+        L.hs_step.argtypes = [P, P, P, P, ctypes.c_int, P]
+        L.hs_observe.argtypes = [P, P, P, P]
+        L.hs_fill_layout.argtypes = [P]
+        _lib = L
+    return _lib
+
+
+class HostEnv(object):
+    """One env of the C++ core on the host: seed / reset / step / observe."""
+
+    def __init__(self, cfg, seed):
+        self.L = lib()
+        self.cfg = cfg
+        self.mt = np.zeros(624, np.uint32)
+        self.L.hs_seed(int(seed), self.mt.ctypes.data)
+        self.mti = ctypes.c_int32(624)
+        self.rec = np.zeros(cfg.rec_bytes, np.uint8)
+        self.hot = np.zeros(16, np.uint8)
+        self.hot[14] = 0xFF              # last_locked = none
+        self.stale = ctypes.c_uint64(0)
+        self.out = np.zeros(147, np.uint8)
+
+    def reset(self):
+        self.L.hs_generate(ctypes.byref(self.cfg), self.mt.ctypes.data, ctypes.byref(self.mti),
+                           self.rec.ctypes.data, self.hot.ctypes.data)
+        self.stale.value = 0
+        return self.observe()
+
+    def observe(self):
+        self.L.hs_observe(ctypes.byref(self.cfg), self.rec.ctypes.data, self.hot.ctypes.data, self.out.ctypes.data)
+        return self.out.reshape(7, 7, 3).copy()
+
+    def step(self, action):
+        rew = ctypes.c_float(0)
+        d = self.L.hs_step(ctypes.byref(self.cfg), self.rec.ctypes.data, self.hot.ctypes.data,
+                           ctypes.byref(self.stale), int(action), ctypes.byref(rew))
+        return self.observe(), np.float32(rew.value), bool(d)
+
+    @property
+    def agent(self):
+        return int(self.hot[0]), int(self.hot[1]), int(self.hot[2])
+
+    @property
+    def max_steps(self):
+        return int(self.hot[6]) | int(self.hot[7]) << 8
+
+    @property
+    def mission(self):
+        from babyai_amd.missions import prog_surface
+        return prog_surface(self.rec[self.cfg.off_prog:self.cfg.off_prog + 112])
+
+    def grid_bytes(self):
+        c = self.cfg
+        return self.rec[:c.ES * c.EH].reshape(c.EH, c.ES)[5:5 + c.H, 5:5 + c.W]

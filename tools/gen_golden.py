@@ -47,6 +47,12 @@ def trace(name, n_envs, n_steps, pre_resets, n_pix):
     envs = []
     for s in seeds:
         env = level_dict[name]()
+        # The constructor runs one reset from OS entropy; for LevelGen levels that can leave a
+        # random stale `locked_room` behind (levelgen.py:284,325) which leaks into later episodes
+        # when implicit_unlock=False (levelgen.py:384).  Clear it so traces are deterministic:
+        # the engine and the oracle define seed() as starting from `locked_room = None`.
+        if hasattr(env, 'locked_room'):
+            env.locked_room = None
         env.seed(int(s))
         envs.append(env)
     pix = [RGBImgPartialObsWrapper(e) for e in envs[:n_pix]]
