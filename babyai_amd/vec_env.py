@@ -1,0 +1,146 @@
+"""Drop-in adapters: the reference's vectorised-env protocols on top of `BatchedBabyAIEnv`.
+
+The reference vectorises with one Python env per OS process:
+  * training   `ParallelEnv(envs)`  babyai/rl/utils/penv.py:18-59, built inside
+               `BaseAlgo.__init__` (babyai/rl/algos/base.py:54) from the env list of
+               scripts/train_rl.py:53-60 (env i seeded with 100*seed + i)
+  * evaluation `ManyEnvs(envs)`     babyai/evaluate.py:58-81, driven by batch_evaluate :85-140
+
+Both speak "list of obs dicts in, zip(*results) out".  The classes below honour exactly that
+surface (same method names, argument meaning, return shapes and auto-reset / freeze
+behaviour) while every env lives on the GPU, so `ObssPreprocessor` (babyai/utils/format.py:100-119),
+`ModelAgent.act_batch` (babyai/utils/agent.py:51-72) and `BaseAlgo.collect_experiences`
+(babyai/rl/algos/base.py:110-251) consume the results unchanged.  See INTEGRATION.md for
+the two-line patch a maintainer would apply.
+
+`make(env_id, num_envs, ...)` is the batched twin of `gym.make(env_id)`.
+"""
+import numpy as np
+
+from .engine import BatchedBabyAIEnv
+from .levels import LEVELS, level_name
+
+
+class _Box(object):
+    """Stand-in for gym.spaces.Box: the reference reads `.shape` and `.high` (format.py:124-126)."""
+
+    def __init__(self, shape):
+        self.shape = shape
+        self.low = np.zeros(shape, np.uint8)
+        self.high = np.full(shape, 255, np.uint8)
+        self.dtype = np.dtype("uint8")
+
+
+class _DictSpace(object):
+    """Stand-in for gym.spaces.Dict({'image': Box})."""
+
+    def __init__(self, spaces):
+        self.spaces = spaces
+
+    def __getitem__(self, key):
+        return self.spaces[key]
+
+
+class _Discrete(object):
+    """Stand-in for gym.spaces.Discrete(7) (model.py:154 reads `.n`)."""
+
+    def __init__(self, n):
+        self.n = n
+
+
+def _spaces(pixel):
+    return _DictSpace({"image": _Box((56, 56, 3) if pixel else (7, 7, 3))}), _Discrete(7)
+
+
+class ObsList(object):
+    """`list[dict]` view over the batched observation: item i is
+    {'image': np.uint8[7,7,3] (or [56,56,3]), 'direction': int, 'mission': str}.
+    Images are copied to the host once per step (one D2H of the whole batch), dicts are built lazily."""
+
+    def __init__(self, image_host, direction_host, missions, pixel):
+        self._image, self._dir, self._missions, self._pixel = image_host, direction_host, missions, pixel
+
+    def __len__(self):
+        return self._image.shape[0]
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        d = {"image": self._image[i], "mission": self._missions[i]}
+        if not self._pixel:           # the pixel wrapper's dict has no 'direction' key
+            d["direction"] = int(self._dir[i])
+        return d
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+class _VecBase(object):
+    def __init__(self, env_id, num_envs, device="cuda:0", pixel=False, auto_reset=True, seeds=None):
+        self.engine = BatchedBabyAIEnv(env_id, num_envs, device=device, pixel=pixel, auto_reset=auto_reset)
+        self.num_envs = num_envs
+        self.pixel = pixel
+        self.observation_space, self.action_space = _spaces(pixel)
+        if seeds is not None:
+            self.seed(seeds)
+
+    def seed(self, seeds):
+        """ManyEnvs.seed(seeds) (evaluate.py:64-65) / per-env env.seed(s) (train_rl.py:59)."""
+        return self.engine.seed(seeds)
+
+    def _obs_list(self, obs):
+        return ObsList(obs["image"].cpu().numpy(), obs["direction"].cpu().numpy(), obs["mission"], self.pixel)
+
+    def reset(self):
+        return self._obs_list(self.engine.reset())
+
+    def step(self, actions):
+        if hasattr(actions, "cpu") and not hasattr(actions, "data_ptr"):
+            actions = np.asarray(actions)
+        obs, reward, done, _ = self.engine.step(actions)
+        reward = reward.cpu().numpy()
+        done = done.cpu().numpy().astype(bool)
+        n = self.num_envs
+        # the reference returns zip(*results): four tuples (obs...), (reward...), (done...), (info...)
+        return iter((self._obs_list(obs), tuple(float(r) for r in reward), tuple(bool(d) for d in done),
+                     tuple({} for _ in range(n))))
+
+    def render(self):
+        raise NotImplementedError
+
+    def close(self):
+        self.engine.close()
+
+
+class BatchedParallelEnv(_VecBase):
+    """`ParallelEnv` protocol (penv.py:18-59): auto-reset -- when an env finishes, the returned obs is the
+    first obs of its next episode while reward/done belong to the terminal step (penv.py:8-11,49-50)."""
+
+    def __init__(self, env_id, num_envs, device="cuda:0", pixel=False, seeds=None):
+        super().__init__(env_id, num_envs, device=device, pixel=pixel, auto_reset=True, seeds=seeds)
+
+
+class BatchedManyEnvs(_VecBase):
+    """`ManyEnvs` protocol (evaluate.py:58-81): no auto-reset; a finished env re-emits its last
+    (obs, reward, done, info) until the next reset()."""
+
+    def __init__(self, env_id, num_envs, device="cuda:0", pixel=False, seeds=None):
+        super().__init__(env_id, num_envs, device=device, pixel=pixel, auto_reset=False, seeds=seeds)
+        self.done = [False] * num_envs
+
+    def reset(self):
+        self.done = [False] * self.num_envs
+        return super().reset()
+
+    def step(self, actions):
+        obs, reward, done, info = super().step(actions)
+        self.done = list(done)
+        return iter((obs, reward, done, info))
+
+
+def make(env_id, num_envs, device="cuda:0", pixel=False, auto_reset=True, seeds=None):
+    """Batched twin of `gym.make(env_id)` (ids registered at babyai/levels/levelgen.py:467-493).
+    Returns the tensor-level `BatchedBabyAIEnv`."""
+    if level_name(env_id) not in LEVELS:
+        raise KeyError("unknown / unsupported level id %r" % (env_id,))
+    return BatchedBabyAIEnv(env_id, num_envs, device=device, seeds=seeds, pixel=pixel, auto_reset=auto_reset)

@@ -81,3 +81,70 @@ def test_manyenvs_freeze(gpu):
     assert was_done.all()
     assert env.reset_count() == n
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level,pixel", [("GoToLocal", False), ("PickupLoc", True), ("BossLevel", False)])
+def test_parallel_env_adapter_vs_oracle(gpu, level, pixel):
+    """The ParallelEnv-protocol adapter against a list of oracle envs driven the way
+    babyai/rl/utils/penv.py drives them (seeds 100*seed+i as in scripts/train_rl.py:59)."""
+    from babyai_amd.vec_env import BatchedParallelEnv
+    from oracle import levels as olevels
+    from gym_minigrid.wrappers import RGBImgPartialObsWrapper
+    n, T = 12, 150
+    seeds = [100 * 3 + i for i in range(n)]
+    venv = BatchedParallelEnv("BabyAI-%s-v0" % level, n, device=gpu, pixel=pixel, seeds=seeds)
+    refs = []
+    for s in seeds:
+        e = olevels.make_env(level)
+        if pixel:
+            e = RGBImgPartialObsWrapper(e)
+        e.seed(s)
+        refs.append(e)
+    obs = venv.reset()
+    robs = [e.reset() for e in refs]
+    rng = np.random.RandomState(5)
+    assert venv.action_space.n == 7
+    assert venv.observation_space.spaces["image"].shape == ((56, 56, 3) if pixel else (7, 7, 3))
+    for t in range(T):
+        for i in range(n):
+            assert np.array_equal(obs[i]["image"], robs[i]["image"]), (t, i)
+            assert obs[i]["mission"] == robs[i]["mission"], (t, i)
+            if not pixel:
+                assert obs[i]["direction"] == robs[i]["direction"]
+        a = rng.randint(0, 7, size=n)
+        obs, reward, done, info = venv.step(a)
+        rr = []
+        for i, e in enumerate(refs):
+            o, r, d, _ = e.step(int(a[i]))
+            if d:
+                o = e.reset()
+            robs[i] = o
+            rr.append((r, d))
+        assert [np.float32(x[0]) for x in rr] == [np.float32(x) for x in reward]
+        assert [bool(x[1]) for x in rr] == list(done)
+    venv.close()
+
+
+@pytest.mark.gpu
+def test_shard_independence(gpu):
+    """Env i's trajectory depends only on its seed and actions: running the batch as two shards gives the
+    same bytes as one batch (the multi-GPU decomposition, exercised on one device)."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    n, T = 512, 96
+    acts = torch.randint(0, 7, (T, n), dtype=torch.uint8, device=gpu)
+    whole = BatchedBabyAIEnv("BabyAI-BossLevel-v0", n, device=gpu, seeds=50)
+    a = BatchedBabyAIEnv("BabyAI-BossLevel-v0", n // 2, device=gpu, seeds=50)
+    b = BatchedBabyAIEnv("BabyAI-BossLevel-v0", n // 2, device=gpu, seeds=50 + n // 2)
+    for e in (whole, a, b):
+        e.reset()
+    for t in range(T):
+        whole.step(acts[t])
+        a.step(acts[t, : n // 2])
+        b.step(acts[t, n // 2:])
+    torch.cuda.synchronize()
+    assert torch.equal(whole.image, torch.cat([a.image, b.image]))
+    assert torch.equal(whole.reward, torch.cat([a.reward, b.reward]))
+    assert torch.equal(whole.done, torch.cat([a.done, b.done]))
+    assert whole.missions() == a.missions() + b.missions()
