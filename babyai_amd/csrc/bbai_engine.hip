@@ -6,11 +6,15 @@
 //                  observation; the 147-byte encodings of a block's 256 envs are staged in LDS
 //                  and written back as one contiguous, dword-coalesced span.  Finished envs are
 //                  compacted into the reset list with one wave-aggregated atomic per wave.
-//   k_reset        wave = env over the reset list: the next level of the env's MT19937 stream is
-//                  generated wave-uniformly with the whole working set in LDS (bbai_gen.hpp).
+//   k_pregen       wave = env: the NEXT level of an env's MT19937 stream is generated wave-uniformly
+//                  with the whole working set in LDS (bbai_gen.hpp) into a per-env look-ahead slot.
+//                  step() draws no randomness, so an env's level sequence is a pure function of
+//                  its seed: generation runs ahead of need on a second HIP stream and overlaps the
+//                  render kernel / the caller's policy instead of sitting on the step path.
+//   k_consume      wave = env over the reset list: look-ahead slot -> live state (coalesced copy).
 //   k_observe_list lane = env over the reset list: first observation of the new episodes.
-//   k_render       RGBImgPartialObsWrapper as a pure tile-atlas gather: the atlas lives in LDS,
-//                  each lane emits 8-byte pixel chunks, a wave writes 512 contiguous bytes.
+//   k_render       RGBImgPartialObsWrapper as a pure tile-atlas gather: atlas + per-cell tile ids
+//                  in LDS, 16 bytes per lane per store, a wave writes 1 KiB of contiguous pixels.
 //
 // Reference semantics: see bbai_step.hpp / bbai_gen.hpp headers for file:line citations.
 #include <hip/hip_runtime.h>
@@ -51,9 +55,14 @@ struct bbai_env {
     uint64_t* stale;      // [n]
     uint32_t* mt;         // [n][624]
     int32_t* mti;         // [n]
-    int32_t* reset_list;  // [n]
-    uint32_t* counters;   // [0] reset list length, [1] generator guard trips
+    uint8_t* next_rec;    // [n][rec_bytes]  look-ahead slot: the env's next level, generated ahead of need
+    Hot* next_hot;        // [n]
+    int32_t* reset_list;  // [2][n]  double-buffered by step parity (pregen of step t reads while step t+1 writes)
+    uint32_t* counters;   // [2][16] [p][0] = reset list length of parity p
     unsigned long long* total_resets;
+    hipStream_t side;     // look-ahead generation stream
+    hipEvent_t ev_consumed, ev_pregen_done;
+    int parity;
     uint8_t* atlas;       // [n_tiles][192]
     uint8_t* lut;         // [2][256]
     int n_tiles;
@@ -63,6 +72,7 @@ struct bbai_env {
 // ------------------------------------------------------------------------------------------
 // k_step
 // ------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int STEP_BLOCK = 256;
 constexpr int OBS_PAD = 148;           // LDS row per env (bytes), dword multiple
 
@@ -176,15 +186,17 @@ struct WaveCtx {
     __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
     __device__ __forceinline__ int nlanes() const { return 64; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ uint32_t shfl_up1(uint32_t v) const { uint32_t t = __shfl_up(v, 1); return threadIdx.x == 0 ? 0u : t; }
+    __device__ __forceinline__ uint32_t shfl_down1(uint32_t v) const { uint32_t t = __shfl_down(v, 1); return threadIdx.x == 63 ? 0u : t; }
+    __device__ __forceinline__ bool any(bool p) const { return __ballot(p) != 0ull; }
 };
 
-__global__ __launch_bounds__(64) void k_reset(LevelCfg c, int64_t n, uint8_t* __restrict__ recs, Hot* __restrict__ hots,
-                                              uint64_t* __restrict__ stales, uint32_t* __restrict__ mts,
-                                              int32_t* __restrict__ mtis, const int32_t* __restrict__ reset_list,
-                                              const uint32_t* __restrict__ counters, int all,
-                                              unsigned long long* __restrict__ total_resets) {
+__global__ __launch_bounds__(64) void k_pregen(LevelCfg c, int64_t n, uint8_t* __restrict__ next_recs,
+                                               Hot* __restrict__ next_hots, uint32_t* __restrict__ mts,
+                                               int32_t* __restrict__ mtis, const int32_t* __restrict__ reset_list,
+                                               const uint32_t* __restrict__ counter, int all) {
     __shared__ GenWork w;
-    const int64_t count = all ? n : (int64_t)counters[0];
+    const int64_t count = all ? n : (int64_t)counter[0];
     const int lane = threadIdx.x;
     for (int64_t it = blockIdx.x; it < count; it += gridDim.x) {
         const int64_t env = all ? it : (int64_t)reset_list[it];
@@ -192,14 +204,14 @@ __global__ __launch_bounds__(64) void k_reset(LevelCfg c, int64_t n, uint8_t* __
         __syncthreads();
         for (int k = lane; k < MT_N; k += 64) w.mt[k] = mt[k];
         const int mti0 = mtis[env];
-        const Hot old = hots[env];
+        const int last_locked0 = next_hots[env].last_locked;      // LevelGen.locked_room survives episodes
         __syncthreads();
-        Gen<WaveCtx> g(WaveCtx(), c, w, mti0, old.last_locked == NONE8 ? -1 : (int)old.last_locked);
+        Gen<WaveCtx> g(WaveCtx(), c, w, mti0, last_locked0 == NONE8 ? -1 : last_locked0);
         const int max_steps = g.generate();
         __syncthreads();
         // write-out: MT state, record planes, tables, program
         for (int k = lane; k < MT_N; k += 64) mt[k] = w.mt[k];
-        uint8_t* rec = recs + env * (int64_t)c.rec_bytes;
+        uint8_t* rec = next_recs + env * (int64_t)c.rec_bytes;
         {
             const uint32_t* src = (const uint32_t*)w.E;
             uint32_t* dst = (uint32_t*)rec;
@@ -226,12 +238,33 @@ __global__ __launch_bounds__(64) void k_reset(LevelCfg c, int64_t n, uint8_t* __
             h.vstate = 0; h.frozen = 0;
             h.last_locked = g.last_locked < 0 ? NONE8 : (uint8_t)g.last_locked;
             h.pad = 0;
-            hots[env] = h;
-            stales[env] = 0;
+            next_hots[env] = h;
             mtis[env] = g.mti;
         }
     }
-    if (blockIdx.x == 0 && lane == 0) atomicAdd(total_resets, (unsigned long long)count);
+}
+
+// look-ahead slot -> live state for the envs that finished (or all, on reset()): one wave copies one record
+__global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t* __restrict__ recs, Hot* __restrict__ hots,
+                                                 uint64_t* __restrict__ stales, const uint8_t* __restrict__ next_recs,
+                                                 const Hot* __restrict__ next_hots, const int32_t* __restrict__ reset_list,
+                                                 const uint32_t* __restrict__ counter, int all,
+                                                 unsigned long long* __restrict__ total_resets) {
+    const int64_t count = all ? n : (int64_t)counter[0];
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const int nvec = c.rec_bytes >> 4;
+    for (int64_t it = wave; it < count; it += nwaves) {
+        const int64_t env = all ? it : (int64_t)reset_list[it];
+        const u32x4* src = (const u32x4*)(next_recs + env * (int64_t)c.rec_bytes);
+        u32x4* dst = (u32x4*)(recs + env * (int64_t)c.rec_bytes);
+        for (int k = lane; k < nvec; k += 64) dst[k] = src[k];
+        if (lane == 0) {
+            hots[env] = next_hots[env];
+            stales[env] = 0;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(total_resets, (unsigned long long)count);
 }
 
 // first observation of freshly generated episodes (lane = env over the reset list)
@@ -248,7 +281,7 @@ __global__ __launch_bounds__(64) void k_observe_list(LevelCfg c, int64_t n, cons
     }
 }
 
-__global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, uint64_t* __restrict__ stales) {
+__global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, Hot* __restrict__ next_hots, uint64_t* __restrict__ stales) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         Hot h;
@@ -256,6 +289,7 @@ __global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, uint64_t* __restri
         h.carry = NONE8; h.frozen = 1; h.last_locked = NONE8;
         h.pre[0] = h.pre[1] = h.pre[2] = h.pre[3] = NONE8;
         hots[i] = h;
+        next_hots[i] = h;
         stales[i] = 0;
     }
 }
@@ -264,31 +298,51 @@ __global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, uint64_t* __restri
 // k_render : encoded obs -> 56x56x3 pixels through the tile atlas
 // ------------------------------------------------------------------------------------------
 constexpr int RENDER_BLOCK = 256;
-constexpr int CHUNKS_PER_ENV = PIX_BYTES / 8;     // 1176 eight-byte chunks
-constexpr int CHUNKS_PER_ROW = PIX * 3 / 8;       // 21
+constexpr int RENDER_GROUP = 8;                   // envs rendered per block iteration
+constexpr int CHUNKS_PER_ROW = PIX * 3 / 8;       // 21 eight-byte chunks per pixel row
+constexpr int VEC_PER_ENV = PIX_BYTES / 16;       // 588 sixteen-byte stores per env
+
+// One 8-byte piece of the env's pixel image: chunk id -> (tile, row in tile, third of the row).
+__device__ __forceinline__ uint64_t render_chunk(const uint8_t* s_atlas, const uint8_t* tiles49, int ch) {
+    const int py = ch / CHUNKS_PER_ROW, cx = ch - py * CHUNKS_PER_ROW;
+    const int ti = cx / 3, part = cx - ti * 3;        // tile column (view x), 8-byte third of the tile row
+    const int tj = py >> 3, ty = py & 7;              // tile row (view y), row inside the tile
+    const int tile = tiles49[ti * VIEW + tj];
+    return *(const uint64_t*)(s_atlas + tile * TILE_BYTES + ty * 24 + part * 8);
+}
 
 __global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_t* __restrict__ image,
                                                          uint8_t* __restrict__ pixels, const uint8_t* __restrict__ atlas,
                                                          const uint8_t* __restrict__ lut, int n_tiles) {
     __shared__ __attribute__((aligned(16))) uint8_t s_atlas[MAX_TILES * TILE_BYTES];
     __shared__ uint8_t s_lut[512];
+    __shared__ uint8_t s_tile[RENDER_GROUP * VIEW * VIEW + 8];
     for (int k = threadIdx.x; k < n_tiles * TILE_BYTES / 8; k += RENDER_BLOCK)
         ((uint64_t*)s_atlas)[k] = ((const uint64_t*)atlas)[k];
     for (int k = threadIdx.x; k < 512; k += RENDER_BLOCK) s_lut[k] = lut[k];
-    __syncthreads();
-    const int64_t total = n * CHUNKS_PER_ENV;
-    for (int64_t g = (int64_t)blockIdx.x * RENDER_BLOCK + threadIdx.x; g < total; g += (int64_t)gridDim.x * RENDER_BLOCK) {
-        const int64_t env = g / CHUNKS_PER_ENV;
-        const int ch = (int)(g - env * CHUNKS_PER_ENV);
-        const int py = ch / CHUNKS_PER_ROW, cx = ch - py * CHUNKS_PER_ROW;
-        const int ti = cx / 3, part = cx - ti * 3;        // tile column (view x), 8-byte third of the tile row
-        const int tj = py >> 3, ty = py & 7;              // tile row (view y), row inside the tile
-        const uint8_t* o = image + env * OBS_BYTES + (ti * VIEW + tj) * 3;
-        const int key = o[0] | (o[1] << 3) | (o[2] << 6);
-        const int agent = (ti == 3 && tj == 6) ? 256 : 0;
-        const int tile = s_lut[agent + key];
-        const uint64_t v = *(const uint64_t*)(s_atlas + tile * TILE_BYTES + ty * 24 + part * 8);
-        ((uint64_t*)pixels)[g] = v;
+    const int64_t ngroups = (n + RENDER_GROUP - 1) / RENDER_GROUP;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t env0 = grp * RENDER_GROUP;
+        const int ne = (int)(n - env0 < RENDER_GROUP ? n - env0 : RENDER_GROUP);
+        __syncthreads();                               // atlas loaded / previous group's tiles consumed
+        // encoded cell -> atlas tile, once per cell (49 per env)
+        for (int c = threadIdx.x; c < ne * VIEW * VIEW; c += RENDER_BLOCK) {
+            const int e = c / (VIEW * VIEW), cell = c - e * (VIEW * VIEW);
+            const uint8_t* o = image + (env0 + e) * OBS_BYTES + cell * 3;
+            const int key = o[0] | (o[1] << 3) | (o[2] << 6);
+            s_tile[c] = s_lut[(cell == 3 * VIEW + 6 ? 256 : 0) + key];
+        }
+        __syncthreads();
+        // 16 bytes per lane per store: a wave writes 1 KiB of contiguous pixels
+        u32x4* out = (u32x4*)(pixels + env0 * PIX_BYTES);
+        for (int q = threadIdx.x; q < ne * VEC_PER_ENV; q += RENDER_BLOCK) {
+            const int e = q / VEC_PER_ENV, k = q - e * VEC_PER_ENV;
+            const uint8_t* t49 = s_tile + e * (VIEW * VIEW);
+            const uint64_t lo = render_chunk(s_atlas, t49, 2 * k);
+            const uint64_t hi = render_chunk(s_atlas, t49, 2 * k + 1);
+            u32x4 v = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+            __builtin_nontemporal_store(v, out + q);
+        }
     }
 }
 
@@ -343,8 +397,10 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->stale, (size_t)n_envs * 8);
     alloc((void**)&e->mt, (size_t)n_envs * MT_N * 4);
     alloc((void**)&e->mti, (size_t)n_envs * 4);
-    alloc((void**)&e->reset_list, (size_t)n_envs * 4);
-    alloc((void**)&e->counters, 64);
+    alloc((void**)&e->next_rec, (size_t)n_envs * c.rec_bytes);
+    alloc((void**)&e->next_hot, (size_t)n_envs * sizeof(Hot));
+    alloc((void**)&e->reset_list, (size_t)n_envs * 4 * 2);
+    alloc((void**)&e->counters, 128);
     alloc((void**)&e->total_resets, 8);
     alloc((void**)&e->atlas, MAX_TILES * TILE_BYTES);
     alloc((void**)&e->lut, 512);
@@ -354,8 +410,16 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
         return BBAI_ERR_NOMEM;
     }
     HIP_TRY(hipMemset(e->rec, 0, (size_t)n_envs * c.rec_bytes));
-    HIP_TRY(hipMemset(e->counters, 0, 64));
+    HIP_TRY(hipMemset(e->next_rec, 0, (size_t)n_envs * c.rec_bytes));
+    HIP_TRY(hipMemset(e->counters, 0, 128));
     HIP_TRY(hipMemset(e->total_resets, 0, 8));
+    {
+        int lo = 0, hi = 0;     // look-ahead generation should get wave slots as soon as any free up
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, hi));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_consumed, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_pregen_done, hipEventDisableTiming));
+    }
     *out = e;
     return BBAI_OK;
 }
@@ -363,9 +427,41 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
 void bbai_destroy(bbai_env* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->reset_list, e->counters, e->total_resets, e->atlas, e->lut};
+    (void)hipDeviceSynchronize();
+    if (e->side) (void)hipStreamDestroy(e->side);
+    if (e->ev_consumed) (void)hipEventDestroy(e->ev_consumed);
+    if (e->ev_pregen_done) (void)hipEventDestroy(e->ev_pregen_done);
+    void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->next_rec, e->next_hot, e->reset_list, e->counters,
+                    e->total_resets, e->atlas, e->lut};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete e;
+}
+
+static unsigned pregen_grid(int64_t count_hint) {
+    // one single-wave workgroup per env, capped at 256 CUs x 32 wave slots
+    int64_t g = std::min<int64_t>(count_hint, 256 * 32);
+    return (unsigned)std::max<int64_t>(g, 1);
+}
+
+// main stream: slots -> live state (+ first obs); side stream: refill the consumed slots.
+static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_t* dirs, int all) {
+    const int p = e->parity;
+    int32_t* list = e->reset_list + (size_t)p * e->n;
+    uint32_t* counter = e->counters + 16 * p;
+    HIP_TRY(hipStreamWaitEvent(s, e->ev_pregen_done, 0));        // every earlier refill has landed
+    const int64_t hint = all ? e->n : std::max<int64_t>(e->n / 64, 64);
+    hipLaunchKernelGGL(k_consume, dim3((unsigned)std::min<int64_t>((hint + 3) / 4, 8192)), dim3(256), 0, s, e->cfg, e->n, e->rec,
+                       e->hot, e->stale, e->next_rec, e->next_hot, list, counter, all, e->total_resets);
+    hipLaunchKernelGGL(k_observe_list, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n,
+                       e->rec, e->hot, image, dirs, list, counter, all);
+    HIP_TRY(hipEventRecord(e->ev_consumed, s));
+    HIP_TRY(hipStreamWaitEvent(e->side, e->ev_consumed, 0));
+    hipLaunchKernelGGL(k_pregen, dim3(pregen_grid(hint)), dim3(64), 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt,
+                       e->mti, list, counter, all);
+    HIP_TRY(hipEventRecord(e->ev_pregen_done, e->side));
+    HIP_TRY(hipGetLastError());
+    e->parity ^= 1;
+    return BBAI_OK;
 }
 
 int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
@@ -388,18 +484,17 @@ int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
     // output index 624: the first draw twists (RandomState.seed leaves pos = N)
     std::vector<int32_t> idx((size_t)n, MT_N);
     HIP_TRY(hipMemcpy(e->mti, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_init_hot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, e->hot, e->stale);
+    HIP_TRY(hipDeviceSynchronize());
+    hipLaunchKernelGGL(k_init_hot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->side, n, e->hot, e->next_hot, e->stale);
+    // fill every env's look-ahead slot with the first level of its stream
+    hipLaunchKernelGGL(k_pregen, dim3(pregen_grid(n)), dim3(64), 0, e->side, e->cfg, n, e->next_rec, e->next_hot, e->mt, e->mti,
+                       e->reset_list, e->counters, 1);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ev_pregen_done, e->side));
     HIP_TRY(hipDeviceSynchronize());
     e->seeded = true;
     e->live = false;
     return BBAI_OK;
-}
-
-static unsigned reset_grid(int64_t count_hint) {
-    // wave-per-env persistent-style grid: enough single-wave blocks to fill 256 CUs x 8 waves/SIMD
-    int64_t g = std::min<int64_t>(count_hint, 256 * 32);
-    return (unsigned)std::max<int64_t>(g, 1);
 }
 
 int bbai_reset(bbai_env* e, uint8_t* image, uint8_t* dirs, void* stream) {
@@ -407,11 +502,8 @@ int bbai_reset(bbai_env* e, uint8_t* image, uint8_t* dirs, void* stream) {
     if (!e->seeded) { snprintf(g_err, sizeof(g_err), "reset before seed"); return BBAI_ERR_STATE; }
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_reset, dim3(reset_grid(e->n)), dim3(64), 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->mt,
-                       e->mti, e->reset_list, e->counters, 1, e->total_resets);
-    hipLaunchKernelGGL(k_observe_list, dim3((unsigned)std::min<int64_t>((e->n + 63) / 64, 65536)), dim3(64), 0, s, e->cfg,
-                       e->n, e->rec, e->hot, image, dirs, e->reset_list, e->counters, 1);
-    HIP_TRY(hipGetLastError());
+    int rc = consume_and_refill(e, s, image, dirs, 1);
+    if (rc != BBAI_OK) return rc;
     e->live = true;
     return BBAI_OK;
 }
@@ -422,17 +514,14 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
     if (!e->live) { snprintf(g_err, sizeof(g_err), "step before reset"); return BBAI_ERR_STATE; }
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(e->counters, 0, 4, s));
+    int32_t* list = e->reset_list + (size_t)e->parity * e->n;
+    uint32_t* counter = e->counters + 16 * e->parity;
+    HIP_TRY(hipMemsetAsync(counter, 0, 4, s));
     hipLaunchKernelGGL(k_step, dim3((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), dim3(STEP_BLOCK), 0, s, e->cfg, e->n,
-                       e->rec, e->hot, e->stale, actions, image, dirs, rewards, dones, auto_reset, e->reset_list, e->counters);
-    if (auto_reset) {
-        // the number of finished envs is only known on the device: fixed grids, device-side count
-        hipLaunchKernelGGL(k_reset, dim3(reset_grid(std::max<int64_t>(e->n / 64, 64))), dim3(64), 0, s, e->cfg, e->n, e->rec,
-                           e->hot, e->stale, e->mt, e->mti, e->reset_list, e->counters, 0, e->total_resets);
-        hipLaunchKernelGGL(k_observe_list, dim3((unsigned)std::min<int64_t>((e->n + 4095) / 4096, 1024)), dim3(64), 0, s,
-                           e->cfg, e->n, e->rec, e->hot, image, dirs, e->reset_list, e->counters, 0);
-    }
+                       e->rec, e->hot, e->stale, actions, image, dirs, rewards, dones, auto_reset, list, counter);
     HIP_TRY(hipGetLastError());
+    // the number of finished envs is only known on the device: fixed grids, device-side count
+    if (auto_reset) return consume_and_refill(e, s, image, dirs, 0);
     return BBAI_OK;
 }
 
@@ -449,8 +538,9 @@ int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream
     if (!e || !image || !pixels) return BBAI_ERR_ARG;
     if (e->n_tiles <= 0) { snprintf(g_err, sizeof(g_err), "render before set_atlas"); return BBAI_ERR_STATE; }
     HIP_TRY(hipSetDevice(e->device));
-    int64_t total = e->n * CHUNKS_PER_ENV;
-    unsigned grid = (unsigned)std::min<int64_t>((total + RENDER_BLOCK - 1) / RENDER_BLOCK, 256 * 16);
+    // 8 groups (64 envs) per block: short-lived blocks keep wave slots turning over for the look-ahead stream
+    int64_t groups = (e->n + RENDER_GROUP - 1) / RENDER_GROUP;
+    unsigned grid = (unsigned)((groups + 7) / 8);
     hipLaunchKernelGGL(k_render, dim3(grid), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut,
                        e->n_tiles);
     HIP_TRY(hipGetLastError());

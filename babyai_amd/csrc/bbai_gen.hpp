@@ -30,14 +30,16 @@ struct GenWork {                                 // lives in LDS on the device
     uint8_t E[GEN_ES * GEN_EH];
     uint8_t I[MAX_W * MAX_W + 3];
     uint8_t app[MAX_OBJ], px[MAX_OBJ], py[MAX_OBJ];
-    uint8_t door_x[MAX_ROOMS][4], door_y[MAX_ROOMS][4], door_obj[MAX_ROOMS][4];
-    uint8_t locked[MAX_ROOMS];
+    uint8_t door_x[MAX_ROOMS][4], door_y[MAX_ROOMS][4];
     uint32_t rowbuf[2][MAX_W + 2];               // reachability rows
+    uint64_t masks[14];                          // object-id sets: [0..3] by type (door,key,ball,box),
+                                                 // [4..9] by colour, [10..13] by location (left,right,front,behind)
     Prog prog;
 };
 
-// Ctx contract: lane(), nlanes(), sync().  Host: 0,1,no-op.  Device: lane id in the
-// wave, 64, workgroup barrier (one wave per workgroup).
+// Ctx contract: lane(), nlanes(), sync(), shfl_up1/shfl_down1(v) (neighbour lane's value, 0 at the
+// ends), any(pred).  Host: 0,1,no-ops.  Device: lane id in the wave, 64, workgroup barrier (one wave
+// per workgroup), wave shuffles / ballot.
 template <class Ctx>
 struct Gen {
     Ctx ctx;
@@ -53,10 +55,19 @@ struct Gen {
                              // episodes; a stale value never `is` a current room (levelgen.py:305-307)
                              // but still feeds rand_obj's implicit_unlock filter (levelgen.py:384-392)
     int S, rows, cols;
+    uint64_t doors;          // bit (16*k + r): room r has a door on side k (0 right, 1 down, 2 left, 3 up)
+    uint32_t locked_mask;    // bit r: room r is behind a locked door (Room.locked)
+    uint32_t inv_cols, inv_s1, inv_es;   // 2^16/d + 1: exact small-range division without the divider
 
     BB_HD Gen(Ctx c, const LevelCfg& cf, GenWork& wk, int mti_, int last_locked_)
         : ctx(c), cfg(cf), w(wk), mti(mti_), nobj(0), ax(0), ay(0), adir(0), agent_set(false),
-          locked_room(-1), last_locked(last_locked_), S(cf.room_size), rows(cf.num_rows), cols(cf.num_cols) {}
+          locked_room(-1), last_locked(last_locked_), S(cf.room_size), rows(cf.num_rows), cols(cf.num_cols),
+          doors(0), locked_mask(0), inv_cols(65536u / (uint32_t)cf.num_cols + 1u),
+          inv_s1(65536u / (uint32_t)(cf.room_size - 1) + 1u), inv_es(65536u / (uint32_t)cf.ES + 1u) {}
+
+    BB_HD int div_cols(int v) const { return (int)(((uint32_t)v * inv_cols) >> 16); }     // v < 64
+    BB_HD int div_s1(int v) const { return (int)(((uint32_t)v * inv_s1) >> 16); }         // v < 64
+    BB_HD int div_es(int v) const { return (int)(((uint32_t)v * inv_es) >> 16); }         // v < 2048
 
     // ---------------- MT19937 (numpy legacy RandomState bit stream) ----------------
     BB_HD static uint32_t mix(uint32_t u, uint32_t v) {
@@ -128,11 +139,13 @@ struct Gen {
     BB_HD int eidx(int x, int y) const { return (y + MARGIN) * cfg.ES + (x + MARGIN); }
     BB_HD int iidx(int x, int y) const { return y * cfg.W + x; }
     BB_HD void set_cell(int x, int y, int e, int id) { w.E[eidx(x, y)] = (uint8_t)e; w.I[iidx(x, y)] = (uint8_t)id; }
-    BB_HD int room_of(int x, int y) const { return (y / (S - 1)) * cols + (x / (S - 1)); }
+    BB_HD int room_of(int x, int y) const { return div_s1(y) * cols + div_s1(x); }
+    BB_HD void room_ij(int r, int& i, int& j) const { j = div_cols(r); i = r - j * cols; }
     BB_HD bool has_neighbor(int r, int k) const {
-        int i = r % cols, j = r / cols;
+        int i, j; room_ij(r, i, j);
         return k == 0 ? i < cols - 1 : k == 1 ? j < rows - 1 : k == 2 ? i > 0 : j > 0;
     }
+    BB_HD bool has_door(int r, int k) const { return doors >> (16 * k + r) & 1; }
     BB_HD int neighbor(int r, int k) const { return k == 0 ? r + 1 : k == 1 ? r + cols : k == 2 ? r - 1 : r - cols; }
     BB_HD void front_of(int& fx, int& fy) const {
         fx = ax + (adir == 0) - (adir == 2);
@@ -144,14 +157,16 @@ struct Gen {
         ctx.sync();
         const int ncell = cfg.ES * cfg.EH;
         for (int idx = ctx.lane(); idx < ncell; idx += ctx.nlanes()) {
-            int x = idx % cfg.ES - MARGIN, y = idx / cfg.ES - MARGIN;
+            int row = div_es(idx);
+            int x = idx - row * cfg.ES - MARGIN, y = row - MARGIN;
             bool inside = x >= 0 && x < cfg.W && y >= 0 && y < cfg.H;
-            bool wall = !inside || x % (S - 1) == 0 || y % (S - 1) == 0;
+            bool wall = true;
+            if (inside) wall = x - div_s1(x) * (S - 1) == 0 || y - div_s1(y) * (S - 1) == 0;
             w.E[idx] = wall ? E_WALL : E_EMPTY;
             if (inside) w.I[iidx(x, y)] = wall ? 1 : 0;
         }
-        for (int idx = ctx.lane(); idx < MAX_ROOMS * 4; idx += ctx.nlanes()) (&w.door_obj[0][0])[idx] = NONE8;
-        for (int idx = ctx.lane(); idx < MAX_ROOMS; idx += ctx.nlanes()) w.locked[idx] = 0;
+        doors = 0;
+        locked_mask = 0;
         ctx.sync();
         for (int j = 0; j < rows; ++j)
             for (int i = 0; i < cols; ++i) {
@@ -180,7 +195,8 @@ struct Gen {
 
     // MiniGridEnv.place_obj restricted to a room rectangle, max_tries = 1000.
     BB_HD bool place_pos(int r, bool reject_next, int& ox, int& oy) {
-        int tx = (r % cols) * (S - 1), ty = (r / cols) * (S - 1);
+        int ri, rj; room_ij(r, ri, rj);
+        int tx = ri * (S - 1), ty = rj * (S - 1);
         int xh = tx + S < cfg.W ? tx + S : cfg.W, yh = ty + S < cfg.H ? ty + S : cfg.H;
         int tries = 0;
         for (;;) {
@@ -215,11 +231,11 @@ struct Gen {
         int id = nobj++;
         int x = w.door_x[r][k], y = w.door_y[r][k];
         int e = e_make(T_DOOR, color, is_locked ? S_LOCKED : S_CLOSED);
-        w.locked[r] = is_locked ? 1 : 0;
+        locked_mask = (locked_mask & ~(1u << r)) | ((is_locked ? 1u : 0u) << r);   // room.locked = locked
         w.app[id] = e; w.px[id] = x; w.py[id] = y;
         set_cell(x, y, e, id + 2);
-        w.door_obj[r][k] = id;
-        w.door_obj[neighbor(r, k)][(k + 2) & 3] = id;
+        doors |= 1ull << (16 * k + r);
+        doors |= 1ull << (16 * ((k + 2) & 3) + neighbor(r, k));
         return id;
     }
     // RoomGrid.place_agent(i=None, j=None): room drawn, then pose re-drawn until the
@@ -247,13 +263,12 @@ struct Gen {
         for (;;) {
             if (itrs > 5000) return false;            // RecursionError('connect_all failed')
             ++itrs;
+            // rooms reachable from the start room through existing doors: bit-parallel closure
+            const uint32_t d0 = (uint32_t)doors & 0x1FFu, d1 = (uint32_t)(doors >> 16) & 0x1FFu;
+            const uint32_t d2 = (uint32_t)(doors >> 32) & 0x1FFu, d3 = (uint32_t)(doors >> 48) & 0x1FFu;
             uint32_t reach = 1u << start;
             for (int pass = 0; pass < nrooms; ++pass) {
-                uint32_t nr = reach;
-                for (int r = 0; r < nrooms; ++r)
-                    if (reach >> r & 1)
-                        for (int k = 0; k < 4; ++k)
-                            if (w.door_obj[r][k] != NONE8) nr |= 1u << neighbor(r, k);
+                uint32_t nr = reach | ((reach & d0) << 1) | ((reach & d1) << cols) | ((reach & d2) >> 1) | ((reach & d3) >> cols);
                 if (nr == reach) break;
                 reach = nr;
             }
@@ -262,8 +277,8 @@ struct Gen {
             int j = rand_int(0, rows);
             int k = rand_int(0, 4);
             int r = j * cols + i;
-            if (!has_neighbor(r, k) || w.door_obj[r][k] != NONE8) continue;
-            if (w.locked[r] || w.locked[neighbor(r, k)]) continue;
+            if (!has_neighbor(r, k) || has_door(r, k)) continue;
+            if ((locked_mask >> r & 1) || (locked_mask >> neighbor(r, k) & 1)) continue;
             int color = rand_color();
             if (add_door(r, k, color, false) < 0) return false;
         }
@@ -296,31 +311,54 @@ struct Gen {
         uint32_t* pass = w.rowbuf[0];
         uint32_t* fl = w.rowbuf[1];
         ctx.sync();
-        for (int y = ctx.lane(); y < H; y += ctx.nlanes()) {
+        if (ctx.nlanes() > 1) {
+            // device: lane y owns grid row y; rows exchange their flood masks with wave shuffles
+            const int y = ctx.lane();
             uint32_t p = 0;
-            for (int x = 0; x < W; ++x) {
-                int e = w.E[eidx(x, y)];
-                if (e == E_EMPTY || e_type(e) == T_DOOR) p |= 1u << x;
-            }
-            pass[y] = p;
-            fl[y] = (y == ay) ? (1u << ax) : 0u;
-        }
-        ctx.sync();
-        for (;;) {
-            bool changed = false;
-            for (int y = 0; y < H; ++y) {
-                uint32_t f = fl[y];
-                uint32_t g = f | (y > 0 ? fl[y - 1] : 0u) | (y + 1 < H ? fl[y + 1] : 0u);
-                g &= pass[y];
-                // horizontal closure inside the row
-                for (;;) {
-                    uint32_t g2 = (g | (g << 1) | (g >> 1)) & pass[y];
+            if (y < H)
+                for (int x = 0; x < W; ++x) {
+                    int e = w.E[eidx(x, y)];
+                    if (e == E_EMPTY || e_type(e) == T_DOOR) p |= 1u << x;
+                }
+            uint32_t f = (y == ay) ? (1u << ax) : 0u;
+            for (;;) {
+                uint32_t g = (f | ctx.shfl_up1(f) | ctx.shfl_down1(f)) & p;
+                for (;;) {                      // horizontal closure inside the row
+                    uint32_t g2 = (g | (g << 1) | (g >> 1)) & p;
                     if (g2 == g) break;
                     g = g2;
                 }
-                if (g != f) { fl[y] = g; changed = true; }
+                bool changed = g != f;
+                f = g;
+                if (!ctx.any(changed)) break;
             }
-            if (!changed) break;
+            if (y < H) fl[y] = f;
+            ctx.sync();
+        } else {
+            for (int y = 0; y < H; ++y) {
+                uint32_t p = 0;
+                for (int x = 0; x < W; ++x) {
+                    int e = w.E[eidx(x, y)];
+                    if (e == E_EMPTY || e_type(e) == T_DOOR) p |= 1u << x;
+                }
+                pass[y] = p;
+                fl[y] = (y == ay) ? (1u << ax) : 0u;
+            }
+            for (;;) {
+                bool changed = false;
+                for (int y = 0; y < H; ++y) {
+                    uint32_t f = fl[y];
+                    uint32_t g = f | (y > 0 ? fl[y - 1] : 0u) | (y + 1 < H ? fl[y + 1] : 0u);
+                    g &= pass[y];
+                    for (;;) {
+                        uint32_t g2 = (g | (g << 1) | (g >> 1)) & pass[y];
+                        if (g2 == g) break;
+                        g = g2;
+                    }
+                    if (g != f) { fl[y] = g; changed = true; }
+                }
+                if (!changed) break;
+            }
         }
         for (int o = 0; o < nobj; ++o) {
             int x = w.px[o], y = w.py[o];
@@ -330,28 +368,44 @@ struct Gen {
         return true;
     }
 
-    // ObjDesc.find_matching_objs(env, use_location=True) over the object table (every
-    // object is in the grid during generation).  type is never None on this path.
-    BB_HD uint64_t find_matching(int type, int color, int loc) const {
-        uint64_t m = 0;
+    // ObjDesc.find_matching_objs(env, use_location=True) over the object table (every object is in
+    // the grid during generation; type is never None on this path).  The agent pose and the object
+    // set are final before any descriptor is drawn, so the per-type / per-colour / per-location id
+    // sets are built once (prep_masks) and a match is three ANDs.
+    BB_HD void prep_masks() {
+        uint64_t mt_[4] = {0, 0, 0, 0}, mc_[6] = {0, 0, 0, 0, 0, 0}, ml_[4] = {0, 0, 0, 0};
         int r = room_of(ax, ay);
-        int tx = (r % cols) * (S - 1), ty = (r / cols) * (S - 1);
+        int ri, rj; room_ij(r, ri, rj);
+        int tx = ri * (S - 1), ty = rj * (S - 1);
         int d1x = (adir == 0) - (adir == 2), d1y = (adir == 1) - (adir == 3);
         int d2x = -d1y, d2y = d1x;
         for (int o = 0; o < nobj; ++o) {
+            const uint64_t bit = 1ull << o;
             int e = w.app[o];
-            if (e_type(e) != type) continue;
-            if (color != 7 && e_color(e) != color) continue;
-            if (loc != LOC_NONE) {
-                int x = w.px[o], y = w.py[o];
-                if (x < tx || y < ty || x >= tx + S || y >= ty + S) continue;
-                int vx = x - ax, vy = y - ay;
-                int p2 = vx * d2x + vy * d2y, p1 = vx * d1x + vy * d1y;
-                bool ok = loc == LOC_LEFT ? p2 < 0 : loc == LOC_RIGHT ? p2 > 0 : loc == LOC_FRONT ? p1 > 0 : p1 < 0;
-                if (!ok) continue;
-            }
-            m |= 1ull << o;
+            int t = e_type(e) - T_DOOR, col = e_color(e);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mt_[q] |= (t == q) ? bit : 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) mc_[q] |= (col == q) ? bit : 0;
+            int x = w.px[o], y = w.py[o];
+            if (x < tx || y < ty || x >= tx + S || y >= ty + S) continue;   // locations: agent's room only
+            int vx = x - ax, vy = y - ay;
+            int p2 = vx * d2x + vy * d2y, p1 = vx * d1x + vy * d1y;
+            ml_[0] |= p2 < 0 ? bit : 0; ml_[1] |= p2 > 0 ? bit : 0;
+            ml_[2] |= p1 > 0 ? bit : 0; ml_[3] |= p1 < 0 ? bit : 0;
         }
+        ctx.sync();
+        if (ctx.lane() == 0) {
+            for (int q = 0; q < 4; ++q) w.masks[q] = mt_[q];
+            for (int q = 0; q < 6; ++q) w.masks[4 + q] = mc_[q];
+            for (int q = 0; q < 4; ++q) w.masks[10 + q] = ml_[q];
+        }
+        ctx.sync();
+    }
+    BB_HD uint64_t find_matching(int type, int color, int loc) const {
+        uint64_t m = w.masks[type - T_DOOR];
+        if (color != 7) m &= w.masks[4 + color];
+        if (loc != LOC_NONE) m &= w.masks[10 + loc - 1];
         return m;
     }
 
@@ -369,7 +423,8 @@ struct Gen {
             uint64_t m = find_matching(type, color, loc);
             if (m == 0) continue;
             if (!cfg.implicit_unlock && last_locked >= 0) {
-                int tx = (last_locked % cols) * (S - 1), ty = (last_locked / cols) * (S - 1);
+                int li, lj; room_ij(last_locked, li, lj);
+                int tx = li * (S - 1), ty = lj * (S - 1);
                 bool any_out = false;
                 for (int o = 0; o < nobj; ++o)
                     if (m >> o & 1) {
@@ -486,6 +541,7 @@ struct Gen {
             break;
         }
         if (!cfg.unblocking && !objs_reachable()) return false;
+        prep_masks();
         return rand_instr();
     }
 
@@ -503,6 +559,7 @@ struct Gen {
         if (cfg.check_reach && !objs_reachable()) return false;
         if (!cfg.redball) target = first + rand_int(0, cfg.num_dists);   // distractors are the last ids
         clear_prog();
+        prep_masks();
         int type = e_type(w.app[target]), color = e_color(w.app[target]);
         w.prog.root = R_ACTION; w.prog.n_a = 1; w.prog.kind[0] = L_GOTO;
         uint64_t m = find_matching(type, color, LOC_NONE);

@@ -14,6 +14,9 @@ struct HostCtx {
     int lane() const { return 0; }
     int nlanes() const { return 1; }
     void sync() const {}
+    uint32_t shfl_up1(uint32_t) const { return 0; }
+    uint32_t shfl_down1(uint32_t) const { return 0; }
+    bool any(bool p) const { return p; }
 };
 
 extern "C" {
