@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64) void k_pregen(LevelCfg c, int64_t n, uint8_t* _
             Hot h;
             h.ax = (uint8_t)g.ax; h.ay = (uint8_t)g.ay; h.dir = (uint8_t)g.adir; h.carry = NONE8;
             h.step = 0; h.max_steps = (uint16_t)max_steps;
-            h.pre[0] = h.pre[1] = h.pre[2] = h.pre[3] = NONE8;
+            h.pre4 = 0xFFFFFFFFu;
             h.vstate = 0; h.frozen = 0;
             h.last_locked = g.last_locked < 0 ? NONE8 : (uint8_t)g.last_locked;
             h.pad = 0;
@@ -287,7 +287,7 @@ __global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, Hot* __restrict__ 
         Hot h;
         memset(&h, 0, sizeof(h));
         h.carry = NONE8; h.frozen = 1; h.last_locked = NONE8;
-        h.pre[0] = h.pre[1] = h.pre[2] = h.pre[3] = NONE8;
+        h.pre4 = 0xFFFFFFFFu;
         hots[i] = h;
         next_hots[i] = h;
         stales[i] = 0;
@@ -311,6 +311,7 @@ __device__ __forceinline__ uint64_t render_chunk(const uint8_t* s_atlas, const u
     return *(const uint64_t*)(s_atlas + tile * TILE_BYTES + ty * 24 + part * 8);
 }
 
+template <bool NT>
 __global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_t* __restrict__ image,
                                                          uint8_t* __restrict__ pixels, const uint8_t* __restrict__ atlas,
                                                          const uint8_t* __restrict__ lut, int n_tiles) {
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_
             const uint64_t lo = render_chunk(s_atlas, t49, 2 * k);
             const uint64_t hi = render_chunk(s_atlas, t49, 2 * k + 1);
             u32x4 v = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
-            __builtin_nontemporal_store(v, out + q);
+            if (NT) __builtin_nontemporal_store(v, out + q); else out[q] = v;
         }
     }
 }
@@ -540,9 +541,15 @@ int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream
     HIP_TRY(hipSetDevice(e->device));
     // 8 groups (64 envs) per block: short-lived blocks keep wave slots turning over for the look-ahead stream
     int64_t groups = (e->n + RENDER_GROUP - 1) / RENDER_GROUP;
-    unsigned grid = (unsigned)((groups + 7) / 8);
-    hipLaunchKernelGGL(k_render, dim3(grid), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut,
-                       e->n_tiles);
+    static const int gpb = getenv("BBAI_RENDER_GPB") ? atoi(getenv("BBAI_RENDER_GPB")) : 8;      // tuning knobs
+    static const int nt = getenv("BBAI_RENDER_NT") ? atoi(getenv("BBAI_RENDER_NT")) : 1;
+    unsigned grid = (unsigned)((groups + gpb - 1) / gpb);
+    if (nt)
+        hipLaunchKernelGGL(k_render<true>, dim3(grid), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas,
+                           e->lut, e->n_tiles);
+    else
+        hipLaunchKernelGGL(k_render<false>, dim3(grid), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas,
+                           e->lut, e->n_tiles);
     HIP_TRY(hipGetLastError());
     return BBAI_OK;
 }

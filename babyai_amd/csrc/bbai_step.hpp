@@ -59,8 +59,9 @@ BB_HD bool verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stal
         return e_state(r.E[e_index(c, fx, fy)]) == S_OPEN;
     }
     // Pickup / PutNext share the preCarrying protocol.
-    int pre = h.pre[leaf];
-    h.pre[leaf] = h.carry;
+    const int sh = 8 * leaf;
+    int pre = (h.pre4 >> sh) & 0xFF;
+    h.pre4 = (h.pre4 & ~(0xFFu << sh)) | ((uint32_t)h.carry << sh);
     if (kind == L_PICKUP) {
         if (action != A_PICKUP) return false;
         return pre == NONE8 && h.carry != NONE8 && (set0 >> h.carry & 1);

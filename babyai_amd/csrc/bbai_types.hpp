@@ -94,7 +94,8 @@ static_assert(sizeof(Prog) == 112, "Prog layout");
 struct Hot {                // 16 bytes, one per env, SoA array => one dwordx4 per lane
     uint8_t ax, ay, dir, carry;
     uint16_t step, max_steps;
-    uint8_t pre[4];         // preCarrying per leaf (verifier.py:321-334,373-395)
+    uint32_t pre4;          // preCarrying per leaf, byte k = leaf k (verifier.py:321-334,373-395); packed so
+                            // the dynamic leaf index is a shift, not a scratch array
     uint8_t vstate;         // bit0 Seq first part done; bits1,2 side-A And a/b; bits3,4 side-B And a/b
     uint8_t frozen;         // ManyEnvs semantics: finished, waiting for an explicit reset
     uint8_t last_locked;    // LevelGen.locked_room survives episodes (levelgen.py:284,325,384): room idx or NONE8

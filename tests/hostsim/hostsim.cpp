@@ -44,7 +44,7 @@ int hs_generate(const LevelCfg* cfg, uint32_t* mt, int32_t* mti, uint8_t* rec, H
     memset(&h, 0, sizeof(h));
     h.ax = g.ax; h.ay = g.ay; h.dir = g.adir; h.carry = NONE8;
     h.step = 0; h.max_steps = (uint16_t)max_steps;
-    for (int k = 0; k < 4; ++k) h.pre[k] = NONE8;
+    h.pre4 = 0xFFFFFFFFu;
     h.last_locked = g.last_locked < 0 ? NONE8 : (uint8_t)g.last_locked;
     *hot = h;
     return g.nobj;

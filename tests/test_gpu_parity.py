@@ -15,7 +15,8 @@ GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.n
 def test_golden_trace(gpu, path):
     import torch
     from babyai_amd.engine import BatchedBabyAIEnv
-    g = np.load(path, allow_pickle=False)
+    with np.load(path, allow_pickle=False) as f:
+        g = {k: f[k] for k in f.files}      # decompress once (NpzFile re-reads on every access)
     name = str(g["level"])
     seeds = g["seeds"]
     n = len(seeds)

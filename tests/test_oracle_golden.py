@@ -46,5 +46,6 @@ def replay(g, n_envs=None, n_steps=None):
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_oracle_matches_reference_trace(path):
-    g = np.load(path, allow_pickle=False)
-    replay(g, n_envs=6, n_steps=min(200, g["actions"].shape[0]))
+    with np.load(path, allow_pickle=False) as f:
+        g = {k: f[k] for k in f.files}      # decompress once (NpzFile re-reads on every access)
+    replay(g)

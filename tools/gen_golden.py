@@ -26,22 +26,56 @@ refenv.import_reference()
 from babyai.levels import level_dict  # noqa: E402
 from gym_minigrid.wrappers import RGBImgPartialObsWrapper  # noqa: E402
 
-# level, n_envs, n_steps, pre_resets, n_pixel_envs
+# level, n_envs, n_steps, pre_resets, n_pixel_envs, expert
+# expert=True: actions come from the reference's own GOFAI expert (babyai/bot.py) with 12% random
+# perturbations, so episodes actually succeed and the traces cover keys, locked doors, pick-up /
+# drop / put-next verification and every Seq/And combination -- things uniform random actions
+# almost never reach.
 PLAN = [
-    ("GoToRedBall", 8, 160, 2, 0),
-    ("GoToLocal", 16, 256, 2, 2),
-    ("PickupLoc", 16, 256, 2, 0),
-    ("GoTo", 8, 320, 2, 0),
-    ("GoToSeq", 6, 200, 1, 0),
-    ("SynthSeq", 8, 200, 3, 0),
-    ("MiniBossLevel", 8, 320, 3, 0),
-    ("BossLevel", 16, 384, 3, 2),
+    ("GoToRedBall", 8, 160, 2, 0, False),
+    ("GoToLocal", 16, 256, 2, 2, False),
+    ("PickupLoc", 16, 256, 2, 0, False),
+    ("GoTo", 8, 320, 2, 0, False),
+    ("GoToSeq", 6, 200, 1, 0, False),
+    ("SynthSeq", 8, 200, 3, 0, False),
+    ("MiniBossLevel", 8, 320, 3, 0, False),
+    ("BossLevel", 16, 384, 3, 2, False),
+    ("PickupLoc", 8, 120, 0, 0, True),
+    ("GoTo", 6, 300, 0, 0, True),
+    ("SynthLoc", 8, 400, 0, 0, True),
+    ("MiniBossLevel", 12, 500, 0, 2, True),
+    ("BossLevel", 12, 900, 0, 0, True),
 ]
 SEED_BASE = 1000
 
 
-def trace(name, n_envs, n_steps, pre_resets, n_pix):
-    rng = np.random.RandomState(abs(hash(name)) % (2 ** 31) if False else sum(map(ord, name)))
+class Driver(object):
+    """Action source for one env: the reference bot with random perturbations, random after a bot failure."""
+
+    def __init__(self, env, rng):
+        from babyai.bot import Bot
+        self.env, self.rng, self.Bot = env, rng, Bot
+        self.new_episode()
+
+    def new_episode(self):
+        self.bot = self.Bot(self.env)
+        self.last = None
+
+    def act(self):
+        a = None
+        if self.bot is not None:
+            try:
+                a = int(self.bot.replan(self.last))
+            except Exception:
+                self.bot = None
+        if a is None or self.rng.rand() < 0.12:
+            a = int(self.rng.randint(0, 7))
+        self.last = a
+        return a
+
+
+def trace(name, n_envs, n_steps, pre_resets, n_pix, expert=False):
+    rng = np.random.RandomState(sum(map(ord, name)) + (77 if expert else 0))
     actions = rng.randint(0, 7, size=(n_steps, n_envs)).astype(np.uint8)
     seeds = np.arange(n_envs, dtype=np.uint64) + SEED_BASE
     envs = []
@@ -79,8 +113,11 @@ def trace(name, n_envs, n_steps, pre_resets, n_pix):
         if i < n_pix:
             pixels[0, i] = pix[i].observation(o)['image']
     n_done = 0
+    drivers = [Driver(e, rng) for e in envs] if expert else None
     for t in range(n_steps):
         for i, e in enumerate(envs):
+            if expert:
+                actions[t, i] = drivers[i].act()
             o, r, d, _ = e.step(int(actions[t, i]))
             reward[t, i] = np.float32(r)
             done[t, i] = d
@@ -88,18 +125,20 @@ def trace(name, n_envs, n_steps, pre_resets, n_pix):
                 o = e.reset()
                 events.append((t + 1, i, o['mission']))
                 n_done += 1
+                if expert:
+                    drivers[i].new_episode()
             image[t + 1, i] = o['image']; direction[t + 1, i] = o['direction']; max_steps[t + 1, i] = e.max_steps
             if i < n_pix:
                 pixels[t + 1, i] = pix[i].observation(o)['image']
-    out = os.path.join(ROOT, 'tests', 'golden', name + '.npz')
+    out = os.path.join(ROOT, 'tests', 'golden', name + ('_expert' if expert else '') + '.npz')
     np.savez_compressed(
         out, level=name, seeds=seeds, actions=actions, pre_image=pre_image,
         pre_mission=np.array(pre_mission, dtype=object).astype(str) if pre_resets else np.zeros((0, n_envs), dtype=str),
         image=image, direction=direction, reward=reward, done=done, max_steps=max_steps, pixels=pixels,
         event_t=np.array([e[0] for e in events], np.int32), event_env=np.array([e[1] for e in events], np.int32),
         event_mission=np.array([e[2] for e in events]).astype(str))
-    print('%-14s envs=%d steps=%d episodes_finished=%d success=%d -> %d KB' % (
-        name, n_envs, n_steps, n_done, int((reward > 0).sum()), os.path.getsize(out) // 1024))
+    print('%-14s%s envs=%d steps=%d episodes_finished=%d success=%d -> %d KB' % (
+        name, ' (expert)' if expert else '', n_envs, n_steps, n_done, int((reward > 0).sum()), os.path.getsize(out) // 1024))
 
 
 if __name__ == '__main__':
