@@ -1,0 +1,129 @@
+"""Full-size (BASELINE.json configs) checks on the GPU through size-independent properties, plus
+oracle spot checks on scattered envs of the 1M-env batch."""
+import numpy as np
+import pytest
+
+N_FULL = 1048576
+
+
+def _expected_pixels(torch, image, atlas_np, lut_np):
+    """RGBImgPartialObsWrapper as a torch gather (independent restatement of k_render's indexing)."""
+    dev = image.device
+    atlas = torch.as_tensor(atlas_np, device=dev)                 # [T, 8, 8, 3]
+    lut = torch.as_tensor(lut_np.astype(np.int64), device=dev)    # [2, 256]
+    img = image.to(torch.int64)
+    key = img[..., 0] | (img[..., 1] << 3) | (img[..., 2] << 6)   # [n, 7(vx), 7(vy)]
+    agent = torch.zeros((7, 7), dtype=torch.int64, device=dev)
+    agent[3, 6] = 1
+    tile = lut[agent.expand_as(key), key]                          # [n, 7, 7]
+    t = atlas[tile]                                                # [n, vx, vy, ty, tx, 3]
+    return t.permute(0, 2, 3, 1, 4, 5).reshape(image.shape[0], 56, 56, 3)
+
+
+@pytest.mark.gpu
+def test_render_full_size_matches_gather(gpu):
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv, ATLAS_PATH
+    env = BatchedBabyAIEnv("BabyAI-BossLevel-v0", N_FULL, device=gpu, pixel=True, seeds=0)
+    obs = env.reset()
+    acts = torch.randint(0, 7, (24, N_FULL), dtype=torch.uint8, device=gpu)
+    for t in range(24):
+        obs, _, _, _ = env.step(acts[t])
+    at = np.load(ATLAS_PATH)
+    chunk = 131072
+    for lo in range(0, N_FULL, chunk):
+        exp = _expected_pixels(torch, env.image[lo:lo + chunk], at["tiles"], at["lut"])
+        assert torch.equal(obs["image"][lo:lo + chunk], exp), "pixel mismatch in envs [%d, %d)" % (lo, lo + chunk)
+    env.close()
+
+
+@pytest.mark.gpu
+def test_full_size_determinism_invariants_and_oracle_spots(gpu):
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from oracle import levels as olevels
+    T = 40
+    a = BatchedBabyAIEnv("BabyAI-BossLevel-v0", N_FULL, device=gpu, seeds=0)
+    b = BatchedBabyAIEnv("BabyAI-BossLevel-v0", N_FULL, device=gpu, seeds=0)
+    a.reset()
+    b.reset()
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(99)
+    acts = torch.randint(0, 7, (T, N_FULL), dtype=torch.uint8, device=gpu, generator=gen)
+    spots = [0, 1, 255, 256, 65535, 65536, 524287, 524288, N_FULL - 257, N_FULL - 1]
+    refs = []
+    for i in spots:
+        e = olevels.make_env("BossLevel")
+        e.seed(i)
+        refs.append((e, e.reset()))
+    img0 = a.image[spots].cpu().numpy()
+    for k, (e, o) in enumerate(refs):
+        assert np.array_equal(img0[k], o["image"]), "env %d first obs" % spots[k]
+        assert a._obs()["mission"][spots[k]] == o["mission"]
+    acts_host = acts[:, spots].cpu().numpy()
+    for t in range(T):
+        a.step(acts[t])
+        b.step(acts[t])
+        img = a.image[spots].cpu().numpy()
+        rew = a.reward[spots].cpu().numpy()
+        dn = a.done[spots].cpu().numpy()
+        for k, (e, _) in enumerate(refs):
+            o, r, d, _ = e.step(int(acts_host[t, k]))
+            if d:
+                o = e.reset()
+            assert np.array_equal(img[k], o["image"]), "env %d step %d" % (spots[k], t)
+            assert np.float32(r) == rew[k] and bool(d) == bool(dn[k])
+    torch.cuda.synchronize()
+    # determinism: two engines, same seeds and actions -> identical bytes (atomics / scheduling leak nothing)
+    assert torch.equal(a.image, b.image) and torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done)
+    assert torch.equal(a.direction, b.direction)
+    # invariants of the encoding
+    img = a.image
+    assert int(a.direction.max()) <= 3
+    types = torch.unique(img[..., 0]).tolist()
+    assert set(types) <= {0, 1, 2, 4, 5, 6, 7}
+    assert bool((img[:, 3, 6, 0] != 0).all()), "the agent's own cell is always visible"
+    unseen = img[..., 0] == 0
+    assert bool((img[..., 1][unseen] == 0).all()) and bool((img[..., 2][unseen] == 0).all())
+    r = a.reward
+    assert bool(((r == 0) | ((r > 0.0999) & (r <= 1.0))).all())
+    assert bool((a.done[r > 0] == 1).all())
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level,n", [("GoToLocal", 65536), ("PickupLoc", 262144), ("GoTo", 131072)])
+def test_config_sizes_oracle_spots(gpu, level, n):
+    """BASELINE.json configs[1..3] at their full sizes: scattered envs against the oracle, crossing resets."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from oracle import levels as olevels
+    T = 150 if level != "GoTo" else 60
+    env = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=7)
+    env.reset()
+    spots = [0, 63, 64, 4097, n // 2, n - 65, n - 1]
+    refs = []
+    for i in spots:
+        e = olevels.make_env(level)
+        e.seed(7 + i)
+        refs.append([e, e.reset()])
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(5)
+    acts = torch.randint(0, 7, (T, n), dtype=torch.uint8, device=gpu, generator=gen)
+    acts_host = acts[:, spots].cpu().numpy()
+    for t in range(T):
+        img = env.image[spots].cpu().numpy()
+        for k, (e, o) in enumerate(refs):
+            assert np.array_equal(img[k], o["image"]), (level, spots[k], t)
+        env.step(acts[t])
+        rew = env.reward[spots].cpu().numpy()
+        for k, (e, _) in enumerate(refs):
+            o, r, d, _ = e.step(int(acts_host[t, k]))
+            if d:
+                o = e.reset()
+            refs[k][1] = o
+            assert np.float32(r) == rew[k]
+    if level != "GoTo":
+        assert env.reset_count() > n       # every env crossed at least one auto-reset on average
+    env.close()
