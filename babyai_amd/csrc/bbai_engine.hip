@@ -311,7 +311,6 @@ __device__ __forceinline__ uint64_t render_chunk(const uint8_t* s_atlas, const u
     return *(const uint64_t*)(s_atlas + tile * TILE_BYTES + ty * 24 + part * 8);
 }
 
-template <bool NT>
 __global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_t* __restrict__ image,
                                                          uint8_t* __restrict__ pixels, const uint8_t* __restrict__ atlas,
                                                          const uint8_t* __restrict__ lut, int n_tiles) {
@@ -342,7 +341,7 @@ __global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_
             const uint64_t lo = render_chunk(s_atlas, t49, 2 * k);
             const uint64_t hi = render_chunk(s_atlas, t49, 2 * k + 1);
             u32x4 v = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
-            if (NT) __builtin_nontemporal_store(v, out + q); else out[q] = v;
+            __builtin_nontemporal_store(v, out + q);   // streaming output: keep it out of L2/MALL
         }
     }
 }
@@ -541,15 +540,13 @@ int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream
     HIP_TRY(hipSetDevice(e->device));
     // 8 groups (64 envs) per block: short-lived blocks keep wave slots turning over for the look-ahead stream
     int64_t groups = (e->n + RENDER_GROUP - 1) / RENDER_GROUP;
-    static const int gpb = getenv("BBAI_RENDER_GPB") ? atoi(getenv("BBAI_RENDER_GPB")) : 8;      // tuning knobs
-    static const int nt = getenv("BBAI_RENDER_NT") ? atoi(getenv("BBAI_RENDER_NT")) : 1;
+    // Measured on MI355X (tools/ubench_store.hip, gpurun_out/sweep): looped 16-byte store streams top out at
+    // ~5.6-5.7 TB/s whatever the per-block span; 8 groups (64 envs, 602 KB) per short-lived block is the best
+    // point and keeps wave slots turning over for the look-ahead stream.
+    const int gpb = 8;
     unsigned grid = (unsigned)((groups + gpb - 1) / gpb);
-    if (nt)
-        hipLaunchKernelGGL(k_render<true>, dim3(grid), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas,
-                           e->lut, e->n_tiles);
-    else
-        hipLaunchKernelGGL(k_render<false>, dim3(grid), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas,
-                           e->lut, e->n_tiles);
+    hipLaunchKernelGGL(k_render, dim3(grid), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut,
+                       e->n_tiles);
     HIP_TRY(hipGetLastError());
     return BBAI_OK;
 }
