@@ -114,6 +114,17 @@ def main():
         dom_ms = avg_ms["step"]
         bytes_per_step = 235
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate
+    # runs; tools/gpu_profile.sh -> tools/summarize_profile.py -> profiles/pmc_latest.json).  Counters cannot be
+    # collected inside this process, so the committed summary is used when it was taken on this exact workload.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        if args.level == "BossLevel" and E == 1048576 and dom in pmc["kernels"]:
+            kk = pmc["kernels"][dom]
+            traffic = kk["FETCH_SIZE"] + kk["WRITE_SIZE"]
+    except Exception:
+        traffic = None
     out = {
         "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -123,7 +134,7 @@ def main():
             "envs_per_gpu": E, "total_envs": E * world, "resets_in_timed_region": resets,
             "parallelism": "env-shards x%d, no collective" % world},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
                      "whole_step_alg_GBs": value / world * bytes_per_step / 1e9,
                      "avg_ms": avg_ms},

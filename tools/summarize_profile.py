@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Condense a tools/gpu_profile.sh run (gpurun_out/<tag>/) into the tracked evidence under profiles/<tag>/:
+rocprofv3 kernel stats CSV, bench JSON lines, and the HBM counter summary (text + profiles/pmc_latest.json,
+which bench.py uses to fill roofline.traffic)."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+src = os.path.join("gpurun_out", tag)
+dst = os.path.join("profiles", tag)
+os.makedirs(dst, exist_ok=True)
+for f in os.listdir(src):
+    if f.endswith(".json"):
+        shutil.copy(os.path.join(src, f), dst)
+ks = os.path.join(src, "stats", "boss_kernel_stats.csv")
+if os.path.isfile(ks):
+    shutil.copy(ks, os.path.join(dst, "rocprofv3_kernel_stats_boss_pixel_1M.csv"))
+summary = {"workload": "BabyAI-BossLevel-v0 pixel, 1048576 envs, bench.py --steps 8 --warmup 2", "unit": "bytes per launch",
+           "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (kernel-trace only); counters are KB per "
+                   "dispatch; steady-state = median over launches (the first k_pregen/k_consume launches cover all envs). "
+                   "gfx950 FETCH_SIZE under-reports wide streaming reads by 2x (MI355X_MICROARCH.md); reported raw.",
+           "kernels": {}}
+lines = []
+for name, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    path = os.path.join(src, name, "boss_counter_collection.csv")
+    if not os.path.isfile(path):
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == key:
+            agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    for k, v in sorted(agg.items()):
+        if not k.startswith("k_"):
+            continue
+        v = sorted(v)
+        med = v[len(v) // 2]
+        summary["kernels"].setdefault(k, {})[key] = med * 1024.0
+        lines.append("%-16s %-11s launches=%3d median=%14.1f KB  min=%14.1f  max=%14.1f" % (k, key, len(v), med, v[0], v[-1]))
+open(os.path.join(dst, "rocprofv3_pmc_hbm_boss_pixel_1M.txt"), "w").write(summary["note"] + "\n\n" + "\n".join(lines) + "\n")
+json.dump(summary, open(os.path.join("profiles", "pmc_latest.json"), "w"), indent=1)
+print("\n".join(lines))
