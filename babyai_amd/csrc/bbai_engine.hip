@@ -366,7 +366,13 @@ int bbai_fill_layout(bbai_level_cfg* cfg) {
 static int validate_cfg(const LevelCfg& c) {
     if (c.kind != K_GOTO && c.kind != K_LEVELGEN) return -1;
     if (c.num_dists < 0) return -1;
-    if (c.kind == K_GOTO && !c.redball && c.num_dists < 1) return -1;
+    if (c.kind == K_GOTO) {
+        if (!c.redball && c.num_dists < 1) return -1;
+        if (c.instr < L_GOTO || c.instr > L_PUTNEXT || c.target < TG_REDBALL || c.target > TG_LOCKED_ROOM_OBJ) return -1;
+        if (c.instr == L_PUTNEXT && (c.target != TG_TWO_DISTS || c.num_dists < 2)) return -1;
+        if ((c.target == TG_LOCKED_DOOR || c.target == TG_LOCKED_ROOM_OBJ) != (c.lock != 0)) return -1;
+        if (c.lock && c.num_rows * c.num_cols < 2) return -1;
+    }
     if (c.kind == K_LEVELGEN) {
         if (c.n_action_kinds < 1 || c.n_action_kinds > 4 || c.n_instr_kinds < 1 || c.n_instr_kinds > 3) return -1;
         for (int i = 0; i < c.n_action_kinds; ++i) if (c.action_kinds[i] < 0 || c.action_kinds[i] > 3) return -1;

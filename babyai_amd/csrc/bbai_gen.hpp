@@ -256,7 +256,21 @@ struct Gen {
         }
     }
     // RoomGrid.connect_all: random doors until every room is reachable from the agent's.
-    BB_HD bool connect_all() {
+    // RoomGrid.add_door(i, j, door_idx=None, color=None, locked=...): side drawn until it has a neighbour and
+    // no door yet, then the colour.
+    BB_HD int add_door_random_side(int r, bool is_locked, int& color_out) {
+        int k;
+        for (;;) {
+            k = rand_int(0, 4);
+            if (has_neighbor(r, k) && !has_door(r, k)) break;
+        }
+        color_out = rand_color();
+        return add_door(r, k, color_out, is_locked);
+    }
+    // position of a colour in COLOR_NAMES (sorted): blue green grey purple red yellow
+    BB_HD static int color_name_pos(int c) { return (0x253014 >> (4 * c)) & 0xF; }   // red4 green1 blue0 purple3 yellow5 grey2
+
+    BB_HD bool connect_all(int excl_color = -1) {
         int start = room_of(ax, ay);
         int nrooms = rows * cols;
         int itrs = 0;
@@ -279,12 +293,19 @@ struct Gen {
             int r = j * cols + i;
             if (!has_neighbor(r, k) || has_door(r, k)) continue;
             if ((locked_mask >> r & 1) || (locked_mask >> neighbor(r, k) & 1)) continue;
-            int color = rand_color();
+            int color;
+            if (excl_color < 0) {
+                color = rand_color();
+            } else {            // door_colors = COLOR_NAMES without the locked door's colour (iclr19_levels.py:443-445)
+                int q = rand_int(0, 5);
+                if (q >= color_name_pos(excl_color)) ++q;
+                color = color_name_to_idx(q);
+            }
             if (add_door(r, k, color, false) < 0) return false;
         }
     }
     // RoomGrid.add_distractors(i=None, j=None).  first_id receives the first new id.
-    BB_HD bool add_distractors(int num, bool all_unique) {
+    BB_HD bool add_distractors(int num, bool all_unique, int room = -1) {
         int count = 0;
         while (count < num) {
             int color = rand_color();
@@ -295,9 +316,13 @@ struct Gen {
                     if (e_type(w.app[o]) != T_DOOR && e_type(w.app[o]) == type && e_color(w.app[o]) == color) dup = true;
                 if (dup) continue;
             }
-            int ri = rand_int(0, cols);
-            int rj = rand_int(0, rows);
-            if (add_object(rj * cols + ri, type, color) < 0) return false;
+            int r = room;
+            if (r < 0) {
+                int ri = rand_int(0, cols);
+                int rj = rand_int(0, rows);
+                r = rj * cols + ri;
+            }
+            if (add_object(r, type, color) < 0) return false;
             ++count;
         }
         return true;
@@ -545,27 +570,98 @@ struct Gen {
         return rand_instr();
     }
 
-    // GoToRedBall / GoToObj / GoToLocal / GoTo gen_mission
+    BB_HD void set_desc(int leaf, int slot, int obj) {
+        int type = e_type(w.app[obj]), color = e_color(w.app[obj]);
+        uint64_t m = find_matching(type, color, LOC_NONE);
+        w.prog.set[leaf][slot] = m;
+        DescInfo d; d.type = type; d.color = color; d.loc = LOC_NONE; d.count = (uint8_t)__builtin_popcountll(m);
+        w.prog.desc[leaf][slot] = d;
+    }
+
+    // The hand-written single-instruction levels (gen_mission of GoToRedBall[Grey] / GoToObj / GoToLocal / GoTo /
+    // Pickup / UnblockPickup / Open / PutNext[Local] and the lock-first pair Unlock / GoToImpUnlock), driven by
+    // the cfg fields; RNG draw order follows iclr19_levels.py line by line.
     BB_HD bool mission_goto() {
-        if (!place_agent()) return false;
-        int target = -1;
-        if (cfg.redball) {
-            target = add_object(0, T_BALL, C_RED);
-            if (target < 0) return false;
+        int target = -1, target2 = -1, locked_door = -1, lock_color = 0;
+        int first = 0, ndist = 0;
+        if (cfg.lock) {
+            // Unlock :424-437 / GoToImpUnlock :311-325 : locked door on a random side of a random room, key elsewhere
+            int id = rand_int(0, cols);
+            int jd = rand_int(0, rows);
+            locked_room = jd * cols + id;
+            locked_door = add_door_random_side(locked_room, true, lock_color);
+            if (locked_door < 0) return false;
+            for (;;) {
+                int ik = rand_int(0, cols);
+                int jk = rand_int(0, rows);
+                if (jk * cols + ik == locked_room) continue;
+                if (add_object(jk * cols + ik, T_KEY, lock_color) < 0) return false;
+                break;
+            }
+            int excl = -1;
+            if (cfg.lock_color_excl && rand_bool()) excl = lock_color;
+            if (!connect_all(excl)) return false;
+            first = nobj;
+            for (int i = 0; i < cols; ++i)
+                for (int j = 0; j < rows; ++j)
+                    if (j * cols + i != locked_room)
+                        if (!add_distractors(cfg.num_dists, false, j * cols + i)) return false;
+            for (;;) {
+                if (!place_agent()) return false;
+                if (room_of(ax, ay) != locked_room) break;
+            }
+            if (cfg.check_reach && !objs_reachable()) return false;
+            if (cfg.target == TG_LOCKED_ROOM_OBJ) {
+                target = nobj;
+                if (!add_distractors(1, false, locked_room)) return false;
+            } else {
+                target = locked_door;
+            }
+        } else {
+            if (!place_agent()) return false;
+            if (cfg.redball) {
+                target = add_object(0, T_BALL, C_RED);
+                if (target < 0) return false;
+            }
+            if (cfg.connect && !connect_all()) return false;
+            first = nobj;
+            ndist = cfg.num_dists;
+            if (!add_distractors(ndist, cfg.all_unique != 0)) return false;
+            if (cfg.grey_dists)
+                for (int o = first; o < nobj; ++o) {
+                    int e = e_make(e_type(w.app[o]), C_GREY, 0);
+                    w.app[o] = e;
+                    w.E[eidx(w.px[o], w.py[o])] = e;
+                }
+            if (cfg.check_reach == 1 && !objs_reachable()) return false;
+            if (cfg.check_reach == 2 && objs_reachable()) return false;     // UnblockPickup :383-386
+            if (cfg.target == TG_DIST) {
+                target = first + rand_int(0, ndist);                        // _rand_elem(objs)
+            } else if (cfg.target == TG_TWO_DISTS) {                        // _rand_subset(objs, 2)
+                int a = rand_int(0, ndist);
+                int b = rand_int(0, ndist - 1);
+                if (b >= a) ++b;
+                target = first + a; target2 = first + b;
+            } else if (cfg.target == TG_DOOR) {
+                // Open :401-411 : doors listed room by room (i outer, j inner), side by side => every door twice
+                int n = 0;
+                for (int r = 0; r < rows * cols; ++r)
+                    for (int k = 0; k < 4; ++k) n += has_door(r, k) ? 1 : 0;
+                if (n == 0) return false;
+                int pick = rand_int(0, n);
+                for (int i = 0; i < cols && target < 0; ++i)
+                    for (int j = 0; j < rows && target < 0; ++j)
+                        for (int k = 0; k < 4; ++k)
+                            if (has_door(j * cols + i, k)) {
+                                if (pick-- == 0) { target = w.I[iidx(w.door_x[j * cols + i][k], w.door_y[j * cols + i][k])] - 2; break; }
+                            }
+            }
         }
-        if (cfg.connect && !connect_all()) return false;
-        int first = nobj;
-        if (!add_distractors(cfg.num_dists, cfg.all_unique != 0)) return false;
-        if (cfg.check_reach && !objs_reachable()) return false;
-        if (!cfg.redball) target = first + rand_int(0, cfg.num_dists);   // distractors are the last ids
         clear_prog();
         prep_masks();
-        int type = e_type(w.app[target]), color = e_color(w.app[target]);
-        w.prog.root = R_ACTION; w.prog.n_a = 1; w.prog.kind[0] = L_GOTO;
-        uint64_t m = find_matching(type, color, LOC_NONE);
-        w.prog.set[0][0] = m;
-        DescInfo d; d.type = type; d.color = color; d.loc = LOC_NONE; d.count = (uint8_t)__builtin_popcountll(m);
-        w.prog.desc[0][0] = d;
+        w.prog.root = R_ACTION; w.prog.n_a = 1; w.prog.kind[0] = (uint8_t)cfg.instr;
+        set_desc(0, 0, target);
+        if (cfg.instr == L_PUTNEXT) set_desc(0, 1, target2);
         if (cfg.doors_open)
             for (int o = 0; o < nobj; ++o)
                 if (e_type(w.app[o]) == T_DOOR) {

@@ -105,6 +105,7 @@ static_assert(sizeof(Hot) == 16, "Hot layout");
 
 // ---- level configuration ---------------------------------------------------
 enum : int { K_GOTO = 0, K_LEVELGEN = 1 };
+enum : int { TG_REDBALL = 0, TG_DIST = 1, TG_DOOR = 2, TG_TWO_DISTS = 3, TG_LOCKED_DOOR = 4, TG_LOCKED_ROOM_OBJ = 5 };
 enum : int { AK_GOTO = 0, AK_PICKUP = 1, AK_OPEN = 2, AK_PUTNEXT = 3 };
 enum : int { IK_ACTION = 0, IK_AND = 1, IK_SEQ = 2 };
 
@@ -113,10 +114,17 @@ struct LevelCfg {
     int32_t room_size, num_rows, num_cols, num_dists;
     // K_GOTO family (iclr19_levels.py:40-63,66-124,224-257)
     int32_t redball;        // place a red ball first and make it the target
-    int32_t connect;        // connect_all() after placing the agent
-    int32_t check_reach;    // check_objs_reachable()
+    int32_t connect;        // connect_all()
+    int32_t check_reach;    // 0 none, 1 check_objs_reachable(), 2 reject when everything IS reachable (UnblockPickup)
     int32_t doors_open;     // open_all_doors() at the end
     int32_t all_unique;     // add_distractors(all_unique=...)
+    // single-instruction hand-written levels (iclr19_levels.py:10-37,187-221,304-491)
+    int32_t instr;          // leaf kind of the mission: L_GOTO / L_PICKUP / L_OPEN / L_PUTNEXT
+    int32_t target;         // TG_*: how the described object(s) are chosen
+    int32_t lock;           // 1: a locked door + its key are placed first; agent placed last, outside the locked room
+    int32_t lock_color_excl;// Unlock: with probability 1/2 connect_all() avoids the locked door's colour
+    int32_t dists_per_room; // 1: num_dists distractors in every room except the locked one
+    int32_t grey_dists;     // GoToRedBallGrey: distractors are recoloured grey
     // K_LEVELGEN (levelgen.py:256-460)
     int32_t locations, unblocking, implicit_unlock;
     int32_t n_action_kinds, action_kinds[4];
@@ -138,7 +146,8 @@ inline int fill_layout(LevelCfg& c) {
     c.ES = round_up(c.W + 2 * MARGIN, 4);
     c.EH = c.H + 2 * MARGIN;
     int ndoors = c.num_rows * (c.num_cols - 1) + c.num_cols * (c.num_rows - 1);
-    c.maxo = round_up(c.num_dists + 2 + ndoors, 8);
+    int nd = c.dists_per_room ? c.num_dists * c.num_rows * c.num_cols : c.num_dists;
+    c.maxo = round_up(nd + 2 + ndoors, 8);
     if (c.maxo > MAX_OBJ) return -1;
     c.off_I = c.ES * c.EH;
     c.off_app = round_up(c.off_I + c.W * c.H, 4);

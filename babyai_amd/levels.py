@@ -10,8 +10,11 @@ generator families:
                 GoToSeq :518-551, Synth :554-594, SynthLoc :597-614, SynthSeq :617-633,
                 MiniBossLevel :636-645, BossLevel :648-652, BossLevelNoUnlock :655-661
 
-Hand-written levels (Unlock, PutNext, GoToImpUnlock, ...) and the bonus levels are not
-covered yet; `make_cfg` raises KeyError for them.
+  * the hand-written single-instruction levels GoToRedBallGrey :10-37, PutNextLocal :187-221,
+    GoToImpUnlock :304-357, Pickup :360-371, UnblockPickup :374-391, Open :394-415, Unlock :418-474,
+    PutNext :477-491 are cfg variants of the K_GOTO generator
+=> every level of iclr19_levels.py is covered.  The bonus levels (bonus_levels.py) are not;
+`make_cfg` raises KeyError for them.
 """
 import ctypes
 
@@ -28,6 +31,8 @@ class LevelCfg(ctypes.Structure):
         ("num_dists", ctypes.c_int32),
         ("redball", ctypes.c_int32), ("connect", ctypes.c_int32), ("check_reach", ctypes.c_int32),
         ("doors_open", ctypes.c_int32), ("all_unique", ctypes.c_int32),
+        ("instr", ctypes.c_int32), ("target", ctypes.c_int32), ("lock", ctypes.c_int32),
+        ("lock_color_excl", ctypes.c_int32), ("dists_per_room", ctypes.c_int32), ("grey_dists", ctypes.c_int32),
         ("locations", ctypes.c_int32), ("unblocking", ctypes.c_int32), ("implicit_unlock", ctypes.c_int32),
         ("n_action_kinds", ctypes.c_int32), ("action_kinds", ctypes.c_int32 * 4),
         ("n_instr_kinds", ctypes.c_int32), ("instr_kinds", ctypes.c_int32 * 3),
@@ -39,11 +44,24 @@ class LevelCfg(ctypes.Structure):
     ]
 
 
+L_GOTO, L_PICKUP, L_OPEN, L_PUTNEXT = 1, 2, 3, 4
+TG_REDBALL, TG_DIST, TG_DOOR, TG_TWO_DISTS, TG_LOCKED_DOOR, TG_LOCKED_ROOM_OBJ = 0, 1, 2, 3, 4, 5
+
+
 def _goto(room_size=8, num_rows=1, num_cols=1, num_dists=8, redball=0, connect=0,
-          check_reach=1, doors_open=0, all_unique=0):
+          check_reach=1, doors_open=0, all_unique=0, instr=L_GOTO, target=None, lock=0,
+          lock_color_excl=0, dists_per_room=0, grey_dists=0):
+    if target is None:
+        target = TG_REDBALL if redball else TG_DIST
     return dict(kind=K_GOTO, room_size=room_size, num_rows=num_rows, num_cols=num_cols,
                 num_dists=num_dists, redball=redball, connect=connect, check_reach=check_reach,
-                doors_open=doors_open, all_unique=all_unique)
+                doors_open=doors_open, all_unique=all_unique, instr=instr, target=target, lock=lock,
+                lock_color_excl=lock_color_excl, dists_per_room=dists_per_room, grey_dists=grey_dists)
+
+
+def _maze(**kw):
+    """RoomGridLevel defaults of the hand-written maze levels: 3x3 rooms of size 8."""
+    return _goto(num_rows=3, num_cols=3, **kw)
 
 
 def _levelgen(room_size=8, num_rows=3, num_cols=3, num_dists=18, locked_room_prob=0.5,
@@ -59,6 +77,7 @@ def _levelgen(room_size=8, num_rows=3, num_cols=3, num_dists=18, locked_room_pro
 
 LEVELS = {
     # --- K_GOTO family -----------------------------------------------------------------
+    "GoToRedBallGrey": _goto(num_dists=7, redball=1, grey_dists=1),
     "GoToRedBall": _goto(num_dists=7, redball=1),
     "GoToRedBallNoDists": _goto(num_dists=0, redball=1),
     "GoToObj": _goto(num_dists=1, all_unique=1, check_reach=0),
@@ -86,6 +105,18 @@ LEVELS = {
     "GoToObjMazeS5": _goto(room_size=5, num_rows=3, num_cols=3, num_dists=1, connect=1),
     "GoToObjMazeS6": _goto(room_size=6, num_rows=3, num_cols=3, num_dists=1, connect=1),
     "GoToObjMazeS7": _goto(room_size=7, num_rows=3, num_cols=3, num_dists=1, connect=1),
+    # hand-written single-instruction levels (iclr19_levels.py:187-221, 304-491)
+    "PutNextLocal": _goto(num_dists=8, all_unique=1, instr=L_PUTNEXT, target=TG_TWO_DISTS),
+    "PutNextLocalS5N3": _goto(room_size=5, num_dists=3, all_unique=1, instr=L_PUTNEXT, target=TG_TWO_DISTS),
+    "PutNextLocalS6N4": _goto(room_size=6, num_dists=4, all_unique=1, instr=L_PUTNEXT, target=TG_TWO_DISTS),
+    "Pickup": _maze(num_dists=18, connect=1, instr=L_PICKUP),
+    "UnblockPickup": _maze(num_dists=20, connect=1, check_reach=2, instr=L_PICKUP),
+    "Open": _maze(num_dists=18, connect=1, instr=L_OPEN, target=TG_DOOR),
+    "PutNext": _maze(num_dists=18, connect=1, instr=L_PUTNEXT, target=TG_TWO_DISTS),
+    "Unlock": _maze(num_dists=3, connect=1, lock=1, lock_color_excl=1, dists_per_room=1, instr=L_OPEN,
+                    target=TG_LOCKED_DOOR),
+    "GoToImpUnlock": _maze(num_dists=2, connect=1, lock=1, dists_per_room=1, instr=L_GOTO,
+                           target=TG_LOCKED_ROOM_OBJ),
     # --- K_LEVELGEN family ---------------------------------------------------------------
     "PickupLoc": _levelgen(action_kinds=("pickup",), instr_kinds=("action",), num_rows=1, num_cols=1,
                            num_dists=8, locked_room_prob=0, locations=True, unblocking=False),
@@ -123,7 +154,8 @@ def fill_layout(cfg):
     cfg.ES = rup(cfg.W + 2 * MARGIN, 4)
     cfg.EH = cfg.H + 2 * MARGIN
     ndoors = cfg.num_rows * (cfg.num_cols - 1) + cfg.num_cols * (cfg.num_rows - 1)
-    cfg.maxo = rup(cfg.num_dists + 2 + ndoors, 8)
+    nd = cfg.num_dists * cfg.num_rows * cfg.num_cols if cfg.dists_per_room else cfg.num_dists
+    cfg.maxo = rup(nd + 2 + ndoors, 8)
     cfg.off_I = cfg.ES * cfg.EH
     cfg.off_app = rup(cfg.off_I + cfg.W * cfg.H, 4)
     cfg.off_pos = cfg.off_app + cfg.maxo

@@ -31,6 +31,7 @@ typedef struct bbai_level_cfg {
     int32_t kind;                       /* 0 = GoTo family, 1 = LevelGen family */
     int32_t room_size, num_rows, num_cols, num_dists;
     int32_t redball, connect, check_reach, doors_open, all_unique;     /* GoTo family */
+    int32_t instr, target, lock, lock_color_excl, dists_per_room, grey_dists;   /* single-instruction levels */
     int32_t locations, unblocking, implicit_unlock;                    /* LevelGen */
     int32_t n_action_kinds, action_kinds[4];    /* 0 goto 1 pickup 2 open 3 putnext, in list order */
     int32_t n_instr_kinds, instr_kinds[3];      /* 0 action 1 and 2 seq, in list order */

@@ -297,34 +297,99 @@ class OracleLevel(RoomGrid):
 
 
 class GoToOracle(OracleLevel):
-    """GoToRedBall / GoToObj / GoToLocal / GoTo families."""
+    """The hand-written single-instruction levels of iclr19_levels.py: GoToRedBall[Grey] :10-63, GoToObj :75-102,
+    GoToLocal :105-184, PutNextLocal :187-221, GoTo :224-301, GoToImpUnlock :304-357, Pickup :360-371,
+    UnblockPickup :374-391, Open :394-415, Unlock :418-474, PutNext :477-491 -- one parameterised restatement."""
 
     def __init__(self, room_size=8, num_rows=1, num_cols=1, num_dists=8, redball=False, connect=False,
-                 check_reach=True, doors_open=False, all_unique=False, seed=None):
+                 check_reach=True, doors_open=False, all_unique=False, instr='goto', target=None,
+                 lock=False, lock_color_excl=False, dists_per_room=False, grey_dists=False, seed=None):
+        if target is None:
+            target = 'redball' if redball else 'dist'
         self.p = dict(num_dists=num_dists, redball=redball, connect=connect, check_reach=check_reach,
-                      doors_open=doors_open, all_unique=all_unique)
+                      doors_open=doors_open, all_unique=all_unique, instr=instr, target=target, lock=lock,
+                      lock_color_excl=lock_color_excl, dists_per_room=dists_per_room, grey_dists=grey_dists)
         super().__init__(room_size=room_size, num_rows=num_rows, num_cols=num_cols, seed=seed)
 
-    def gen_mission(self):
+    def _reachable_ok(self):
+        try:
+            self.all_reachable()
+            return True
+        except Reject:
+            return False
+
+    def _all_doors(self):
+        out = []
+        for i in range(self.num_cols):
+            for j in range(self.num_rows):
+                out += [d for d in self.get_room(i, j).doors if d]
+        return out
+
+    def _gen_locked(self):
+        """Unlock / GoToImpUnlock: locked door + key first, agent last and outside the locked room."""
+        p = self.p
+        ci = self._rand_int(0, self.num_cols)
+        cj = self._rand_int(0, self.num_rows)
+        door, _ = self.add_door(ci, cj, locked=True)
+        locked = self.get_room(ci, cj)
+        while True:
+            ki = self._rand_int(0, self.num_cols)
+            kj = self._rand_int(0, self.num_rows)
+            if (ki, kj) != (ci, cj):
+                self.add_object(ki, kj, 'key', door.color)
+                break
+        if p['lock_color_excl'] and self._rand_bool():
+            self.connect_all(door_colors=[c for c in COLOR_NAMES if c != door.color])
+        else:
+            self.connect_all()
+        for i in range(self.num_cols):
+            for j in range(self.num_rows):
+                if (i, j) != (ci, cj):
+                    self.add_distractors(i, j, num_distractors=p['num_dists'], all_unique=False)
+        while True:
+            self.place_agent()
+            if self.room_from_pos(*self.agent_pos) is not locked:
+                break
+        if p['check_reach']:
+            self.all_reachable()
+        if p['target'] == 'locked_room_obj':
+            obj, = self.add_distractors(ci, cj, num_distractors=1, all_unique=False)
+            return [obj]
+        return [door]
+
+    def _gen_open(self):
         p = self.p
         self.place_agent()
-        target = None
+        ball = None
         if p['redball']:
-            target, _ = self.add_object(0, 0, 'ball', 'red')
+            ball, _ = self.add_object(0, 0, 'ball', 'red')
         if p['connect']:
             self.connect_all()
         dists = self.add_distractors(num_distractors=p['num_dists'], all_unique=p['all_unique'])
-        if p['check_reach']:
+        if p['grey_dists']:
+            for d in dists:
+                d.color = 'grey'
+        if p['check_reach'] == 2:
+            if self._reachable_ok():
+                raise Reject('everything reachable')
+        elif p['check_reach']:
             self.all_reachable()
-        if target is None:
-            target = self._rand_elem(dists)
-        self.instrs = Clause('goto', Desc(target.type, target.color))
+        if p['target'] == 'redball':
+            return [ball]
+        if p['target'] == 'dist':
+            return [self._rand_elem(dists)]
+        if p['target'] == 'two_dists':
+            return self._rand_subset(dists, 2)
+        return [self._rand_elem(self._all_doors())]
+
+    def gen_mission(self):
+        p = self.p
+        objs = self._gen_locked() if p['lock'] else self._gen_open()
+        descs = [Desc(o.type, o.color) for o in objs]
+        self.instrs = Clause(p['instr'], *descs)
         if p['doors_open']:
-            for i in range(self.num_cols):
-                for j in range(self.num_rows):
-                    for door in self.get_room(i, j).doors:
-                        if door:
-                            door.is_open = True
+            for door in self._all_doors():
+                door.is_open = True
 
 
 class LevelGenOracle(OracleLevel):
@@ -429,6 +494,7 @@ def _l(**kw):
 # Constructor arguments per level (iclr19_levels.py; written out independently of babyai_amd/levels.py,
 # tests/test_levels_table.py checks the two tables agree).
 SPECS = {
+    'GoToRedBallGrey': _g(num_dists=7, redball=True, grey_dists=True),
     'GoToRedBall': _g(num_dists=7, redball=True),
     'GoToRedBallNoDists': _g(num_dists=0, redball=True),
     'GoToObj': _g(num_dists=1, all_unique=True, check_reach=False),
@@ -449,6 +515,17 @@ SPECS = {
     'GoToObjMazeS5': _g(room_size=5, num_rows=3, num_cols=3, num_dists=1, connect=True),
     'GoToObjMazeS6': _g(room_size=6, num_rows=3, num_cols=3, num_dists=1, connect=True),
     'GoToObjMazeS7': _g(room_size=7, num_rows=3, num_cols=3, num_dists=1, connect=True),
+    'PutNextLocal': _g(num_dists=8, all_unique=True, instr='putnext', target='two_dists'),
+    'PutNextLocalS5N3': _g(room_size=5, num_dists=3, all_unique=True, instr='putnext', target='two_dists'),
+    'PutNextLocalS6N4': _g(room_size=6, num_dists=4, all_unique=True, instr='putnext', target='two_dists'),
+    'Pickup': _g(num_rows=3, num_cols=3, num_dists=18, connect=True, instr='pickup'),
+    'UnblockPickup': _g(num_rows=3, num_cols=3, num_dists=20, connect=True, check_reach=2, instr='pickup'),
+    'Open': _g(num_rows=3, num_cols=3, num_dists=18, connect=True, instr='open', target='door'),
+    'PutNext': _g(num_rows=3, num_cols=3, num_dists=18, connect=True, instr='putnext', target='two_dists'),
+    'Unlock': _g(num_rows=3, num_cols=3, num_dists=3, connect=True, lock=True, lock_color_excl=True,
+                 dists_per_room=True, instr='open', target='locked_door'),
+    'GoToImpUnlock': _g(num_rows=3, num_cols=3, num_dists=2, connect=True, lock=True, dists_per_room=True,
+                        instr='goto', target='locked_room_obj'),
     'PickupLoc': _l(action_kinds=('pickup',), instr_kinds=('action',), num_rows=1, num_cols=1, num_dists=8,
                     locked_room_prob=0, locations=True, unblocking=False),
     'GoToSeq': _l(action_kinds=('goto',), locked_room_prob=0, locations=False, unblocking=False),

@@ -67,6 +67,11 @@ def test_tables_agree():
             for k, dflt in (("locations", True), ("unblocking", True), ("implicit_unlock", True)):
                 assert bool(p[k]) == bool(kw.get(k, dflt)), (name, k)
         else:
-            for k, dflt in (("redball", False), ("connect", False), ("check_reach", True), ("doors_open", False),
-                            ("all_unique", False)):
+            for k, dflt in (("redball", False), ("connect", False), ("doors_open", False), ("all_unique", False),
+                            ("lock", False), ("lock_color_excl", False), ("dists_per_room", False), ("grey_dists", False)):
                 assert bool(p[k]) == bool(kw.get(k, dflt)), (name, k)
+            assert p["check_reach"] == int(kw.get("check_reach", True)), name
+            assert p["instr"] == {"goto": 1, "pickup": 2, "open": 3, "putnext": 4}[kw.get("instr", "goto")], name
+            tg = kw.get("target", "redball" if kw.get("redball") else "dist")
+            assert p["target"] == {"redball": 0, "dist": 1, "door": 2, "two_dists": 3, "locked_door": 4,
+                                   "locked_room_obj": 5}[tg], name

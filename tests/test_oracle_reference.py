@@ -62,6 +62,8 @@ def test_reference_constructor_args_match_table(level_dict):
                 assert bool(getattr(ref, k)) == bool(kw.get(k, d))
         elif hasattr(ref, "num_dists"):
             assert ref.num_dists == kw.get("num_dists", 8)
+        elif hasattr(ref, "num_objs"):
+            assert ref.num_objs == kw.get("num_dists", 8)
 
 
 def test_reference_own_smoke_test_passes_on_shim(level_dict):

@@ -45,6 +45,14 @@ PLAN = [
     ("SynthLoc", 8, 400, 0, 0, True),
     ("MiniBossLevel", 12, 500, 0, 2, True),
     ("BossLevel", 12, 900, 0, 0, True),
+    ("GoToRedBallGrey", 6, 100, 1, 0, False),
+    ("PutNextLocal", 8, 200, 1, 0, True),
+    ("Unlock", 8, 260, 1, 0, True),
+    ("GoToImpUnlock", 6, 300, 1, 0, True),
+    ("Open", 6, 150, 1, 0, True),
+    ("PutNext", 6, 300, 0, 0, True),
+    ("UnblockPickup", 6, 250, 1, 0, True),
+    ("Pickup", 4, 150, 0, 0, True),
 ]
 SEED_BASE = 1000
 
@@ -142,5 +150,7 @@ def trace(name, n_envs, n_steps, pre_resets, n_pix, expert=False):
 
 
 if __name__ == '__main__':
+    only = set(sys.argv[1:])
     for p in PLAN:
-        trace(*p)
+        if not only or p[0] in only:
+            trace(*p)
