@@ -60,6 +60,7 @@ struct bbai_env {
     int32_t* reset_list;  // [2][n]  double-buffered by step parity (pregen of step t reads while step t+1 writes)
     uint32_t* counters;   // [2][16] [p][0] = reset list length of parity p
     unsigned long long* total_resets;
+    uint8_t* tokens;      // optional caller-owned [n][72] mission token buffer kept current on resets
     hipStream_t side;     // look-ahead generation stream
     hipEvent_t ev_consumed, ev_pregen_done;
     int parity;
@@ -347,6 +348,51 @@ __global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_
 }
 
 // ------------------------------------------------------------------------------------------
+// k_tokens : mission strings as fixed-vocabulary token ids, produced on the device from the compiled
+// instruction program (grammar: babyai/levels/verifier.py:64-94,248-249,287-288,318-319,366-367,439-440,
+// 480-481,526-527).  Vocabulary ids = babyai_amd/missions.py VOCAB (1..32, 0 = padding).
+// ------------------------------------------------------------------------------------------
+constexpr int TOK_MAX = 72;      // longest sentence: two And-pairs of put-next clauses with locations
+struct TokOut {
+    uint8_t* p; int n;
+    __device__ __forceinline__ void put(int id) { if (n < TOK_MAX) p[n++] = (uint8_t)id; }
+};
+__device__ __forceinline__ void tok_desc(TokOut& o, DescInfo d) {
+    o.put(d.count > 1 ? 9 : 8);                         // a / the
+    if (d.color != 7) o.put(11 + d.color);              // red green blue purple yellow grey
+    o.put(24 - d.type);                                 // box ball key door
+    if (d.loc == LOC_FRONT) { o.put(21); o.put(22); o.put(23); o.put(24); }      // in front of you
+    else if (d.loc == LOC_BEHIND) { o.put(25); o.put(24); }                     // behind you
+    else if (d.loc == LOC_LEFT) { o.put(26); o.put(27); o.put(28); }            // on your left
+    else if (d.loc == LOC_RIGHT) { o.put(26); o.put(27); o.put(29); }           // on your right
+}
+__device__ __forceinline__ void tok_side(TokOut& o, const Prog* p, int base, int n) {
+    for (int q = 0; q < n; ++q) {
+        if (q) o.put(30);                                                        // and
+        const int kind = p->kind[base + q];
+        if (kind == L_GOTO) { o.put(1); o.put(2); }                              // go to
+        else if (kind == L_PICKUP) { o.put(3); o.put(4); }                       // pick up
+        else if (kind == L_OPEN) o.put(5);                                       // open
+        else o.put(6);                                                           // put
+        tok_desc(o, p->desc[base + q][0]);
+        if (kind == L_PUTNEXT) { o.put(7); o.put(2); tok_desc(o, p->desc[base + q][1]); }   // next to
+    }
+}
+__global__ __launch_bounds__(64) void k_tokens(LevelCfg c, int64_t n, const uint8_t* __restrict__ recs, uint8_t* __restrict__ tokens,
+                                               const int32_t* __restrict__ reset_list, const uint32_t* __restrict__ counter, int all) {
+    const int64_t count = all ? n : (int64_t)counter[0];
+    for (int64_t it = (int64_t)blockIdx.x * 64 + threadIdx.x; it < count; it += (int64_t)gridDim.x * 64) {
+        const int64_t env = all ? it : (int64_t)reset_list[it];
+        const Prog* p = (const Prog*)(recs + env * (int64_t)c.rec_bytes + c.off_prog);
+        TokOut o; o.p = tokens + env * TOK_MAX; o.n = 0;
+        tok_side(o, p, 0, p->n_a);
+        if (p->root == R_BEFORE) { o.put(31); tok_side(o, p, 2, p->n_b); }                   // , then
+        else if (p->root == R_AFTER) { o.put(32); o.put(24); tok_side(o, p, 2, p->n_b); }    // after you
+        while (o.n < TOK_MAX) o.p[o.n++] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
 extern "C" {
@@ -460,6 +506,9 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
                        e->hot, e->stale, e->next_rec, e->next_hot, list, counter, all, e->total_resets);
     hipLaunchKernelGGL(k_observe_list, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n,
                        e->rec, e->hot, image, dirs, list, counter, all);
+    if (e->tokens)
+        hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n, e->rec,
+                           e->tokens, list, counter, all);
     HIP_TRY(hipEventRecord(e->ev_consumed, s));
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_consumed, 0));
     hipLaunchKernelGGL(k_pregen, dim3(pregen_grid(hint)), dim3(64), 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt,
@@ -554,6 +603,22 @@ int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream
     hipLaunchKernelGGL(k_render, dim3(grid), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut,
                        e->n_tiles);
     HIP_TRY(hipGetLastError());
+    return BBAI_OK;
+}
+
+// Register (or clear with NULL) a caller-owned uint8[n][72] device buffer that the engine keeps filled with the
+// mission token ids of every env's current episode (rewritten whenever an env is reset).
+int bbai_set_token_buffer(bbai_env* e, uint8_t* tokens_dev) {
+    if (!e) return BBAI_ERR_ARG;
+    e->tokens = tokens_dev;
+    if (tokens_dev && e->live) {        // episodes already running: fill every row now
+        HIP_TRY(hipSetDevice(e->device));
+        HIP_TRY(hipDeviceSynchronize());
+        hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((e->n + 63) / 64, 4096)), dim3(64), 0, 0, e->cfg, e->n, e->rec,
+                           tokens_dev, e->reset_list, e->counters, 1);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
     return BBAI_OK;
 }
 

@@ -26,6 +26,7 @@ ATLAS_PATH = os.path.join(_HERE, "data", "tile_atlas_ts8.npz")
 OBS_BYTES = 147
 PIX = 56
 PROG_BYTES = 112
+TOK_MAX = 72
 
 _lib = None
 
@@ -54,6 +55,7 @@ def load_library():
     lib.bbai_step.argtypes = [P, P, P, P, P, P, I32, P]
     lib.bbai_set_atlas.argtypes = [P, P, I32, P]
     lib.bbai_render.argtypes = [P, P, P, P]
+    lib.bbai_set_token_buffer.argtypes = [P, P]
     lib.bbai_export_state.argtypes = [P, I64, I64, P, P, P]
     lib.bbai_import_state.argtypes = [P, I64, I64, P, P, P]
     lib.bbai_get_programs.argtypes = [P, I64, I64, P]
@@ -64,7 +66,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = (
     "bbai_version", "bbai_last_error", "bbai_fill_layout", "bbai_create", "bbai_destroy", "bbai_seed",
-    "bbai_reset", "bbai_step", "bbai_set_atlas", "bbai_render", "bbai_export_state", "bbai_import_state",
+    "bbai_reset", "bbai_step", "bbai_set_atlas", "bbai_render", "bbai_set_token_buffer", "bbai_export_state", "bbai_import_state",
     "bbai_get_programs", "bbai_reset_count",
 )
 
@@ -248,6 +250,15 @@ class BatchedBabyAIEnv(object):
         assert rec.shape == (count, self.cfg.rec_bytes) and hot.shape == (count, 16) and stale.shape == (count,)
         _check(self.lib, self.lib.bbai_import_state(self.handle, first, count, rec.ctypes.data, hot.ctypes.data,
                                                      stale.ctypes.data), "bbai_import_state")
+
+    def enable_instr_tokens(self):
+        """Keep `self.instr` (uint8[N, 72] on the device) filled with the mission token ids of the current
+        episodes -- the tensor fast path that replaces per-step regex tokenisation (format.py:59-75)."""
+        if getattr(self, "instr", None) is None:
+            with self.torch.cuda.device(self.dev_index):
+                self.instr = self.torch.zeros((self.num_envs, TOK_MAX), dtype=self.torch.uint8, device=self.device)
+            _check(self.lib, self.lib.bbai_set_token_buffer(self.handle, self.instr.data_ptr()), "bbai_set_token_buffer")
+        return self.instr
 
     def reset_count(self):
         v = ctypes.c_uint64(0)

@@ -82,6 +82,12 @@ int bbai_step(bbai_env* env, const uint8_t* actions_dev, uint8_t* image_dev, uin
 int bbai_set_atlas(bbai_env* env, const uint8_t* tiles_host, int n_tiles, const uint8_t* lut_host /* [2][256] */);
 int bbai_render(bbai_env* env, const uint8_t* image_dev, uint8_t* pixels_dev, void* stream);
 
+/* Mission text as token ids, device-resident (replaces the per-step regex tokenisation of every mission in
+ * InstructionsPreprocessor, babyai/utils/format.py:59-75): register a caller-owned uint8[N][72] buffer; the engine
+ * rewrites env i's row whenever env i starts a new episode.  Ids follow babyai_amd/missions.py VOCAB, 0 = padding. */
+#define BBAI_TOK_MAX 72
+int bbai_set_token_buffer(bbai_env* env, uint8_t* tokens_dev);
+
 /* State access (host buffers; synchronous): parity tests, checkpoints, mission strings. */
 int bbai_export_state(bbai_env* env, int64_t first, int64_t count, uint8_t* rec_host,
                       uint8_t* hot_host /* 16 B each */, uint64_t* stale_host);

@@ -149,3 +149,38 @@ def test_shard_independence(gpu):
     assert torch.equal(whole.reward, torch.cat([a.reward, b.reward]))
     assert torch.equal(whole.done, torch.cat([a.done, b.done]))
     assert whole.missions() == a.missions() + b.missions()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", ["BossLevel", "PutNextLocal", "SynthSeq"])
+def test_device_mission_tokens(gpu, level):
+    """k_tokens == tokenising the mission string the oracle/reference produces (format.py:64 regex split),
+    initially and after auto-resets; the tensor preprocessor pads like InstructionsPreprocessor."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from babyai_amd.missions import tokenize
+    from babyai_amd.preprocess import TensorObssPreprocessor
+    n = 256
+    env = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=11)
+    env.reset()
+    pre = TensorObssPreprocessor(env)          # registered after reset: rows are filled immediately
+    rng = np.random.RandomState(1)
+    for t in range(130 if level == "PutNextLocal" else 30):
+        obs, _, _, _ = env.step(torch.as_tensor(rng.randint(0, 7, size=n).astype(np.uint8), device=gpu))
+    batch = pre(obs)
+    torch.cuda.synchronize()
+    tok = env.instr.cpu().numpy()
+    missions = env.missions()
+    longest = 0
+    for i in range(n):
+        ids = tokenize(missions[i])
+        assert list(tok[i, :len(ids)]) == ids and not tok[i, len(ids):].any(), (i, missions[i])
+        longest = max(longest, len(ids))
+    assert batch.instr.shape == (n, longest) and batch.instr.dtype == torch.int64
+    assert batch.image.dtype == torch.float32 and batch.image.shape == (n, 7, 7, 3)
+    assert torch.equal(batch.image.to(torch.uint8), env.image)
+    sub = batch[torch.arange(0, n, 2, device=gpu)]
+    assert len(sub) == n // 2 and sub.instr.shape[0] == n // 2
+    if level == "PutNextLocal":
+        assert env.reset_count() > n
+    env.close()
