@@ -55,6 +55,8 @@ struct bbai_env {
     uint64_t* stale;      // [n]
     uint32_t* mt;         // [n][624]
     int32_t* mti;         // [n]
+    uint32_t* vhead;      // [n]     verifier program head (SoA, see VProg)
+    uint64_t* vset;       // [8][n]  obj_set bitmasks, k = 2*leaf + slot
     uint8_t* next_rec;    // [n][rec_bytes]  look-ahead slot: the env's next level, generated ahead of need
     Hot* next_hot;        // [n]
     int32_t* reset_list;  // [2][n]  double-buffered by step parity (pregen of step t reads while step t+1 writes)
@@ -115,6 +117,7 @@ __device__ __forceinline__ void observe_lane(const LevelCfg& c, const uint8_t* _
 
 __global__ __launch_bounds__(STEP_BLOCK) void k_step(LevelCfg c, int64_t n, uint8_t* __restrict__ recs,
                                                      Hot* __restrict__ hots, uint64_t* __restrict__ stales,
+                                                     const uint32_t* __restrict__ vheads, const uint64_t* __restrict__ vsets,
                                                      const uint8_t* __restrict__ actions, uint8_t* __restrict__ image,
                                                      uint8_t* __restrict__ dirs, float* __restrict__ rewards,
                                                      uint8_t* __restrict__ dones, int auto_reset,
@@ -130,7 +133,8 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(LevelCfg c, int64_t n, uint
         if (!h.frozen) {
             uint64_t stale = stales[env];
             float reward;
-            bool done = step_env(c, rec, h, stale, actions[env], reward);
+            VProg vp; vp.head = vheads[env]; vp.sets = vsets + env; vp.stride = n;
+            bool done = step_env(c, rec, vp, h, stale, actions[env], reward);
             if (done && !auto_reset) h.frozen = 1;
             want_reset = done && auto_reset;
             hots[env] = h;
@@ -248,7 +252,8 @@ __global__ __launch_bounds__(64) void k_pregen(LevelCfg c, int64_t n, uint8_t* _
 // look-ahead slot -> live state for the envs that finished (or all, on reset()): one wave copies one record
 __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t* __restrict__ recs, Hot* __restrict__ hots,
                                                  uint64_t* __restrict__ stales, const uint8_t* __restrict__ next_recs,
-                                                 const Hot* __restrict__ next_hots, const int32_t* __restrict__ reset_list,
+                                                 const Hot* __restrict__ next_hots, uint32_t* __restrict__ vheads,
+                                                 uint64_t* __restrict__ vsets, const int32_t* __restrict__ reset_list,
                                                  const uint32_t* __restrict__ counter, int all,
                                                  unsigned long long* __restrict__ total_resets) {
     const int64_t count = all ? n : (int64_t)counter[0];
@@ -260,12 +265,27 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
         const u32x4* src = (const u32x4*)(next_recs + env * (int64_t)c.rec_bytes);
         u32x4* dst = (u32x4*)(recs + env * (int64_t)c.rec_bytes);
         for (int k = lane; k < nvec; k += 64) dst[k] = src[k];
+        // the verifier's SoA view of the new program
+        const Prog* p = (const Prog*)(next_recs + env * (int64_t)c.rec_bytes + c.off_prog);
+        if (lane < 8) vsets[(int64_t)lane * n + env] = p->set[lane >> 1][lane & 1];
+        if (lane == 8) vheads[env] = vhead_pack(*p);
         if (lane == 0) {
             hots[env] = next_hots[env];
             stales[env] = 0;
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(total_resets, (unsigned long long)count);
+}
+
+// rebuild the SoA verifier view from the records (after bbai_import_state)
+__global__ void k_sync_prog(LevelCfg c, int64_t n, int64_t first, int64_t count, const uint8_t* __restrict__ recs,
+                            uint32_t* __restrict__ vheads, uint64_t* __restrict__ vsets) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int64_t env = first + i;
+    const Prog* p = (const Prog*)(recs + env * (int64_t)c.rec_bytes + c.off_prog);
+    for (int k = 0; k < 8; ++k) vsets[(int64_t)k * n + env] = p->set[k >> 1][k & 1];
+    vheads[env] = vhead_pack(*p);
 }
 
 // first observation of freshly generated episodes (lane = env over the reset list)
@@ -449,6 +469,8 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->stale, (size_t)n_envs * 8);
     alloc((void**)&e->mt, (size_t)n_envs * MT_N * 4);
     alloc((void**)&e->mti, (size_t)n_envs * 4);
+    alloc((void**)&e->vhead, (size_t)n_envs * 4);
+    alloc((void**)&e->vset, (size_t)n_envs * 8 * 8);
     alloc((void**)&e->next_rec, (size_t)n_envs * c.rec_bytes);
     alloc((void**)&e->next_hot, (size_t)n_envs * sizeof(Hot));
     alloc((void**)&e->reset_list, (size_t)n_envs * 4 * 2);
@@ -463,6 +485,8 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     }
     HIP_TRY(hipMemset(e->rec, 0, (size_t)n_envs * c.rec_bytes));
     HIP_TRY(hipMemset(e->next_rec, 0, (size_t)n_envs * c.rec_bytes));
+    HIP_TRY(hipMemset(e->vhead, 0, (size_t)n_envs * 4));
+    HIP_TRY(hipMemset(e->vset, 0, (size_t)n_envs * 64));
     HIP_TRY(hipMemset(e->counters, 0, 128));
     HIP_TRY(hipMemset(e->total_resets, 0, 8));
     {
@@ -483,7 +507,7 @@ void bbai_destroy(bbai_env* e) {
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->ev_consumed) (void)hipEventDestroy(e->ev_consumed);
     if (e->ev_pregen_done) (void)hipEventDestroy(e->ev_pregen_done);
-    void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->next_rec, e->next_hot, e->reset_list, e->counters,
+    void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->reset_list, e->counters,
                     e->total_resets, e->atlas, e->lut};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete e;
@@ -503,7 +527,7 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
     HIP_TRY(hipStreamWaitEvent(s, e->ev_pregen_done, 0));        // every earlier refill has landed
     const int64_t hint = all ? e->n : std::max<int64_t>(e->n / 64, 64);
     hipLaunchKernelGGL(k_consume, dim3((unsigned)std::min<int64_t>((hint + 3) / 4, 8192)), dim3(256), 0, s, e->cfg, e->n, e->rec,
-                       e->hot, e->stale, e->next_rec, e->next_hot, list, counter, all, e->total_resets);
+                       e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, list, counter, all, e->total_resets);
     hipLaunchKernelGGL(k_observe_list, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n,
                        e->rec, e->hot, image, dirs, list, counter, all);
     if (e->tokens)
@@ -573,7 +597,7 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
     uint32_t* counter = e->counters + 16 * e->parity;
     HIP_TRY(hipMemsetAsync(counter, 0, 4, s));
     hipLaunchKernelGGL(k_step, dim3((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), dim3(STEP_BLOCK), 0, s, e->cfg, e->n,
-                       e->rec, e->hot, e->stale, actions, image, dirs, rewards, dones, auto_reset, list, counter);
+                       e->rec, e->hot, e->stale, e->vhead, e->vset, actions, image, dirs, rewards, dones, auto_reset, list, counter);
     HIP_TRY(hipGetLastError());
     // the number of finished envs is only known on the device: fixed grids, device-side count
     if (auto_reset) return consume_and_refill(e, s, image, dirs, 0);
@@ -639,6 +663,12 @@ int bbai_import_state(bbai_env* e, int64_t first, int64_t count, const uint8_t* 
     if (rec) HIP_TRY(hipMemcpy(e->rec + first * e->cfg.rec_bytes, rec, (size_t)count * e->cfg.rec_bytes, hipMemcpyHostToDevice));
     if (hot) HIP_TRY(hipMemcpy(e->hot + first, hot, (size_t)count * sizeof(Hot), hipMemcpyHostToDevice));
     if (stale) HIP_TRY(hipMemcpy(e->stale + first, stale, (size_t)count * 8, hipMemcpyHostToDevice));
+    if (rec && count > 0) {
+        hipLaunchKernelGGL(k_sync_prog, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, e->cfg, e->n, first, count, e->rec,
+                           e->vhead, e->vset);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
     e->live = true;
     return BBAI_OK;
 }

@@ -18,13 +18,13 @@
 
 namespace bbai {
 
-struct EnvRef {             // views into one env's record
-    uint8_t* E; uint8_t* I; uint8_t* app; uint8_t* pos; const Prog* prog;
+struct EnvRef {             // views into one env's record + its verifier program (SoA)
+    uint8_t* E; uint8_t* I; uint8_t* app; uint8_t* pos; VProg prog;
 };
-BB_HD EnvRef env_ref(const LevelCfg& c, uint8_t* rec) {
+BB_HD EnvRef env_ref(const LevelCfg& c, uint8_t* rec, const VProg& vp) {
     EnvRef r;
     r.E = rec; r.I = rec + c.off_I; r.app = rec + c.off_app; r.pos = rec + c.off_pos;
-    r.prog = (const Prog*)(rec + c.off_prog);
+    r.prog = vp;
     return r;
 }
 
@@ -34,15 +34,18 @@ BB_HD int dir_dy(int d) { return (d == 1) - (d == 3); }
 // One ActionInstr.verify_action.  `visited` semantics: preCarrying is only updated when the
 // leaf is actually evaluated (verifier.py:331-334,394-396).
 BB_HD bool verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int leaf, int action) {
-    const int kind = r.prog->kind[leaf];
-    const uint64_t set0 = r.prog->set[leaf][0];
+    const int kind = r.prog.kind(leaf);
+    const uint64_t set0 = r.prog.set(leaf, 0);
     if (kind == L_GOTO) {
         // success iff front_pos is one of the recorded positions (obj_poss): live tracked
         // object in the front cell, or the remembered cell of one that left the grid since
-        // the last refresh.
+        // the last refresh.  The id plane is only consulted when the appearance plane (whose
+        // lines the observation needs anyway) shows an object there.
         int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
-        int id = r.I[i_index(c, fx, fy)];
-        if (id >= 2 && (set0 >> (id - 2) & 1)) return true;
+        if (e_type(r.E[e_index(c, fx, fy)]) >= T_DOOR) {
+            int id = r.I[i_index(c, fx, fy)];
+            if (id >= 2 && (set0 >> (id - 2) & 1)) return true;
+        }
         uint64_t m = set0 & stale;
         while (m) {
             int o = __builtin_ctzll(m);
@@ -54,9 +57,10 @@ BB_HD bool verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stal
     if (kind == L_OPEN) {
         if (action != A_TOGGLE) return false;
         int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
+        int fe = r.E[e_index(c, fx, fy)];
+        if (e_type(fe) != T_DOOR || e_state(fe) != S_OPEN) return false;
         int id = r.I[i_index(c, fx, fy)];
-        if (id < 2 || !(set0 >> (id - 2) & 1)) return false;
-        return e_state(r.E[e_index(c, fx, fy)]) == S_OPEN;
+        return id >= 2 && (set0 >> (id - 2) & 1);
     }
     // Pickup / PutNext share the preCarrying protocol.
     const int sh = 8 * leaf;
@@ -70,7 +74,7 @@ BB_HD bool verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stal
     if (action != A_DROP) return false;
     if (pre == NONE8 || !(set0 >> pre & 1)) return false;
     if (h.carry == pre) return false;               // drop failed: cur_pos == (-1,-1)
-    const uint64_t set1 = r.prog->set[leaf][1];
+    const uint64_t set1 = r.prog.set(leaf, 1);
     int x = r.pos[2 * pre], y = r.pos[2 * pre + 1];
     const int nx[4] = {x + 1, x - 1, x, x}, ny[4] = {y, y, y + 1, y - 1};
     for (int q = 0; q < 4; ++q) {
@@ -91,13 +95,13 @@ BB_HD bool verify_side(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stal
 }
 
 BB_HD bool verify_root(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action) {
-    const Prog* p = r.prog;
-    if (p->root == R_ACTION || p->root == R_AND) return verify_side(c, r, h, stale, 0, p->n_a, 1, action);
+    const VProg* p = &r.prog;
+    if (p->root() == R_ACTION || p->root() == R_AND) return verify_side(c, r, h, stale, 0, p->n_a(), 1, action);
     // Before: a then b; After: b then a.  The second part is verified with the SAME action in
     // the step the first part completes (verifier.py:463-464,504-505).
-    const bool before = p->root == R_BEFORE;
-    const int b1 = before ? 0 : 2, n1 = before ? p->n_a : p->n_b, s1 = before ? 1 : 3;
-    const int b2 = before ? 2 : 0, n2 = before ? p->n_b : p->n_a, s2 = before ? 3 : 1;
+    const bool before = p->root() == R_BEFORE;
+    const int b1 = before ? 0 : 2, n1 = before ? p->n_a() : p->n_b(), s1 = before ? 1 : 3;
+    const int b2 = before ? 2 : 0, n2 = before ? p->n_b() : p->n_a(), s2 = before ? 3 : 1;
     if (!(h.vstate & 1)) {
         if (!verify_side(c, r, h, stale, b1, n1, s1, action)) return false;
         h.vstate |= 1;
@@ -118,8 +122,8 @@ BB_HD float success_reward(int step, int max_steps) {
 }
 
 // MiniGridEnv.step + RoomGridLevel.step for one env.  Returns done; reward by reference.
-BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, Hot& h, uint64_t& stale, int action, float& reward) {
-    EnvRef r = env_ref(c, rec);
+BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, float& reward) {
+    EnvRef r = env_ref(c, rec, vp);
     h.step = (uint16_t)(h.step + 1);
     const int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
     const int ei = e_index(c, fx, fy), ii = i_index(c, fx, fy);

@@ -91,6 +91,24 @@ struct Prog {               // 112 bytes
 };
 static_assert(sizeof(Prog) == 112, "Prog layout");
 
+// The verifier's per-step view of the program, kept OUT of the record as struct-of-arrays so that k_step reads
+// it coalesced: a packed head word (tree shape + leaf kinds) and the obj_set bitmasks, set[k][env] with
+// k = 2*leaf + slot -- a single-leaf mission touches 4 + 8 bytes per env-step instead of a 112-byte gather.
+BB_HD uint32_t vhead_pack(const Prog& p) {
+    return (uint32_t)p.root | ((uint32_t)p.n_a << 2) | ((uint32_t)p.n_b << 4) | ((uint32_t)p.kind[0] << 8) |
+           ((uint32_t)p.kind[1] << 11) | ((uint32_t)p.kind[2] << 14) | ((uint32_t)p.kind[3] << 17);
+}
+struct VProg {
+    uint32_t head;
+    const uint64_t* sets;       // set(leaf, slot) = sets[(2*leaf + slot) * stride]
+    int64_t stride;
+    BB_HD int root() const { return head & 3; }
+    BB_HD int n_a() const { return (head >> 2) & 3; }
+    BB_HD int n_b() const { return (head >> 4) & 3; }
+    BB_HD int kind(int leaf) const { return (head >> (8 + 3 * leaf)) & 7; }
+    BB_HD uint64_t set(int leaf, int slot) const { return sets[(int64_t)(2 * leaf + slot) * stride]; }
+};
+
 struct Hot {                // 16 bytes, one per env, SoA array => one dwordx4 per lane
     uint8_t ax, ay, dir, carry;
     uint16_t step, max_steps;

@@ -51,7 +51,11 @@ int hs_generate(const LevelCfg* cfg, uint32_t* mt, int32_t* mti, uint8_t* rec, H
 }
 
 int hs_step(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int action, float* reward) {
-    return step_env(*cfg, rec, *hot, *stale, action, *reward) ? 1 : 0;
+    const Prog* p = (const Prog*)(rec + cfg->off_prog);
+    uint64_t sets[8];
+    for (int k = 0; k < 8; ++k) sets[k] = p->set[k >> 1][k & 1];
+    VProg vp; vp.head = vhead_pack(*p); vp.sets = sets; vp.stride = 1;
+    return step_env(*cfg, rec, vp, *hot, *stale, action, *reward) ? 1 : 0;
 }
 
 void hs_observe(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, uint8_t* out) {
