@@ -11,8 +11,8 @@
 //                  step() draws no randomness, so an env's level sequence is a pure function of
 //                  its seed: generation runs ahead of need on a second HIP stream and overlaps the
 //                  render kernel / the caller's policy instead of sitting on the step path.
-//   k_consume      wave = env over the reset list: look-ahead slot -> live state (coalesced copy).
-//   k_observe_list lane = env over the reset list: first observation of the new episodes.
+//   k_consume      wave = env over the reset list: look-ahead slot -> live state (coalesced copy), SoA verifier
+//                  view, first observation of the new episode.
 //   k_render       RGBImgPartialObsWrapper as a pure tile-atlas gather: atlas + per-cell tile ids
 //                  in LDS, 16 bytes per lane per store, a wave writes 1 KiB of contiguous pixels.
 //
@@ -57,15 +57,20 @@ struct bbai_env {
     int32_t* mti;         // [n]
     uint32_t* vhead;      // [n]     verifier program head (SoA, see VProg)
     uint64_t* vset;       // [8][n]  obj_set bitmasks, k = 2*leaf + slot
-    uint8_t* next_rec;    // [n][rec_bytes]  look-ahead slot: the env's next level, generated ahead of need
-    Hot* next_hot;        // [n]
-    int32_t* reset_list;  // [2][n]  double-buffered by step parity (pregen of step t reads while step t+1 writes)
-    uint32_t* counters;   // [2][16] [p][0] = reset list length of parity p
+    // look-ahead ring of depth D: every env has D pre-generated levels; a finished env consumes slot hot.slot and the
+    // side stream refills exactly that slot.  A refill issued at consume-tick t only has to land before tick t+D.
+    int depth;
+    uint8_t* next_rec;    // [D][n][rec_bytes]
+    Hot* next_hot;        // [D][n]
+    uint8_t* slot_ring;   // [D+1][n]  slot consumed by env at a given tick (read by that tick's refill)
+    int32_t* reset_list;  // [D+1][n]  ring by consume-tick (the refill of tick t reads while later steps write)
+    uint32_t* counters;   // [D+1][16] [r][0] = reset list length of ring entry r
     unsigned long long* total_resets;
     uint8_t* tokens;      // optional caller-owned [n][72] mission token buffer kept current on resets
     hipStream_t side;     // look-ahead generation stream
-    hipEvent_t ev_consumed, ev_pregen_done;
-    int parity;
+    hipEvent_t ev_consumed, ev_pregen[8];
+    int64_t tick;         // number of consume_and_refill calls so far
+    bool counter_clean;   // the current ring counter was zeroed by the previous k_consume
     uint8_t* atlas;       // [n_tiles][192]
     uint8_t* lut;         // [2][256]
     int n_tiles;
@@ -199,7 +204,8 @@ struct WaveCtx {
 __global__ __launch_bounds__(64) void k_pregen(LevelCfg c, int64_t n, uint8_t* __restrict__ next_recs,
                                                Hot* __restrict__ next_hots, uint32_t* __restrict__ mts,
                                                int32_t* __restrict__ mtis, const int32_t* __restrict__ reset_list,
-                                               const uint32_t* __restrict__ counter, int all) {
+                                               const uint32_t* __restrict__ counter, int all, int depth,
+                                               const uint8_t* __restrict__ slots) {
     __shared__ GenWork w;
     const int64_t count = all ? n : (int64_t)counter[0];
     const int lane = threadIdx.x;
@@ -209,14 +215,16 @@ __global__ __launch_bounds__(64) void k_pregen(LevelCfg c, int64_t n, uint8_t* _
         __syncthreads();
         for (int k = lane; k < MT_N; k += 64) w.mt[k] = mt[k];
         const int mti0 = mtis[env];
-        const int last_locked0 = next_hots[env].last_locked;      // LevelGen.locked_room survives episodes
+        const int slot = slots[env];                               // the ring slot this env just consumed
+        const int prev = slot == 0 ? depth - 1 : slot - 1;         // holds the level generated just before this one
+        const int last_locked0 = next_hots[(int64_t)prev * n + env].last_locked;   // LevelGen.locked_room survives episodes
         __syncthreads();
         Gen<WaveCtx> g(WaveCtx(), c, w, mti0, last_locked0 == NONE8 ? -1 : last_locked0);
         const int max_steps = g.generate();
         __syncthreads();
         // write-out: MT state, record planes, tables, program
         for (int k = lane; k < MT_N; k += 64) mt[k] = w.mt[k];
-        uint8_t* rec = next_recs + env * (int64_t)c.rec_bytes;
+        uint8_t* rec = next_recs + ((int64_t)slot * n + env) * (int64_t)c.rec_bytes;
         {
             const uint32_t* src = (const uint32_t*)w.E;
             uint32_t* dst = (uint32_t*)rec;
@@ -242,8 +250,8 @@ __global__ __launch_bounds__(64) void k_pregen(LevelCfg c, int64_t n, uint8_t* _
             h.pre4 = 0xFFFFFFFFu;
             h.vstate = 0; h.frozen = 0;
             h.last_locked = g.last_locked < 0 ? NONE8 : (uint8_t)g.last_locked;
-            h.pad = 0;
-            next_hots[env] = h;
+            h.slot = 0;
+            next_hots[(int64_t)slot * n + env] = h;
             mtis[env] = g.mti;
         }
     }
@@ -255,26 +263,39 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
                                                  const Hot* __restrict__ next_hots, uint32_t* __restrict__ vheads,
                                                  uint64_t* __restrict__ vsets, const int32_t* __restrict__ reset_list,
                                                  const uint32_t* __restrict__ counter, int all,
-                                                 unsigned long long* __restrict__ total_resets) {
+                                                 unsigned long long* __restrict__ total_resets, int depth,
+                                                 uint8_t* __restrict__ slots_out, uint8_t* __restrict__ image,
+                                                 uint8_t* __restrict__ dirs, uint32_t* __restrict__ next_counter) {
     const int64_t count = all ? n : (int64_t)counter[0];
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
     const int nvec = c.rec_bytes >> 4;
     for (int64_t it = wave; it < count; it += nwaves) {
         const int64_t env = all ? it : (int64_t)reset_list[it];
-        const u32x4* src = (const u32x4*)(next_recs + env * (int64_t)c.rec_bytes);
+        const int slot = hots[env].slot;
+        const uint8_t* nrec = next_recs + ((int64_t)slot * n + env) * (int64_t)c.rec_bytes;
+        const u32x4* src = (const u32x4*)nrec;
         u32x4* dst = (u32x4*)(recs + env * (int64_t)c.rec_bytes);
         for (int k = lane; k < nvec; k += 64) dst[k] = src[k];
         // the verifier's SoA view of the new program
-        const Prog* p = (const Prog*)(next_recs + env * (int64_t)c.rec_bytes + c.off_prog);
+        const Prog* p = (const Prog*)(nrec + c.off_prog);
         if (lane < 8) vsets[(int64_t)lane * n + env] = p->set[lane >> 1][lane & 1];
         if (lane == 8) vheads[env] = vhead_pack(*p);
         if (lane == 0) {
-            hots[env] = next_hots[env];
+            Hot h = next_hots[(int64_t)slot * n + env];
+            h.slot = (uint8_t)(slot + 1 == depth ? 0 : slot + 1);
+            hots[env] = h;
             stales[env] = 0;
+            slots_out[env] = (uint8_t)slot;
+            // first observation of the new episode, straight from the slot (identical bytes to the live copy)
+            observe_lane(c, nrec, h, image + env * OBS_BYTES);
+            dirs[env] = h.dir;
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(total_resets, (unsigned long long)count);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(total_resets, (unsigned long long)count);
+        if (next_counter) next_counter[0] = 0;      // the ring entry the next step's k_step will append to
+    }
 }
 
 // rebuild the SoA verifier view from the records (after bbai_import_state)
@@ -288,21 +309,7 @@ __global__ void k_sync_prog(LevelCfg c, int64_t n, int64_t first, int64_t count,
     vheads[env] = vhead_pack(*p);
 }
 
-// first observation of freshly generated episodes (lane = env over the reset list)
-__global__ __launch_bounds__(64) void k_observe_list(LevelCfg c, int64_t n, const uint8_t* __restrict__ recs,
-                                                     const Hot* __restrict__ hots, uint8_t* __restrict__ image,
-                                                     uint8_t* __restrict__ dirs, const int32_t* __restrict__ reset_list,
-                                                     const uint32_t* __restrict__ counters, int all) {
-    const int64_t count = all ? n : (int64_t)counters[0];
-    for (int64_t it = (int64_t)blockIdx.x * 64 + threadIdx.x; it < count; it += (int64_t)gridDim.x * 64) {
-        const int64_t env = all ? it : (int64_t)reset_list[it];
-        const Hot h = hots[env];
-        observe_lane(c, recs + env * (int64_t)c.rec_bytes, h, image + env * OBS_BYTES);
-        dirs[env] = h.dir;
-    }
-}
-
-__global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, Hot* __restrict__ next_hots, uint64_t* __restrict__ stales) {
+__global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, Hot* __restrict__ next_hots, uint64_t* __restrict__ stales, int depth) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         Hot h;
@@ -310,7 +317,7 @@ __global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, Hot* __restrict__ 
         h.carry = NONE8; h.frozen = 1; h.last_locked = NONE8;
         h.pre4 = 0xFFFFFFFFu;
         hots[i] = h;
-        next_hots[i] = h;
+        for (int d = 0; d < depth; ++d) next_hots[(int64_t)d * n + i] = h;
         stales[i] = 0;
     }
 }
@@ -471,10 +478,17 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->mti, (size_t)n_envs * 4);
     alloc((void**)&e->vhead, (size_t)n_envs * 4);
     alloc((void**)&e->vset, (size_t)n_envs * 8 * 8);
-    alloc((void**)&e->next_rec, (size_t)n_envs * c.rec_bytes);
-    alloc((void**)&e->next_hot, (size_t)n_envs * sizeof(Hot));
-    alloc((void**)&e->reset_list, (size_t)n_envs * 4 * 2);
-    alloc((void**)&e->counters, 128);
+    {
+        const char* ev = getenv("BBAI_LOOKAHEAD");       // look-ahead depth (levels generated ahead per env), default 2
+        int d = ev ? atoi(ev) : 2;
+        e->depth = d < 1 ? 1 : (d > 8 ? 8 : d);
+    }
+    const size_t D = (size_t)e->depth;
+    alloc((void**)&e->next_rec, D * (size_t)n_envs * c.rec_bytes);
+    alloc((void**)&e->next_hot, D * (size_t)n_envs * sizeof(Hot));
+    alloc((void**)&e->slot_ring, (D + 1) * (size_t)n_envs);
+    alloc((void**)&e->reset_list, (D + 1) * (size_t)n_envs * 4);
+    alloc((void**)&e->counters, (D + 1) * 64);
     alloc((void**)&e->total_resets, 8);
     alloc((void**)&e->atlas, MAX_TILES * TILE_BYTES);
     alloc((void**)&e->lut, 512);
@@ -484,17 +498,18 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
         return BBAI_ERR_NOMEM;
     }
     HIP_TRY(hipMemset(e->rec, 0, (size_t)n_envs * c.rec_bytes));
-    HIP_TRY(hipMemset(e->next_rec, 0, (size_t)n_envs * c.rec_bytes));
+    HIP_TRY(hipMemset(e->next_rec, 0, D * (size_t)n_envs * c.rec_bytes));
+    HIP_TRY(hipMemset(e->slot_ring, 0, (D + 1) * (size_t)n_envs));
     HIP_TRY(hipMemset(e->vhead, 0, (size_t)n_envs * 4));
     HIP_TRY(hipMemset(e->vset, 0, (size_t)n_envs * 64));
-    HIP_TRY(hipMemset(e->counters, 0, 128));
+    HIP_TRY(hipMemset(e->counters, 0, (D + 1) * 64));
     HIP_TRY(hipMemset(e->total_resets, 0, 8));
     {
         int lo = 0, hi = 0;     // look-ahead generation should get wave slots as soon as any free up
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIP_TRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, hi));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_consumed, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_pregen_done, hipEventDisableTiming));
+        for (int k = 0; k < e->depth; ++k) HIP_TRY(hipEventCreateWithFlags(&e->ev_pregen[k], hipEventDisableTiming));
     }
     *out = e;
     return BBAI_OK;
@@ -506,8 +521,8 @@ void bbai_destroy(bbai_env* e) {
     (void)hipDeviceSynchronize();
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->ev_consumed) (void)hipEventDestroy(e->ev_consumed);
-    if (e->ev_pregen_done) (void)hipEventDestroy(e->ev_pregen_done);
-    void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->reset_list, e->counters,
+    for (int k = 0; k < 8; ++k) if (e->ev_pregen[k]) (void)hipEventDestroy(e->ev_pregen[k]);
+    void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->slot_ring, e->reset_list, e->counters,
                     e->total_resets, e->atlas, e->lut};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete e;
@@ -521,25 +536,28 @@ static unsigned pregen_grid(int64_t count_hint) {
 
 // main stream: slots -> live state (+ first obs); side stream: refill the consumed slots.
 static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_t* dirs, int all) {
-    const int p = e->parity;
-    int32_t* list = e->reset_list + (size_t)p * e->n;
-    uint32_t* counter = e->counters + 16 * p;
-    HIP_TRY(hipStreamWaitEvent(s, e->ev_pregen_done, 0));        // every earlier refill has landed
+    const int D = e->depth;
+    const int r = (int)(e->tick % (D + 1));          // ring entry of this consume-tick (list, counter, slot ids)
+    const int q = (int)(e->tick % D);                // event of the refill issued D ticks ago == the one we re-record
+    int32_t* list = e->reset_list + (size_t)r * e->n;
+    uint32_t* counter = e->counters + 16 * r;
+    uint8_t* slots = e->slot_ring + (size_t)r * e->n;
+    HIP_TRY(hipStreamWaitEvent(s, e->ev_pregen[q], 0));          // the slots consumed now were refilled >= D ticks ago
     const int64_t hint = all ? e->n : std::max<int64_t>(e->n / 64, 64);
     hipLaunchKernelGGL(k_consume, dim3((unsigned)std::min<int64_t>((hint + 3) / 4, 8192)), dim3(256), 0, s, e->cfg, e->n, e->rec,
-                       e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, list, counter, all, e->total_resets);
-    hipLaunchKernelGGL(k_observe_list, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n,
-                       e->rec, e->hot, image, dirs, list, counter, all);
+                       e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, list, counter, all, e->total_resets, D, slots,
+                       image, dirs, e->counters + 16 * (int)((e->tick + 1) % (D + 1)));
     if (e->tokens)
         hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n, e->rec,
                            e->tokens, list, counter, all);
     HIP_TRY(hipEventRecord(e->ev_consumed, s));
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_consumed, 0));
     hipLaunchKernelGGL(k_pregen, dim3(pregen_grid(hint)), dim3(64), 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt,
-                       e->mti, list, counter, all);
-    HIP_TRY(hipEventRecord(e->ev_pregen_done, e->side));
+                       e->mti, list, counter, all, D, slots);
+    HIP_TRY(hipEventRecord(e->ev_pregen[q], e->side));
     HIP_TRY(hipGetLastError());
-    e->parity ^= 1;
+    e->tick++;
+    e->counter_clean = true;
     return BBAI_OK;
 }
 
@@ -564,12 +582,16 @@ int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
     std::vector<int32_t> idx((size_t)n, MT_N);
     HIP_TRY(hipMemcpy(e->mti, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipDeviceSynchronize());
-    hipLaunchKernelGGL(k_init_hot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->side, n, e->hot, e->next_hot, e->stale);
-    // fill every env's look-ahead slot with the first level of its stream
-    hipLaunchKernelGGL(k_pregen, dim3(pregen_grid(n)), dim3(64), 0, e->side, e->cfg, n, e->next_rec, e->next_hot, e->mt, e->mti,
-                       e->reset_list, e->counters, 1);
+    hipLaunchKernelGGL(k_init_hot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->side, n, e->hot, e->next_hot, e->stale, e->depth);
+    // fill every env's look-ahead ring with the first D levels of its stream (slot order == stream order)
+    for (int d = 0; d < e->depth; ++d) {
+        HIP_TRY(hipMemsetAsync(e->slot_ring, d, (size_t)n, e->side));
+        hipLaunchKernelGGL(k_pregen, dim3(pregen_grid(n)), dim3(64), 0, e->side, e->cfg, n, e->next_rec, e->next_hot, e->mt, e->mti,
+                           e->reset_list, e->counters, 1, e->depth, e->slot_ring);
+    }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e->ev_pregen_done, e->side));
+    for (int k = 0; k < e->depth; ++k) HIP_TRY(hipEventRecord(e->ev_pregen[k], e->side));
+    e->tick = 0;
     HIP_TRY(hipDeviceSynchronize());
     e->seeded = true;
     e->live = false;
@@ -593,9 +615,11 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
     if (!e->live) { snprintf(g_err, sizeof(g_err), "step before reset"); return BBAI_ERR_STATE; }
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
-    int32_t* list = e->reset_list + (size_t)e->parity * e->n;
-    uint32_t* counter = e->counters + 16 * e->parity;
-    HIP_TRY(hipMemsetAsync(counter, 0, 4, s));
+    const int r = (int)(e->tick % (e->depth + 1));
+    int32_t* list = e->reset_list + (size_t)r * e->n;
+    uint32_t* counter = e->counters + 16 * r;
+    if (!auto_reset || !e->counter_clean) HIP_TRY(hipMemsetAsync(counter, 0, 4, s));
+    e->counter_clean = false;
     hipLaunchKernelGGL(k_step, dim3((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), dim3(STEP_BLOCK), 0, s, e->cfg, e->n,
                        e->rec, e->hot, e->stale, e->vhead, e->vset, actions, image, dirs, rewards, dones, auto_reset, list, counter);
     HIP_TRY(hipGetLastError());

@@ -40,9 +40,28 @@ struct GenWork {                                 // lives in LDS on the device
 // Ctx contract: lane(), nlanes(), sync(), shfl_up1/shfl_down1(v) (neighbour lane's value, 0 at the
 // ends), any(pred).  Host: 0,1,no-ops.  Device: lane id in the wave, 64, workgroup barrier (one wave
 // per workgroup), wave shuffles / ballot.
+// Optional phase profiling (tools/genprof.hip): a Ctx that defines `static constexpr bool kProfile = true` and
+// `now()` gets per-phase cycle totals in prof[]; the product contexts leave it off and the hooks vanish.
+template <class C, class = void> struct ctx_profiles { static constexpr bool value = false; };
+template <class C> struct ctx_profiles<C, decltype((void)C::kProfile)> { static constexpr bool value = C::kProfile; };
+enum : int { PH_BUILD = 0, PH_LOCK = 1, PH_CONNECT = 2, PH_DISTS = 3, PH_AGENT = 4, PH_REACH = 5, PH_INSTR = 6, PH_VALIDATE = 7,
+             PH_ATTEMPTS = 8, PH_DRAWS = 9, PH_TWISTS = 10, PH_N = 11 };
+
 template <class Ctx>
 struct Gen {
     Ctx ctx;
+    unsigned long long prof[PH_N] = {};
+    unsigned long long t_last = 0;
+    BB_HD void tick(int phase) {
+        if constexpr (ctx_profiles<Ctx>::value) {
+            unsigned long long t = ctx.now();
+            prof[phase] += t - t_last;
+            t_last = t;
+        }
+    }
+    BB_HD void count(int what) {
+        if constexpr (ctx_profiles<Ctx>::value) prof[what]++;
+    }
     const LevelCfg& cfg;
     GenWork& w;
     int mti;                 // MT19937 output index (wave-uniform)
@@ -110,7 +129,8 @@ struct Gen {
         twist_chunk(623, 624);    // uses new[396] and new[0]
     }
     BB_HD uint32_t next_u32() {
-        if (mti >= MT_N) { twist(); mti = 0; }
+        if (mti >= MT_N) { twist(); mti = 0; count(PH_TWISTS); }
+        count(PH_DRAWS);
         uint32_t y = w.mt[mti++];
         y ^= (y >> 11);
         y ^= (y << 7) & 0x9d2c5680u;
@@ -537,6 +557,7 @@ struct Gen {
 
     // LevelGen.gen_mission
     BB_HD bool mission_levelgen() {
+        tick(PH_BUILD);
         if (rand_float01() < cfg.locked_room_prob) {
             // add_locked_room
             int door_color;
@@ -558,16 +579,23 @@ struct Gen {
                 break;
             }
         }
+        tick(PH_LOCK);
         if (!connect_all()) return false;
+        tick(PH_CONNECT);
         if (!add_distractors(cfg.num_dists, false)) return false;
+        tick(PH_DISTS);
         for (;;) {
             if (!place_agent()) return false;
             if (room_of(ax, ay) == locked_room) continue;
             break;
         }
+        tick(PH_AGENT);
         if (!cfg.unblocking && !objs_reachable()) return false;
+        tick(PH_REACH);
         prep_masks();
-        return rand_instr();
+        bool ok = rand_instr();
+        tick(PH_INSTR);
+        return ok;
     }
 
     BB_HD void set_desc(int leaf, int slot, int obj) {
@@ -618,23 +646,28 @@ struct Gen {
                 target = locked_door;
             }
         } else {
+            tick(PH_BUILD);
             if (!place_agent()) return false;
+            tick(PH_AGENT);
             if (cfg.redball) {
                 target = add_object(0, T_BALL, C_RED);
                 if (target < 0) return false;
             }
             if (cfg.connect && !connect_all()) return false;
+            tick(PH_CONNECT);
             first = nobj;
             ndist = cfg.num_dists;
             if (!add_distractors(ndist, cfg.all_unique != 0)) return false;
+            tick(PH_DISTS);
             if (cfg.grey_dists)
                 for (int o = first; o < nobj; ++o) {
                     int e = e_make(e_type(w.app[o]), C_GREY, 0);
                     w.app[o] = e;
                     w.E[eidx(w.px[o], w.py[o])] = e;
                 }
-            if (cfg.check_reach == 1 && !objs_reachable()) return false;
-            if (cfg.check_reach == 2 && objs_reachable()) return false;     // UnblockPickup :383-386
+            if (cfg.check_reach == 1 && !objs_reachable()) { tick(PH_REACH); return false; }
+            if (cfg.check_reach == 2 && objs_reachable()) { tick(PH_REACH); return false; }     // UnblockPickup :383-386
+            tick(PH_REACH);
             if (cfg.target == TG_DIST) {
                 target = first + rand_int(0, ndist);                        // _rand_elem(objs)
             } else if (cfg.target == TG_TWO_DISTS) {                        // _rand_subset(objs, 2)
@@ -674,10 +707,15 @@ struct Gen {
     // RoomGridLevel._gen_grid: retry until a mission is generated and validated.
     // Returns max_steps (levelgen.py:42-45).
     BB_HD int generate() {
+        if constexpr (ctx_profiles<Ctx>::value) t_last = ctx.now();
         for (;;) {
+            count(PH_ATTEMPTS);
             build_rooms();
             bool ok = cfg.kind == K_LEVELGEN ? mission_levelgen() : mission_goto();
-            if (ok && validate()) break;
+            tick(PH_INSTR);
+            bool v = ok && validate();
+            tick(PH_VALIDATE);
+            if (v) break;
         }
         ctx.sync();
         int navs = 0;

@@ -117,7 +117,7 @@ struct Hot {                // 16 bytes, one per env, SoA array => one dwordx4 p
     uint8_t vstate;         // bit0 Seq first part done; bits1,2 side-A And a/b; bits3,4 side-B And a/b
     uint8_t frozen;         // ManyEnvs semantics: finished, waiting for an explicit reset
     uint8_t last_locked;    // LevelGen.locked_room survives episodes (levelgen.py:284,325,384): room idx or NONE8
-    uint8_t pad;
+    uint8_t slot;           // look-ahead ring: which slot holds this env's next level
 };
 static_assert(sizeof(Hot) == 16, "Hot layout");
 
