@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prewarm-seconds", type=float, default=2.0, help="untimed GPU activity before the warmup steps")
     args = ap.parse_args()
 
     import torch
@@ -72,6 +73,17 @@ def main():
     gen.manual_seed(1234 + rank)
     actions = torch.randint(0, 7, (K + W, E), dtype=torch.uint8, device=dev, generator=gen)
     torch.cuda.synchronize()
+
+    # clock ramp: a cold GPU spends its first second or so below its sustained clocks; keep it busy with an
+    # untimed fill stream before the (short) warmup so the timed region sees steady-state clocks
+    if args.prewarm_seconds > 0:
+        scratch = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        t_end = time.perf_counter() + args.prewarm_seconds
+        while time.perf_counter() < t_end:
+            for _ in range(20):
+                scratch.fill_(1)
+            torch.cuda.synchronize()
+        del scratch
 
     def barrier():
         if dist is not None:
