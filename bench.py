@@ -37,7 +37,9 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prewarm-seconds", type=float, default=2.0, help="untimed GPU activity before the warmup steps")
+    ap.add_argument("--prewarm-seconds", type=float, default=1.0, help="untimed GPU activity before the warmup steps")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (test rigs: ranks may share a GPU)")
+    ap.add_argument("--share-device", action="store_true", help="test rigs only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -48,8 +50,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.share_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU path)")
@@ -86,6 +93,7 @@ def main():
         del scratch
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -102,10 +110,11 @@ def main():
     dt = time.perf_counter() - t0
     resets = env.reset_count() - resets0
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        rdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
+        tt = torch.tensor([dt], device=rdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        rr = torch.tensor([resets], device=dev, dtype=torch.int64)
+        rr = torch.tensor([resets], device=rdev, dtype=torch.int64)
         dist.all_reduce(rr)
         resets = int(rr.item())
 
