@@ -57,20 +57,25 @@ struct bbai_env {
     int32_t* mti;         // [n]
     uint32_t* vhead;      // [n]     verifier program head (SoA, see VProg)
     uint64_t* vset;       // [8][n]  obj_set bitmasks, k = 2*leaf + slot
-    // look-ahead ring of depth D: every env has D pre-generated levels; a finished env consumes slot hot.slot and the
-    // side stream refills exactly that slot.  A refill issued at consume-tick t only has to land before tick t+D.
-    int depth;
+    // Look-ahead ring of depth D = 2B: every env owns D pre-generated levels; a finished env consumes slot hot.slot.
+    // Consume-ticks are grouped into windows of B ticks; the slots consumed during window w are refilled by ONE
+    // k_pregen launch at the end of the window (so the generator's slowest level is paid once per B ticks), and
+    // that refill only has to land before window w+2 starts (worst case an env consumes one slot per tick).
+    int depth, period;    // D, B
     uint8_t* next_rec;    // [D][n][rec_bytes]
     Hot* next_hot;        // [D][n]
-    uint8_t* slot_ring;   // [D+1][n]  slot consumed by env at a given tick (read by that tick's refill)
-    int32_t* reset_list;  // [D+1][n]  ring by consume-tick (the refill of tick t reads while later steps write)
-    uint32_t* counters;   // [D+1][16] [r][0] = reset list length of ring entry r
+    uint8_t* pending;     // [3][n]  per window buffer: slots consumed by env in the window (0 = not in the window)
+    uint8_t* first_slot;  // [3][n]  first slot the env consumed in the window
+    int32_t* win_list;    // [3][n]  unique envs of the window (when it was not a reset-everything window)
+    uint32_t* win_count;  // [3][16]
+    int win_all[3];       // window contained a reset() of every env: refill iterates all envs
+    int32_t* reset_list;  // [n]     envs finished by the current step (k_step -> k_consume / k_tokens)
+    uint32_t* counters;   // [16]    [0] = reset list length
     unsigned long long* total_resets;
     uint8_t* tokens;      // optional caller-owned [n][72] mission token buffer kept current on resets
     hipStream_t side;     // look-ahead generation stream
-    hipEvent_t ev_consumed, ev_pregen[8];
+    hipEvent_t ev_consumed, ev_refill[3];
     int64_t tick;         // number of consume_and_refill calls so far
-    bool counter_clean;   // the current ring counter was zeroed by the previous k_consume
     uint8_t* atlas;       // [n_tiles][192]
     uint8_t* lut;         // [2][256]
     int n_tiles;
@@ -118,6 +123,34 @@ __device__ __forceinline__ void observe_lane(const LevelCfg& c, const uint8_t* _
             uint8_t* o = dst + (vi * VIEW + vj) * 3;
             o[0] = v ? e_type(e) : 0; o[1] = v ? e_color(e) : 0; o[2] = v ? e_state(e) : 0;
         }
+}
+
+// Wave-cooperative observation of ONE env (used where a wave owns an env: k_consume): lane l < 49 owns view cell
+// (vi, vj) = (l % 7, l / 7); the opacity mask of the whole view is one ballot; every lane runs the 7-row
+// visibility sweep on it and writes its own three bytes.
+__device__ __forceinline__ void observe_wave(const LevelCfg& c, const uint8_t* __restrict__ rec, const Hot& h,
+                                             uint8_t* __restrict__ dst, int lane) {
+    const int vi = lane % VIEW, vj = lane / VIEW;
+    int e = E_EMPTY;
+    if (lane < VIEW * VIEW) {
+        int x, y;
+        view_to_world(h.ax, h.ay, h.dir, vi, vj, x, y);
+        e = rec[e_index(c, x, y)];
+    }
+    const unsigned long long opaque = __ballot(lane < VIEW * VIEW && e_opaque(e));
+    uint32_t opq[VIEW], vis[VIEW];
+#pragma unroll
+    for (int r = 0; r < VIEW; ++r) opq[r] = (uint32_t)(opaque >> (VIEW * r)) & 0x7Fu;
+    process_vis_rows(opq, vis);
+    if (lane < VIEW * VIEW) {
+        if (vi == 3 && vj == 6) e = h.carry != NONE8 ? rec[c.off_app + h.carry] : (int)E_EMPTY;
+        uint32_t row = 0;
+#pragma unroll
+        for (int r = 0; r < VIEW; ++r) row = (vj == r) ? vis[r] : row;
+        const bool v = row >> vi & 1;
+        uint8_t* o = dst + (vi * VIEW + vj) * 3;
+        o[0] = v ? e_type(e) : 0; o[1] = v ? e_color(e) : 0; o[2] = v ? e_state(e) : 0;
+    }
 }
 
 __global__ __launch_bounds__(STEP_BLOCK) void k_step(LevelCfg c, int64_t n, uint8_t* __restrict__ recs,
@@ -203,56 +236,73 @@ struct WaveCtx {
 
 __global__ __launch_bounds__(64) void k_pregen(LevelCfg c, int64_t n, uint8_t* __restrict__ next_recs,
                                                Hot* __restrict__ next_hots, uint32_t* __restrict__ mts,
-                                               int32_t* __restrict__ mtis, const int32_t* __restrict__ reset_list,
-                                               const uint32_t* __restrict__ counter, int all, int depth,
-                                               const uint8_t* __restrict__ slots) {
+                                               int32_t* __restrict__ mtis, const int32_t* __restrict__ win_list,
+                                               const uint32_t* __restrict__ win_count, int all, int depth,
+                                               uint8_t* __restrict__ pending, const uint8_t* __restrict__ first_slot) {
     __shared__ GenWork w;
-    const int64_t count = all ? n : (int64_t)counter[0];
+    int64_t count = n;
+    if (!all) {                                          // window list = concatenated per-tick lists
+        count = 0;
+        for (int j = 0; j < 8; ++j) count += (int64_t)win_count[1 + j];
+    }
     const int lane = threadIdx.x;
     for (int64_t it = blockIdx.x; it < count; it += gridDim.x) {
-        const int64_t env = all ? it : (int64_t)reset_list[it];
+        const int64_t env = all ? it : (int64_t)win_list[it];
+        if (env < 0) continue;                           // repeat consumption of an env already listed in this window
+        const int cnt = pending[env];                    // levels to generate for this env (consecutive ring slots)
+        if (cnt == 0) continue;                          // (all-mode: env was not consumed in this window)
         uint32_t* mt = mts + env * MT_N;
         __syncthreads();
         for (int k = lane; k < MT_N; k += 64) w.mt[k] = mt[k];
-        const int mti0 = mtis[env];
-        const int slot = slots[env];                               // the ring slot this env just consumed
-        const int prev = slot == 0 ? depth - 1 : slot - 1;         // holds the level generated just before this one
-        const int last_locked0 = next_hots[(int64_t)prev * n + env].last_locked;   // LevelGen.locked_room survives episodes
+        int mti = mtis[env];
+        int slot = first_slot[env];
+        const int prev = slot == 0 ? depth - 1 : slot - 1;          // holds the level generated just before
+        int last_locked = next_hots[(int64_t)prev * n + env].last_locked;   // LevelGen.locked_room survives episodes
+        last_locked = last_locked == NONE8 ? -1 : last_locked;
+        for (int j = 0; j < cnt; ++j) {
+            __syncthreads();
+            Gen<WaveCtx> g(WaveCtx(), c, w, mti, last_locked);
+            const int max_steps = g.generate();
+            mti = g.mti;
+            last_locked = g.last_locked;
+            __syncthreads();
+            // write-out: record planes, tables, program
+            uint8_t* rec = next_recs + ((int64_t)slot * n + env) * (int64_t)c.rec_bytes;
+            {
+                const uint32_t* src = (const uint32_t*)w.E;
+                uint32_t* dst = (uint32_t*)rec;
+                const int ndw = (c.ES * c.EH) >> 2;
+                for (int k = lane; k < ndw; k += 64) dst[k] = src[k];
+            }
+            for (int k = lane; k < c.W * c.H; k += 64) rec[c.off_I + k] = w.I[k];
+            for (int k = lane; k < c.maxo; k += 64) {
+                bool used = k < g.nobj;
+                rec[c.off_app + k] = used ? w.app[k] : 0;
+                rec[c.off_pos + 2 * k] = used ? w.px[k] : 0;
+                rec[c.off_pos + 2 * k + 1] = used ? w.py[k] : 0;
+            }
+            {
+                const uint32_t* src = (const uint32_t*)&w.prog;
+                uint32_t* dst = (uint32_t*)(rec + c.off_prog);
+                for (int k = lane; k < (int)(sizeof(Prog) / 4); k += 64) dst[k] = src[k];
+            }
+            if (lane == 0) {
+                Hot h;
+                h.ax = (uint8_t)g.ax; h.ay = (uint8_t)g.ay; h.dir = (uint8_t)g.adir; h.carry = NONE8;
+                h.step = 0; h.max_steps = (uint16_t)max_steps;
+                h.pre4 = 0xFFFFFFFFu;
+                h.vstate = 0; h.frozen = 0;
+                h.last_locked = last_locked < 0 ? NONE8 : (uint8_t)last_locked;
+                h.slot = 0;
+                next_hots[(int64_t)slot * n + env] = h;
+            }
+            slot = slot + 1 == depth ? 0 : slot + 1;
+        }
         __syncthreads();
-        Gen<WaveCtx> g(WaveCtx(), c, w, mti0, last_locked0 == NONE8 ? -1 : last_locked0);
-        const int max_steps = g.generate();
-        __syncthreads();
-        // write-out: MT state, record planes, tables, program
         for (int k = lane; k < MT_N; k += 64) mt[k] = w.mt[k];
-        uint8_t* rec = next_recs + ((int64_t)slot * n + env) * (int64_t)c.rec_bytes;
-        {
-            const uint32_t* src = (const uint32_t*)w.E;
-            uint32_t* dst = (uint32_t*)rec;
-            const int ndw = (c.ES * c.EH) >> 2;
-            for (int k = lane; k < ndw; k += 64) dst[k] = src[k];
-        }
-        for (int k = lane; k < c.W * c.H; k += 64) rec[c.off_I + k] = w.I[k];
-        for (int k = lane; k < c.maxo; k += 64) {
-            bool used = k < g.nobj;
-            rec[c.off_app + k] = used ? w.app[k] : 0;
-            rec[c.off_pos + 2 * k] = used ? w.px[k] : 0;
-            rec[c.off_pos + 2 * k + 1] = used ? w.py[k] : 0;
-        }
-        {
-            const uint32_t* src = (const uint32_t*)&w.prog;
-            uint32_t* dst = (uint32_t*)(rec + c.off_prog);
-            for (int k = lane; k < (int)(sizeof(Prog) / 4); k += 64) dst[k] = src[k];
-        }
         if (lane == 0) {
-            Hot h;
-            h.ax = (uint8_t)g.ax; h.ay = (uint8_t)g.ay; h.dir = (uint8_t)g.adir; h.carry = NONE8;
-            h.step = 0; h.max_steps = (uint16_t)max_steps;
-            h.pre4 = 0xFFFFFFFFu;
-            h.vstate = 0; h.frozen = 0;
-            h.last_locked = g.last_locked < 0 ? NONE8 : (uint8_t)g.last_locked;
-            h.slot = 0;
-            next_hots[(int64_t)slot * n + env] = h;
-            mtis[env] = g.mti;
+            mtis[env] = mti;
+            pending[env] = 0;                            // buffer entry is free for a later window
         }
     }
 }
@@ -264,9 +314,14 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
                                                  uint64_t* __restrict__ vsets, const int32_t* __restrict__ reset_list,
                                                  const uint32_t* __restrict__ counter, int all,
                                                  unsigned long long* __restrict__ total_resets, int depth,
-                                                 uint8_t* __restrict__ slots_out, uint8_t* __restrict__ image,
-                                                 uint8_t* __restrict__ dirs, uint32_t* __restrict__ next_counter) {
+                                                 uint8_t* __restrict__ pending, uint8_t* __restrict__ first_slot,
+                                                 int32_t* __restrict__ win_list, uint32_t* __restrict__ win_count, int pos,
+                                                 uint8_t* __restrict__ image, uint8_t* __restrict__ dirs) {
     const int64_t count = all ? n : (int64_t)counter[0];
+    // this tick's entries go behind those of the window's earlier ticks (their counts were written by earlier
+    // launches); no atomics: an env appears at most once per tick, repeats within the window are marked -1
+    int64_t base = 0;
+    for (int j = 0; j < pos; ++j) base += (int64_t)win_count[1 + j];
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
     const int nvec = c.rec_bytes >> 4;
@@ -281,20 +336,24 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
         const Prog* p = (const Prog*)(nrec + c.off_prog);
         if (lane < 8) vsets[(int64_t)lane * n + env] = p->set[lane >> 1][lane & 1];
         if (lane == 8) vheads[env] = vhead_pack(*p);
+        Hot h = next_hots[(int64_t)slot * n + env];
+        h.slot = (uint8_t)(slot + 1 == depth ? 0 : slot + 1);
+        // first observation of the new episode, straight from the slot (identical bytes to the live copy)
+        observe_wave(c, nrec, h, image + env * OBS_BYTES, lane);
         if (lane == 0) {
-            Hot h = next_hots[(int64_t)slot * n + env];
-            h.slot = (uint8_t)(slot + 1 == depth ? 0 : slot + 1);
             hots[env] = h;
             stales[env] = 0;
-            slots_out[env] = (uint8_t)slot;
-            // first observation of the new episode, straight from the slot (identical bytes to the live copy)
-            observe_lane(c, nrec, h, image + env * OBS_BYTES);
             dirs[env] = h.dir;
+            // window bookkeeping for the batched refill: first consumption in this window registers the env
+            const int pend = pending[env];
+            if (pend == 0) first_slot[env] = (uint8_t)slot;
+            if (!all) win_list[base + it] = pend == 0 ? (int32_t)env : -1;
+            pending[env] = (uint8_t)(pend + 1);
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(total_resets, (unsigned long long)count);
-        if (next_counter) next_counter[0] = 0;      // the ring entry the next step's k_step will append to
+        win_count[1 + pos] = all ? 0u : (uint32_t)count;
     }
 }
 
@@ -479,16 +538,21 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->vhead, (size_t)n_envs * 4);
     alloc((void**)&e->vset, (size_t)n_envs * 8 * 8);
     {
-        const char* ev = getenv("BBAI_LOOKAHEAD");       // look-ahead depth (levels generated ahead per env), default 2
-        int d = ev ? atoi(ev) : 2;
-        e->depth = d < 1 ? 1 : (d > 8 ? 8 : d);
+        const char* ev = getenv("BBAI_LOOKAHEAD");       // refill period B (ticks per refill); ring depth D = 2B
+        // default: 4 ticks per refill while the 8-slot ring stays under 4 GiB, else 2 (e.g. 1M BossLevel envs)
+        int b = ev ? atoi(ev) : ((size_t)n_envs * c.rec_bytes * 8 <= ((size_t)4 << 30) ? 4 : 2);
+        e->period = b < 1 ? 1 : (b > 8 ? 8 : b);
+        e->depth = 2 * e->period;
     }
     const size_t D = (size_t)e->depth;
     alloc((void**)&e->next_rec, D * (size_t)n_envs * c.rec_bytes);
     alloc((void**)&e->next_hot, D * (size_t)n_envs * sizeof(Hot));
-    alloc((void**)&e->slot_ring, (D + 1) * (size_t)n_envs);
-    alloc((void**)&e->reset_list, (D + 1) * (size_t)n_envs * 4);
-    alloc((void**)&e->counters, (D + 1) * 64);
+    alloc((void**)&e->pending, 3 * (size_t)n_envs);
+    alloc((void**)&e->first_slot, 3 * (size_t)n_envs);
+    alloc((void**)&e->win_list, 3 * (size_t)n_envs * 4);
+    alloc((void**)&e->win_count, 3 * 64);
+    alloc((void**)&e->reset_list, (size_t)n_envs * 4);
+    alloc((void**)&e->counters, 64);
     alloc((void**)&e->total_resets, 8);
     alloc((void**)&e->atlas, MAX_TILES * TILE_BYTES);
     alloc((void**)&e->lut, 512);
@@ -499,17 +563,19 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     }
     HIP_TRY(hipMemset(e->rec, 0, (size_t)n_envs * c.rec_bytes));
     HIP_TRY(hipMemset(e->next_rec, 0, D * (size_t)n_envs * c.rec_bytes));
-    HIP_TRY(hipMemset(e->slot_ring, 0, (D + 1) * (size_t)n_envs));
+    HIP_TRY(hipMemset(e->pending, 0, 3 * (size_t)n_envs));
+    HIP_TRY(hipMemset(e->first_slot, 0, 3 * (size_t)n_envs));
+    HIP_TRY(hipMemset(e->win_count, 0, 3 * 64));
     HIP_TRY(hipMemset(e->vhead, 0, (size_t)n_envs * 4));
     HIP_TRY(hipMemset(e->vset, 0, (size_t)n_envs * 64));
-    HIP_TRY(hipMemset(e->counters, 0, (D + 1) * 64));
+    HIP_TRY(hipMemset(e->counters, 0, 64));
     HIP_TRY(hipMemset(e->total_resets, 0, 8));
     {
         int lo = 0, hi = 0;     // look-ahead generation should get wave slots as soon as any free up
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIP_TRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, hi));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_consumed, hipEventDisableTiming));
-        for (int k = 0; k < e->depth; ++k) HIP_TRY(hipEventCreateWithFlags(&e->ev_pregen[k], hipEventDisableTiming));
+        for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreateWithFlags(&e->ev_refill[k], hipEventDisableTiming));
     }
     *out = e;
     return BBAI_OK;
@@ -521,8 +587,8 @@ void bbai_destroy(bbai_env* e) {
     (void)hipDeviceSynchronize();
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->ev_consumed) (void)hipEventDestroy(e->ev_consumed);
-    for (int k = 0; k < 8; ++k) if (e->ev_pregen[k]) (void)hipEventDestroy(e->ev_pregen[k]);
-    void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->slot_ring, e->reset_list, e->counters,
+    for (int k = 0; k < 3; ++k) if (e->ev_refill[k]) (void)hipEventDestroy(e->ev_refill[k]);
+    void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_list, e->win_count, e->reset_list, e->counters,
                     e->total_resets, e->atlas, e->lut};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete e;
@@ -536,28 +602,41 @@ static unsigned pregen_grid(int64_t count_hint) {
 
 // main stream: slots -> live state (+ first obs); side stream: refill the consumed slots.
 static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_t* dirs, int all) {
-    const int D = e->depth;
-    const int r = (int)(e->tick % (D + 1));          // ring entry of this consume-tick (list, counter, slot ids)
-    const int q = (int)(e->tick % D);                // event of the refill issued D ticks ago == the one we re-record
-    int32_t* list = e->reset_list + (size_t)r * e->n;
-    uint32_t* counter = e->counters + 16 * r;
-    uint8_t* slots = e->slot_ring + (size_t)r * e->n;
-    HIP_TRY(hipStreamWaitEvent(s, e->ev_pregen[q], 0));          // the slots consumed now were refilled >= D ticks ago
+    const int D = e->depth, B = e->period;
+    const int64_t w = e->tick / B;                   // window of this consume-tick
+    const int wb = (int)(w % 3);                     // its buffer (pending / first_slot / list / count / event)
+    const int pos = (int)(e->tick % B);
+    if (pos == 0) {
+        // Window start: the slots consumed from now on were refilled by window w-2 at the latest (buffer (w+1)%3):
+        // wait for that refill; its buffer becomes the one window w+1 will use, so clear its count.
+        const int ob = (int)((w + 1) % 3);
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_refill[ob], 0));
+        HIP_TRY(hipMemsetAsync(e->win_count + 16 * ob, 0, 64, s));
+        e->win_all[ob] = 0;
+    }
+    if (all) e->win_all[wb] = 1;
     const int64_t hint = all ? e->n : std::max<int64_t>(e->n / 64, 64);
     hipLaunchKernelGGL(k_consume, dim3((unsigned)std::min<int64_t>((hint + 3) / 4, 8192)), dim3(256), 0, s, e->cfg, e->n, e->rec,
-                       e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, list, counter, all, e->total_resets, D, slots,
-                       image, dirs, e->counters + 16 * (int)((e->tick + 1) % (D + 1)));
+                       e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, e->reset_list, e->counters, all, e->total_resets,
+                       D, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n, e->win_list + (size_t)wb * e->n,
+                       e->win_count + 16 * wb, pos, image, dirs);
     if (e->tokens)
         hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n, e->rec,
-                           e->tokens, list, counter, all);
-    HIP_TRY(hipEventRecord(e->ev_consumed, s));
-    HIP_TRY(hipStreamWaitEvent(e->side, e->ev_consumed, 0));
-    hipLaunchKernelGGL(k_pregen, dim3(pregen_grid(hint)), dim3(64), 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt,
-                       e->mti, list, counter, all, D, slots);
-    HIP_TRY(hipEventRecord(e->ev_pregen[q], e->side));
+                           e->tokens, e->reset_list, e->counters, all);
     HIP_TRY(hipGetLastError());
+    if (pos == B - 1) {
+        // Window end: one refill launch for everything consumed in the window, on the look-ahead stream.
+        const int wall = e->win_all[wb];
+        const int64_t rh = wall ? e->n : std::max<int64_t>((int64_t)B * (e->n / 64), 64);
+        HIP_TRY(hipEventRecord(e->ev_consumed, s));
+        HIP_TRY(hipStreamWaitEvent(e->side, e->ev_consumed, 0));
+        hipLaunchKernelGGL(k_pregen, dim3(pregen_grid(rh)), dim3(64), 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt,
+                           e->mti, e->win_list + (size_t)wb * e->n, e->win_count + 16 * wb, wall, D,
+                           e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n);
+        HIP_TRY(hipEventRecord(e->ev_refill[wb], e->side));
+        HIP_TRY(hipGetLastError());
+    }
     e->tick++;
-    e->counter_clean = true;
     return BBAI_OK;
 }
 
@@ -584,13 +663,14 @@ int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
     HIP_TRY(hipDeviceSynchronize());
     hipLaunchKernelGGL(k_init_hot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->side, n, e->hot, e->next_hot, e->stale, e->depth);
     // fill every env's look-ahead ring with the first D levels of its stream (slot order == stream order)
-    for (int d = 0; d < e->depth; ++d) {
-        HIP_TRY(hipMemsetAsync(e->slot_ring, d, (size_t)n, e->side));
-        hipLaunchKernelGGL(k_pregen, dim3(pregen_grid(n)), dim3(64), 0, e->side, e->cfg, n, e->next_rec, e->next_hot, e->mt, e->mti,
-                           e->reset_list, e->counters, 1, e->depth, e->slot_ring);
-    }
+    HIP_TRY(hipMemsetAsync(e->pending, e->depth, (size_t)n, e->side));
+    HIP_TRY(hipMemsetAsync(e->first_slot, 0, (size_t)n, e->side));
+    hipLaunchKernelGGL(k_pregen, dim3(pregen_grid(n)), dim3(64), 0, e->side, e->cfg, n, e->next_rec, e->next_hot, e->mt, e->mti,
+                       e->win_list, e->win_count, 1, e->depth, e->pending, e->first_slot);
     HIP_TRY(hipGetLastError());
-    for (int k = 0; k < e->depth; ++k) HIP_TRY(hipEventRecord(e->ev_pregen[k], e->side));
+    for (int k = 0; k < 3; ++k) HIP_TRY(hipEventRecord(e->ev_refill[k], e->side));
+    HIP_TRY(hipMemsetAsync(e->win_count, 0, 3 * 64, e->side));
+    e->win_all[0] = e->win_all[1] = e->win_all[2] = 0;
     e->tick = 0;
     HIP_TRY(hipDeviceSynchronize());
     e->seeded = true;
@@ -615,11 +695,9 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
     if (!e->live) { snprintf(g_err, sizeof(g_err), "step before reset"); return BBAI_ERR_STATE; }
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
-    const int r = (int)(e->tick % (e->depth + 1));
-    int32_t* list = e->reset_list + (size_t)r * e->n;
-    uint32_t* counter = e->counters + 16 * r;
-    if (!auto_reset || !e->counter_clean) HIP_TRY(hipMemsetAsync(counter, 0, 4, s));
-    e->counter_clean = false;
+    int32_t* list = e->reset_list;
+    uint32_t* counter = e->counters;
+    HIP_TRY(hipMemsetAsync(counter, 0, 4, s));
     hipLaunchKernelGGL(k_step, dim3((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), dim3(STEP_BLOCK), 0, s, e->cfg, e->n,
                        e->rec, e->hot, e->stale, e->vhead, e->vset, actions, image, dirs, rewards, dones, auto_reset, list, counter);
     HIP_TRY(hipGetLastError());
