@@ -184,3 +184,83 @@ def test_device_mission_tokens(gpu, level):
     if level == "PutNextLocal":
         assert env.reset_count() > n
     env.close()
+
+
+def _oracle_envs(level, seeds, pixel=False):
+    from oracle import levels as olevels
+    out = []
+    for s in seeds:
+        e = olevels.make_env(level)
+        e.seed(int(s))
+        out.append(e)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 63, 257, 1000])
+def test_odd_batch_sizes(gpu, n):
+    """Batch sizes that are not multiples of the wave / block / render-group sizes."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    env = BatchedBabyAIEnv("BabyAI-GoToLocal-v0", n, device=gpu, pixel=True, seeds=3)
+    obs = env.reset()
+    spots = sorted(set([0, n // 2, n - 1]))
+    refs = _oracle_envs("GoToLocal", [3 + i for i in spots])
+    ro = [e.reset() for e in refs]
+    rng = np.random.RandomState(n)
+    from gym_minigrid.wrappers import RGBImgPartialObsWrapper
+    for t in range(90):
+        img = env.image.cpu().numpy()
+        for k, i in enumerate(spots):
+            assert np.array_equal(img[i], ro[k]["image"]), (n, i, t)
+        if t % 30 == 0:
+            pix = obs["image"].cpu().numpy()
+            for k, i in enumerate(spots):
+                assert np.array_equal(pix[i], refs[k].get_obs_render(ro[k]["image"], tile_size=8)), (n, i, t)
+        a = rng.randint(0, 7, size=n).astype(np.uint8)
+        obs, reward, done, _ = env.step(torch.as_tensor(a, device=gpu))
+        for k, i in enumerate(spots):
+            o, r, d, _ = refs[k].step(int(a[i]))
+            if d:
+                o = refs[k].reset()
+            ro[k] = o
+    env.close()
+
+
+@pytest.mark.gpu
+def test_explicit_resets_reseed_and_manyenvs_windows(gpu):
+    """reset() at arbitrary points (the look-ahead windows must hand out the stream's levels in order), ManyEnvs
+    mode (no auto-reset), then re-seeding the same engine."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    n = 96
+    env = BatchedBabyAIEnv("BabyAI-MiniBossLevel-v0", n, device=gpu, auto_reset=False)
+    rng = np.random.RandomState(4)
+    for base in (21, 500):                       # second pass = re-seed of a used engine
+        env.seed(base)
+        refs = _oracle_envs("MiniBossLevel", [base + i for i in range(n)])
+        frozen = np.zeros(n, bool)
+        last = [None] * n
+        for phase, steps in enumerate([0, 3, 1, 7, 0, 2, 25, 4, 1, 1, 1, 9]):
+            env.reset()
+            torch.cuda.synchronize()
+            ro = [e.reset() for e in refs]
+            frozen[:] = False
+            img = env.image.cpu().numpy()
+            ms = env.missions()
+            for i in range(n):
+                assert np.array_equal(img[i], ro[i]["image"]), (base, phase, i)
+                assert ms[i] == ro[i]["mission"], (base, phase, i)
+            for t in range(steps):
+                a = rng.randint(0, 7, size=n).astype(np.uint8)
+                obs, reward, done, _ = env.step(torch.as_tensor(a, device=gpu))
+                img = env.image.cpu().numpy()
+                rew = reward.cpu().numpy()
+                dn = done.cpu().numpy()
+                for i in range(n):
+                    if not frozen[i]:
+                        o, r, d, _ = refs[i].step(int(a[i]))
+                        last[i] = (o["image"], np.float32(r), bool(d))
+                        frozen[i] = bool(d)
+                    assert np.array_equal(img[i], last[i][0]) and rew[i] == last[i][1] and bool(dn[i]) == last[i][2]
+    env.close()
