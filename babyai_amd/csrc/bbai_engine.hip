@@ -1,10 +1,11 @@
 // bbai_engine.hip -- HIP kernels + C ABI of the batched BabyAI engine (gfx950 / MI355X).
 //
 // Kernels (all integer / byte work, HBM- and latency-bound; no MFMA by design):
-//   k_step         lane = env.  Coalesced SoA loads of the 16-byte hot state, action and stale
-//                  set; per-lane transition + verifier on the env's record; 7x7 egocentric
-//                  observation; the 147-byte encodings of a block's 256 envs are staged in LDS
-//                  and written back as one contiguous, dword-coalesced span.  Finished envs are
+//   k_step         lane = env.  Coalesced SoA loads of the 16-byte hot state, action, stale set and
+//                  verifier program; per-lane transition + verifier on the env's record; the 7x7
+//                  window is fetched as 7 rows x 3 dwords, staged in LDS and read back in view
+//                  orientation; the 147-byte encodings of a block's 256 envs are staged in LDS and
+//                  written back as one contiguous, dword-coalesced span.  Finished envs are
 //                  compacted into the reset list with one wave-aggregated atomic per wave.
 //   k_pregen       wave = env: the NEXT level of an env's MT19937 stream is generated wave-uniformly
 //                  with the whole working set in LDS (bbai_gen.hpp) into a per-env look-ahead slot.
@@ -89,40 +90,70 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int STEP_BLOCK = 256;
 constexpr int OBS_PAD = 148;           // LDS row per env (bytes), dword multiple
 
-__device__ __forceinline__ void observe_lane(const LevelCfg& c, const uint8_t* __restrict__ rec, const Hot& h,
-                                             uint8_t* __restrict__ dst /* LDS or global, byte addressed */) {
-    const uint8_t* E = rec;
-    const int fx = dir_dx(h.dir), fy = dir_dy(h.dir);
-    const int rx = -fy, ry = fx;
-    // world cell of view (0,0): pos + f*6 + r*(-3); stepping vi adds r, stepping vj subtracts f
-    const int x00 = h.ax + fx * 6 - rx * 3, y00 = h.ay + fy * 6 - ry * 3;
-    const int base = (y00 + MARGIN) * c.ES + (x00 + MARGIN);
-    const int dvi = ry * c.ES + rx;      // address step for vi+1
-    const int dvj = -(fy * c.ES + fx);   // address step for vj+1
-    uint8_t cell[VIEW][VIEW];
-    uint32_t opq[VIEW], vis[VIEW];
+// Observation with the 7x7 window staged in LDS (the k_step path).  49 scattered byte loads per lane keep the
+// texture-address unit busy for most of k_step (tools/step_ab.py ablation), so the window is fetched in WORLD
+// orientation as 7 rows x 3 aligned dwords, byte-aligned with v_alignbyte, parked in the tail of the lane's own
+// LDS obs row, and read back in VIEW orientation (rotation = per-direction address arithmetic on ds_read_u8).
+// All of a lane's reads precede its writes and lanes only touch their own row, so no barrier is needed here.
+__device__ __forceinline__ void observe_lane_lds(const LevelCfg& c, const uint8_t* __restrict__ rec, const Hot& h,
+                                                 uint8_t* __restrict__ row /* this lane's OBS_PAD-byte LDS row */) {
+    const int dir = h.dir;
+    // Grid.slice extents (get_view_exts): top-left world cell of the axis-aligned 7x7 window
+    const int tx = h.ax + (dir == 0 ? 0 : dir == 2 ? -6 : -3);
+    const int ty = h.ay + (dir == 1 ? 0 : dir == 3 ? -6 : -3);
+    const int a0 = (ty + MARGIN) * c.ES + (tx + MARGIN);
+    const int off = a0 & 3;                                  // same for every row: ES is a multiple of 4
+    const uint32_t* q = (const uint32_t*)(rec + (a0 - off));
+    const int es4 = c.ES >> 2;
+    uint32_t* win = (uint32_t*)(row + 88);                   // 7 rows x 8 bytes, dword aligned (row = tid * 148)
 #pragma unroll
-    for (int vj = 0; vj < VIEW; ++vj) {
-        uint32_t o = 0;
-#pragma unroll
-        for (int vi = 0; vi < VIEW; ++vi) {
-            int e = E[base + vi * dvi + vj * dvj];
-            cell[vj][vi] = (uint8_t)e;
-            o |= (e_opaque(e) ? 1u : 0u) << vi;
-        }
-        opq[vj] = o;
+    for (int r = 0; r < VIEW; ++r) {
+        const uint32_t d0 = q[r * es4], d1 = q[r * es4 + 1], d2 = q[r * es4 + 2];
+        win[2 * r] = __builtin_amdgcn_alignbyte(d1, d0, off);
+        win[2 * r + 1] = __builtin_amdgcn_alignbyte(d2, d1, off);
     }
-    process_vis_rows(opq, vis);
-    cell[6][3] = h.carry != NONE8 ? rec[c.off_app + h.carry] : (uint8_t)E_EMPTY;
+    // view (vi, vj) -> window byte: dir3 (vj, vi), dir0 (vi, 6-vj), dir1 (6-vj, 6-vi), dir2 (6-vi, vj); row pitch 8
+    const int k0 = dir == 0 ? 6 : dir == 1 ? 54 : dir == 2 ? 48 : 0;
+    const int kvi = dir == 0 ? 8 : dir == 1 ? -1 : dir == 2 ? -8 : 1;
+    const int kvj = dir == 0 ? -1 : dir == 1 ? -8 : dir == 2 ? 1 : 8;
+    const uint8_t* wb = row + 88 + k0;
+    uint32_t cp[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // the 49 cells, 4 per dword, view order [vi][vj]
+    uint32_t opq[VIEW] = {0, 0, 0, 0, 0, 0, 0}, vis[VIEW];
 #pragma unroll
     for (int vi = 0; vi < VIEW; ++vi)
 #pragma unroll
         for (int vj = 0; vj < VIEW; ++vj) {
-            int e = cell[vj][vi];
-            bool v = vis[vj] >> vi & 1;
-            uint8_t* o = dst + (vi * VIEW + vj) * 3;
-            o[0] = v ? e_type(e) : 0; o[1] = v ? e_color(e) : 0; o[2] = v ? e_state(e) : 0;
+            const int idx = vi * VIEW + vj;
+            const uint32_t e = wb[kvi * vi + kvj * vj];
+            cp[idx >> 2] |= e << (8 * (idx & 3));
+            opq[vj] |= (e_opaque((int)e) ? 1u : 0u) << vi;
         }
+    process_vis_rows(opq, vis);
+    {   // the agent's own cell (3,6) shows what it carries
+        const uint32_t ce = h.carry != NONE8 ? rec[c.off_app + h.carry] : (uint32_t)E_EMPTY;
+        constexpr int idx = 3 * VIEW + 6;
+        cp[idx >> 2] = (cp[idx >> 2] & ~(0xFFu << (8 * (idx & 3)))) | (ce << (8 * (idx & 3)));
+    }
+    uint32_t od[37];
+#pragma unroll
+    for (int k = 0; k < 37; ++k) od[k] = 0;
+#pragma unroll
+    for (int vi = 0; vi < VIEW; ++vi)
+#pragma unroll
+        for (int vj = 0; vj < VIEW; ++vj) {
+            const int idx = vi * VIEW + vj;
+            const uint32_t e = (cp[idx >> 2] >> (8 * (idx & 3))) & 0xFFu;
+            const uint32_t m = (vis[vj] >> vi & 1u) ? 0xFFu : 0u;
+            const uint32_t ch[3] = {(e & 7u) & m, ((e >> 3) & 7u) & m, (e >> 6) & m};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int b = 3 * idx + k;
+                od[b >> 2] |= ch[k] << (8 * (b & 3));
+            }
+        }
+    uint32_t* o = (uint32_t*)row;
+#pragma unroll
+    for (int k = 0; k < 37; ++k) o[k] = od[k];
 }
 
 // Wave-cooperative observation of ONE env (used where a wave owns an env: k_consume): lane l < 49 owns view cell
@@ -180,7 +211,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(LevelCfg c, int64_t n, uint
             rewards[env] = reward;
             dones[env] = done ? 1 : 0;
             dirs[env] = h.dir;
-            observe_lane(c, rec, h, s_obs + threadIdx.x * OBS_PAD);
+            observe_lane_lds(c, rec, h, s_obs + threadIdx.x * OBS_PAD);
         }
         // frozen envs keep re-emitting their last outputs: copy them through LDS unchanged
         else {
@@ -201,18 +232,29 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(LevelCfg c, int64_t n, uint
         }
     }
     __syncthreads();
-    // cooperative, dword-coalesced write of the block's contiguous obs span
+    // cooperative, dword-coalesced write of the block's contiguous obs span.  LDS rows are 148 B apart, the output
+    // is 147-B packed: output dword d starts at byte off = 4d % 147 of row e = 4d / 147; when it lies inside the row
+    // it is two aligned LDS dwords funnel-shifted by off & 3 (148 is a dword multiple), else (3 of 147) bytewise.
     const int64_t nb = n - env0 < STEP_BLOCK ? n - env0 : STEP_BLOCK;      // envs in this block
     const int total = (int)nb * OBS_BYTES;
     uint8_t* out = image + env0 * OBS_BYTES;                              // 256*147 is a dword multiple
     const int ndw = total >> 2;
+    const uint32_t* s_obs32 = (const uint32_t*)s_obs;
     for (int d = threadIdx.x; d < ndw; d += STEP_BLOCK) {
-        uint32_t v = 0;
+        const int b = 4 * d;
+        const int e = b / OBS_BYTES, off = b - e * OBS_BYTES;
+        uint32_t v;
+        if (off <= OBS_BYTES - 4) {
+            const int q = e * (OBS_PAD / 4) + (off >> 2);
+            v = __builtin_amdgcn_alignbyte(s_obs32[q + 1], s_obs32[q], off & 3);
+        } else {
+            v = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int b = 4 * d + k;
-            int e = b / OBS_BYTES, off = b - e * OBS_BYTES;
-            v |= (uint32_t)s_obs[e * OBS_PAD + off] << (8 * k);
+            for (int k = 0; k < 4; ++k) {
+                const int bb = b + k;
+                const int ee = bb / OBS_BYTES, oo = bb - ee * OBS_BYTES;
+                v |= (uint32_t)s_obs[ee * OBS_PAD + oo] << (8 * k);
+            }
         }
         ((uint32_t*)out)[d] = v;
     }
@@ -223,7 +265,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(LevelCfg c, int64_t n, uint
 }
 
 // ------------------------------------------------------------------------------------------
-// k_reset : one wavefront generates one env's next level
+// k_pregen / k_consume : look-ahead level generation (one wavefront generates one env's levels)
 // ------------------------------------------------------------------------------------------
 struct WaveCtx {
     __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
