@@ -581,8 +581,10 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->vset, (size_t)n_envs * 8 * 8);
     {
         const char* ev = getenv("BBAI_LOOKAHEAD");       // refill period B (ticks per refill); ring depth D = 2B
-        // default: 4 ticks per refill while the 8-slot ring stays under 4 GiB, else 2 (e.g. 1M BossLevel envs)
-        int b = ev ? atoi(ev) : ((size_t)n_envs * c.rec_bytes * 8 <= ((size_t)4 << 30) ? 4 : 2);
+        // default: the longest period (8, 4, 2 ticks per refill) whose 2B-slot ring stays under 4 GiB
+        // (1M BossLevel envs -> 2; 131072 GoTo envs -> 8)
+        const size_t slot_bytes = (size_t)n_envs * c.rec_bytes, cap = (size_t)4 << 30;
+        int b = ev ? atoi(ev) : (slot_bytes * 16 <= cap ? 8 : slot_bytes * 8 <= cap ? 4 : 2);
         e->period = b < 1 ? 1 : (b > 8 ? 8 : b);
         e->depth = 2 * e->period;
     }
