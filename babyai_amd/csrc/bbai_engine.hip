@@ -322,6 +322,7 @@ __global__ __launch_bounds__(64) void k_pregen(LevelCfg c, int64_t n, uint8_t* _
                 rec[c.off_app + k] = used ? w.app[k] : 0;
                 rec[c.off_pos + 2 * k] = used ? w.px[k] : 0;
                 rec[c.off_pos + 2 * k + 1] = used ? w.py[k] : 0;
+                rec[c.off_cont + k] = used ? w.cont[k] : NONE8;
             }
             {
                 const uint32_t* src = (const uint32_t*)&w.prog;
@@ -383,8 +384,12 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
         // first observation of the new episode, straight from the slot (identical bytes to the live copy)
         observe_wave(c, nrec, h, image + env * OBS_BYTES, lane);
         if (lane == 0) {
+            uint64_t stale0 = 0;
+            // PutNext*Carrying: the first observation above still shows the object on the grid (the reference builds
+            // it before handing the object to the agent, bonus_levels.py:821-829); now move it into the agent's hands
+            if (p->start_carry != NONE8) apply_start_carry(c, recs + env * (int64_t)c.rec_bytes, h, stale0, p->start_carry);
             hots[env] = h;
-            stales[env] = 0;
+            stales[env] = stale0;
             dirs[env] = h.dir;
             // window bookkeeping for the batched refill: first consumption in this window registers the env
             const int pend = pending[env];
@@ -488,7 +493,7 @@ struct TokOut {
 __device__ __forceinline__ void tok_desc(TokOut& o, DescInfo d) {
     o.put(d.count > 1 ? 9 : 8);                         // a / the
     if (d.color != 7) o.put(11 + d.color);              // red green blue purple yellow grey
-    o.put(24 - d.type);                                 // box ball key door
+    o.put(d.type == 0 ? 10 : 24 - d.type);              // object | box ball key door
     if (d.loc == LOC_FRONT) { o.put(21); o.put(22); o.put(23); o.put(24); }      // in front of you
     else if (d.loc == LOC_BEHIND) { o.put(25); o.put(24); }                     // behind you
     else if (d.loc == LOC_LEFT) { o.put(26); o.put(27); o.put(28); }            // on your left
@@ -538,7 +543,8 @@ int bbai_fill_layout(bbai_level_cfg* cfg) {
 }
 
 static int validate_cfg(const LevelCfg& c) {
-    if (c.kind != K_GOTO && c.kind != K_LEVELGEN) return -1;
+    if (c.kind != K_GOTO && c.kind != K_LEVELGEN && c.kind != K_BONUS) return -1;
+    if (c.kind == K_BONUS && (c.script < 1 || c.script >= BS_COUNT)) return -1;
     if (c.num_dists < 0) return -1;
     if (c.kind == K_GOTO) {
         if (!c.redball && c.num_dists < 1) return -1;

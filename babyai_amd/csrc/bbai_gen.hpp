@@ -30,6 +30,7 @@ struct GenWork {                                 // lives in LDS on the device
     uint8_t E[GEN_ES * GEN_EH];
     uint8_t I[MAX_W * MAX_W + 3];
     uint8_t app[MAX_OBJ], px[MAX_OBJ], py[MAX_OBJ];
+    uint8_t cont[MAX_OBJ];                       // box contents (object id revealed on toggle) or NONE8; px == NONE8: hidden
     uint8_t door_x[MAX_ROOMS][4], door_y[MAX_ROOMS][4];
     uint32_t rowbuf[2][MAX_W + 2];               // reachability rows
     uint64_t masks[14];                          // object-id sets: [0..3] by type (door,key,ball,box),
@@ -241,7 +242,7 @@ struct Gen {
         if (nobj >= cfg.maxo) return -1;
         int id = nobj++;
         int e = e_make(type, color, 0);
-        w.app[id] = e; w.px[id] = x; w.py[id] = y;
+        w.app[id] = e; w.px[id] = x; w.py[id] = y; w.cont[id] = NONE8;
         set_cell(x, y, e, id + 2);
         return id;
     }
@@ -252,7 +253,7 @@ struct Gen {
         int x = w.door_x[r][k], y = w.door_y[r][k];
         int e = e_make(T_DOOR, color, is_locked ? S_LOCKED : S_CLOSED);
         locked_mask = (locked_mask & ~(1u << r)) | ((is_locked ? 1u : 0u) << r);   // room.locked = locked
-        w.app[id] = e; w.px[id] = x; w.py[id] = y;
+        w.app[id] = e; w.px[id] = x; w.py[id] = y; w.cont[id] = NONE8;
         set_cell(x, y, e, id + 2);
         doors |= 1ull << (16 * k + r);
         doors |= 1ull << (16 * ((k + 2) & 3) + neighbor(r, k));
@@ -260,10 +261,13 @@ struct Gen {
     }
     // RoomGrid.place_agent(i=None, j=None): room drawn, then pose re-drawn until the
     // front cell is empty or a wall.
-    BB_HD bool place_agent() {
-        int i = rand_int(0, cols);
-        int j = rand_int(0, rows);
-        int r = j * cols + i;
+    BB_HD bool place_agent(int room = -1) {
+        int r = room;
+        if (r < 0) {
+            int i = rand_int(0, cols);
+            int j = rand_int(0, rows);
+            r = j * cols + i;
+        }
         for (;;) {
             agent_set = false;
             int x, y;
@@ -425,6 +429,7 @@ struct Gen {
         int d1x = (adir == 0) - (adir == 2), d1y = (adir == 1) - (adir == 3);
         int d2x = -d1y, d2y = d1x;
         for (int o = 0; o < nobj; ++o) {
+            if (w.px[o] == NONE8) continue;              // hidden inside a box: not in the grid, matches nothing
             const uint64_t bit = 1ull << o;
             int e = w.app[o];
             int t = e_type(e) - T_DOOR, col = e_color(e);
@@ -448,7 +453,7 @@ struct Gen {
         ctx.sync();
     }
     BB_HD uint64_t find_matching(int type, int color, int loc) const {
-        uint64_t m = w.masks[type - T_DOOR];
+        uint64_t m = type == 0 ? (w.masks[0] | w.masks[1] | w.masks[2] | w.masks[3]) : w.masks[type - T_DOOR];
         if (color != 7) m &= w.masks[4 + color];
         if (loc != LOC_NONE) m &= w.masks[10 + loc - 1];
         return m;
@@ -497,6 +502,7 @@ struct Gen {
         uint32_t* p = (uint32_t*)&w.prog;
         for (int k = ctx.lane(); k < (int)(sizeof(Prog) / 4); k += ctx.nlanes()) p[k] = 0;
         ctx.sync();
+        w.prog.start_carry = NONE8;
     }
     // LevelGen.rand_instr (depth <= 2: seq -> and -> action).
     BB_HD bool rand_instr() {
@@ -598,12 +604,332 @@ struct Gen {
         return ok;
     }
 
-    BB_HD void set_desc(int leaf, int slot, int obj) {
-        int type = e_type(w.app[obj]), color = e_color(w.app[obj]);
-        uint64_t m = find_matching(type, color, LOC_NONE);
+    // ObjDesc(type, color, loc) resolved against the final scene.  type 0 = any type, color 7 = any colour.
+    // With type None the reference also matches wall cells of that colour (verifier.py:112-127): they cannot be
+    // picked up or opened, but they count for the "a"/"the" article.
+    BB_HD void set_desc_tcl(int leaf, int slot, int type, int color, int loc) {
+        uint64_t m = find_matching(type, color, loc);
         w.prog.set[leaf][slot] = m;
-        DescInfo d; d.type = type; d.color = color; d.loc = LOC_NONE; d.count = (uint8_t)__builtin_popcountll(m);
+        int cnt = __builtin_popcountll(m);
+        if (type == 0 && color == C_GREY && loc == LOC_NONE) cnt += 2;      // the room walls are grey: plural for sure
+        DescInfo d; d.type = type; d.color = color; d.loc = loc; d.count = (uint8_t)(cnt > 255 ? 255 : cnt);
         w.prog.desc[leaf][slot] = d;
+    }
+    BB_HD void set_desc(int leaf, int slot, int obj) {
+        set_desc_tcl(leaf, slot, e_type(w.app[obj]), e_color(w.app[obj]), LOC_NONE);
+    }
+
+    // ---------------- helpers of the bonus scripts ----------------
+    // _rand_subset(COLOR_NAMES, k): repeated _rand_elem on the shrinking (sorted-name) list
+    BB_HD void rand_subset_colors(int k, int* out) {
+        uint32_t avail = 0x3F;
+        for (int q = 0; q < k; ++q) {
+            int pick = rand_int(0, 6 - q);
+            int pos = 0;
+            for (int b = 0; b < 6; ++b)
+                if (avail >> b & 1) { if (pick-- == 0) { pos = b; break; } }
+            avail &= ~(1u << pos);
+            out[q] = color_name_to_idx(pos);
+        }
+    }
+    // _rand_subset(list of n ids starting at first, 2)
+    BB_HD void rand_subset2(int first, int n, int& a, int& b) {
+        int i = rand_int(0, n);
+        int j = rand_int(0, n - 1);
+        if (j >= i) ++j;
+        a = first + i; b = first + j;
+    }
+    // RoomGrid.add_object(i, j, kind=None|k, color=None|c)
+    BB_HD int add_object_rand(int r, int type /* 0 = random */, int color /* -1 = random */) {
+        if (type == 0) type = T_KEY + rand_int(0, 3);
+        if (color < 0) color = rand_color();
+        return add_object(r, type, color);
+    }
+    // RoomGrid.add_door(i, j, door_idx=k|None, color=c|None, locked=b|None): draws in that order
+    BB_HD int add_door_opt(int r, int k, int color, int locked /* -1 = random */) {
+        if (k < 0)
+            for (;;) {
+                k = rand_int(0, 4);
+                if (has_neighbor(r, k) && !has_door(r, k)) break;
+            }
+        if (color < 0) color = rand_color();
+        if (locked < 0) locked = rand_bool() ? 1 : 0;
+        return add_door(r, k, color, locked != 0);
+    }
+    // RoomGrid.remove_wall(i, j, wall_idx): the wall segment between two rooms becomes floor; counts as a connection
+    BB_HD void remove_wall(int r, int k) {
+        int ri, rj; room_ij(r, ri, rj);
+        int tx = ri * (S - 1), ty = rj * (S - 1);
+        for (int q = 1; q < S - 1; ++q) {
+            int x = k == 0 ? tx + S - 1 : k == 2 ? tx : tx + q;
+            int y = k == 1 ? ty + S - 1 : k == 3 ? ty : ty + q;
+            set_cell(x, y, E_EMPTY, 0);
+        }
+        doors |= 1ull << (16 * k + r);
+        doors |= 1ull << (16 * ((k + 2) & 3) + neighbor(r, k));
+    }
+    BB_HD void one_leaf(int kind, bool strict = false) {
+        clear_prog();
+        prep_masks();
+        w.prog.root = R_ACTION; w.prog.n_a = 1; w.prog.kind[0] = (uint8_t)kind;
+        w.prog.strict = strict ? 1 : 0;
+        w.prog.start_carry = NONE8;
+    }
+
+    // gen_mission of the bonus levels (babyai/levels/bonus_levels.py), one case per level class.
+    BB_HD bool mission_bonus() {
+        const int mid = (rows > 1 ? cols : 0) + (cols > 1 ? 1 : 0);       // room (1,1) of a 3x3 maze, (1,0) of a 1x3
+        const int R11 = rows >= 2 && cols >= 2 ? 1 * cols + 1 : mid;
+        int colors[6];
+        switch (cfg.script) {
+        case BS_GOTO_REDBLUE_BALL: {                    // :7-40
+            if (!place_agent()) return false;
+            int first = nobj;
+            if (!add_distractors(cfg.num_dists, false)) return false;
+            for (int o = first; o < nobj; ++o)
+                if (e_type(w.app[o]) == T_BALL && (e_color(w.app[o]) == C_BLUE || e_color(w.app[o]) == C_RED)) return false;
+            int color = rand_int(0, 2) == 0 ? C_RED : C_BLUE;
+            int obj = add_object(0, T_BALL, color);
+            if (obj < 0) return false;
+            if (!objs_reachable()) return false;
+            one_leaf(L_GOTO); set_desc(0, 0, obj);
+            return true;
+        }
+        case BS_OPEN_RED_DOOR: {                        // :43-62
+            if (add_door(0, 0, C_RED, false) < 0) return false;
+            if (!place_agent(0)) return false;
+            one_leaf(L_OPEN); set_desc_tcl(0, 0, T_DOOR, C_RED, LOC_NONE);
+            return true;
+        }
+        case BS_OPEN_DOOR: {                            // :65-99  sp[0]: 0 random, 1 color, 2 loc; sp[1]: debug
+            rand_subset_colors(4, colors);
+            int first = nobj;
+            for (int k = 0; k < 4; ++k)
+                if (add_door(R11, k, colors[k], false) < 0) return false;
+            int sel = cfg.sp[0];
+            if (sel == 0) sel = 1 + rand_int(0, 2);
+            int loc = LOC_NONE;
+            if (sel == 2) loc = 1 + rand_int(0, 4);
+            if (!place_agent(R11)) return false;
+            one_leaf(L_OPEN, cfg.sp[1] != 0);
+            if (sel == 1) set_desc_tcl(0, 0, T_DOOR, e_color(w.app[first]), LOC_NONE);
+            else set_desc_tcl(0, 0, T_DOOR, 7, loc);
+            return true;
+        }
+        case BS_GOTO_DOOR: {                            // :150-171
+            int first = nobj;
+            for (int k = 0; k < 4; ++k)
+                if (add_door_opt(R11, -1, -1, -1) < 0) return false;
+            if (!place_agent(R11)) return false;
+            int obj = first + rand_int(0, 4);
+            one_leaf(L_GOTO); set_desc_tcl(0, 0, T_DOOR, e_color(w.app[obj]), LOC_NONE);
+            return true;
+        }
+        case BS_GOTO_OBJ_DOOR: {                        // :174-197
+            if (!place_agent(R11)) return false;
+            int first = nobj;
+            if (!add_distractors(8, false, R11)) return false;
+            for (int k = 0; k < 4; ++k)
+                if (add_door_opt(R11, -1, -1, -1) < 0) return false;
+            if (!objs_reachable()) return false;
+            int obj = first + rand_int(0, 12);
+            one_leaf(L_GOTO); set_desc(0, 0, obj);
+            return true;
+        }
+        case BS_ACTION_OBJ_DOOR: {                      // :200-234
+            int first = nobj;
+            if (!add_distractors(5, true, R11)) return false;
+            for (int k = 0; k < 4; ++k)
+                if (add_door_opt(R11, -1, -1, 0) < 0) return false;
+            if (!place_agent(R11)) return false;
+            int obj = first + rand_int(0, 9);
+            bool go = rand_bool();
+            int kind = go ? L_GOTO : (e_type(w.app[obj]) == T_DOOR ? L_OPEN : L_PICKUP);
+            one_leaf(kind); set_desc(0, 0, obj);
+            return true;
+        }
+        case BS_UNLOCK_LOCAL: {                         // :237-264  sp[0]: distractors
+            int door = add_door_opt(R11, -1, -1, 1);
+            if (door < 0) return false;
+            if (add_object(R11, T_KEY, e_color(w.app[door])) < 0) return false;
+            if (cfg.sp[0] && !add_distractors(3, true, R11)) return false;
+            if (!place_agent(R11)) return false;
+            one_leaf(L_OPEN); set_desc_tcl(0, 0, T_DOOR, 7, LOC_NONE);
+            return true;
+        }
+        case BS_KEY_IN_BOX: {                           // :267-287
+            int door = add_door_opt(R11, -1, -1, 1);
+            if (door < 0) return false;
+            int box_color = rand_color();
+            int box = add_object(R11, T_BOX, box_color);
+            if (box < 0 || nobj >= cfg.maxo) return false;
+            int key = nobj++;                            // lives inside the box until it is toggled
+            w.app[key] = e_make(T_KEY, e_color(w.app[door]), 0); w.px[key] = NONE8; w.py[key] = NONE8; w.cont[key] = NONE8;
+            w.cont[box] = (uint8_t)key;
+            if (!place_agent(R11)) return false;
+            one_leaf(L_OPEN); set_desc_tcl(0, 0, T_DOOR, 7, LOC_NONE);
+            return true;
+        }
+        case BS_UNLOCK_PICKUP: {                        // :290-329  1x2 rooms; sp[0]: distractors
+            int obj = add_object_rand(1, T_BOX, -1);
+            if (obj < 0) return false;
+            int door = add_door_opt(0, 0, -1, 1);
+            if (door < 0) return false;
+            if (add_object(0, T_KEY, e_color(w.app[door])) < 0) return false;
+            if (cfg.sp[0] && !add_distractors(4, true)) return false;
+            if (!place_agent(0)) return false;
+            one_leaf(L_PICKUP); set_desc(0, 0, obj);
+            return true;
+        }
+        case BS_BLOCKED_UNLOCK_PICKUP: {                // :332-361
+            int obj = add_object_rand(1, T_BOX, -1);
+            if (obj < 0) return false;
+            int door = add_door_opt(0, 0, -1, 1);
+            if (door < 0) return false;
+            int color = rand_color();
+            if (nobj >= cfg.maxo) return false;
+            int ball = nobj++;                           // grid.set(): put right in front of the door, no sampling
+            int bx = w.px[door] - 1, by = w.py[door];
+            w.app[ball] = e_make(T_BALL, color, 0); w.px[ball] = bx; w.py[ball] = by; w.cont[ball] = NONE8;
+            set_cell(bx, by, w.app[ball], ball + 2);
+            if (add_object(0, T_KEY, e_color(w.app[door])) < 0) return false;
+            if (!place_agent(0)) return false;
+            one_leaf(L_PICKUP); set_desc_tcl(0, 0, T_BOX, 7, LOC_NONE);
+            return true;
+        }
+        case BS_UNLOCK_TO_UNLOCK: {                     // :364-398  1x3 rooms
+            rand_subset_colors(2, colors);
+            if (add_door(0, 0, colors[0], true) < 0) return false;
+            if (add_object(2, T_KEY, colors[0]) < 0) return false;
+            if (add_door(1, 0, colors[1], true) < 0) return false;
+            if (add_object(1, T_KEY, colors[1]) < 0) return false;
+            if (add_object_rand(0, T_BALL, -1) < 0) return false;
+            if (!place_agent(1)) return false;
+            one_leaf(L_PICKUP); set_desc_tcl(0, 0, T_BALL, 7, LOC_NONE);
+            return true;
+        }
+        case BS_PICKUP_DIST: {                          // :401-444  sp[0]: debug (strict)
+            int first = nobj;
+            if (!add_distractors(5, true)) return false;
+            if (!place_agent(0)) return false;
+            int obj = first + rand_int(0, 5);
+            int sel = rand_int(0, 3);                    // "type", "color", "both"
+            int type = e_type(w.app[obj]), color = e_color(w.app[obj]);
+            if (sel == 1) type = 0; else if (sel == 0) color = 7;
+            one_leaf(L_PICKUP, cfg.sp[0] != 0); set_desc_tcl(0, 0, type, color, LOC_NONE);
+            return true;
+        }
+        case BS_PICKUP_ABOVE: {                         // :447-469
+            int obj = add_object_rand(0 * cols + 1, 0, -1);
+            if (obj < 0) return false;
+            if (add_door_opt(R11, 3, -1, 0) < 0) return false;
+            if (!place_agent(R11)) return false;
+            if (!connect_all()) return false;
+            one_leaf(L_PICKUP); set_desc(0, 0, obj);
+            return true;
+        }
+        case BS_OPEN_TWO_DOORS: {                       // :472-562  sp[0], sp[1]: fixed colours + 1 (0 = random); sp[2]: strict
+            rand_subset_colors(2, colors);
+            int c1 = cfg.sp[0] ? cfg.sp[0] - 1 : colors[0];
+            int c2 = cfg.sp[1] ? cfg.sp[1] - 1 : colors[1];
+            if (add_door(R11, 2, c1, false) < 0) return false;
+            if (add_door(R11, 0, c2, false) < 0) return false;
+            if (!place_agent(R11)) return false;
+            clear_prog(); prep_masks();
+            w.prog.root = R_BEFORE; w.prog.n_a = 1; w.prog.n_b = 1; w.prog.kind[0] = L_OPEN; w.prog.kind[2] = L_OPEN;
+            w.prog.strict = cfg.sp[2] ? 1 : 0; w.prog.start_carry = NONE8;
+            set_desc_tcl(0, 0, T_DOOR, c1, LOC_NONE);
+            set_desc_tcl(2, 0, T_DOOR, c2, LOC_NONE);
+            return true;
+        }
+        case BS_FIND_OBJ: {                             // :565-611
+            int i = rand_int(0, rows);
+            int j = rand_int(0, cols);
+            int obj = add_object_rand(j * cols + i, 0, -1);
+            if (obj < 0) return false;
+            if (!place_agent(R11)) return false;
+            if (!connect_all()) return false;
+            one_leaf(L_PICKUP); set_desc_tcl(0, 0, e_type(w.app[obj]), 7, LOC_NONE);
+            return true;
+        }
+        case BS_KEY_CORRIDOR: {                         // :614-704  3 columns, `rows` rows
+            for (int j = 1; j < rows; ++j) remove_wall(j * cols + 1, 3);
+            int room_idx = rand_int(0, rows);
+            int door = add_door_opt(room_idx * cols + 2, 2, -1, 1);
+            if (door < 0) return false;
+            int obj = add_object_rand(room_idx * cols + 2, T_BALL, -1);
+            if (obj < 0) return false;
+            int kj = rand_int(0, rows);
+            if (add_object(kj * cols + 0, T_KEY, e_color(w.app[door])) < 0) return false;
+            if (!place_agent((rows / 2) * cols + 1)) return false;
+            if (!connect_all()) return false;
+            one_leaf(L_PICKUP); set_desc_tcl(0, 0, T_BALL, 7, LOC_NONE);
+            return true;
+        }
+        case BS_ONE_ROOM: {                             // :707-763
+            if (add_object_rand(0, T_BALL, -1) < 0) return false;
+            if (!place_agent()) return false;
+            one_leaf(L_PICKUP); set_desc_tcl(0, 0, T_BALL, 7, LOC_NONE);
+            return true;
+        }
+        case BS_PUT_NEXT: {                             // :766-904  1x2 rooms; num_dists per room; sp[0]: start carrying
+            if (!place_agent(0)) return false;
+            int fl = nobj;
+            if (!add_distractors(cfg.num_dists, true, 0)) return false;
+            int fr = nobj;
+            if (!add_distractors(cfg.num_dists, true, 1)) return false;
+            remove_wall(0, 0);
+            int a = fl + rand_int(0, cfg.num_dists);
+            int b = fr + rand_int(0, cfg.num_dists);
+            if (rand_bool()) { int t = a; a = b; b = t; }
+            one_leaf(L_PUTNEXT);
+            set_desc(0, 0, a); set_desc(0, 1, b);
+            if (cfg.sp[0]) w.prog.start_carry = (uint8_t)a;
+            return true;
+        }
+        case BS_MOVE_TWO_ACROSS: {                      // :907-971
+            if (!place_agent(0)) return false;
+            int fl = nobj;
+            if (!add_distractors(cfg.num_dists, true, 0)) return false;
+            int fr = nobj;
+            if (!add_distractors(cfg.num_dists, true, 1)) return false;
+            remove_wall(0, 0);
+            int a, d, b, c2;
+            rand_subset2(fl, cfg.num_dists, a, d);
+            rand_subset2(fr, cfg.num_dists, b, c2);
+            clear_prog(); prep_masks();
+            w.prog.root = R_BEFORE; w.prog.n_a = 1; w.prog.n_b = 1; w.prog.kind[0] = L_PUTNEXT; w.prog.kind[2] = L_PUTNEXT;
+            w.prog.strict = 0; w.prog.start_carry = NONE8;
+            set_desc(0, 0, a); set_desc(0, 1, b);
+            set_desc(2, 0, c2); set_desc(2, 1, d);
+            return true;
+        }
+        case BS_OPEN_DOORS_ORDER: {                     // :974-1049  sp[0]: num_doors, sp[1]: debug
+            const int nd = cfg.sp[0];
+            rand_subset_colors(nd, colors);
+            int first = nobj;
+            for (int k = 0; k < nd; ++k)
+                if (add_door_opt(R11, -1, colors[k], 0) < 0) return false;
+            if (!place_agent(R11)) return false;
+            int d1, d2;
+            rand_subset2(first, nd, d1, d2);
+            int mode = rand_int(0, 3);
+            clear_prog(); prep_masks();
+            const bool dbg = cfg.sp[1] != 0;
+            w.prog.start_carry = NONE8;
+            w.prog.kind[0] = L_OPEN; w.prog.n_a = 1;
+            set_desc_tcl(0, 0, T_DOOR, e_color(w.app[d1]), LOC_NONE);
+            if (mode == 0) {
+                w.prog.root = R_ACTION; w.prog.strict = dbg ? 1 : 0;
+            } else {
+                w.prog.root = mode == 1 ? R_BEFORE : R_AFTER;
+                w.prog.kind[2] = L_OPEN; w.prog.n_b = 1; w.prog.strict = dbg ? 5 : 0;
+                set_desc_tcl(2, 0, T_DOOR, e_color(w.app[d2]), LOC_NONE);
+            }
+            return true;
+        }
+        default: return false;
+        }
     }
 
     // The hand-written single-instruction levels (gen_mission of GoToRedBall[Grey] / GoToObj / GoToLocal / GoTo /
@@ -711,7 +1037,7 @@ struct Gen {
         for (;;) {
             count(PH_ATTEMPTS);
             build_rooms();
-            bool ok = cfg.kind == K_LEVELGEN ? mission_levelgen() : mission_goto();
+            bool ok = cfg.kind == K_LEVELGEN ? mission_levelgen() : cfg.kind == K_BONUS ? mission_bonus() : mission_goto();
             tick(PH_INSTR);
             bool v = ok && validate();
             tick(PH_VALIDATE);

@@ -19,11 +19,12 @@
 namespace bbai {
 
 struct EnvRef {             // views into one env's record + its verifier program (SoA)
-    uint8_t* E; uint8_t* I; uint8_t* app; uint8_t* pos; VProg prog;
+    uint8_t* E; uint8_t* I; uint8_t* app; uint8_t* pos; uint8_t* cont; VProg prog;
 };
+enum : int { V_CONTINUE = 0, V_SUCCESS = 1, V_FAILURE = 2 };
 BB_HD EnvRef env_ref(const LevelCfg& c, uint8_t* rec, const VProg& vp) {
     EnvRef r;
-    r.E = rec; r.I = rec + c.off_I; r.app = rec + c.off_app; r.pos = rec + c.off_pos;
+    r.E = rec; r.I = rec + c.off_I; r.app = rec + c.off_app; r.pos = rec + c.off_pos; r.cont = rec + c.off_cont;
     r.prog = vp;
     return r;
 }
@@ -33,7 +34,7 @@ BB_HD int dir_dy(int d) { return (d == 1) - (d == 3); }
 
 // One ActionInstr.verify_action.  `visited` semantics: preCarrying is only updated when the
 // leaf is actually evaluated (verifier.py:331-334,394-396).
-BB_HD bool verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int leaf, int action) {
+BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int leaf, int action) {
     const int kind = r.prog.kind(leaf);
     const uint64_t set0 = r.prog.set(leaf, 0);
     if (kind == L_GOTO) {
@@ -44,66 +45,74 @@ BB_HD bool verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stal
         int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
         if (e_type(r.E[e_index(c, fx, fy)]) >= T_DOOR) {
             int id = r.I[i_index(c, fx, fy)];
-            if (id >= 2 && (set0 >> (id - 2) & 1)) return true;
+            if (id >= 2 && (set0 >> (id - 2) & 1)) return V_SUCCESS;
         }
         uint64_t m = set0 & stale;
         while (m) {
             int o = __builtin_ctzll(m);
             m &= m - 1;
-            if (r.pos[2 * o] == fx && r.pos[2 * o + 1] == fy) return true;
+            if (r.pos[2 * o] == fx && r.pos[2 * o + 1] == fy) return V_SUCCESS;
         }
-        return false;
+        return V_CONTINUE;
     }
     if (kind == L_OPEN) {
-        if (action != A_TOGGLE) return false;
+        if (action != A_TOGGLE) return V_CONTINUE;
         int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
         int fe = r.E[e_index(c, fx, fy)];
-        if (e_type(fe) != T_DOOR || e_state(fe) != S_OPEN) return false;
-        int id = r.I[i_index(c, fx, fy)];
-        return id >= 2 && (set0 >> (id - 2) & 1);
+        if (e_type(fe) != T_DOOR) return V_CONTINUE;
+        if (e_state(fe) == S_OPEN) {
+            int id = r.I[i_index(c, fx, fy)];
+            if (id >= 2 && (set0 >> (id - 2) & 1)) return V_SUCCESS;
+        }
+        // strict: toggling any door without completing the instruction fails (verifier.py:270-272)
+        return r.prog.strict(leaf) ? V_FAILURE : V_CONTINUE;
     }
     // Pickup / PutNext share the preCarrying protocol.
     const int sh = 8 * leaf;
     int pre = (h.pre4 >> sh) & 0xFF;
     h.pre4 = (h.pre4 & ~(0xFFu << sh)) | ((uint32_t)h.carry << sh);
     if (kind == L_PICKUP) {
-        if (action != A_PICKUP) return false;
-        return pre == NONE8 && h.carry != NONE8 && (set0 >> h.carry & 1);
+        if (action != A_PICKUP) return V_CONTINUE;
+        if (pre == NONE8 && h.carry != NONE8 && (set0 >> h.carry & 1)) return V_SUCCESS;
+        // strict: holding anything after a pickup action that did not complete the instruction (verifier.py:343-346)
+        return (r.prog.strict(leaf) && h.carry != NONE8) ? V_FAILURE : V_CONTINUE;
     }
     // L_PUTNEXT
-    if (action != A_DROP) return false;
-    if (pre == NONE8 || !(set0 >> pre & 1)) return false;
-    if (h.carry == pre) return false;               // drop failed: cur_pos == (-1,-1)
+    if (action != A_DROP) return V_CONTINUE;
+    if (pre == NONE8 || !(set0 >> pre & 1)) return V_CONTINUE;
+    if (h.carry == pre) return V_CONTINUE;          // drop failed: cur_pos == (-1,-1)
     const uint64_t set1 = r.prog.set(leaf, 1);
     int x = r.pos[2 * pre], y = r.pos[2 * pre + 1];
     const int nx[4] = {x + 1, x - 1, x, x}, ny[4] = {y, y, y + 1, y - 1};
     for (int q = 0; q < 4; ++q) {
         int id = r.I[i_index(c, nx[q], ny[q])];
-        if (id >= 2 && (set1 >> (id - 2) & 1)) return true;
+        if (id >= 2 && (set1 >> (id - 2) & 1)) return V_SUCCESS;
     }
-    return false;
+    return V_CONTINUE;
 }
 
 // One side of a Seq (an ActionInstr, or an AndInstr of two).  bit_a/bit_b: And progress bits.
-BB_HD bool verify_side(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int base, int n, int bit_a, int action) {
+// An AndInstr never reports failure (verifier.py:536-550); a lone ActionInstr passes it through.
+BB_HD int verify_side(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int base, int n, int bit_a, int action) {
     if (n == 1) return verify_leaf(c, r, h, stale, base, action);
     if (!(h.vstate >> bit_a & 1))
-        if (verify_leaf(c, r, h, stale, base, action)) h.vstate |= 1 << bit_a;
+        if (verify_leaf(c, r, h, stale, base, action) == V_SUCCESS) h.vstate |= 1 << bit_a;
     if (!(h.vstate >> (bit_a + 1) & 1))
-        if (verify_leaf(c, r, h, stale, base + 1, action)) h.vstate |= 1 << (bit_a + 1);
-    return (h.vstate >> bit_a & 3) == 3;
+        if (verify_leaf(c, r, h, stale, base + 1, action) == V_SUCCESS) h.vstate |= 1 << (bit_a + 1);
+    return (h.vstate >> bit_a & 3) == 3 ? V_SUCCESS : V_CONTINUE;
 }
 
-BB_HD bool verify_root(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action) {
+BB_HD int verify_root(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action) {
     const VProg* p = &r.prog;
     if (p->root() == R_ACTION || p->root() == R_AND) return verify_side(c, r, h, stale, 0, p->n_a(), 1, action);
     // Before: a then b; After: b then a.  The second part is verified with the SAME action in
-    // the step the first part completes (verifier.py:463-464,504-505).
+    // the step the first part completes (verifier.py:463-464,504-505); a failure of either part fails.
     const bool before = p->root() == R_BEFORE;
     const int b1 = before ? 0 : 2, n1 = before ? p->n_a() : p->n_b(), s1 = before ? 1 : 3;
     const int b2 = before ? 2 : 0, n2 = before ? p->n_b() : p->n_a(), s2 = before ? 3 : 1;
     if (!(h.vstate & 1)) {
-        if (!verify_side(c, r, h, stale, b1, n1, s1, action)) return false;
+        int st = verify_side(c, r, h, stale, b1, n1, s1, action);
+        if (st != V_SUCCESS) return st;
         h.vstate |= 1;
     }
     return verify_side(c, r, h, stale, b2, n2, s2, action);
@@ -160,9 +169,15 @@ BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, ui
             } else {
                 r.E[ei] = (uint8_t)e_make(T_DOOR, e_color(fe), e_state(fe) == S_OPEN ? S_CLOSED : S_OPEN);
             }
-        } else if (e_type(fe) == T_BOX) {            // box is replaced by its (empty) contents
+        } else if (e_type(fe) == T_BOX) {            // box is replaced by its contents (nothing, or a hidden object)
             int o = r.I[ii] - 2;
-            r.E[ei] = E_EMPTY; r.I[ii] = 0;
+            int inner = r.cont[o];
+            if (inner == NONE8) {
+                r.E[ei] = E_EMPTY; r.I[ii] = 0;
+            } else {
+                r.E[ei] = r.app[inner]; r.I[ii] = (uint8_t)(inner + 2);
+                r.pos[2 * inner] = (uint8_t)fx; r.pos[2 * inner + 1] = (uint8_t)fy;
+            }
             stale |= 1ull << o;
         }
         break;
@@ -170,11 +185,23 @@ BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, ui
     }
     // every drop ACTION refreshes the tracked positions (levelgen.py:53-54)
     if (action == A_DROP) stale = 0;
-    bool success = verify_root(c, r, h, stale, action);
+    const int status = verify_root(c, r, h, stale, action);
     bool done = h.step >= h.max_steps;
     reward = 0.0f;
-    if (success) { done = true; reward = success_reward(h.step, h.max_steps); }
+    if (status == V_SUCCESS) { done = true; reward = success_reward(h.step, h.max_steps); }
+    else if (status == V_FAILURE) done = true;      // levelgen.py:62-64
     return done;
+}
+
+// bonus_levels.py:821-829: right after reset (and after the first observation was produced) the object is taken
+// off the grid and put in the agent's hands; its recorded position stays behind (stale), exactly as if picked up.
+BB_HD void apply_start_carry(const LevelCfg& c, uint8_t* rec, Hot& h, uint64_t& stale, int obj) {
+    uint8_t* pos = rec + c.off_pos;
+    const int x = pos[2 * obj], y = pos[2 * obj + 1];
+    rec[e_index(c, x, y)] = E_EMPTY;
+    rec[c.off_I + i_index(c, x, y)] = 0;
+    h.carry = (uint8_t)obj;
+    stale |= 1ull << obj;
 }
 
 // Grid.process_vis on 7-bit row masks.  opq[vj] bit vi = cell (vi,vj) blocks sight.

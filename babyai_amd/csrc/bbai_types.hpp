@@ -87,7 +87,9 @@ struct Prog {               // 112 bytes
     uint8_t kind[4];        // L_* ; leaves 0,1 = side A (two => And), leaves 2,3 = side B
     uint8_t root;           // R_*
     uint8_t n_a, n_b;       // leaves on each side
-    uint8_t pad[9];
+    uint8_t strict;         // bit k: leaf k verifies in strict mode (verifier.py:270-272,343-346)
+    uint8_t start_carry;    // NONE8, or the object the agent holds right after reset (bonus_levels.py:821-829)
+    uint8_t pad[7];
 };
 static_assert(sizeof(Prog) == 112, "Prog layout");
 
@@ -96,7 +98,8 @@ static_assert(sizeof(Prog) == 112, "Prog layout");
 // k = 2*leaf + slot -- a single-leaf mission touches 4 + 8 bytes per env-step instead of a 112-byte gather.
 BB_HD uint32_t vhead_pack(const Prog& p) {
     return (uint32_t)p.root | ((uint32_t)p.n_a << 2) | ((uint32_t)p.n_b << 4) | ((uint32_t)p.kind[0] << 8) |
-           ((uint32_t)p.kind[1] << 11) | ((uint32_t)p.kind[2] << 14) | ((uint32_t)p.kind[3] << 17);
+           ((uint32_t)p.kind[1] << 11) | ((uint32_t)p.kind[2] << 14) | ((uint32_t)p.kind[3] << 17) |
+           ((uint32_t)(p.strict & 15) << 20);
 }
 struct VProg {
     uint32_t head;
@@ -106,6 +109,7 @@ struct VProg {
     BB_HD int n_a() const { return (head >> 2) & 3; }
     BB_HD int n_b() const { return (head >> 4) & 3; }
     BB_HD int kind(int leaf) const { return (head >> (8 + 3 * leaf)) & 7; }
+    BB_HD bool strict(int leaf) const { return (head >> (20 + leaf)) & 1; }
     BB_HD uint64_t set(int leaf, int slot) const { return sets[(int64_t)(2 * leaf + slot) * stride]; }
 };
 
@@ -122,7 +126,11 @@ struct Hot {                // 16 bytes, one per env, SoA array => one dwordx4 p
 static_assert(sizeof(Hot) == 16, "Hot layout");
 
 // ---- level configuration ---------------------------------------------------
-enum : int { K_GOTO = 0, K_LEVELGEN = 1 };
+enum : int { K_GOTO = 0, K_LEVELGEN = 1, K_BONUS = 2 };
+enum : int { BS_GOTO_REDBLUE_BALL = 1, BS_OPEN_RED_DOOR, BS_OPEN_DOOR, BS_GOTO_DOOR, BS_GOTO_OBJ_DOOR, BS_ACTION_OBJ_DOOR,
+             BS_UNLOCK_LOCAL, BS_KEY_IN_BOX, BS_UNLOCK_PICKUP, BS_BLOCKED_UNLOCK_PICKUP, BS_UNLOCK_TO_UNLOCK, BS_PICKUP_DIST,
+             BS_PICKUP_ABOVE, BS_OPEN_TWO_DOORS, BS_FIND_OBJ, BS_KEY_CORRIDOR, BS_ONE_ROOM, BS_PUT_NEXT, BS_MOVE_TWO_ACROSS,
+             BS_OPEN_DOORS_ORDER, BS_COUNT };
 enum : int { TG_REDBALL = 0, TG_DIST = 1, TG_DOOR = 2, TG_TWO_DISTS = 3, TG_LOCKED_DOOR = 4, TG_LOCKED_ROOM_OBJ = 5 };
 enum : int { AK_GOTO = 0, AK_PICKUP = 1, AK_OPEN = 2, AK_PUTNEXT = 3 };
 enum : int { IK_ACTION = 0, IK_AND = 1, IK_SEQ = 2 };
@@ -143,6 +151,8 @@ struct LevelCfg {
     int32_t lock_color_excl;// Unlock: with probability 1/2 connect_all() avoids the locked door's colour
     int32_t dists_per_room; // 1: num_dists distractors in every room except the locked one
     int32_t grey_dists;     // GoToRedBallGrey: distractors are recoloured grey
+    // K_BONUS: hand-written gen_mission scripts of bonus_levels.py (BS_*), with up to four integer parameters
+    int32_t script, sp[4];
     // K_LEVELGEN (levelgen.py:256-460)
     int32_t locations, unblocking, implicit_unlock;
     int32_t n_action_kinds, action_kinds[4];
@@ -150,7 +160,7 @@ struct LevelCfg {
     double locked_room_prob;
     // derived layout (fill_layout)
     int32_t W, H, ES, EH, maxo;
-    int32_t off_I, off_app, off_pos, off_prog, rec_bytes;
+    int32_t off_I, off_app, off_pos, off_cont, off_prog, rec_bytes;
 };
 
 BB_HD int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -165,12 +175,14 @@ inline int fill_layout(LevelCfg& c) {
     c.EH = c.H + 2 * MARGIN;
     int ndoors = c.num_rows * (c.num_cols - 1) + c.num_cols * (c.num_rows - 1);
     int nd = c.dists_per_room ? c.num_dists * c.num_rows * c.num_cols : c.num_dists;
+    if (c.kind == K_BONUS) nd = 24;               // bonus scripts place at most 2*9 + a few objects
     c.maxo = round_up(nd + 2 + ndoors, 8);
     if (c.maxo > MAX_OBJ) return -1;
     c.off_I = c.ES * c.EH;
     c.off_app = round_up(c.off_I + c.W * c.H, 4);
     c.off_pos = c.off_app + c.maxo;
-    c.off_prog = round_up(c.off_pos + 2 * c.maxo, 16);
+    c.off_cont = c.off_pos + 2 * c.maxo;          // contains[k]: object revealed when box k is toggled (NONE8 = empty)
+    c.off_prog = round_up(c.off_cont + c.maxo, 16);
     c.rec_bytes = round_up(c.off_prog + (int)sizeof(Prog), 64);
     return 0;
 }

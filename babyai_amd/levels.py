@@ -18,7 +18,7 @@ generator families:
 """
 import ctypes
 
-K_GOTO, K_LEVELGEN = 0, 1
+K_GOTO, K_LEVELGEN, K_BONUS = 0, 1, 2
 AK = {"goto": 0, "pickup": 1, "open": 2, "putnext": 3}
 IK = {"action": 0, "and": 1, "seq": 2}
 
@@ -33,6 +33,7 @@ class LevelCfg(ctypes.Structure):
         ("doors_open", ctypes.c_int32), ("all_unique", ctypes.c_int32),
         ("instr", ctypes.c_int32), ("target", ctypes.c_int32), ("lock", ctypes.c_int32),
         ("lock_color_excl", ctypes.c_int32), ("dists_per_room", ctypes.c_int32), ("grey_dists", ctypes.c_int32),
+        ("script", ctypes.c_int32), ("sp", ctypes.c_int32 * 4),
         ("locations", ctypes.c_int32), ("unblocking", ctypes.c_int32), ("implicit_unlock", ctypes.c_int32),
         ("n_action_kinds", ctypes.c_int32), ("action_kinds", ctypes.c_int32 * 4),
         ("n_instr_kinds", ctypes.c_int32), ("instr_kinds", ctypes.c_int32 * 3),
@@ -40,7 +41,7 @@ class LevelCfg(ctypes.Structure):
         ("W", ctypes.c_int32), ("H", ctypes.c_int32), ("ES", ctypes.c_int32), ("EH", ctypes.c_int32),
         ("maxo", ctypes.c_int32),
         ("off_I", ctypes.c_int32), ("off_app", ctypes.c_int32), ("off_pos", ctypes.c_int32),
-        ("off_prog", ctypes.c_int32), ("rec_bytes", ctypes.c_int32),
+        ("off_cont", ctypes.c_int32), ("off_prog", ctypes.c_int32), ("rec_bytes", ctypes.c_int32),
     ]
 
 
@@ -73,6 +74,19 @@ def _levelgen(room_size=8, num_rows=3, num_cols=3, num_dists=18, locked_room_pro
                 locations=int(locations), unblocking=int(unblocking),
                 implicit_unlock=int(implicit_unlock),
                 action_kinds=tuple(action_kinds), instr_kinds=tuple(instr_kinds))
+
+
+(BS_GOTO_REDBLUE_BALL, BS_OPEN_RED_DOOR, BS_OPEN_DOOR, BS_GOTO_DOOR, BS_GOTO_OBJ_DOOR, BS_ACTION_OBJ_DOOR,
+ BS_UNLOCK_LOCAL, BS_KEY_IN_BOX, BS_UNLOCK_PICKUP, BS_BLOCKED_UNLOCK_PICKUP, BS_UNLOCK_TO_UNLOCK, BS_PICKUP_DIST,
+ BS_PICKUP_ABOVE, BS_OPEN_TWO_DOORS, BS_FIND_OBJ, BS_KEY_CORRIDOR, BS_ONE_ROOM, BS_PUT_NEXT, BS_MOVE_TWO_ACROSS,
+ BS_OPEN_DOORS_ORDER) = range(1, 21)
+_COLOR_IDX = {"red": 0, "green": 1, "blue": 2, "purple": 3, "yellow": 4, "grey": 5}
+
+
+def _bonus(script, room_size=8, num_rows=3, num_cols=3, num_dists=0, sp=()):
+    """A hand-written gen_mission of bonus_levels.py (device twin: Gen::mission_bonus)."""
+    return dict(kind=K_BONUS, script=script, room_size=room_size, num_rows=num_rows, num_cols=num_cols,
+                num_dists=num_dists, sp=tuple(sp))
 
 
 LEVELS = {
@@ -117,6 +131,57 @@ LEVELS = {
                     target=TG_LOCKED_DOOR),
     "GoToImpUnlock": _maze(num_dists=2, connect=1, lock=1, dists_per_room=1, instr=L_GOTO,
                            target=TG_LOCKED_ROOM_OBJ),
+    # --- bonus levels (bonus_levels.py; file:line next to each case of Gen::mission_bonus) ------------
+    "GoToRedBlueBall": _bonus(BS_GOTO_REDBLUE_BALL, num_rows=1, num_cols=1, num_dists=7),
+    "OpenRedDoor": _bonus(BS_OPEN_RED_DOOR, room_size=5, num_rows=1, num_cols=2),
+    "OpenDoor": _bonus(BS_OPEN_DOOR, sp=(0, 0)),
+    "OpenDoorDebug": _bonus(BS_OPEN_DOOR, sp=(0, 1)),
+    "OpenDoorColor": _bonus(BS_OPEN_DOOR, sp=(1, 0)),
+    "OpenDoorLoc": _bonus(BS_OPEN_DOOR, sp=(2, 0)),
+    "GoToDoor": _bonus(BS_GOTO_DOOR, room_size=7),
+    "GoToObjDoor": _bonus(BS_GOTO_OBJ_DOOR, room_size=8),
+    "ActionObjDoor": _bonus(BS_ACTION_OBJ_DOOR, room_size=7),
+    "UnlockLocal": _bonus(BS_UNLOCK_LOCAL, sp=(0,)),
+    "UnlockLocalDist": _bonus(BS_UNLOCK_LOCAL, sp=(1,)),
+    "KeyInBox": _bonus(BS_KEY_IN_BOX),
+    "UnlockPickup": _bonus(BS_UNLOCK_PICKUP, room_size=6, num_rows=1, num_cols=2, sp=(0,)),
+    "UnlockPickupDist": _bonus(BS_UNLOCK_PICKUP, room_size=6, num_rows=1, num_cols=2, sp=(1,)),
+    "BlockedUnlockPickup": _bonus(BS_BLOCKED_UNLOCK_PICKUP, room_size=6, num_rows=1, num_cols=2),
+    "UnlockToUnlock": _bonus(BS_UNLOCK_TO_UNLOCK, room_size=6, num_rows=1, num_cols=3),
+    "PickupDist": _bonus(BS_PICKUP_DIST, room_size=7, num_rows=1, num_cols=1, sp=(0,)),
+    "PickupDistDebug": _bonus(BS_PICKUP_DIST, room_size=7, num_rows=1, num_cols=1, sp=(1,)),
+    "PickupAbove": _bonus(BS_PICKUP_ABOVE, room_size=6),
+    "OpenTwoDoors": _bonus(BS_OPEN_TWO_DOORS, room_size=6, sp=(0, 0, 0)),
+    "OpenTwoDoorsDebug": _bonus(BS_OPEN_TWO_DOORS, room_size=6, sp=(0, 0, 1)),
+    "OpenRedBlueDoors": _bonus(BS_OPEN_TWO_DOORS, room_size=6, sp=(1 + 0, 1 + 2, 0)),
+    "OpenRedBlueDoorsDebug": _bonus(BS_OPEN_TWO_DOORS, room_size=6, sp=(1 + 0, 1 + 2, 1)),
+    "FindObjS5": _bonus(BS_FIND_OBJ, room_size=5),
+    "FindObjS6": _bonus(BS_FIND_OBJ, room_size=6),
+    "FindObjS7": _bonus(BS_FIND_OBJ, room_size=7),
+    "KeyCorridorS3R1": _bonus(BS_KEY_CORRIDOR, room_size=3, num_rows=1),
+    "KeyCorridorS3R2": _bonus(BS_KEY_CORRIDOR, room_size=3, num_rows=2),
+    "KeyCorridorS3R3": _bonus(BS_KEY_CORRIDOR, room_size=3, num_rows=3),
+    "KeyCorridorS4R3": _bonus(BS_KEY_CORRIDOR, room_size=4, num_rows=3),
+    "KeyCorridorS5R3": _bonus(BS_KEY_CORRIDOR, room_size=5, num_rows=3),
+    "KeyCorridorS6R3": _bonus(BS_KEY_CORRIDOR, room_size=6, num_rows=3),
+    "1RoomS8": _bonus(BS_ONE_ROOM, room_size=8, num_rows=1, num_cols=1),
+    "1RoomS12": _bonus(BS_ONE_ROOM, room_size=12, num_rows=1, num_cols=1),
+    "1RoomS16": _bonus(BS_ONE_ROOM, room_size=16, num_rows=1, num_cols=1),
+    "1RoomS20": _bonus(BS_ONE_ROOM, room_size=20, num_rows=1, num_cols=1),
+    "PutNextS4N1": _bonus(BS_PUT_NEXT, room_size=4, num_rows=1, num_cols=2, num_dists=1, sp=(0,)),
+    "PutNextS5N1": _bonus(BS_PUT_NEXT, room_size=5, num_rows=1, num_cols=2, num_dists=1, sp=(0,)),
+    "PutNextS5N2": _bonus(BS_PUT_NEXT, room_size=5, num_rows=1, num_cols=2, num_dists=2, sp=(0,)),
+    "PutNextS6N3": _bonus(BS_PUT_NEXT, room_size=6, num_rows=1, num_cols=2, num_dists=3, sp=(0,)),
+    "PutNextS7N4": _bonus(BS_PUT_NEXT, room_size=7, num_rows=1, num_cols=2, num_dists=4, sp=(0,)),
+    "PutNextS5N2Carrying": _bonus(BS_PUT_NEXT, room_size=5, num_rows=1, num_cols=2, num_dists=2, sp=(1,)),
+    "PutNextS6N3Carrying": _bonus(BS_PUT_NEXT, room_size=6, num_rows=1, num_cols=2, num_dists=3, sp=(1,)),
+    "PutNextS7N4Carrying": _bonus(BS_PUT_NEXT, room_size=7, num_rows=1, num_cols=2, num_dists=4, sp=(1,)),
+    "MoveTwoAcrossS5N2": _bonus(BS_MOVE_TWO_ACROSS, room_size=5, num_rows=1, num_cols=2, num_dists=2),
+    "MoveTwoAcrossS8N9": _bonus(BS_MOVE_TWO_ACROSS, room_size=8, num_rows=1, num_cols=2, num_dists=9),
+    "OpenDoorsOrderN2": _bonus(BS_OPEN_DOORS_ORDER, room_size=6, sp=(2, 0)),
+    "OpenDoorsOrderN4": _bonus(BS_OPEN_DOORS_ORDER, room_size=6, sp=(4, 0)),
+    "OpenDoorsOrderN2Debug": _bonus(BS_OPEN_DOORS_ORDER, room_size=6, sp=(2, 1)),
+    "OpenDoorsOrderN4Debug": _bonus(BS_OPEN_DOORS_ORDER, room_size=6, sp=(4, 1)),
     # --- K_LEVELGEN family ---------------------------------------------------------------
     "PickupLoc": _levelgen(action_kinds=("pickup",), instr_kinds=("action",), num_rows=1, num_cols=1,
                            num_dists=8, locked_room_prob=0, locations=True, unblocking=False),
@@ -155,11 +220,14 @@ def fill_layout(cfg):
     cfg.EH = cfg.H + 2 * MARGIN
     ndoors = cfg.num_rows * (cfg.num_cols - 1) + cfg.num_cols * (cfg.num_rows - 1)
     nd = cfg.num_dists * cfg.num_rows * cfg.num_cols if cfg.dists_per_room else cfg.num_dists
+    if cfg.kind == K_BONUS:
+        nd = 24
     cfg.maxo = rup(nd + 2 + ndoors, 8)
     cfg.off_I = cfg.ES * cfg.EH
     cfg.off_app = rup(cfg.off_I + cfg.W * cfg.H, 4)
     cfg.off_pos = cfg.off_app + cfg.maxo
-    cfg.off_prog = rup(cfg.off_pos + 2 * cfg.maxo, 16)
+    cfg.off_cont = cfg.off_pos + 2 * cfg.maxo
+    cfg.off_prog = rup(cfg.off_cont + cfg.maxo, 16)
     cfg.rec_bytes = rup(cfg.off_prog + PROG, 64)
     return cfg
 
@@ -181,6 +249,9 @@ def make_cfg(env_id):
             cfg.n_instr_kinds = len(v)
             for i, a in enumerate(v):
                 cfg.instr_kinds[i] = IK[a]
+        elif k == "sp":
+            for i, a in enumerate(v):
+                cfg.sp[i] = int(a)
         else:
             setattr(cfg, k, v)
     return fill_layout(cfg)

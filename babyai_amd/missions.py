@@ -9,7 +9,7 @@ on demand, following the reference grammar (babyai/levels/verifier.py:64-94 ObjD
 import numpy as np
 
 PROG_BYTES = 112
-TYPE_NAME = {4: "door", 5: "key", 6: "ball", 7: "box"}
+TYPE_NAME = {0: "object", 4: "door", 5: "key", 6: "ball", 7: "box"}    # 0: ObjDesc(type=None)
 COLOR_NAME = {0: "red", 1: "green", 2: "blue", 3: "purple", 4: "yellow", 5: "grey"}
 L_GOTO, L_PICKUP, L_OPEN, L_PUTNEXT = 1, 2, 3, 4
 R_ACTION, R_AND, R_BEFORE, R_AFTER = 0, 1, 2, 3

@@ -28,16 +28,17 @@ enum bbai_status {
  * (babyai/levels/iclr19_levels.py; LevelGen babyai/levels/levelgen.py:262-291) as data.
  * Layout fields (W..rec_bytes) are derived by bbai_fill_layout. */
 typedef struct bbai_level_cfg {
-    int32_t kind;                       /* 0 = GoTo family, 1 = LevelGen family */
+    int32_t kind;                       /* 0 = GoTo family, 1 = LevelGen family, 2 = bonus-level scripts */
     int32_t room_size, num_rows, num_cols, num_dists;
     int32_t redball, connect, check_reach, doors_open, all_unique;     /* GoTo family */
     int32_t instr, target, lock, lock_color_excl, dists_per_room, grey_dists;   /* single-instruction levels */
+    int32_t script, sp[4];              /* kind 2: bonus_levels.py gen_mission script id + parameters */
     int32_t locations, unblocking, implicit_unlock;                    /* LevelGen */
     int32_t n_action_kinds, action_kinds[4];    /* 0 goto 1 pickup 2 open 3 putnext, in list order */
     int32_t n_instr_kinds, instr_kinds[3];      /* 0 action 1 and 2 seq, in list order */
     double locked_room_prob;
     int32_t W, H, ES, EH, maxo;
-    int32_t off_I, off_app, off_pos, off_prog, rec_bytes;
+    int32_t off_I, off_app, off_pos, off_cont, off_prog, rec_bytes;
 } bbai_level_cfg;
 
 typedef struct bbai_env bbai_env;       /* opaque: N envs of one level on one device */

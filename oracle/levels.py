@@ -22,7 +22,8 @@ What follows which reference code (all under /root/reference/babyai/levels/):
   OracleLevel.all_reachable        levelgen.py:201-253
   LevelGenOracle.gen_mission etc.  levelgen.py:293-460
   GoToOracle.gen_mission           iclr19_levels.py:40-63, 75-124, 224-257
-`strict` modes and BABYAI_DONE_ACTIONS (verifier.py:17) are outside the hot path scope.
+  BonusOracle.gen_*                bonus_levels.py (line ranges in each method's docstring)
+BABYAI_DONE_ACTIONS (verifier.py:17) and SeqInstr-level `strict` (unused by any level) are not restated.
 """
 import os
 import sys
@@ -31,7 +32,7 @@ _SHIM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shim")
 if _SHIM not in sys.path:
     sys.path.insert(0, _SHIM)
 
-from gym_minigrid.minigrid import COLOR_NAMES, DIR_TO_VEC  # noqa: E402
+from gym_minigrid.minigrid import COLOR_NAMES, DIR_TO_VEC, Ball, Box, Key  # noqa: E402
 from gym_minigrid.roomgrid import RoomGrid  # noqa: E402
 
 TYPES_ALL = ['box', 'ball', 'key', 'door']
@@ -107,8 +108,8 @@ class Clause(object):
     """One action instruction: kind in goto / pickup / open / putnext."""
     VERB = {'goto': 'go to ', 'pickup': 'pick up ', 'open': 'open ', 'putnext': 'put '}
 
-    def __init__(self, kind, d1, d2=None):
-        self.kind, self.d1, self.d2 = kind, d1, d2
+    def __init__(self, kind, d1, d2=None, strict=False):
+        self.kind, self.d1, self.d2, self.strict = kind, d1, d2, strict
         self.held_before = None
 
     def descs(self):
@@ -148,11 +149,17 @@ class Clause(object):
             cell = env.grid.get(*env.front_pos)
             if cell is not None and any(cell is d for d in self.d1.objs) and cell.is_open:
                 return 'success'
+            if self.strict and cell is not None and cell.type == 'door':
+                return 'failure'          # verifier.py:270-272
             return 'continue'
         before, self.held_before = self.held_before, env.carrying
         if self.kind == 'pickup':
-            if action == A.pickup and before is None and any(env.carrying is o for o in self.d1.objs):
+            if action != A.pickup:
+                return 'continue'
+            if before is None and any(env.carrying is o for o in self.d1.objs):
                 return 'success'
+            if self.strict and env.carrying:
+                return 'failure'          # verifier.py:343-346
             return 'continue'
         # putnext
         if action != A.drop:
@@ -200,10 +207,12 @@ class Combo(object):
             return 'success' if self.sa == 'success' and self.sb == 'success' else 'continue'
         first, second = (self.a, self.b) if self.how == 'before' else (self.b, self.a)
         if not getattr(self, '_first_done', False):
-            if first.verify(action) != 'success':
-                return 'continue'
+            st = first.verify(action)
+            if st != 'success':
+                return 'failure' if st == 'failure' else 'continue'
             self._first_done = True
-        return 'success' if second.verify(action) == 'success' else 'continue'
+        st = second.verify(action)
+        return st if st in ('success', 'failure') else 'continue'
 
     def start_seq(self):
         self._first_done = False
@@ -238,9 +247,13 @@ class OracleLevel(RoomGrid):
         obs, reward, done, info = super().step(action)
         if action == self.actions.drop:
             self.instrs.refresh()
-        if self.instrs.verify(action) == 'success':
+        status = self.instrs.verify(action)
+        if status == 'success':
             done = True
             reward = self._reward()
+        elif status == 'failure':
+            done = True
+            reward = 0
         return obs, reward, done, info
 
     def _gen_grid(self, width, height):
@@ -392,6 +405,224 @@ class GoToOracle(OracleLevel):
                 door.is_open = True
 
 
+class BonusOracle(OracleLevel):
+    """The hand-written levels of bonus_levels.py, one method per reference class (file:line in each docstring).
+    `script` selects the method; `sp` carries the class parameters."""
+
+    def __init__(self, script, room_size=8, num_rows=3, num_cols=3, num_dists=0, sp=(), seed=None):
+        self.script, self.n_objs, self.sp = script, num_dists, tuple(sp)
+        self.held_at_start = None
+        super().__init__(room_size=room_size, num_rows=num_rows, num_cols=num_cols, seed=seed)
+
+    def gen_mission(self):
+        self.held_at_start = None
+        getattr(self, 'gen_' + self.script)()
+
+    def reset(self, **kw):
+        obs = super().reset(**kw)
+        if self.held_at_start is not None:        # bonus_levels.py:821-829 -- AFTER the first obs was built
+            self.grid.set(*self.held_at_start.init_pos, None)
+            self.carrying = self.held_at_start
+        return obs
+
+    def _doors(self, n, room=(1, 1), **kw):
+        return [self.add_door(room[0], room[1], **kw)[0] for _ in range(n)]
+
+    def gen_goto_redblue_ball(self):
+        """bonus_levels.py:7-40"""
+        self.place_agent()
+        for d in self.add_distractors(num_distractors=self.n_objs, all_unique=False):
+            if d.type == 'ball' and d.color in ('blue', 'red'):
+                raise Reject('second red/blue ball')
+        obj, _ = self.add_object(0, 0, 'ball', self._rand_elem(['red', 'blue']))
+        self.all_reachable()
+        self.instrs = Clause('goto', Desc(obj.type, obj.color))
+
+    def gen_open_red_door(self):
+        """:43-62"""
+        self.add_door(0, 0, 0, 'red', locked=False)
+        self.place_agent(0, 0)
+        self.instrs = Clause('open', Desc('door', 'red'))
+
+    def gen_open_door(self):
+        """:65-147  sp = (select_by: 0 random / 1 color / 2 loc, debug)"""
+        doors = [self.add_door(1, 1, door_idx=k, color=c, locked=False)[0]
+                 for k, c in enumerate(self._rand_subset(COLOR_NAMES, 4))]
+        how = self.sp[0] or 1 + ['color', 'loc'].index(self._rand_elem(['color', 'loc']))
+        if how == 1:
+            desc = Desc('door', doors[0].color)
+        else:
+            desc = Desc('door', loc=self._rand_elem(LOCS))
+        self.place_agent(1, 1)
+        self.instrs = Clause('open', desc, strict=bool(self.sp[1]))
+
+    def gen_goto_door(self):
+        """:150-171"""
+        doors = self._doors(4)
+        self.place_agent(1, 1)
+        self.instrs = Clause('goto', Desc('door', self._rand_elem(doors).color))
+
+    def gen_goto_obj_door(self):
+        """:174-197"""
+        self.place_agent(1, 1)
+        objs = self.add_distractors(1, 1, num_distractors=8, all_unique=False)
+        objs += self._doors(4)
+        self.all_reachable()
+        o = self._rand_elem(objs)
+        self.instrs = Clause('goto', Desc(o.type, o.color))
+
+    def gen_action_obj_door(self):
+        """:200-234"""
+        objs = self.add_distractors(1, 1, num_distractors=5)
+        objs += self._doors(4, locked=False)
+        self.place_agent(1, 1)
+        o = self._rand_elem(objs)
+        kind = 'goto' if self._rand_bool() else ('open' if o.type == 'door' else 'pickup')
+        self.instrs = Clause(kind, Desc(o.type, o.color))
+
+    def gen_unlock_local(self):
+        """:237-264  sp = (distractors,)"""
+        door, _ = self.add_door(1, 1, locked=True)
+        self.add_object(1, 1, 'key', door.color)
+        if self.sp[0]:
+            self.add_distractors(1, 1, num_distractors=3)
+        self.place_agent(1, 1)
+        self.instrs = Clause('open', Desc('door'))
+
+    def gen_key_in_box(self):
+        """:267-287"""
+        door, _ = self.add_door(1, 1, locked=True)
+        self.place_in_room(1, 1, Box(self._rand_color(), Key(door.color)))
+        self.place_agent(1, 1)
+        self.instrs = Clause('open', Desc('door'))
+
+    def gen_unlock_pickup(self):
+        """:290-329  sp = (distractors,)"""
+        box, _ = self.add_object(1, 0, kind='box')
+        door, _ = self.add_door(0, 0, 0, locked=True)
+        self.add_object(0, 0, 'key', door.color)
+        if self.sp[0]:
+            self.add_distractors(num_distractors=4)
+        self.place_agent(0, 0)
+        self.instrs = Clause('pickup', Desc(box.type, box.color))
+
+    def gen_blocked_unlock_pickup(self):
+        """:332-361"""
+        self.add_object(1, 0, kind='box')
+        door, pos = self.add_door(0, 0, 0, locked=True)
+        self.grid.set(pos[0] - 1, pos[1], Ball(self._rand_color()))
+        self.add_object(0, 0, 'key', door.color)
+        self.place_agent(0, 0)
+        self.instrs = Clause('pickup', Desc('box'))
+
+    def gen_unlock_to_unlock(self):
+        """:364-398"""
+        ca, cb = self._rand_subset(COLOR_NAMES, 2)
+        self.add_door(0, 0, door_idx=0, color=ca, locked=True)
+        self.add_object(2, 0, kind='key', color=ca)
+        self.add_door(1, 0, door_idx=0, color=cb, locked=True)
+        self.add_object(1, 0, kind='key', color=cb)
+        self.add_object(0, 0, kind='ball')
+        self.place_agent(1, 0)
+        self.instrs = Clause('pickup', Desc('ball'))
+
+    def gen_pickup_dist(self):
+        """:401-444  sp = (debug,)"""
+        objs = self.add_distractors(num_distractors=5)
+        self.place_agent(0, 0)
+        o = self._rand_elem(objs)
+        how = self._rand_elem(['type', 'color', 'both'])
+        desc = Desc(None if how == 'color' else o.type, None if how == 'type' else o.color)
+        self.instrs = Clause('pickup', desc, strict=bool(self.sp[0]))
+
+    def gen_pickup_above(self):
+        """:447-469"""
+        o, _ = self.add_object(1, 0)
+        self.add_door(1, 1, 3, locked=False)
+        self.place_agent(1, 1)
+        self.connect_all()
+        self.instrs = Clause('pickup', Desc(o.type, o.color))
+
+    def gen_open_two_doors(self):
+        """:472-562  sp = (first colour index + 1 or 0, second colour index + 1 or 0, strict)"""
+        names = ['red', 'green', 'blue', 'purple', 'yellow', 'grey']
+        drawn = self._rand_subset(COLOR_NAMES, 2)
+        c1 = names[self.sp[0] - 1] if self.sp[0] else drawn[0]
+        c2 = names[self.sp[1] - 1] if self.sp[1] else drawn[1]
+        d1, _ = self.add_door(1, 1, 2, color=c1, locked=False)
+        d2, _ = self.add_door(1, 1, 0, color=c2, locked=False)
+        self.place_agent(1, 1)
+        self.instrs = Combo('before', Clause('open', Desc(d1.type, d1.color), strict=bool(self.sp[2])),
+                            Clause('open', Desc(d2.type, d2.color)))
+
+    def gen_find_obj(self):
+        """:565-611"""
+        i = self._rand_int(0, self.num_rows)
+        j = self._rand_int(0, self.num_cols)
+        o, _ = self.add_object(i, j)
+        self.place_agent(1, 1)
+        self.connect_all()
+        self.instrs = Clause('pickup', Desc(o.type))
+
+    def gen_key_corridor(self):
+        """:614-704"""
+        for j in range(1, self.num_rows):
+            self.remove_wall(1, j, 3)
+        row = self._rand_int(0, self.num_rows)
+        door, _ = self.add_door(2, row, 2, locked=True)
+        o, _ = self.add_object(2, row, kind='ball')
+        self.add_object(0, self._rand_int(0, self.num_rows), 'key', door.color)
+        self.place_agent(1, self.num_rows // 2)
+        self.connect_all()
+        self.instrs = Clause('pickup', Desc(o.type))
+
+    def gen_one_room(self):
+        """:707-763"""
+        o, _ = self.add_object(0, 0, kind='ball')
+        self.place_agent()
+        self.instrs = Clause('pickup', Desc(o.type))
+
+    def _two_rooms(self):
+        self.place_agent(0, 0)
+        left = self.add_distractors(0, 0, self.n_objs)
+        right = self.add_distractors(1, 0, self.n_objs)
+        self.remove_wall(0, 0, 0)
+        return left, right
+
+    def gen_put_next(self):
+        """:766-904  sp = (start_carrying,)"""
+        left, right = self._two_rooms()
+        a = self._rand_elem(left)
+        b = self._rand_elem(right)
+        if self._rand_bool():
+            a, b = b, a
+        self.instrs = Clause('putnext', Desc(a.type, a.color), Desc(b.type, b.color))
+        if self.sp[0]:
+            self.held_at_start = a
+
+    def gen_move_two_across(self):
+        """:907-971"""
+        left, right = self._two_rooms()
+        a, d = self._rand_subset(left, 2)
+        b, c = self._rand_subset(right, 2)
+        self.instrs = Combo('before', Clause('putnext', Desc(a.type, a.color), Desc(b.type, b.color)),
+                            Clause('putnext', Desc(c.type, c.color), Desc(d.type, d.color)))
+
+    def gen_open_doors_order(self):
+        """:974-1049  sp = (num_doors, debug)"""
+        n, dbg = self.sp[0], bool(self.sp[1])
+        doors = [self.add_door(1, 1, color=c, locked=False)[0] for c in self._rand_subset(COLOR_NAMES, n)]
+        self.place_agent(1, 1)
+        d1, d2 = self._rand_subset(doors, 2)
+        mode = self._rand_int(0, 3)
+        first = Clause('open', Desc(d1.type, d1.color), strict=dbg)
+        if mode == 0:
+            self.instrs = first
+        else:
+            self.instrs = Combo('before' if mode == 1 else 'after', first,
+                                Clause('open', Desc(d2.type, d2.color), strict=dbg))
+
+
 class LevelGenOracle(OracleLevel):
     """The general mission sampler (LevelGen) and all its parameterisations."""
 
@@ -491,6 +722,10 @@ def _l(**kw):
     return ('levelgen', kw)
 
 
+def _b(script, **kw):
+    return ('bonus', dict(script=script, **kw))
+
+
 # Constructor arguments per level (iclr19_levels.py; written out independently of babyai_amd/levels.py,
 # tests/test_levels_table.py checks the two tables agree).
 SPECS = {
@@ -526,6 +761,51 @@ SPECS = {
                  dists_per_room=True, instr='open', target='locked_door'),
     'GoToImpUnlock': _g(num_rows=3, num_cols=3, num_dists=2, connect=True, lock=True, dists_per_room=True,
                         instr='goto', target='locked_room_obj'),
+    'GoToRedBlueBall': _b('goto_redblue_ball', num_rows=1, num_cols=1, num_dists=7),
+    'OpenRedDoor': _b('open_red_door', room_size=5, num_rows=1, num_cols=2),
+    'OpenDoor': _b('open_door', sp=(0, 0)), 'OpenDoorDebug': _b('open_door', sp=(0, 1)),
+    'OpenDoorColor': _b('open_door', sp=(1, 0)), 'OpenDoorLoc': _b('open_door', sp=(2, 0)),
+    'GoToDoor': _b('goto_door', room_size=7), 'GoToObjDoor': _b('goto_obj_door'),
+    'ActionObjDoor': _b('action_obj_door', room_size=7),
+    'UnlockLocal': _b('unlock_local', sp=(0,)), 'UnlockLocalDist': _b('unlock_local', sp=(1,)),
+    'KeyInBox': _b('key_in_box'),
+    'UnlockPickup': _b('unlock_pickup', room_size=6, num_rows=1, num_cols=2, sp=(0,)),
+    'UnlockPickupDist': _b('unlock_pickup', room_size=6, num_rows=1, num_cols=2, sp=(1,)),
+    'BlockedUnlockPickup': _b('blocked_unlock_pickup', room_size=6, num_rows=1, num_cols=2),
+    'UnlockToUnlock': _b('unlock_to_unlock', room_size=6, num_rows=1, num_cols=3),
+    'PickupDist': _b('pickup_dist', room_size=7, num_rows=1, num_cols=1, sp=(0,)),
+    'PickupDistDebug': _b('pickup_dist', room_size=7, num_rows=1, num_cols=1, sp=(1,)),
+    'PickupAbove': _b('pickup_above', room_size=6),
+    'OpenTwoDoors': _b('open_two_doors', room_size=6, sp=(0, 0, 0)),
+    'OpenTwoDoorsDebug': _b('open_two_doors', room_size=6, sp=(0, 0, 1)),
+    'OpenRedBlueDoors': _b('open_two_doors', room_size=6, sp=(1, 3, 0)),
+    'OpenRedBlueDoorsDebug': _b('open_two_doors', room_size=6, sp=(1, 3, 1)),
+    'FindObjS5': _b('find_obj', room_size=5), 'FindObjS6': _b('find_obj', room_size=6),
+    'FindObjS7': _b('find_obj', room_size=7),
+    'KeyCorridorS3R1': _b('key_corridor', room_size=3, num_rows=1),
+    'KeyCorridorS3R2': _b('key_corridor', room_size=3, num_rows=2),
+    'KeyCorridorS3R3': _b('key_corridor', room_size=3, num_rows=3),
+    'KeyCorridorS4R3': _b('key_corridor', room_size=4, num_rows=3),
+    'KeyCorridorS5R3': _b('key_corridor', room_size=5, num_rows=3),
+    'KeyCorridorS6R3': _b('key_corridor', room_size=6, num_rows=3),
+    '1RoomS8': _b('one_room', room_size=8, num_rows=1, num_cols=1),
+    '1RoomS12': _b('one_room', room_size=12, num_rows=1, num_cols=1),
+    '1RoomS16': _b('one_room', room_size=16, num_rows=1, num_cols=1),
+    '1RoomS20': _b('one_room', room_size=20, num_rows=1, num_cols=1),
+    'PutNextS4N1': _b('put_next', room_size=4, num_rows=1, num_cols=2, num_dists=1, sp=(0,)),
+    'PutNextS5N1': _b('put_next', room_size=5, num_rows=1, num_cols=2, num_dists=1, sp=(0,)),
+    'PutNextS5N2': _b('put_next', room_size=5, num_rows=1, num_cols=2, num_dists=2, sp=(0,)),
+    'PutNextS6N3': _b('put_next', room_size=6, num_rows=1, num_cols=2, num_dists=3, sp=(0,)),
+    'PutNextS7N4': _b('put_next', room_size=7, num_rows=1, num_cols=2, num_dists=4, sp=(0,)),
+    'PutNextS5N2Carrying': _b('put_next', room_size=5, num_rows=1, num_cols=2, num_dists=2, sp=(1,)),
+    'PutNextS6N3Carrying': _b('put_next', room_size=6, num_rows=1, num_cols=2, num_dists=3, sp=(1,)),
+    'PutNextS7N4Carrying': _b('put_next', room_size=7, num_rows=1, num_cols=2, num_dists=4, sp=(1,)),
+    'MoveTwoAcrossS5N2': _b('move_two_across', room_size=5, num_rows=1, num_cols=2, num_dists=2),
+    'MoveTwoAcrossS8N9': _b('move_two_across', room_size=8, num_rows=1, num_cols=2, num_dists=9),
+    'OpenDoorsOrderN2': _b('open_doors_order', room_size=6, sp=(2, 0)),
+    'OpenDoorsOrderN4': _b('open_doors_order', room_size=6, sp=(4, 0)),
+    'OpenDoorsOrderN2Debug': _b('open_doors_order', room_size=6, sp=(2, 1)),
+    'OpenDoorsOrderN4Debug': _b('open_doors_order', room_size=6, sp=(4, 1)),
     'PickupLoc': _l(action_kinds=('pickup',), instr_kinds=('action',), num_rows=1, num_cols=1, num_dists=8,
                     locked_room_prob=0, locations=True, unblocking=False),
     'GoToSeq': _l(action_kinds=('goto',), locked_room_prob=0, locations=False, unblocking=False),
@@ -554,7 +834,7 @@ def level_name(env_id):
 def make_env(env_id, seed=None):
     """Oracle twin of gym.make('BabyAI-<Level>-v0'); `seed` is the constructor seed."""
     fam, kw = SPECS[level_name(env_id)]
-    cls = GoToOracle if fam == 'goto' else LevelGenOracle
+    cls = {'goto': GoToOracle, 'levelgen': LevelGenOracle, 'bonus': BonusOracle}[fam]
     env = cls(seed=seed, **kw)
     if seed is None and fam == 'levelgen':
         # the constructor's entropy-seeded reset must not leak a stale locked_room into the seeded

@@ -39,6 +39,7 @@ int hs_generate(const LevelCfg* cfg, uint32_t* mt, int32_t* mti, uint8_t* rec, H
     memcpy(rec + cfg->off_I, w.I, cfg->W * cfg->H);
     memcpy(rec + cfg->off_app, w.app, cfg->maxo);
     for (int o = 0; o < cfg->maxo; ++o) { rec[cfg->off_pos + 2 * o] = w.px[o]; rec[cfg->off_pos + 2 * o + 1] = w.py[o]; }
+    for (int o = 0; o < cfg->maxo; ++o) rec[cfg->off_cont + o] = o < g.nobj ? w.cont[o] : NONE8;
     memcpy(rec + cfg->off_prog, &w.prog, sizeof(Prog));
     Hot h;
     memset(&h, 0, sizeof(h));
@@ -48,6 +49,15 @@ int hs_generate(const LevelCfg* cfg, uint32_t* mt, int32_t* mti, uint8_t* rec, H
     h.last_locked = g.last_locked < 0 ? NONE8 : (uint8_t)g.last_locked;
     *hot = h;
     return g.nobj;
+}
+
+// PutNext*Carrying (bonus_levels.py:821-829): AFTER the first observation the object leaves the grid into the
+// agent's hands.  Call once after hs_generate + hs_observe; returns 1 if something was picked up.
+int hs_start_carry(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale) {
+    const Prog* p = (const Prog*)(rec + cfg->off_prog);
+    if (p->start_carry == NONE8) return 0;
+    apply_start_carry(*cfg, rec, *hot, *stale, p->start_carry);
+    return 1;
 }
 
 int hs_step(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int action, float* reward) {

@@ -26,6 +26,7 @@ def lib():
         L.hs_step.argtypes = [P, P, P, P, ctypes.c_int, P]
         L.hs_observe.argtypes = [P, P, P, P]
         L.hs_fill_layout.argtypes = [P]
+        L.hs_start_carry.argtypes = [P, P, P, P]
         _lib = L
     return _lib
 
@@ -49,7 +50,10 @@ class HostEnv(object):
         self.L.hs_generate(ctypes.byref(self.cfg), self.mt.ctypes.data, ctypes.byref(self.mti),
                            self.rec.ctypes.data, self.hot.ctypes.data)
         self.stale.value = 0
-        return self.observe()
+        img = self.observe()
+        # PutNext*Carrying: the object moves into the agent's hands right after the first observation
+        self.L.hs_start_carry(ctypes.byref(self.cfg), self.rec.ctypes.data, self.hot.ctypes.data, ctypes.byref(self.stale))
+        return img
 
     def observe(self):
         self.L.hs_observe(ctypes.byref(self.cfg), self.rec.ctypes.data, self.hot.ctypes.data, self.out.ctypes.data)

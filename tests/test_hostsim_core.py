@@ -53,9 +53,19 @@ def test_core_matches_oracle(name):
 def test_tables_agree():
     """babyai_amd/levels.py and oracle/levels.py were written independently; they must agree."""
     assert set(LEVELS) == set(olevels.SPECS)
+    script_ids = {"goto_redblue_ball": 1, "open_red_door": 2, "open_door": 3, "goto_door": 4, "goto_obj_door": 5,
+                  "action_obj_door": 6, "unlock_local": 7, "key_in_box": 8, "unlock_pickup": 9, "blocked_unlock_pickup": 10,
+                  "unlock_to_unlock": 11, "pickup_dist": 12, "pickup_above": 13, "open_two_doors": 14, "find_obj": 15,
+                  "key_corridor": 16, "one_room": 17, "put_next": 18, "move_two_across": 19, "open_doors_order": 20}
     for name, (fam, kw) in olevels.SPECS.items():
         p = LEVELS[name]
-        assert (p["kind"] == 0) == (fam == "goto")
+        assert p["kind"] == {"goto": 0, "levelgen": 1, "bonus": 2}[fam]
+        if fam == "bonus":
+            assert p["script"] == script_ids[kw["script"]], name
+            for k, dflt in (("room_size", 8), ("num_rows", 3), ("num_cols", 3), ("num_dists", 0)):
+                assert p[k] == kw.get(k, dflt), (name, k)
+            assert tuple(p["sp"]) == tuple(kw.get("sp", ())), name
+            continue
         env_defaults = dict(room_size=8, num_rows=1 if fam == "goto" else 3, num_cols=1 if fam == "goto" else 3)
         for k in ("room_size", "num_rows", "num_cols"):
             assert p[k] == kw.get(k, env_defaults[k]), (name, k)

@@ -50,9 +50,19 @@ def test_reference_constructor_args_match_table(level_dict):
     """The level table restates the reference constructors: compare against live reference objects."""
     for name, (fam, kw) in olevels.SPECS.items():
         ref = level_dict[name](seed=1)
-        assert ref.room_size == kw.get("room_size", 8)
-        assert ref.num_rows == kw.get("num_rows", 1 if fam == "goto" else 3)
-        assert ref.num_cols == kw.get("num_cols", 1 if fam == "goto" else 3)
+        assert ref.room_size == kw.get("room_size", 8), name
+        assert ref.num_rows == kw.get("num_rows", 1 if fam == "goto" else 3), name
+        assert ref.num_cols == kw.get("num_cols", 1 if fam == "goto" else 3), name
+        if fam == "bonus":
+            if hasattr(ref, "objs_per_room"):
+                assert ref.objs_per_room == kw["num_dists"], name
+            if hasattr(ref, "num_doors"):
+                assert ref.num_doors == kw["sp"][0], name
+            if hasattr(ref, "debug"):
+                assert bool(ref.debug) == bool(kw["sp"][-1]), name
+            if hasattr(ref, "start_carrying"):
+                assert bool(ref.start_carrying) == bool(kw["sp"][0]), name
+            continue
         if fam == "levelgen":
             assert list(ref.action_kinds) == list(kw.get("action_kinds", ("goto", "pickup", "open", "putnext")))
             assert list(ref.instr_kinds) == list(kw.get("instr_kinds", ("action", "and", "seq")))

@@ -14,6 +14,7 @@ Protocol recorded = the reference's ParallelEnv worker (babyai/rl/utils/penv.py:
 `pre_resets` extra reset() calls are recorded first (they exercise the persistent RNG stream).
 """
 import os
+import signal
 import sys
 
 import numpy as np
@@ -53,8 +54,28 @@ PLAN = [
     ("PutNext", 6, 300, 0, 0, True),
     ("UnblockPickup", 6, 250, 1, 0, True),
     ("Pickup", 4, 150, 0, 0, True),
+    # bonus levels: strict ("Debug") verifiers, key inside a box, removed walls, start-carrying resets
+    ("KeyInBox", 6, 200, 1, 0, True),
+    ("OpenDoorsOrderN4Debug", 8, 160, 1, 0, True),
+    ("PickupDistDebug", 8, 120, 1, 0, True),
+    ("OpenTwoDoorsDebug", 6, 160, 0, 0, True),
+    ("PutNextS6N3Carrying", 8, 200, 1, 2, True),
+    ("MoveTwoAcrossS5N2", 6, 240, 0, 0, True),
+    ("KeyCorridorS4R3", 6, 300, 1, 0, True),
+    ("UnlockToUnlock", 6, 300, 0, 0, True),
+    ("BlockedUnlockPickup", 6, 200, 0, 0, True),
+    ("ActionObjDoor", 8, 120, 1, 0, True),
+    ("1RoomS12", 4, 120, 0, 0, True),
 ]
 SEED_BASE = 1000
+
+
+class BotTimeout(BaseException):
+    pass
+
+
+def _on_alarm(signum, frame):
+    raise BotTimeout()
 
 
 class Driver(object):
@@ -73,8 +94,16 @@ class Driver(object):
         a = None
         if self.bot is not None:
             try:
-                a = int(self.bot.replan(self.last))
-            except Exception:
+                # the reference bot can spin forever on some bonus levels: give every decision a 2 s budget
+                signal.signal(signal.SIGALRM, _on_alarm)
+                signal.setitimer(signal.ITIMER_REAL, 2.0)
+                try:
+                    a = int(self.bot.replan(self.last))
+                finally:
+                    signal.setitimer(signal.ITIMER_REAL, 0)
+            except BaseException as exc:
+                if isinstance(exc, KeyboardInterrupt):
+                    raise
                 self.bot = None
         if a is None or self.rng.rand() < 0.12:
             a = int(self.rng.randint(0, 7))
