@@ -13,8 +13,10 @@ generator families:
   * the hand-written single-instruction levels GoToRedBallGrey :10-37, PutNextLocal :187-221,
     GoToImpUnlock :304-357, Pickup :360-371, UnblockPickup :374-391, Open :394-415, Unlock :418-474,
     PutNext :477-491 are cfg variants of the K_GOTO generator
-=> every level of iclr19_levels.py is covered.  The bonus levels (bonus_levels.py) are not;
-`make_cfg` raises KeyError for them.
+  * K_BONUS     the 50 levels of bonus_levels.py: one gen_mission script id (BS_*) per level class with
+                up to four integer parameters (device twin: Gen::mission_bonus, bbai_gen.hpp)
+=> every level of iclr19_levels.py and bonus_levels.py is covered (97 ids); `make_cfg` raises KeyError
+for anything else (the Level_Test* layouts of test_levels.py).
 """
 import ctypes
 
