@@ -668,6 +668,14 @@ struct Gen {
         doors |= 1ull << (16 * k + r);
         doors |= 1ull << (16 * ((k + 2) & 3) + neighbor(r, k));
     }
+    // grid.set(x, y, obj) / place_obj(obj, (x, y), (1, 1)): an object at an exact cell, no sampling, no draws
+    BB_HD int put_fixed(int type, int color, int x, int y) {
+        if (nobj >= cfg.maxo) return 0;
+        int id = nobj++;
+        w.app[id] = e_make(type, color, 0); w.px[id] = x; w.py[id] = y; w.cont[id] = NONE8;
+        set_cell(x, y, w.app[id], id + 2);
+        return id;
+    }
     BB_HD void one_leaf(int kind, bool strict = false) {
         clear_prog();
         prep_masks();
@@ -926,6 +934,99 @@ struct Gen {
                 w.prog.kind[2] = L_OPEN; w.prog.n_b = 1; w.prog.strict = dbg ? 5 : 0;
                 set_desc_tcl(2, 0, T_DOOR, e_color(w.app[d2]), LOC_NONE);
             }
+            return true;
+        }
+        // ---- test_levels.py: fixed layouts (objects put at exact cells, agent pose assigned) ----
+        case BS_TEST_GOTO_BLOCKED: {                    // test_levels.py:13-38
+            if (!place_agent()) return false;           // draws are consumed, the pose is then overwritten
+            ax = 3; ay = 3; adir = 0;
+            int obj = put_fixed(T_BALL, C_YELLOW, 1, 1);
+            for (int i = 1; i <= 3; ++i)
+                for (int j = 1; j <= 3; ++j)
+                    if (!((i == 1 && j == 1) || (i == 3 && j == 3))) put_fixed(T_BALL, C_RED, i, j);
+            one_leaf(L_GOTO); set_desc(0, 0, obj);
+            return true;
+        }
+        case BS_TEST_PUTNEXT_BLOCKED: {                 // :41-66
+            if (!place_agent()) return false;
+            ax = 3; ay = 3; adir = 0;
+            int o1 = put_fixed(T_BALL, C_YELLOW, 4, 4);
+            int o2 = put_fixed(T_BALL, C_BLUE, 1, 1);
+            put_fixed(T_BALL, C_RED, 1, 2);
+            put_fixed(T_BALL, C_RED, 2, 1);
+            one_leaf(L_PUTNEXT); set_desc(0, 0, o1); set_desc(0, 1, o2);
+            return true;
+        }
+        case BS_TEST_PUTNEXT_DOOR1:
+        case BS_TEST_PUTNEXT_DOOR2: {                   // :69-107  2x1 rooms
+            ax = 3; ay = 3; adir = 0;
+            int door = add_door_opt(0, -1, C_RED, 0);
+            if (door < 0) return false;
+            int o1 = put_fixed(T_BALL, C_YELLOW, 4, 4);
+            int o2 = put_fixed(T_BALL, C_BLUE, w.px[door], w.py[door] + 1);
+            clear_prog(); prep_masks();
+            w.prog.strict = 0;
+            if (cfg.script == BS_TEST_PUTNEXT_DOOR1) {
+                w.prog.root = R_BEFORE; w.prog.n_a = 1; w.prog.n_b = 1; w.prog.kind[0] = L_OPEN; w.prog.kind[2] = L_PUTNEXT;
+                set_desc_tcl(0, 0, T_DOOR, C_RED, LOC_NONE);
+                set_desc(2, 0, o1); set_desc(2, 1, o2);
+            } else {
+                w.prog.root = R_ACTION; w.prog.n_a = 1; w.prog.kind[0] = L_PUTNEXT;
+                set_desc(0, 0, o1); set_desc(0, 1, o2);
+            }
+            return true;
+        }
+        case BS_TEST_PUTNEXT_IDENTICAL: {               // :110-138
+            ax = 3; ay = 3; adir = 0;
+            put_fixed(T_BOX, C_YELLOW, 1, 1);
+            put_fixed(T_BALL, C_BLUE, 4, 4);
+            put_fixed(T_BALL, C_RED, 2, 2);
+            clear_prog(); prep_masks();
+            w.prog.root = R_BEFORE; w.prog.n_a = 1; w.prog.n_b = 1; w.prog.kind[0] = L_PUTNEXT; w.prog.kind[2] = L_PUTNEXT;
+            set_desc_tcl(0, 0, T_BALL, C_BLUE, LOC_NONE); set_desc_tcl(0, 1, T_BOX, C_YELLOW, LOC_NONE);
+            set_desc_tcl(2, 0, T_BOX, C_YELLOW, LOC_NONE); set_desc_tcl(2, 1, T_BALL, 7, LOC_NONE);
+            return true;
+        }
+        case BS_TEST_UNBLOCKING_LOOP: {                 // :141-168  2x2 rooms
+            ax = 15; ay = 4; adir = 2;
+            if (add_door(0, 1, C_RED, false) < 0) return false;
+            if (add_door(1 * cols + 0, 0, C_RED, false) < 0) return false;
+            if (add_door(1 * cols + 1, 3, C_BLUE, false) < 0) return false;
+            put_fixed(T_BOX, C_YELLOW, 9, 1);
+            put_fixed(T_BALL, C_BLUE, 5, 3);
+            put_fixed(T_BALL, C_YELLOW, 6, 2);
+            put_fixed(T_KEY, C_BLUE, 15, 15);
+            clear_prog(); prep_masks();
+            w.prog.root = R_BEFORE; w.prog.n_a = 1; w.prog.n_b = 2;
+            w.prog.kind[0] = L_PUTNEXT; w.prog.kind[2] = L_GOTO; w.prog.kind[3] = L_GOTO;
+            set_desc_tcl(0, 0, T_KEY, C_BLUE, LOC_NONE); set_desc_tcl(0, 1, T_DOOR, C_BLUE, LOC_NONE);
+            set_desc_tcl(2, 0, T_BALL, C_YELLOW, LOC_NONE); set_desc_tcl(3, 0, T_BOX, C_YELLOW, LOC_NONE);
+            return true;
+        }
+        case BS_TEST_PUTNEXT_CLOSE_DOOR: {              // :171-201  2x2 rooms
+            ax = 5; ay = 10; adir = 2;
+            int d1 = add_door(0, 1, C_RED, false);
+            if (d1 < 0) return false;
+            if (add_door(1 * cols + 0, 0, C_RED, false) < 0) return false;
+            if (add_door(1 * cols + 1, 3, C_BLUE, false) < 0) return false;
+            const int px1 = w.px[d1], py1 = w.py[d1];
+            put_fixed(T_BALL, C_BLUE, px1, py1 - 1);
+            put_fixed(T_BALL, C_BLUE, px1, py1 - 2);
+            if (px1 - 1 >= 1) put_fixed(T_BOX, C_GREEN, px1 - 1, py1 - 1);
+            if (px1 + 1 < 8) put_fixed(T_BOX, C_GREEN, px1 + 1, py1 - 1);
+            put_fixed(T_BOX, C_YELLOW, 3, 15);
+            one_leaf(L_PUTNEXT);
+            set_desc_tcl(0, 0, T_BOX, C_YELLOW, LOC_NONE); set_desc_tcl(0, 1, T_BALL, C_BLUE, LOC_NONE);
+            return true;
+        }
+        case BS_TEST_LOTS_OF_BLOCKERS: {                // :204-232
+            ax = 5; ay = 5; adir = 0;
+            const int bx[6] = {2, 2, 2, 3, 2, 1}, by[6] = {1, 2, 3, 4, 6, 3};
+            for (int q = 0; q < 6; ++q) put_fixed(T_BOX, C_YELLOW, bx[q], by[q]);
+            put_fixed(T_BALL, C_BLUE, 1, 2);
+            put_fixed(T_BALL, C_RED, 3, 6);
+            one_leaf(L_PUTNEXT);
+            set_desc_tcl(0, 0, T_BALL, C_RED, LOC_NONE); set_desc_tcl(0, 1, T_BALL, C_BLUE, LOC_NONE);
             return true;
         }
         default: return false;

@@ -130,7 +130,10 @@ enum : int { K_GOTO = 0, K_LEVELGEN = 1, K_BONUS = 2 };
 enum : int { BS_GOTO_REDBLUE_BALL = 1, BS_OPEN_RED_DOOR, BS_OPEN_DOOR, BS_GOTO_DOOR, BS_GOTO_OBJ_DOOR, BS_ACTION_OBJ_DOOR,
              BS_UNLOCK_LOCAL, BS_KEY_IN_BOX, BS_UNLOCK_PICKUP, BS_BLOCKED_UNLOCK_PICKUP, BS_UNLOCK_TO_UNLOCK, BS_PICKUP_DIST,
              BS_PICKUP_ABOVE, BS_OPEN_TWO_DOORS, BS_FIND_OBJ, BS_KEY_CORRIDOR, BS_ONE_ROOM, BS_PUT_NEXT, BS_MOVE_TWO_ACROSS,
-             BS_OPEN_DOORS_ORDER, BS_COUNT };
+             BS_OPEN_DOORS_ORDER,
+             // test_levels.py: hand-built bot-regression layouts
+             BS_TEST_GOTO_BLOCKED, BS_TEST_PUTNEXT_BLOCKED, BS_TEST_PUTNEXT_DOOR1, BS_TEST_PUTNEXT_DOOR2,
+             BS_TEST_PUTNEXT_IDENTICAL, BS_TEST_UNBLOCKING_LOOP, BS_TEST_PUTNEXT_CLOSE_DOOR, BS_TEST_LOTS_OF_BLOCKERS, BS_COUNT };
 enum : int { TG_REDBALL = 0, TG_DIST = 1, TG_DOOR = 2, TG_TWO_DISTS = 3, TG_LOCKED_DOOR = 4, TG_LOCKED_ROOM_OBJ = 5 };
 enum : int { AK_GOTO = 0, AK_PICKUP = 1, AK_OPEN = 2, AK_PUTNEXT = 3 };
 enum : int { IK_ACTION = 0, IK_AND = 1, IK_SEQ = 2 };

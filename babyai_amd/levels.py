@@ -15,8 +15,8 @@ generator families:
     PutNext :477-491 are cfg variants of the K_GOTO generator
   * K_BONUS     the 50 levels of bonus_levels.py: one gen_mission script id (BS_*) per level class with
                 up to four integer parameters (device twin: Gen::mission_bonus, bbai_gen.hpp)
-=> every level of iclr19_levels.py and bonus_levels.py is covered (97 ids); `make_cfg` raises KeyError
-for anything else (the Level_Test* layouts of test_levels.py).
+                and the 8 fixed regression layouts of test_levels.py
+=> every level the reference registers (105 ids) is covered; `make_cfg` raises KeyError for anything else.
 """
 import ctypes
 
@@ -81,7 +81,8 @@ def _levelgen(room_size=8, num_rows=3, num_cols=3, num_dists=18, locked_room_pro
 (BS_GOTO_REDBLUE_BALL, BS_OPEN_RED_DOOR, BS_OPEN_DOOR, BS_GOTO_DOOR, BS_GOTO_OBJ_DOOR, BS_ACTION_OBJ_DOOR,
  BS_UNLOCK_LOCAL, BS_KEY_IN_BOX, BS_UNLOCK_PICKUP, BS_BLOCKED_UNLOCK_PICKUP, BS_UNLOCK_TO_UNLOCK, BS_PICKUP_DIST,
  BS_PICKUP_ABOVE, BS_OPEN_TWO_DOORS, BS_FIND_OBJ, BS_KEY_CORRIDOR, BS_ONE_ROOM, BS_PUT_NEXT, BS_MOVE_TWO_ACROSS,
- BS_OPEN_DOORS_ORDER) = range(1, 21)
+ BS_OPEN_DOORS_ORDER, BS_TEST_GOTO_BLOCKED, BS_TEST_PUTNEXT_BLOCKED, BS_TEST_PUTNEXT_DOOR1, BS_TEST_PUTNEXT_DOOR2,
+ BS_TEST_PUTNEXT_IDENTICAL, BS_TEST_UNBLOCKING_LOOP, BS_TEST_PUTNEXT_CLOSE_DOOR, BS_TEST_LOTS_OF_BLOCKERS) = range(1, 29)
 _COLOR_IDX = {"red": 0, "green": 1, "blue": 2, "purple": 3, "yellow": 4, "grey": 5}
 
 
@@ -184,6 +185,15 @@ LEVELS = {
     "OpenDoorsOrderN4": _bonus(BS_OPEN_DOORS_ORDER, room_size=6, sp=(4, 0)),
     "OpenDoorsOrderN2Debug": _bonus(BS_OPEN_DOORS_ORDER, room_size=6, sp=(2, 1)),
     "OpenDoorsOrderN4Debug": _bonus(BS_OPEN_DOORS_ORDER, room_size=6, sp=(4, 1)),
+    # --- test_levels.py: hand-built regression layouts for the bot (test_levels.py:13-232) ---------------
+    "TestGoToBlocked": _bonus(BS_TEST_GOTO_BLOCKED, room_size=9, num_rows=1, num_cols=1),
+    "TestPutNextToBlocked": _bonus(BS_TEST_PUTNEXT_BLOCKED, room_size=9, num_rows=1, num_cols=1),
+    "TestPutNextToCloseToDoor1": _bonus(BS_TEST_PUTNEXT_DOOR1, room_size=9, num_rows=2, num_cols=1),
+    "TestPutNextToCloseToDoor2": _bonus(BS_TEST_PUTNEXT_DOOR2, room_size=9, num_rows=2, num_cols=1),
+    "TestPutNextToIdentical": _bonus(BS_TEST_PUTNEXT_IDENTICAL, room_size=9, num_rows=1, num_cols=1),
+    "TestUnblockingLoop": _bonus(BS_TEST_UNBLOCKING_LOOP, room_size=9, num_rows=2, num_cols=2),
+    "TestPutNextCloseToDoor": _bonus(BS_TEST_PUTNEXT_CLOSE_DOOR, room_size=9, num_rows=2, num_cols=2),
+    "TestLotsOfBlockers": _bonus(BS_TEST_LOTS_OF_BLOCKERS, room_size=8, num_rows=1, num_cols=1),
     # --- K_LEVELGEN family ---------------------------------------------------------------
     "PickupLoc": _levelgen(action_kinds=("pickup",), instr_kinds=("action",), num_rows=1, num_cols=1,
                            num_dists=8, locked_room_prob=0, locations=True, unblocking=False),

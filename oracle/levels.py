@@ -23,6 +23,7 @@ What follows which reference code (all under /root/reference/babyai/levels/):
   LevelGenOracle.gen_mission etc.  levelgen.py:293-460
   GoToOracle.gen_mission           iclr19_levels.py:40-63, 75-124, 224-257
   BonusOracle.gen_*                bonus_levels.py (line ranges in each method's docstring)
+  FixedLayoutOracle.lay_*          test_levels.py (line ranges in each method's docstring)
 BABYAI_DONE_ACTIONS (verifier.py:17) and SeqInstr-level `strict` (unused by any level) are not restated.
 """
 import os
@@ -623,6 +624,112 @@ class BonusOracle(OracleLevel):
                                 Clause('open', Desc(d2.type, d2.color), strict=dbg))
 
 
+class FixedLayoutOracle(OracleLevel):
+    """The hand-built regression layouts of test_levels.py (:13-232): exact cells, assigned agent pose."""
+
+    def __init__(self, script, room_size=9, num_rows=1, num_cols=1, seed=None):
+        self.script = script
+        super().__init__(room_size=room_size, num_rows=num_rows, num_cols=num_cols, seed=seed)
+
+    def gen_mission(self):
+        getattr(self, 'lay_' + self.script)()
+
+    def _pose(self, x, y, d):
+        import numpy as np
+        self.agent_pos = np.array([x, y])
+        self.agent_dir = d
+
+    def _at(self, obj, x, y):
+        self.place_obj(obj, (x, y), (1, 1))
+        return obj
+
+    def lay_goto_blocked(self):
+        """:13-38"""
+        self.place_agent()
+        self._pose(3, 3, 0)
+        target = Ball('yellow')
+        self.grid.set(1, 1, target)
+        for i in (1, 2, 3):
+            for j in (1, 2, 3):
+                if (i, j) not in ((1, 1), (3, 3)):
+                    self._at(Ball('red'), i, j)
+        self.instrs = Clause('goto', Desc('ball', 'yellow'))
+
+    def lay_putnext_blocked(self):
+        """:41-66"""
+        self.place_agent()
+        self._pose(3, 3, 0)
+        self._at(Ball('yellow'), 4, 4)
+        self._at(Ball('blue'), 1, 1)
+        self.grid.set(1, 2, Ball('red'))
+        self.grid.set(2, 1, Ball('red'))
+        self.instrs = Clause('putnext', Desc('ball', 'yellow'), Desc('ball', 'blue'))
+
+    def _door_and_balls(self):
+        self._pose(3, 3, 0)
+        door, pos = self.add_door(0, 0, None, 'red', False)
+        self._at(Ball('yellow'), 4, 4)
+        self._at(Ball('blue'), pos[0], pos[1] + 1)
+        return Clause('putnext', Desc('ball', 'yellow'), Desc('ball', 'blue'))
+
+    def lay_putnext_door1(self):
+        """:69-96"""
+        put = self._door_and_balls()
+        self.instrs = Combo('before', Clause('open', Desc('door', 'red')), put)
+
+    def lay_putnext_door2(self):
+        """:99-107"""
+        self.instrs = self._door_and_balls()
+
+    def lay_putnext_identical(self):
+        """:110-138"""
+        self._pose(3, 3, 0)
+        self._at(Box('yellow'), 1, 1)
+        self._at(Ball('blue'), 4, 4)
+        self._at(Ball('red'), 2, 2)
+        self.instrs = Combo('before', Clause('putnext', Desc('ball', 'blue'), Desc('box', 'yellow')),
+                            Clause('putnext', Desc('box', 'yellow'), Desc('ball', None)))
+
+    def _three_doors(self):
+        _, p1 = self.add_door(0, 0, 1, 'red', False)
+        self.add_door(0, 1, 0, 'red', False)
+        self.add_door(1, 1, 3, 'blue', False)
+        return p1
+
+    def lay_unblocking_loop(self):
+        """:141-168"""
+        self._pose(15, 4, 2)
+        self._three_doors()
+        self._at(Box('yellow'), 9, 1)
+        self._at(Ball('blue'), 5, 3)
+        self._at(Ball('yellow'), 6, 2)
+        self._at(Key('blue'), 15, 15)
+        self.instrs = Combo('before', Clause('putnext', Desc('key', 'blue'), Desc('door', 'blue')),
+                            Combo('and', Clause('goto', Desc('ball', 'yellow')), Clause('goto', Desc('box', 'yellow'))))
+
+    def lay_putnext_close_door(self):
+        """:171-201"""
+        self._pose(5, 10, 2)
+        px, py = self._three_doors()
+        self._at(Ball('blue'), px, py - 1)
+        self._at(Ball('blue'), px, py - 2)
+        if px - 1 >= 1:
+            self._at(Box('green'), px - 1, py - 1)
+        if px + 1 < 8:
+            self._at(Box('green'), px + 1, py - 1)
+        self._at(Box('yellow'), 3, 15)
+        self.instrs = Clause('putnext', Desc('box', 'yellow'), Desc('ball', 'blue'))
+
+    def lay_lots_of_blockers(self):
+        """:204-232"""
+        self._pose(5, 5, 0)
+        for x, y in ((2, 1), (2, 2), (2, 3), (3, 4), (2, 6), (1, 3)):
+            self._at(Box('yellow'), x, y)
+        self._at(Ball('blue'), 1, 2)
+        self._at(Ball('red'), 3, 6)
+        self.instrs = Clause('putnext', Desc('ball', 'red'), Desc('ball', 'blue'))
+
+
 class LevelGenOracle(OracleLevel):
     """The general mission sampler (LevelGen) and all its parameterisations."""
 
@@ -726,6 +833,10 @@ def _b(script, **kw):
     return ('bonus', dict(script=script, **kw))
 
 
+def _t(script, **kw):
+    return ('fixed', dict(script=script, **kw))
+
+
 # Constructor arguments per level (iclr19_levels.py; written out independently of babyai_amd/levels.py,
 # tests/test_levels_table.py checks the two tables agree).
 SPECS = {
@@ -806,6 +917,12 @@ SPECS = {
     'OpenDoorsOrderN4': _b('open_doors_order', room_size=6, sp=(4, 0)),
     'OpenDoorsOrderN2Debug': _b('open_doors_order', room_size=6, sp=(2, 1)),
     'OpenDoorsOrderN4Debug': _b('open_doors_order', room_size=6, sp=(4, 1)),
+    'TestGoToBlocked': _t('goto_blocked'), 'TestPutNextToBlocked': _t('putnext_blocked'),
+    'TestPutNextToCloseToDoor1': _t('putnext_door1', num_rows=2), 'TestPutNextToCloseToDoor2': _t('putnext_door2', num_rows=2),
+    'TestPutNextToIdentical': _t('putnext_identical'),
+    'TestUnblockingLoop': _t('unblocking_loop', num_rows=2, num_cols=2),
+    'TestPutNextCloseToDoor': _t('putnext_close_door', num_rows=2, num_cols=2),
+    'TestLotsOfBlockers': _t('lots_of_blockers', room_size=8),
     'PickupLoc': _l(action_kinds=('pickup',), instr_kinds=('action',), num_rows=1, num_cols=1, num_dists=8,
                     locked_room_prob=0, locations=True, unblocking=False),
     'GoToSeq': _l(action_kinds=('goto',), locked_room_prob=0, locations=False, unblocking=False),
@@ -834,7 +951,7 @@ def level_name(env_id):
 def make_env(env_id, seed=None):
     """Oracle twin of gym.make('BabyAI-<Level>-v0'); `seed` is the constructor seed."""
     fam, kw = SPECS[level_name(env_id)]
-    cls = {'goto': GoToOracle, 'levelgen': LevelGenOracle, 'bonus': BonusOracle}[fam]
+    cls = {'goto': GoToOracle, 'levelgen': LevelGenOracle, 'bonus': BonusOracle, 'fixed': FixedLayoutOracle}[fam]
     env = cls(seed=seed, **kw)
     if seed is None and fam == 'levelgen':
         # the constructor's entropy-seeded reset must not leak a stale locked_room into the seeded

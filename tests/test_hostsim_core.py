@@ -59,7 +59,14 @@ def test_tables_agree():
                   "key_corridor": 16, "one_room": 17, "put_next": 18, "move_two_across": 19, "open_doors_order": 20}
     for name, (fam, kw) in olevels.SPECS.items():
         p = LEVELS[name]
-        assert p["kind"] == {"goto": 0, "levelgen": 1, "bonus": 2}[fam]
+        assert p["kind"] == {"goto": 0, "levelgen": 1, "bonus": 2, "fixed": 2}[fam]
+        if fam == "fixed":
+            fixed_ids = {"goto_blocked": 21, "putnext_blocked": 22, "putnext_door1": 23, "putnext_door2": 24,
+                         "putnext_identical": 25, "unblocking_loop": 26, "putnext_close_door": 27, "lots_of_blockers": 28}
+            assert p["script"] == fixed_ids[kw["script"]], name
+            for k, dflt in (("room_size", 9), ("num_rows", 1), ("num_cols", 1)):
+                assert p[k] == kw.get(k, dflt), (name, k)
+            continue
         if fam == "bonus":
             assert p["script"] == script_ids[kw["script"]], name
             for k, dflt in (("room_size", 8), ("num_rows", 3), ("num_cols", 3), ("num_dists", 0)):

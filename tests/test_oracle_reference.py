@@ -50,6 +50,9 @@ def test_reference_constructor_args_match_table(level_dict):
     """The level table restates the reference constructors: compare against live reference objects."""
     for name, (fam, kw) in olevels.SPECS.items():
         ref = level_dict[name](seed=1)
+        if fam == "fixed":
+            assert (ref.room_size, ref.num_rows, ref.num_cols) == (kw.get("room_size", 9), kw.get("num_rows", 1), kw.get("num_cols", 1))
+            continue
         assert ref.room_size == kw.get("room_size", 8), name
         assert ref.num_rows == kw.get("num_rows", 1 if fam == "goto" else 3), name
         assert ref.num_cols == kw.get("num_cols", 1 if fam == "goto" else 3), name
@@ -85,3 +88,9 @@ def test_reference_own_smoke_test_passes_on_shim(level_dict):
         assert m0.unwrapped.grid == m1.unwrapped.grid and m0.surface == m1.surface
         obs = m0.reset()
         assert obs["mission"] == m0.surface
+
+
+def test_level_table_covers_every_registered_level(level_dict):
+    """All 105 ids the reference registers (levelgen.py:467-493) are in the engine's and the oracle's tables."""
+    from babyai_amd.levels import LEVELS
+    assert set(level_dict.keys()) == set(LEVELS) == set(olevels.SPECS)

@@ -66,6 +66,10 @@ PLAN = [
     ("BlockedUnlockPickup", 6, 200, 0, 0, True),
     ("ActionObjDoor", 8, 120, 1, 0, True),
     ("1RoomS12", 4, 120, 0, 0, True),
+    # test_levels.py fixed layouts
+    ("TestUnblockingLoop", 4, 200, 1, 0, True),
+    ("TestPutNextCloseToDoor", 4, 160, 0, 0, True),
+    ("TestPutNextToIdentical", 3, 120, 0, 0, True),
 ]
 SEED_BASE = 1000
 
