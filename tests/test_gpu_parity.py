@@ -301,3 +301,38 @@ def test_every_registered_level_vs_oracle(gpu):
                     o = refs[i].reset()
                 ro[i] = o
         env.close()
+
+
+@pytest.mark.gpu
+def test_render_every_tile_vs_oracle(gpu):
+    """k_render on synthetic encodings that contain every (type, colour, state) cell the engine can emit, in
+    ordinary cells and in the agent's own cell, against the oracle's RGBImgPartialObsWrapper rasteriser."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from oracle import levels as olevels
+    cells = [(0, 0, 0), (1, 0, 0), (2, 5, 0)]
+    cells += [(t, c, 0) for t in (5, 6, 7) for c in range(6)]
+    cells += [(4, c, s) for c in range(6) for s in range(3)]
+    carried = [(1, 0, 0)] + [(t, c, 0) for t in (5, 6, 7) for c in range(6)]
+    n = len(carried)
+    rng = np.random.RandomState(3)
+    img = np.zeros((n, 7, 7, 3), np.uint8)
+    for e in range(n):
+        for vi in range(7):
+            for vj in range(7):
+                img[e, vi, vj] = cells[(e * 49 + vi * 7 + vj + int(rng.randint(0, 3))) % len(cells)]
+        img[e, 3, 6] = carried[e]
+    env = BatchedBabyAIEnv("BabyAI-GoToLocal-v0", n, device=gpu, pixel=True, seeds=0)
+    env.reset()
+    torch.cuda.synchronize()
+    env.image.copy_(torch.as_tensor(img, device=gpu))
+    obs = env._obs()
+    torch.cuda.synchronize()
+    pix = obs["image"].cpu().numpy()
+    ref_env = olevels.make_env("GoToLocal")
+    seen = set()
+    for e in range(n):
+        assert np.array_equal(pix[e], ref_env.get_obs_render(img[e], tile_size=8)), e
+        seen |= {tuple(x) for x in img[e].reshape(-1, 3)}
+    assert seen >= set(cells)
+    env.close()
