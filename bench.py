@@ -25,6 +25,16 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
+# BASELINE.json configs (per-GPU env counts; C4/C5 are quoted on 8 GPUs with 131072 envs each, the default
+# bench runs C5's level and obs mode with all 1 048 576 envs on ONE GPU, which is the headline metric's shape)
+CONFIGS = {
+    "C2": dict(level="GoToLocal", envs=65536, pixel=False),
+    "C3": dict(level="PickupLoc", envs=262144, pixel=False),
+    "C4": dict(level="GoTo", envs=131072, pixel=False),
+    "C5": dict(level="BossLevel", envs=131072, pixel=True),
+    "C5-1gpu": dict(level="BossLevel", envs=1048576, pixel=True),
+}
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -35,12 +45,17 @@ def main():
     ap.add_argument("--level", default="BossLevel")
     ap.add_argument("--no-pixel", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="a BASELINE.json config by name (overrides --level/--envs/--no-pixel); default = C5 on one GPU")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prewarm-seconds", type=float, default=1.0, help="untimed GPU activity before the warmup steps")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (test rigs: ranks may share a GPU)")
     ap.add_argument("--share-device", action="store_true", help="test rigs only: every rank uses cuda:0")
     args = ap.parse_args()
+    if args.config:
+        cfgsel = CONFIGS[args.config]
+        args.level, args.envs, args.no_pixel = cfgsel["level"], cfgsel["envs"], not cfgsel["pixel"]
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
