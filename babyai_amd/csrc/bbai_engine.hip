@@ -7,13 +7,15 @@
 //                  orientation; the 147-byte encodings of a block's 256 envs are staged in LDS and
 //                  written back as one contiguous, dword-coalesced span.  Finished envs are
 //                  compacted into the reset list with one wave-aggregated atomic per wave.
-//   k_pregen       wave = env: the NEXT level of an env's MT19937 stream is generated wave-uniformly
-//                  with the whole working set in LDS (bbai_gen.hpp) into a per-env look-ahead slot.
+//   k_pregen       wave = env: the NEXT levels of an env's MT19937 stream are generated wave-uniformly
+//                  with the whole working set in LDS (bbai_gen.hpp) into the env's look-ahead ring.
 //                  step() draws no randomness, so an env's level sequence is a pure function of
-//                  its seed: generation runs ahead of need on a second HIP stream and overlaps the
-//                  render kernel / the caller's policy instead of sitting on the step path.
+//                  its seed: generation runs ahead of need on a second HIP stream, one launch per
+//                  window of B consume-ticks, and overlaps the render kernel / the caller's policy
+//                  instead of sitting on the step path.
 //   k_consume      wave = env over the reset list: look-ahead slot -> live state (coalesced copy), SoA verifier
 //                  view, first observation of the new episode.
+//   k_tokens       lane = env over the reset list: mission text as fixed-vocabulary token ids.
 //   k_render       RGBImgPartialObsWrapper as a pure tile-atlas gather: atlas + per-cell tile ids
 //                  in LDS, 16 bytes per lane per store, a wave writes 1 KiB of contiguous pixels.
 //

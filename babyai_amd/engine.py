@@ -42,6 +42,9 @@ def load_library():
         return _lib
     if not os.path.isfile(LIB_PATH):
         raise EngineError("HIP engine %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    # torch first: the PyTorch-ROCm wheel carries its own libamdhip64; whichever HIP runtime is mapped first serves
+    # the whole process, and the engine must share torch's (device pointers and streams cross the boundary).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     P, I64, I32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
     lib.bbai_version.restype = ctypes.c_int
@@ -225,6 +228,8 @@ class BatchedBabyAIEnv(object):
 
     # ---- state access -------------------------------------------------------------------
     def programs(self, first=0, count=None):
+        if not self.handle:
+            raise EngineError("engine is closed (mission strings are fetched lazily: read them before close())")
         count = self.num_envs - first if count is None else count
         out = np.zeros((count, PROG_BYTES), dtype=np.uint8)
         _check(self.lib, self.lib.bbai_get_programs(self.handle, first, count, out.ctypes.data), "bbai_get_programs")

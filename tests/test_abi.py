@@ -22,6 +22,7 @@ def test_header_and_binding_agree():
 def test_library_exports_all_symbols():
     import __graft_entry__
     __graft_entry__.build()
+    import torch  # noqa: F401  (same load order as the product: torch's HIP runtime first)
     lib = ctypes.CDLL(os.path.join(ROOT, "babyai_amd", "libbbai_hip.so"))
     for sym in declared_symbols():
         assert hasattr(lib, sym), sym
@@ -33,6 +34,7 @@ def test_layout_python_twin_matches_native():
     from babyai_amd.levels import LEVELS, LevelCfg, make_cfg
     import __graft_entry__
     __graft_entry__.build()
+    import torch  # noqa: F401
     lib = ctypes.CDLL(os.path.join(ROOT, "babyai_amd", "libbbai_hip.so"))
     lib.bbai_fill_layout.argtypes = [ctypes.c_void_p]
     for name in LEVELS:
