@@ -336,3 +336,55 @@ def test_render_every_tile_vs_oracle(gpu):
         seen |= {tuple(x) for x in img[e].reshape(-1, 3)}
     assert seen >= set(cells)
     env.close()
+
+
+class _ScriptedAgent(object):
+    """Deterministic stand-in for ModelAgent: the action depends on the step count and the obs bytes only."""
+
+    def __init__(self):
+        self.t = 0
+
+    def act_batch(self, many_obs):
+        self.t += 1
+        acts = [(int(o["image"].astype(np.int64).sum()) * 7 + self.t * 3 + k) % 7 for k, o in enumerate(many_obs)]
+        return {"action": np.array(acts)}
+
+    def analyze_feedback(self, reward, done):
+        pass
+
+
+@pytest.mark.gpu
+def test_batch_evaluate_matches_reference_driver(gpu):
+    """babyai_amd.evaluate.batch_evaluate vs the reference's evaluation loop (babyai/evaluate.py:85-140) run over
+    oracle envs with the ManyEnvs freeze-after-done rule (evaluate.py:73-81): identical logs."""
+    from babyai_amd.evaluate import batch_evaluate
+    name, seed, episodes = "BabyAI-GoToLocal-v0", 31, 20
+    logs = batch_evaluate(_ScriptedAgent(), name, seed, episodes, device=gpu)
+    # reference driver restated over oracle envs
+    envs = _oracle_envs("GoToLocal", [0] * episodes)
+    agent = _ScriptedAgent()
+    for e, s in zip(envs, range(seed, seed + episodes)):
+        e.seed(s)
+    many_obs = [e.reset() for e in envs]
+    last = [None] * episodes
+    done_flags = [False] * episodes
+    num_frames = np.zeros(episodes, dtype="int64")
+    returns = np.zeros(episodes)
+    already = np.zeros(episodes, dtype=bool)
+    cur = 0
+    while (num_frames == 0).any():
+        action = agent.act_batch(many_obs)["action"]
+        results = [e.step(int(a)) if not d else last[k] for k, (e, a, d) in enumerate(zip(envs, action, done_flags))]
+        done_flags = [r[2] for r in results]
+        last = results
+        many_obs = [r[0] for r in results]
+        reward = np.array([r[1] for r in results])
+        done = np.array(done_flags)
+        just = done & ~already
+        returns += reward * just
+        cur += 1
+        num_frames[just] = cur
+        already[done] = True
+    assert list(logs["num_frames_per_episode"]) == list(num_frames)
+    assert np.array_equal(np.float32(logs["return_per_episode"]), np.float32(returns))
+    assert list(logs["seed_per_episode"]) == list(range(seed, seed + episodes))
