@@ -388,3 +388,33 @@ def test_batch_evaluate_matches_reference_driver(gpu):
     assert list(logs["num_frames_per_episode"]) == list(num_frames)
     assert np.array_equal(np.float32(logs["return_per_episode"]), np.float32(returns))
     assert list(logs["seed_per_episode"]) == list(range(seed, seed + episodes))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("period", ["1", "2", "8"])
+def test_autoreset_with_interleaved_resets(gpu, period, monkeypatch):
+    """Auto-reset stepping with explicit reset() calls thrown in, for several refill periods (BBAI_LOOKAHEAD):
+    the look-ahead ring must hand every env its stream's levels in order whatever the window phase."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    monkeypatch.setenv("BBAI_LOOKAHEAD", period)
+    n = 64
+    env = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=9)     # tiny level: episodes of a few steps
+    refs = _oracle_envs("GoToObjS4", [9 + i for i in range(n)])
+    rng = np.random.RandomState(int(period))
+    env.reset()
+    ro = [e.reset() for e in refs]
+    for t in range(160):
+        if t in (5, 6, 40, 41, 42, 43, 97):           # explicit resets at assorted window phases
+            env.reset()
+            ro = [e.reset() for e in refs]
+        img = env.image.cpu().numpy()
+        for i in range(n):
+            assert np.array_equal(img[i], ro[i]["image"]), (period, t, i)
+        a = rng.choice([0, 1, 2], size=n).astype(np.uint8)
+        env.step(torch.as_tensor(a, device=gpu))
+        for i in range(n):
+            o, r, d, _ = refs[i].step(int(a[i]))
+            ro[i] = refs[i].reset() if d else o
+    assert env.reset_count() > 7 * n
+    env.close()
