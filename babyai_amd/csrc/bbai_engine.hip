@@ -73,7 +73,10 @@ struct bbai_env {
     uint32_t* win_count;  // [3][16]
     int win_all[3];       // window contained a reset() of every env: refill iterates all envs
     int32_t* reset_list;  // [n]     envs finished by the current step (k_step -> k_consume / k_tokens)
-    uint32_t* counters;   // [16]    [0] = reset list length
+    uint32_t* counters;   // [2][16] [p][0] = reset list length; ping-pong by step parity so that k_consume can zero the
+                          //         other one for the next step (no memset launch on the step path)
+    int step_parity;
+    bool next_counter_clean;
     unsigned long long* total_resets;
     uint8_t* tokens;      // optional caller-owned [n][72] mission token buffer kept current on resets
     hipStream_t side;     // look-ahead generation stream
@@ -361,7 +364,8 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
                                                  unsigned long long* __restrict__ total_resets, int depth,
                                                  uint8_t* __restrict__ pending, uint8_t* __restrict__ first_slot,
                                                  int32_t* __restrict__ win_list, uint32_t* __restrict__ win_count, int pos,
-                                                 uint8_t* __restrict__ image, uint8_t* __restrict__ dirs) {
+                                                 uint8_t* __restrict__ image, uint8_t* __restrict__ dirs,
+                                                 uint32_t* __restrict__ other_counter) {
     const int64_t count = all ? n : (int64_t)counter[0];
     // this tick's entries go behind those of the window's earlier ticks (their counts were written by earlier
     // launches); no atomics: an env appears at most once per tick, repeats within the window are marked -1
@@ -403,6 +407,7 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(total_resets, (unsigned long long)count);
         win_count[1 + pos] = all ? 0u : (uint32_t)count;
+        other_counter[0] = 0;       // the next step's k_step appends to the other ping-pong counter from zero
     }
 }
 
@@ -604,7 +609,7 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->win_list, 3 * (size_t)n_envs * 4);
     alloc((void**)&e->win_count, 3 * 64);
     alloc((void**)&e->reset_list, (size_t)n_envs * 4);
-    alloc((void**)&e->counters, 64);
+    alloc((void**)&e->counters, 128);
     alloc((void**)&e->total_resets, 8);
     alloc((void**)&e->atlas, MAX_TILES * TILE_BYTES);
     alloc((void**)&e->lut, 512);
@@ -620,7 +625,7 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     HIP_TRY(hipMemset(e->win_count, 0, 3 * 64));
     HIP_TRY(hipMemset(e->vhead, 0, (size_t)n_envs * 4));
     HIP_TRY(hipMemset(e->vset, 0, (size_t)n_envs * 64));
-    HIP_TRY(hipMemset(e->counters, 0, 64));
+    HIP_TRY(hipMemset(e->counters, 0, 128));
     HIP_TRY(hipMemset(e->total_resets, 0, 8));
     {
         int lo = 0, hi = 0;     // look-ahead generation should get wave slots as soon as any free up
@@ -669,12 +674,15 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
     if (all) e->win_all[wb] = 1;
     const int64_t hint = all ? e->n : std::max<int64_t>(e->n / 64, 64);
     hipLaunchKernelGGL(k_consume, dim3((unsigned)std::min<int64_t>((hint + 3) / 4, 8192)), dim3(256), 0, s, e->cfg, e->n, e->rec,
-                       e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, e->reset_list, e->counters, all, e->total_resets,
-                       D, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n, e->win_list + (size_t)wb * e->n,
-                       e->win_count + 16 * wb, pos, image, dirs);
+                       e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, e->reset_list, e->counters + 16 * e->step_parity, all,
+                       e->total_resets, D, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n,
+                       e->win_list + (size_t)wb * e->n, e->win_count + 16 * wb, pos, image, dirs,
+                       e->counters + 16 * (e->step_parity ^ 1));
     if (e->tokens)
         hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n, e->rec,
-                           e->tokens, e->reset_list, e->counters, all);
+                           e->tokens, e->reset_list, e->counters + 16 * e->step_parity, all);
+    e->step_parity ^= 1;
+    e->next_counter_clean = true;
     HIP_TRY(hipGetLastError());
     if (pos == B - 1) {
         // Window end: one refill launch for everything consumed in the window, on the look-ahead stream.
@@ -748,8 +756,9 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
     int32_t* list = e->reset_list;
-    uint32_t* counter = e->counters;
-    HIP_TRY(hipMemsetAsync(counter, 0, 4, s));
+    uint32_t* counter = e->counters + 16 * e->step_parity;
+    if (!e->next_counter_clean) HIP_TRY(hipMemsetAsync(counter, 0, 4, s));   // (k_consume of the previous step zeroes it)
+    e->next_counter_clean = false;
     hipLaunchKernelGGL(k_step, dim3((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), dim3(STEP_BLOCK), 0, s, e->cfg, e->n,
                        e->rec, e->hot, e->stale, e->vhead, e->vset, actions, image, dirs, rewards, dones, auto_reset, list, counter);
     HIP_TRY(hipGetLastError());
