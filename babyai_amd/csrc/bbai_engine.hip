@@ -77,7 +77,7 @@ struct bbai_env {
                           //         other one for the next step (no memset launch on the step path)
     int step_parity;
     bool next_counter_clean;
-    unsigned long long* total_resets;
+    unsigned long long* total_resets;   // [0] resets so far, [1] generator give-ups (last-resort guard)
     uint8_t* tokens;      // optional caller-owned [n][72] mission token buffer kept current on resets
     hipStream_t side;     // look-ahead generation stream
     hipEvent_t ev_consumed, ev_refill[3];
@@ -285,7 +285,8 @@ __global__ __launch_bounds__(64) void k_pregen(LevelCfg c, int64_t n, uint8_t* _
                                                Hot* __restrict__ next_hots, uint32_t* __restrict__ mts,
                                                int32_t* __restrict__ mtis, const int32_t* __restrict__ win_list,
                                                const uint32_t* __restrict__ win_count, int all, int depth,
-                                               uint8_t* __restrict__ pending, const uint8_t* __restrict__ first_slot) {
+                                               uint8_t* __restrict__ pending, const uint8_t* __restrict__ first_slot,
+                                               unsigned long long* __restrict__ gen_failures) {
     __shared__ GenWork w;
     int64_t count = n;
     if (!all) {                                          // window list = concatenated per-tick lists
@@ -340,6 +341,10 @@ __global__ __launch_bounds__(64) void k_pregen(LevelCfg c, int64_t n, uint8_t* _
                 h.step = 0; h.max_steps = (uint16_t)max_steps;
                 h.pre4 = 0xFFFFFFFFu;
                 h.vstate = 0; h.frozen = 0;
+                if (g.gave_up) {                 // never seen; keeps an impossible level from hanging the device
+                    h.frozen = 2;
+                    atomicAdd(gen_failures, 1ull);
+                }
                 h.last_locked = last_locked < 0 ? NONE8 : (uint8_t)last_locked;
                 h.slot = 0;
                 next_hots[(int64_t)slot * n + env] = h;
@@ -610,7 +615,7 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->win_count, 3 * 64);
     alloc((void**)&e->reset_list, (size_t)n_envs * 4);
     alloc((void**)&e->counters, 128);
-    alloc((void**)&e->total_resets, 8);
+    alloc((void**)&e->total_resets, 16);
     alloc((void**)&e->atlas, MAX_TILES * TILE_BYTES);
     alloc((void**)&e->lut, 512);
     if (err != hipSuccess) {
@@ -626,7 +631,7 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     HIP_TRY(hipMemset(e->vhead, 0, (size_t)n_envs * 4));
     HIP_TRY(hipMemset(e->vset, 0, (size_t)n_envs * 64));
     HIP_TRY(hipMemset(e->counters, 0, 128));
-    HIP_TRY(hipMemset(e->total_resets, 0, 8));
+    HIP_TRY(hipMemset(e->total_resets, 0, 16));
     {
         int lo = 0, hi = 0;     // look-ahead generation should get wave slots as soon as any free up
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -692,7 +697,7 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
         HIP_TRY(hipStreamWaitEvent(e->side, e->ev_consumed, 0));
         hipLaunchKernelGGL(k_pregen, dim3(pregen_grid(rh)), dim3(64), 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt,
                            e->mti, e->win_list + (size_t)wb * e->n, e->win_count + 16 * wb, wall, D,
-                           e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n);
+                           e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n, e->total_resets + 1);
         HIP_TRY(hipEventRecord(e->ev_refill[wb], e->side));
         HIP_TRY(hipGetLastError());
     }
@@ -726,7 +731,7 @@ int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
     HIP_TRY(hipMemsetAsync(e->pending, e->depth, (size_t)n, e->side));
     HIP_TRY(hipMemsetAsync(e->first_slot, 0, (size_t)n, e->side));
     hipLaunchKernelGGL(k_pregen, dim3(pregen_grid(n)), dim3(64), 0, e->side, e->cfg, n, e->next_rec, e->next_hot, e->mt, e->mti,
-                       e->win_list, e->win_count, 1, e->depth, e->pending, e->first_slot);
+                       e->win_list, e->win_count, 1, e->depth, e->pending, e->first_slot, e->total_resets + 1);
     HIP_TRY(hipGetLastError());
     for (int k = 0; k < 3; ++k) HIP_TRY(hipEventRecord(e->ev_refill[k], e->side));
     HIP_TRY(hipMemsetAsync(e->win_count, 0, 3 * 64, e->side));
@@ -842,6 +847,16 @@ int bbai_get_programs(bbai_env* e, int64_t first, int64_t count, uint8_t* prog) 
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy2D(prog, sizeof(Prog), e->rec + first * e->cfg.rec_bytes + e->cfg.off_prog, (size_t)e->cfg.rec_bytes,
                         sizeof(Prog), (size_t)count, hipMemcpyDeviceToHost));
+    return BBAI_OK;
+}
+
+int bbai_generator_failures(bbai_env* e, uint64_t* out) {
+    if (!e || !out) return BBAI_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpy(&v, e->total_resets + 1, 8, hipMemcpyDeviceToHost));
+    *out = (uint64_t)v;
     return BBAI_OK;
 }
 

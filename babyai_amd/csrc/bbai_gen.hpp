@@ -75,6 +75,7 @@ struct Gen {
                              // episodes; a stale value never `is` a current room (levelgen.py:305-307)
                              // but still feeds rand_obj's implicit_unlock filter (levelgen.py:384-392)
     int S, rows, cols;
+    bool gave_up;            // generate() hit the last-resort attempt cap
     uint64_t doors;          // bit (16*k + r): room r has a door on side k (0 right, 1 down, 2 left, 3 up)
     uint32_t locked_mask;    // bit r: room r is behind a locked door (Room.locked)
     uint32_t inv_cols, inv_s1, inv_es;   // 2^16/d + 1: exact small-range division without the divider
@@ -82,7 +83,7 @@ struct Gen {
     BB_HD Gen(Ctx c, const LevelCfg& cf, GenWork& wk, int mti_, int last_locked_)
         : ctx(c), cfg(cf), w(wk), mti(mti_), nobj(0), ax(0), ay(0), adir(0), agent_set(false),
           locked_room(-1), last_locked(last_locked_), S(cf.room_size), rows(cf.num_rows), cols(cf.num_cols),
-          doors(0), locked_mask(0), inv_cols(65536u / (uint32_t)cf.num_cols + 1u),
+          gave_up(false), doors(0), locked_mask(0), inv_cols(65536u / (uint32_t)cf.num_cols + 1u),
           inv_s1(65536u / (uint32_t)(cf.room_size - 1) + 1u), inv_es(65536u / (uint32_t)cf.ES + 1u) {}
 
     BB_HD int div_cols(int v) const { return (int)(((uint32_t)v * inv_cols) >> 16); }     // v < 64
@@ -268,7 +269,11 @@ struct Gen {
             int j = rand_int(0, rows);
             r = j * cols + i;
         }
-        for (;;) {
+        // TERMINATION GUARD (deliberate deviation, shared with the oracle shim): the reference re-draws the pose for
+        // ever; in a crowded room whose free cells all face objects or doors no pose is ever accepted and the
+        // reference never returns (e.g. MiniBossLevel, seed 100758, 2nd level).  After 1000 rejected poses the
+        // attempt is abandoned like the other RecursionError cases and the level is re-generated.
+        for (int pose_tries = 0; pose_tries <= 1000; ++pose_tries) {
             agent_set = false;
             int x, y;
             if (!place_pos(r, false, x, y)) return false;
@@ -278,6 +283,7 @@ struct Gen {
             int id = w.I[iidx(fx, fy)];
             if (id == 0 || id == 1) return true;
         }
+        return false;
     }
     // RoomGrid.connect_all: random doors until every room is reachable from the agent's.
     // RoomGrid.add_door(i, j, door_idx=None, color=None, locked=...): side drawn until it has a neighbour and
@@ -1135,7 +1141,12 @@ struct Gen {
     // Returns max_steps (levelgen.py:42-45).
     BB_HD int generate() {
         if constexpr (ctx_profiles<Ctx>::value) t_last = ctx.now();
-        for (;;) {
+        gave_up = false;
+        for (int attempts = 0;; ++attempts) {
+            // Last-resort guard against a generation that can never succeed (every known unbounded loop of the
+            // reference is bounded above; this only keeps an unknown one from hanging the GPU): the caller freezes
+            // the env and counts the failure (bbai_generator_failures) instead of spinning for ever.
+            if (attempts >= 200000) { gave_up = true; break; }
             count(PH_ATTEMPTS);
             build_rooms();
             bool ok = cfg.kind == K_LEVELGEN ? mission_levelgen() : cfg.kind == K_BONUS ? mission_bonus() : mission_goto();

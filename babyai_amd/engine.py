@@ -63,6 +63,7 @@ def load_library():
     lib.bbai_import_state.argtypes = [P, I64, I64, P, P, P]
     lib.bbai_get_programs.argtypes = [P, I64, I64, P]
     lib.bbai_reset_count.argtypes = [P, P]
+    lib.bbai_generator_failures.argtypes = [P, P]
     _lib = lib
     return lib
 
@@ -70,7 +71,7 @@ def load_library():
 EXPORTED_SYMBOLS = (
     "bbai_version", "bbai_last_error", "bbai_fill_layout", "bbai_create", "bbai_destroy", "bbai_seed",
     "bbai_reset", "bbai_step", "bbai_set_atlas", "bbai_render", "bbai_set_token_buffer", "bbai_export_state", "bbai_import_state",
-    "bbai_get_programs", "bbai_reset_count",
+    "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures",
 )
 
 
@@ -268,6 +269,11 @@ class BatchedBabyAIEnv(object):
     def reset_count(self):
         v = ctypes.c_uint64(0)
         _check(self.lib, self.lib.bbai_reset_count(self.handle, ctypes.byref(v)), "bbai_reset_count")
+        return int(v.value)
+
+    def generator_failures(self):
+        v = ctypes.c_uint64(0)
+        _check(self.lib, self.lib.bbai_generator_failures(self.handle, ctypes.byref(v)), "bbai_generator_failures")
         return int(v.value)
 
     def max_steps(self):

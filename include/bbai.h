@@ -99,6 +99,10 @@ int bbai_get_programs(bbai_env* env, int64_t first, int64_t count, uint8_t* prog
 /* Number of level generations (resets) performed so far, all envs. */
 int bbai_reset_count(bbai_env* env, uint64_t* out);
 
+/* Levels the generator gave up on (last-resort guard after 200 000 rejected attempts; the env is frozen).  Expected 0:
+ * every unbounded rejection loop of the reference that can spin for ever is bounded explicitly. */
+int bbai_generator_failures(bbai_env* env, uint64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

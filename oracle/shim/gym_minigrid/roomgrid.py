@@ -207,13 +207,18 @@ class RoomGrid(MiniGridEnv):
             j = self._rand_int(0, self.num_rows)
         room = self.room_grid[j][i]
 
-        # Find a position that is not right in front of an object
-        while True:
+        # Find a position that is not right in front of an object.
+        # TERMINATION GUARD -- deliberate deviation from the published algorithm, which loops `while True`: in a
+        # crowded room whose free cells all face objects or doors no pose is ever accepted and the call never
+        # returns (found with BabyAI-MiniBossLevel-v0, seed 100758, 2nd level: ~1 in 10^6 levels).  After 1000
+        # rejected poses give up the way place_obj does (RecursionError => the level is re-generated,
+        # babyai/levels/levelgen.py:90-92).  The engine's generator applies the same bound (bbai_gen.hpp).
+        for _ in range(1001):
             super().place_agent(room.top, room.size, rand_dir, max_tries=1000)
             front_cell = self.grid.get(*self.front_pos)
             if front_cell is None or front_cell.type == 'wall':
-                break
-        return self.agent_pos
+                return self.agent_pos
+        raise RecursionError('no admissible agent pose in the room')
 
     def connect_all(self, door_colors=COLOR_NAMES, max_itrs=5000):
         start_room = self.room_from_pos(*self.agent_pos)
