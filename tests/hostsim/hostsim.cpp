@@ -37,8 +37,13 @@ int hs_generate(const LevelCfg* cfg, uint32_t* mt, int32_t* mti, uint8_t* rec, H
     memset(rec, 0, cfg->rec_bytes);
     memcpy(rec, w.E, cfg->ES * cfg->EH);
     memcpy(rec + cfg->off_I, w.I, cfg->W * cfg->H);
-    memcpy(rec + cfg->off_app, w.app, cfg->maxo);
-    for (int o = 0; o < cfg->maxo; ++o) { rec[cfg->off_pos + 2 * o] = w.px[o]; rec[cfg->off_pos + 2 * o + 1] = w.py[o]; }
+    // object tables: unused entries are written as zeros / NONE8, exactly like the device write-out (k_pregen)
+    for (int o = 0; o < cfg->maxo; ++o) {
+        const bool used = o < g.nobj;
+        rec[cfg->off_app + o] = used ? w.app[o] : 0;
+        rec[cfg->off_pos + 2 * o] = used ? w.px[o] : 0;
+        rec[cfg->off_pos + 2 * o + 1] = used ? w.py[o] : 0;
+    }
     for (int o = 0; o < cfg->maxo; ++o) rec[cfg->off_cont + o] = o < g.nobj ? w.cont[o] : NONE8;
     memcpy(rec + cfg->off_prog, &w.prog, sizeof(Prog));
     Hot h;

@@ -418,3 +418,73 @@ def test_autoreset_with_interleaved_resets(gpu, period, monkeypatch):
             ro[i] = refs[i].reset() if d else o
     assert env.reset_count() > 7 * n
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", ["BossLevel", "GoTo", "MiniBossLevel", "KeyCorridorS3R3", "PutNextS5N2Carrying", "Unlock"])
+def test_device_generator_equals_host_build_exhaustively(gpu, level):
+    """Every env of a batch: the records, hot state and programs produced by the wave-per-env device generator
+    (LDS working set, lane-split MT twist / grid fill / flood fill) equal, byte for byte, what the same headers
+    produce when compiled for the host with one lane -- three consecutive levels of 8192 seeds."""
+    import ctypes
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from babyai_amd.levels import make_cfg
+    from hostsim_util import HostEnv
+    n = 8192
+    env = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=70000)
+    cfg = make_cfg(level)
+    sims = [HostEnv(cfg, 70000 + i) for i in range(n)]
+    for ep in range(3):
+        env.reset()
+        torch.cuda.synchronize()
+        rec, hot, stale = env.export_state()
+        img = env.image.cpu().numpy()
+        for i, sim in enumerate(sims):
+            first = sim.reset()
+            assert np.array_equal(rec[i], sim.rec), (level, ep, i, "record")
+            h = sim.hot.copy()
+            g = hot[i].copy()
+            g[15] = h[15] = 0           # ring slot index: engine bookkeeping only
+            assert np.array_equal(g, h), (level, ep, i, "hot", g, h)
+            assert stale[i] == sim.stale.value
+            assert np.array_equal(img[i], first), (level, ep, i, "first obs")
+    assert env.generator_failures() == 0
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", ["BossLevel", "MiniBossLevel", "PutNextS5N2Carrying", "OpenDoorsOrderN4Debug"])
+def test_device_step_equals_host_build_exhaustively(gpu, level):
+    """Every env of a batch, every step: k_step (LDS-staged window, SoA verifier view, fused copy-out) + auto-reset
+    against the host build of the same headers -- image, reward bits, done, hot state and stale set."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from babyai_amd.levels import make_cfg
+    from hostsim_util import HostEnv
+    n, T = 3072, 70
+    env = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=5000)
+    cfg = make_cfg(level)
+    sims = [HostEnv(cfg, 5000 + i) for i in range(n)]
+    env.reset()
+    for s in sims:
+        s.reset()
+    rng = np.random.RandomState(12)
+    for t in range(T):
+        a = rng.choice(7, size=n, p=[0.14, 0.14, 0.3, 0.12, 0.1, 0.15, 0.05]).astype(np.uint8)
+        env.step(torch.as_tensor(a, device=gpu))
+        torch.cuda.synchronize()
+        img = env.image.cpu().numpy()
+        rew = env.reward.cpu().numpy()
+        dn = env.done.cpu().numpy()
+        _, hot, stale = env.export_state()
+        for i, s in enumerate(sims):
+            o, r, d = s.step(int(a[i]))
+            assert r.view(np.uint32) == rew[i].view(np.uint32) and d == bool(dn[i]), (level, t, i)
+            if d:
+                o = s.reset()
+            assert np.array_equal(img[i], o), (level, t, i)
+            g, h = hot[i].copy(), s.hot.copy()
+            g[15] = h[15] = 0
+            assert np.array_equal(g, h) and stale[i] == s.stale.value, (level, t, i)
+    env.close()
