@@ -16,7 +16,7 @@ import os
 
 import numpy as np
 
-from .levels import LevelCfg, make_cfg
+from .levels import make_cfg
 from . import missions
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
