@@ -138,6 +138,55 @@ class BatchedManyEnvs(_VecBase):
         return iter((obs, reward, done, info))
 
 
+class Actions(object):
+    """MiniGridEnv.Actions (names used by scripts/manual_control.py:51-74, babyai/utils/agent.py:89)."""
+    left, right, forward, pickup, drop, toggle, done = range(7)
+
+
+class SingleEnv(object):
+    """The single-env protocol (babyai/levels/levelgen.py:35,49; callers babyai/evaluate.py:20-33,
+    scripts/enjoy.py:56-60): `seed(int)`, `reset() -> obs`, `step(int) -> (obs, float, bool, dict)` on a batch of one.
+    Mostly for tools and debugging -- one env per launch wastes the GPU."""
+
+    actions = Actions
+
+    def __init__(self, env_id, device="cuda:0", pixel=False, seed=None):
+        self.engine = BatchedBabyAIEnv(env_id, 1, device=device, pixel=pixel, auto_reset=False)
+        self.pixel = pixel
+        self.observation_space, self.action_space = _spaces(pixel)
+        self.step_count = 0
+        self.mission = self.surface = ""
+        if seed is not None:
+            self.seed(seed)
+
+    def seed(self, seed=1337):
+        self.engine.seed([int(seed)])
+        return [seed]
+
+    def _one(self, obs):
+        d = {"image": obs["image"][0].cpu().numpy(), "mission": obs["mission"][0]}
+        if not self.pixel:
+            d["direction"] = int(obs["direction"][0])
+        self.mission = self.surface = d["mission"]
+        return d
+
+    @property
+    def max_steps(self):
+        return int(self.engine.max_steps()[0])
+
+    def reset(self):
+        self.step_count = 0
+        return self._one(self.engine.reset())
+
+    def step(self, action):
+        obs, reward, done, _ = self.engine.step(np.array([int(action)], dtype=np.uint8))
+        self.step_count += 1
+        return self._one(obs), float(reward[0]), bool(done[0]), {}
+
+    def close(self):
+        self.engine.close()
+
+
 def make(env_id, num_envs, device="cuda:0", pixel=False, auto_reset=True, seeds=None):
     """Batched twin of `gym.make(env_id)` (ids registered at babyai/levels/levelgen.py:467-493).
     Returns the tensor-level `BatchedBabyAIEnv`."""

@@ -488,3 +488,28 @@ def test_device_step_equals_host_build_exhaustively(gpu, level):
             g[15] = h[15] = 0
             assert np.array_equal(g, h) and stale[i] == s.stale.value, (level, t, i)
     env.close()
+
+
+@pytest.mark.gpu
+def test_single_env_protocol(gpu):
+    """seed / reset / step on a batch of one, with the attributes the reference's callers read
+    (babyai/evaluate.py:20-33: mission, step loop; scripts/manual_control.py: actions enum)."""
+    from babyai_amd.vec_env import SingleEnv
+    from oracle import levels as olevels
+    env = SingleEnv("BabyAI-PickupLoc-v0", device=gpu, seed=5)
+    ref = olevels.make_env("PickupLoc")
+    ref.seed(5)
+    rng = np.random.RandomState(2)
+    for ep in range(4):
+        o, ro = env.reset(), ref.reset()
+        assert o["mission"] == ro["mission"] == env.mission and env.max_steps == ref.max_steps
+        assert np.array_equal(o["image"], ro["image"]) and o["direction"] == ro["direction"]
+        while True:
+            a = int(rng.randint(0, 7))
+            (o, r, d, info), (ro, rr, rd, _) = env.step(a), ref.step(a)
+            assert np.array_equal(o["image"], ro["image"]) and np.float32(rr) == np.float32(r) and d == bool(rd) and info == {}
+            assert env.step_count == ref.step_count
+            if d:
+                break
+    assert env.actions.toggle == 5 and env.action_space.n == 7
+    env.close()
