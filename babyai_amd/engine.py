@@ -129,6 +129,10 @@ class BatchedBabyAIEnv(object):
     def __init__(self, env_id, num_envs, device="cuda:0", seeds=None, pixel=False, auto_reset=True):
         import torch
         self.torch = torch
+        if os.environ.get("BABYAI_DONE_ACTIONS"):
+            # babyai/levels/verifier.py:17,221-230,543-545: any non-empty value switches the verifier to
+            # "done"-action semantics, which the engine does not implement -- refuse rather than diverge.
+            raise EngineError("BABYAI_DONE_ACTIONS is set: the done-action verifier mode is not supported")
         if not torch.cuda.is_available():
             raise EngineError("no ROCm GPU visible: the batched engine has no CPU path")
         self.lib = load_library()
