@@ -513,3 +513,33 @@ def test_single_env_protocol(gpu):
                 break
     assert env.actions.toggle == 5 and env.action_space.n == 7
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", ["GoToObjS4", "PickupLoc"])
+def test_device_rollout_engine_equals_oracle_rollout(gpu, level):
+    """babyai_amd.rollout.DeviceRollout on the engine vs the same collector over oracle envs on CPU tensors
+    (which tests/test_rollout.py pins to the reference's BaseAlgo.collect_experiences, base.py:131-260):
+    every experience field and the episode logs must agree exactly across rollouts with auto-resets."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from babyai_amd.rollout import DeviceRollout
+    from rollout_util import OracleTensorEnv, ToyACModel
+    n, T = 48, 32
+    seeds = [700 + i for i in range(n)]
+    env = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=seeds)
+    dev = DeviceRollout(env, ToyACModel(), T, 0.99, 0.95, reward_scale=20.0)
+    cpu = DeviceRollout(OracleTensorEnv(level, seeds), ToyACModel(), T, 0.99, 0.95, reward_scale=20.0)
+    done_total = 0
+    for it in range(3):
+        e1, l1 = dev.collect_experiences()
+        e2, l2 = cpu.collect_experiences()
+        for f in ("memory", "mask", "action", "value", "reward", "advantage", "returnn", "log_prob"):
+            a, b = e1[f].cpu(), e2[f]
+            assert a.shape == b.shape and a.dtype == b.dtype, f
+            assert torch.equal(a, b), (level, it, f)
+        assert torch.equal(e1.obs.image.cpu(), e2.obs.image) and torch.equal(e1.obs.instr.cpu(), e2.obs.instr)
+        assert l1 == l2
+        done_total += l1["episodes_done"]
+    assert done_total >= n // 2
+    env.close()
