@@ -252,6 +252,15 @@ class BatchedBabyAIEnv(object):
                                                      stale.ctypes.data), "bbai_export_state")
         return rec, hot, stale
 
+    def grid_encoding(self, first=0, count=None):
+        """uint8[count, W, H, 3]: the full-grid `env.grid.encode()` (type, colour, state per cell, indexed [x, y]) and
+        the agent poses int[count, 3] = (x, y, dir) -- the `unwrapped.grid` / `agent_pos` view that the reference's own
+        level test compares between same-seed envs (babyai/levels/levelgen.py:531-537)."""
+        rec, hot, _ = self.export_state(first, count)
+        c = self.cfg
+        e = rec[:, :c.ES * c.EH].reshape(-1, c.EH, c.ES)[:, 5:5 + c.H, 5:5 + c.W].transpose(0, 2, 1)
+        return np.stack([e & 7, (e >> 3) & 7, e >> 6], axis=-1).astype(np.uint8), hot[:, :3].astype(np.int64)
+
     def import_state(self, rec, hot, stale, first=0):
         rec = np.ascontiguousarray(rec, dtype=np.uint8)
         hot = np.ascontiguousarray(hot, dtype=np.uint8)

@@ -143,6 +143,21 @@ class Actions(object):
     left, right, forward, pickup, drop, toggle, done = range(7)
 
 
+class _GridSnapshot(object):
+    def __init__(self, enc):
+        self._enc = enc
+        self.width, self.height = enc.shape[0], enc.shape[1]
+
+    def encode(self):
+        return self._enc.copy()
+
+    def __eq__(self, other):
+        return np.array_equal(self._enc, other.encode())
+
+    def __ne__(self, other):
+        return not self == other
+
+
 class SingleEnv(object):
     """The single-env protocol (babyai/levels/levelgen.py:35,49; callers babyai/evaluate.py:20-33,
     scripts/enjoy.py:56-60): `seed(int)`, `reset() -> obs`, `step(int) -> (obs, float, bool, dict)` on a batch of one.
@@ -173,6 +188,23 @@ class SingleEnv(object):
     @property
     def max_steps(self):
         return int(self.engine.max_steps()[0])
+
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def grid(self):
+        """Snapshot of the full grid; `.encode()` and `==` as used at levelgen.py:534-536."""
+        return _GridSnapshot(self.engine.grid_encoding()[0][0])
+
+    @property
+    def agent_pos(self):
+        return tuple(int(v) for v in self.engine.grid_encoding()[1][0][:2])
+
+    @property
+    def agent_dir(self):
+        return int(self.engine.grid_encoding()[1][0][2])
 
     def reset(self):
         self.step_count = 0

@@ -509,8 +509,16 @@ def test_single_env_protocol(gpu):
             (o, r, d, info), (ro, rr, rd, _) = env.step(a), ref.step(a)
             assert np.array_equal(o["image"], ro["image"]) and np.float32(rr) == np.float32(r) and d == bool(rd) and info == {}
             assert env.step_count == ref.step_count
+            # unwrapped.grid / agent pose: the full-state view levelgen.py:531-537 compares between same-seed envs
+            assert np.array_equal(env.unwrapped.grid.encode(), ref.grid.encode())
+            assert env.agent_pos == tuple(ref.agent_pos) and env.agent_dir == ref.agent_dir
             if d:
                 break
+    twin = SingleEnv("BabyAI-PickupLoc-v0", device=gpu, seed=5)
+    env.seed(5)
+    env.reset(), twin.reset()
+    assert env.unwrapped.grid == twin.unwrapped.grid and env.surface == twin.surface
+    twin.close()
     assert env.actions.toggle == 5 and env.action_space.n == 7
     env.close()
 
