@@ -49,6 +49,28 @@ static thread_local char g_err[512] = "";
         }                                                                                     \
     } while (0)
 
+#define ARG_FAIL(msg)                                                                        \
+    do {                                                                                      \
+        snprintf(g_err, sizeof(g_err), "%s: %s", __func__, msg);                              \
+        return BBAI_ERR_ARG;                                                                  \
+    } while (0)
+
+// Entry points run on the handle's device but must leave the caller's current device alone (torch tracks the
+// HIP current device of the thread; a library that changes it redirects the caller's later allocations).
+struct DeviceGuard {
+    int prev = -1, err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev); else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define ON_DEVICE(dev)                                                                        \
+    DeviceGuard guard_(dev);                                                                  \
+    HIP_TRY((hipError_t)guard_.err)
+
 struct bbai_env {
     LevelCfg cfg;
     int64_t n;
@@ -546,13 +568,15 @@ int bbai_version(void) { return 100; }
 const char* bbai_last_error(void) { return g_err; }
 
 int bbai_fill_layout(bbai_level_cfg* cfg) {
-    if (!cfg) return BBAI_ERR_ARG;
+    if (!cfg) ARG_FAIL("null cfg");
     LevelCfg c;
     memcpy(&c, cfg, sizeof(c));
     if (fill_layout(c) != 0) { snprintf(g_err, sizeof(g_err), "unsupported level geometry"); return BBAI_ERR_ARG; }
     memcpy(cfg, &c, sizeof(c));
     return BBAI_OK;
 }
+
+static int create_finish(bbai_env* e);
 
 static int validate_cfg(const LevelCfg& c) {
     if (c.kind != K_GOTO && c.kind != K_LEVELGEN && c.kind != K_BONUS) return -1;
@@ -584,7 +608,7 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
         snprintf(g_err, sizeof(g_err), "level configuration rejected (layout not filled or out of range)");
         return BBAI_ERR_ARG;
     }
-    HIP_TRY(hipSetDevice(device));
+    ON_DEVICE(device);
     bbai_env* e = new bbai_env();
     memset(e, 0, sizeof(*e));
     e->cfg = c; e->n = n_envs; e->device = device;
@@ -623,6 +647,18 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
         bbai_destroy(e);
         return BBAI_ERR_NOMEM;
     }
+    int rc = create_finish(e);
+    if (rc != BBAI_OK) { bbai_destroy(e); return rc; }      // g_err holds the failing call
+    *out = e;
+    return BBAI_OK;
+}
+
+}  // extern "C"
+
+static int create_finish(bbai_env* e) {
+    const LevelCfg& c = e->cfg;
+    const int64_t n_envs = e->n;
+    const size_t D = (size_t)e->depth;
     HIP_TRY(hipMemset(e->rec, 0, (size_t)n_envs * c.rec_bytes));
     HIP_TRY(hipMemset(e->next_rec, 0, D * (size_t)n_envs * c.rec_bytes));
     HIP_TRY(hipMemset(e->pending, 0, 3 * (size_t)n_envs));
@@ -639,13 +675,14 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
         HIP_TRY(hipEventCreateWithFlags(&e->ev_consumed, hipEventDisableTiming));
         for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreateWithFlags(&e->ev_refill[k], hipEventDisableTiming));
     }
-    *out = e;
     return BBAI_OK;
 }
 
+extern "C" {
+
 void bbai_destroy(bbai_env* e) {
     if (!e) return;
-    (void)hipSetDevice(e->device);
+    DeviceGuard guard_(e->device);
     (void)hipDeviceSynchronize();
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->ev_consumed) (void)hipEventDestroy(e->ev_consumed);
@@ -707,7 +744,7 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
 
 int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
     if (!e || !seeds || n != e->n) { snprintf(g_err, sizeof(g_err), "seed: need exactly n_envs seeds"); return BBAI_ERR_ARG; }
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     const int64_t chunk = 65536;
     std::vector<uint32_t> buf((size_t)std::min<int64_t>(chunk, n) * MT_N);
     unsigned hw = std::thread::hardware_concurrency();
@@ -744,9 +781,9 @@ int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
 }
 
 int bbai_reset(bbai_env* e, uint8_t* image, uint8_t* dirs, void* stream) {
-    if (!e || !image || !dirs) return BBAI_ERR_ARG;
+    if (!e || !image || !dirs) ARG_FAIL("null handle or output buffer");
     if (!e->seeded) { snprintf(g_err, sizeof(g_err), "reset before seed"); return BBAI_ERR_STATE; }
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     hipStream_t s = (hipStream_t)stream;
     int rc = consume_and_refill(e, s, image, dirs, 1);
     if (rc != BBAI_OK) return rc;
@@ -756,9 +793,13 @@ int bbai_reset(bbai_env* e, uint8_t* image, uint8_t* dirs, void* stream) {
 
 int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, uint8_t* dones,
               int auto_reset, void* stream) {
-    if (!e || !actions || !image || !dirs || !rewards || !dones) return BBAI_ERR_ARG;
+    if (!e || !actions || !image || !dirs || !rewards || !dones) ARG_FAIL("null handle or buffer");
     if (!e->live) { snprintf(g_err, sizeof(g_err), "step before reset"); return BBAI_ERR_STATE; }
-    HIP_TRY(hipSetDevice(e->device));
+    if (auto_reset && !e->seeded) {     // live through import_state only: there is no level stream to reset from
+        snprintf(g_err, sizeof(g_err), "auto-reset step before seed");
+        return BBAI_ERR_STATE;
+    }
+    ON_DEVICE(e->device);
     hipStream_t s = (hipStream_t)stream;
     int32_t* list = e->reset_list;
     uint32_t* counter = e->counters + 16 * e->step_parity;
@@ -773,8 +814,8 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
 }
 
 int bbai_set_atlas(bbai_env* e, const uint8_t* tiles, int n_tiles, const uint8_t* lut) {
-    if (!e || !tiles || !lut || n_tiles < 1 || n_tiles > MAX_TILES) return BBAI_ERR_ARG;
-    HIP_TRY(hipSetDevice(e->device));
+    if (!e || !tiles || !lut || n_tiles < 1 || n_tiles > MAX_TILES) ARG_FAIL("null pointer or tile count out of range");
+    ON_DEVICE(e->device);
     HIP_TRY(hipMemcpy(e->atlas, tiles, (size_t)n_tiles * TILE_BYTES, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->lut, lut, 512, hipMemcpyHostToDevice));
     e->n_tiles = n_tiles;
@@ -782,9 +823,9 @@ int bbai_set_atlas(bbai_env* e, const uint8_t* tiles, int n_tiles, const uint8_t
 }
 
 int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream) {
-    if (!e || !image || !pixels) return BBAI_ERR_ARG;
+    if (!e || !image || !pixels) ARG_FAIL("null handle or buffer");
     if (e->n_tiles <= 0) { snprintf(g_err, sizeof(g_err), "render before set_atlas"); return BBAI_ERR_STATE; }
-    HIP_TRY(hipSetDevice(e->device));
+    ON_DEVICE(e->device);
     // 8 groups (64 envs) per block: short-lived blocks keep wave slots turning over for the look-ahead stream
     int64_t groups = (e->n + RENDER_GROUP - 1) / RENDER_GROUP;
     // Measured on MI355X (tools/ubench_store.hip, gpurun_out/sweep): looped 16-byte store streams top out at
@@ -801,10 +842,10 @@ int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream
 // Register (or clear with NULL) a caller-owned uint8[n][72] device buffer that the engine keeps filled with the
 // mission token ids of every env's current episode (rewritten whenever an env is reset).
 int bbai_set_token_buffer(bbai_env* e, uint8_t* tokens_dev) {
-    if (!e) return BBAI_ERR_ARG;
+    if (!e) ARG_FAIL("null handle");
     e->tokens = tokens_dev;
     if (tokens_dev && e->live) {        // episodes already running: fill every row now
-        HIP_TRY(hipSetDevice(e->device));
+        ON_DEVICE(e->device);
         HIP_TRY(hipDeviceSynchronize());
         hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((e->n + 63) / 64, 4096)), dim3(64), 0, 0, e->cfg, e->n, e->rec,
                            tokens_dev, e->reset_list, e->counters, 1);
@@ -815,8 +856,8 @@ int bbai_set_token_buffer(bbai_env* e, uint8_t* tokens_dev) {
 }
 
 int bbai_export_state(bbai_env* e, int64_t first, int64_t count, uint8_t* rec, uint8_t* hot, uint64_t* stale) {
-    if (!e || first < 0 || count < 0 || first + count > e->n) return BBAI_ERR_ARG;
-    HIP_TRY(hipSetDevice(e->device));
+    if (!e || first < 0 || count < 0 || first + count > e->n) ARG_FAIL("null handle or env range out of bounds");
+    ON_DEVICE(e->device);
     HIP_TRY(hipDeviceSynchronize());
     if (rec) HIP_TRY(hipMemcpy(rec, e->rec + first * e->cfg.rec_bytes, (size_t)count * e->cfg.rec_bytes, hipMemcpyDeviceToHost));
     if (hot) HIP_TRY(hipMemcpy(hot, e->hot + first, (size_t)count * sizeof(Hot), hipMemcpyDeviceToHost));
@@ -825,8 +866,8 @@ int bbai_export_state(bbai_env* e, int64_t first, int64_t count, uint8_t* rec, u
 }
 
 int bbai_import_state(bbai_env* e, int64_t first, int64_t count, const uint8_t* rec, const uint8_t* hot, const uint64_t* stale) {
-    if (!e || first < 0 || count < 0 || first + count > e->n) return BBAI_ERR_ARG;
-    HIP_TRY(hipSetDevice(e->device));
+    if (!e || first < 0 || count < 0 || first + count > e->n) ARG_FAIL("null handle or env range out of bounds");
+    ON_DEVICE(e->device);
     HIP_TRY(hipDeviceSynchronize());
     if (rec) HIP_TRY(hipMemcpy(e->rec + first * e->cfg.rec_bytes, rec, (size_t)count * e->cfg.rec_bytes, hipMemcpyHostToDevice));
     if (hot) HIP_TRY(hipMemcpy(e->hot + first, hot, (size_t)count * sizeof(Hot), hipMemcpyHostToDevice));
@@ -842,8 +883,8 @@ int bbai_import_state(bbai_env* e, int64_t first, int64_t count, const uint8_t* 
 }
 
 int bbai_get_programs(bbai_env* e, int64_t first, int64_t count, uint8_t* prog) {
-    if (!e || !prog || first < 0 || count < 0 || first + count > e->n) return BBAI_ERR_ARG;
-    HIP_TRY(hipSetDevice(e->device));
+    if (!e || !prog || first < 0 || count < 0 || first + count > e->n) ARG_FAIL("null pointer or env range out of bounds");
+    ON_DEVICE(e->device);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy2D(prog, sizeof(Prog), e->rec + first * e->cfg.rec_bytes + e->cfg.off_prog, (size_t)e->cfg.rec_bytes,
                         sizeof(Prog), (size_t)count, hipMemcpyDeviceToHost));
@@ -851,8 +892,8 @@ int bbai_get_programs(bbai_env* e, int64_t first, int64_t count, uint8_t* prog) 
 }
 
 int bbai_generator_failures(bbai_env* e, uint64_t* out) {
-    if (!e || !out) return BBAI_ERR_ARG;
-    HIP_TRY(hipSetDevice(e->device));
+    if (!e || !out) ARG_FAIL("null pointer");
+    ON_DEVICE(e->device);
     HIP_TRY(hipDeviceSynchronize());
     unsigned long long v = 0;
     HIP_TRY(hipMemcpy(&v, e->total_resets + 1, 8, hipMemcpyDeviceToHost));
@@ -861,8 +902,8 @@ int bbai_generator_failures(bbai_env* e, uint64_t* out) {
 }
 
 int bbai_reset_count(bbai_env* e, uint64_t* out) {
-    if (!e || !out) return BBAI_ERR_ARG;
-    HIP_TRY(hipSetDevice(e->device));
+    if (!e || !out) ARG_FAIL("null pointer");
+    ON_DEVICE(e->device);
     HIP_TRY(hipDeviceSynchronize());
     unsigned long long v = 0;
     HIP_TRY(hipMemcpy(&v, e->total_resets, 8, hipMemcpyDeviceToHost));

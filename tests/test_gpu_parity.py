@@ -551,3 +551,28 @@ def test_device_rollout_engine_equals_oracle_rollout(gpu, level):
         done_total += l1["episodes_done"]
     assert done_total >= n // 2
     env.close()
+
+
+@pytest.mark.gpu
+def test_state_errors_are_reported_not_undefined(gpu):
+    """Protocol misuse comes back as an error code + message through the C ABI, never as undefined device work."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv, EngineError
+    env = BatchedBabyAIEnv("BabyAI-GoToLocal-v0", 8, device=gpu)          # not seeded
+    with pytest.raises(EngineError, match="reset before seed"):
+        env.reset()
+    with pytest.raises(EngineError, match="step before reset"):
+        env.step(torch.zeros(8, dtype=torch.uint8, device=gpu))
+    donor = BatchedBabyAIEnv("BabyAI-GoToLocal-v0", 8, device=gpu, seeds=1)
+    donor.reset()
+    env.import_state(*donor.export_state())                               # live, but without a level stream
+    with pytest.raises(EngineError, match="auto-reset step before seed"):
+        env.step(torch.zeros(8, dtype=torch.uint8, device=gpu))
+    env.auto_reset = False                                                # ManyEnvs protocol needs no stream
+    donor.auto_reset = False
+    a = torch.full((8,), 2, dtype=torch.uint8, device=gpu)
+    o1, o2 = env.step(a), donor.step(a)
+    assert torch.equal(o1[0]["image"], o2[0]["image"]) and torch.equal(o1[1], o2[1]) and torch.equal(o1[2], o2[2])
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(7, dtype=torch.uint8, device=gpu))
+    env.close(); donor.close()
