@@ -2,7 +2,6 @@
 verifier, observation) compiled for the host CPU with a single lane.  Test harness only."""
 import ctypes
 import os
-import subprocess
 
 import numpy as np
 
@@ -15,10 +14,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        csrc = os.path.join(os.path.dirname(HERE), "babyai_amd", "csrc")
-        deps = [SRC] + [os.path.join(csrc, f) for f in os.listdir(csrc)]
-        if not os.path.isfile(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unknown-pragmas", "-o", LIB, SRC])
+        import sys
+        sys.path.insert(0, os.path.dirname(HERE))
+        import __graft_entry__
+        __graft_entry__.build_hostsim()          # content-stamped: rebuilds iff a source byte changed
         L = ctypes.CDLL(LIB)
         P = ctypes.c_void_p
         L.hs_seed.argtypes = [ctypes.c_uint64, P]
