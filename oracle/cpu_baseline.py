@@ -55,6 +55,46 @@ def run(level="BossLevel", pixel=True, seconds=12.0):
     }
 
 
+def c1(steps=10000, seed=0, use_reference=False):
+    """BASELINE.json configs[0]: BabyAI-GoToRedBall-v0, ONE env, seed 0, `steps` random actions over
+    all 7 actions with auto-reset, encoded obs -- the plumbing / single-core CPU figure.  `use_reference` runs the
+    reference's own level class on the shim instead of the stand-alone oracle (build container only).
+    Also returns a digest of every (obs, reward, done) so the two can be compared."""
+    import hashlib
+    if _ROOT not in sys.path:
+        sys.path.insert(0, _ROOT)
+    import numpy as np
+    if use_reference:
+        from oracle import refenv
+        refenv.import_reference()
+        import gym
+        env = gym.make("BabyAI-GoToRedBall-v0")
+    else:
+        from oracle import levels as olevels
+        env = olevels.make_env("GoToRedBall")
+    env.seed(seed)
+    obs = env.reset()
+    acts = np.random.RandomState(seed).randint(0, 7, size=steps)
+    h = hashlib.sha256()
+    episodes = 0
+    t0 = time.perf_counter()
+    for a in acts:
+        obs, reward, done, _ = env.step(int(a))
+        h.update(obs["image"].tobytes())
+        h.update(np.float32(reward).tobytes())
+        h.update(bytes([int(obs["direction"]), int(done)]))
+        if done:
+            episodes += 1
+            obs = env.reset()
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "reference" if use_reference else "port",
+            "sample": "BabyAI-GoToRedBall-v0, 1 env, seed %d, %d random-action steps, %d episodes" % (seed, steps, episodes),
+            "digest": h.hexdigest()}
+
+
 if __name__ == "__main__":
     import json
+    if sys.argv[1:2] == ["c1"]:
+        print(json.dumps(c1(use_reference="--reference" in sys.argv)))
+        sys.exit(0)
     print(json.dumps(run(*(sys.argv[1:2] or ["BossLevel"]), pixel="--no-pixel" not in sys.argv, seconds=4.0)))

@@ -576,3 +576,23 @@ def test_state_errors_are_reported_not_undefined(gpu):
     with pytest.raises(ValueError):
         env.step(torch.zeros(7, dtype=torch.uint8, device=gpu))
     env.close(); donor.close()
+
+
+@pytest.mark.gpu
+def test_c1_plumbing_config_on_the_engine(gpu):
+    """BASELINE.json configs[0] through the single-env protocol: same digest as the reference (tests/test_oracle_golden.py)."""
+    import hashlib
+    from babyai_amd.vec_env import SingleEnv
+    from test_oracle_golden import C1_DIGEST
+    env = SingleEnv("BabyAI-GoToRedBall-v0", device=gpu, seed=0)
+    env.reset()
+    h = hashlib.sha256()
+    for a in np.random.RandomState(0).randint(0, 7, size=10000):
+        obs, reward, done, _ = env.step(int(a))
+        h.update(obs["image"].tobytes())
+        h.update(np.float32(reward).tobytes())
+        h.update(bytes([int(obs["direction"]), int(done)]))
+        if done:
+            env.reset()
+    env.close()
+    assert h.hexdigest() == C1_DIGEST

@@ -49,3 +49,15 @@ def test_oracle_matches_reference_trace(path):
     with np.load(path, allow_pickle=False) as f:
         g = {k: f[k] for k in f.files}      # decompress once (NpzFile re-reads on every access)
     replay(g)
+
+
+C1_DIGEST = "d86a76540bee1af95d9efc7e4f6217a1f849f603dd33e6ba5eebccd24a079582"
+
+
+def test_c1_plumbing_config_known_answer():
+    """BASELINE.json configs[0]: GoToRedBall, 1 env, seed 0, 10 000 random-action steps.  The digest of every
+    (image, reward, direction, done) was produced by the reference's own Level_GoToRedBall on the shim
+    (`python -m oracle.cpu_baseline c1 --reference`) and is reproduced by the stand-alone oracle."""
+    from oracle import cpu_baseline
+    out = cpu_baseline.c1()
+    assert out["digest"] == C1_DIGEST and "182 episodes" in out["sample"]

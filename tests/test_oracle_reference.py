@@ -94,3 +94,9 @@ def test_level_table_covers_every_registered_level(level_dict):
     """All 105 ids the reference registers (levelgen.py:467-493) are in the engine's and the oracle's tables."""
     from babyai_amd.levels import LEVELS
     assert set(level_dict.keys()) == set(LEVELS) == set(olevels.SPECS)
+
+
+def test_c1_digest_from_the_reference_itself():
+    from oracle import cpu_baseline
+    from test_oracle_golden import C1_DIGEST
+    assert cpu_baseline.c1(use_reference=True)["digest"] == C1_DIGEST
