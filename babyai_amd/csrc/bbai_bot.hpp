@@ -1,0 +1,688 @@
+// bbai_bot.hpp -- the GOFAI expert of the reference (babyai/bot.py), one decision per env-step, as scalar
+// per-env code over the engine's env record (lane = env on the device; the same header builds for the host in
+// tests/hostsim).  It reproduces `Bot.replan(action_taken)` DECISION FOR DECISION, including the points where the
+// reference bot gives up (assertion / DisappearedBoxError / AttributeError -> `dead`), because demonstrations are
+// only comparable when the two experts act identically (babyai/utils/agent.py:139-146, scripts/make_agent_demos.py).
+//
+// Follows (reference file:line, /root/reference/babyai/bot.py):
+//   Subgoal._plan_undo_action                         :109-137
+//   Close / Open / Drop / Pickup subgoals             :139-275
+//   GoNextToSubgoal                                   :277-449
+//   ExploreSubgoal                                    :452-500
+//   Bot.__init__ / _process_instr                     :524-545, :900-939
+//   Bot.replan                                        :547-597
+//   Bot._find_obj_pos                                 :599-656   (obj_set / obj_poss index quirk kept, see find_obj_pos)
+//   Bot._process_obs / _remember_current_state        :658-695
+//   Bot._closest_wall_or_door_given_dir               :697-708
+//   Bot._breadth_first_search / _shortest_path        :710-806
+//   Bot._find_drop_pos                                :808-898
+//   Bot._check_erroneous_box_opening                  :941-949
+//   ObjDesc.find_matching_objs (key descriptors)      babyai/levels/verifier.py:96-161
+//
+// BFS note: the reference appends every neighbour to a FIFO and discards already-visited positions when they are
+// popped; since the first entry queued for a position is also the first popped, marking positions when they are
+// QUEUED visits the same positions in the same order with the same predecessors, and bounds the queue by W*H.
+#pragma once
+#include "bbai_types.hpp"
+#include "bbai_step.hpp"
+
+namespace bbai {
+
+constexpr int BOT_STACK = 48;       // subgoal stack depth (overflow => dead, counted)
+constexpr int BOT_KEYS = 5;         // same-colour keys a key descriptor can list (overflow => dead, counted)
+constexpr int BOT_MAX_CELLS = MAX_W * MAX_W;
+constexpr int BOT_MAX_ITERS = 1000; // replanning rounds per decision (the reference would spin for ever)
+constexpr int BOT_DEAD = 0xFF;      // action value reported for a dead bot
+
+enum : uint8_t { SG_CLOSE = 0, SG_OPEN, SG_DROP, SG_PICKUP, SG_GONEXT, SG_EXPLORE };
+enum : uint8_t { RS_NONE = 0, RS_UNLOCK, RS_KEEPKEY, RS_PUTNEXT, RS_EXPLORE, RS_OPEN };
+enum : uint8_t { DT_NONE = 0, DT_DESC, DT_KEYS, DT_OBJ, DT_POS };
+enum : uint8_t { DEAD_NO = 0, DEAD_REFERENCE = 1, DEAD_CAPACITY = 2 };   // 2: our fixed-size structures overflowed
+
+struct Subgoal {            // 24 bytes
+    uint8_t kind, reason, dtype;
+    uint8_t a, b;           // DT_DESC: a = 2*leaf+slot; DT_OBJ: a = object; DT_POS: (a, b) = (x, y) as int8
+    uint8_t nkeys;          // DT_KEYS: frozen obj_set / obj_poss of ObjDesc('key', colour)
+    uint8_t keys[BOT_KEYS][3];
+    uint8_t pad[3];
+};
+static_assert(sizeof(Subgoal) == 24, "Subgoal layout");
+
+struct BotState {
+    uint32_t vis[MAX_W];            // vis[y] bit x : Bot.vis_mask
+    uint8_t ipos[MAX_OBJ][2];       // object positions when the episode started (order of ObjDesc.obj_set)
+    Subgoal stack[BOT_STACK];
+    uint8_t sp, dead;
+    uint8_t prev_ax, prev_ay, prev_carry;
+    uint8_t door_was_open;          // 0 / 1, 2 = attribute never set
+    uint8_t prev_fwd_type;          // T_* of prev_fwd_cell, 0 = None
+    uint8_t pad;
+};
+
+struct BotWork {                    // BFS scratch (two searches alive at once in _shortest_path)
+    uint16_t prev1[BOT_MAX_CELLS], q1[BOT_MAX_CELLS];
+    uint16_t prev2[BOT_MAX_CELLS], q2[BOT_MAX_CELLS];
+};
+
+struct Bot {
+    const LevelCfg& c;
+    const uint8_t* rec;
+    const Hot& h;
+    uint64_t stale;
+    BotState& s;
+    BotWork& w;
+    const uint8_t *E, *I, *app, *pos;
+    const Prog* prog;
+    bool raised;
+
+    BB_HD Bot(const LevelCfg& c_, const uint8_t* rec_, const Hot& h_, uint64_t stale_, BotState& s_, BotWork& w_)
+        : c(c_), rec(rec_), h(h_), stale(stale_), s(s_), w(w_), raised(false) {
+        E = rec; I = rec + c.off_I; app = rec + c.off_app; pos = rec + c.off_pos;
+        prog = (const Prog*)(rec + c.off_prog);
+    }
+
+    // ---- small helpers -------------------------------------------------------------------------------------
+    BB_HD void die(int why = DEAD_REFERENCE) { if (!raised) { raised = true; s.dead = (uint8_t)why; } }
+    BB_HD int cell(int x, int y) const { return E[e_index(c, x, y)]; }               // margin makes +-5 safe
+    BB_HD bool in_grid(int x, int y) const { return x >= 0 && y >= 0 && x < c.W && y < c.H; }
+    BB_HD bool seen(int x, int y) const { return in_grid(x, y) && (s.vis[y] >> x & 1); }
+    BB_HD static bool is_none(int e) { return e == E_EMPTY; }
+    BB_HD static bool open_door(int e) { return e_type(e) == T_DOOR && e_state(e) == S_OPEN; }
+    BB_HD int fx() const { return h.ax + dir_dx(h.dir); }
+    BB_HD int fy() const { return h.ay + dir_dy(h.dir); }
+    BB_HD int rx() const { return -dir_dy(h.dir); }                                   // right_vec = (-dy, dx)
+    BB_HD int ry() const { return dir_dx(h.dir); }
+    BB_HD bool carrying() const { return h.carry != NONE8; }
+    BB_HD bool obj_in_grid(int o) const {
+        int x = pos[2 * o], y = pos[2 * o + 1];
+        return in_grid(x, y) && I[i_index(c, x, y)] == o + 2;
+    }
+
+    BB_HD void push(const Subgoal& g) {
+        if (s.sp >= BOT_STACK) { die(DEAD_CAPACITY); return; }
+        s.stack[s.sp++] = g;
+    }
+    BB_HD void pop() { if (s.sp) --s.sp; }
+    BB_HD static Subgoal mk(int kind, int reason = RS_NONE) {
+        Subgoal g = {};
+        g.kind = (uint8_t)kind; g.reason = (uint8_t)reason; g.dtype = DT_NONE;
+        return g;
+    }
+    BB_HD static Subgoal go_pos(int x, int y, int reason = RS_NONE) {
+        Subgoal g = mk(SG_GONEXT, reason);
+        g.dtype = DT_POS; g.a = (uint8_t)(int8_t)x; g.b = (uint8_t)(int8_t)y;
+        return g;
+    }
+    // GoNextToSubgoal(bot, drop_pos) where _find_drop_pos may have returned None: tuple(None) raises when used
+    BB_HD static Subgoal go_maybe(bool ok, int x, int y) { return ok ? go_pos(x, y) : mk(SG_GONEXT); }
+    BB_HD static Subgoal go_desc(int k, int reason = RS_NONE) {
+        Subgoal g = mk(SG_GONEXT, reason);
+        g.dtype = DT_DESC; g.a = (uint8_t)k;
+        return g;
+    }
+    BB_HD static Subgoal go_obj(int o, int reason) {
+        Subgoal g = mk(SG_GONEXT, reason);
+        g.dtype = DT_OBJ; g.a = (uint8_t)o;
+        return g;
+    }
+
+    // ---- BFS (bot.py:710-806) ---------------------------------------------------------------------------------
+    enum { ACC_POS, ACC_UNSEEN, ACC_DOOR_UNLOCKED, ACC_DOOR, ACC_UNBLOCK, ACC_EMPTY };
+    struct Accept { int kind, x, y; bool has_except; int ex, ey; };
+
+    BB_HD bool match_empty(int x, int y, const Accept& a) const {                     // :873-885
+        if (x == h.ax && y == h.ay) return false;
+        if (a.has_except && x == a.ex && y == a.ey) return false;
+        return seen(x, y) && is_none(cell(x, y));
+    }
+    BB_HD bool match_unblock(int x, int y, const Accept& a) const {                   // :815-871
+        if (!match_empty(x, y, a)) return false;
+        const int dk[8] = {-1, 0, 1, 1, 1, 0, -1, -1}, dl[8] = {-1, -1, -1, 0, 1, 1, 1, 0};
+        int cls[8];
+        for (int q = 0; q < 8; ++q) {
+            const int nx = x + dk[q], ny = y + dl[q];
+            const int e = cell(nx, ny);
+            const bool v = seen(nx, ny);
+            if (v && e_type(e) == T_WALL) cls[q] = 1;
+            else if (v && (is_none(e) || open_door(e) || (nx == h.ax && ny == h.ay)) && !(a.has_except && nx == a.ex && ny == a.ey)) cls[q] = 0;
+            else cls[q] = 2;
+        }
+        int changes = 0;
+        for (int q = 0; q < 8; ++q) if ((cls[(q + 1) % 8] != 0) != (cls[q] != 0)) ++changes;
+        for (int q = 0; q < 8; ++q)
+            if (cls[q] == 2 && cls[(q + 7) % 8] != 0 && cls[(q + 1) % 8] != 0) return false;
+        return changes <= 2;
+    }
+    BB_HD bool accept(const Accept& a, int x, int y, int e) const {
+        switch (a.kind) {
+        case ACC_POS: return x == a.x && y == a.y;
+        case ACC_UNSEEN: return !seen(x, y);
+        case ACC_DOOR_UNLOCKED: return e_type(e) == T_DOOR && e_state(e) == S_CLOSED;
+        case ACC_DOOR: return e_type(e) == T_DOOR && e_state(e) != S_OPEN;
+        case ACC_UNBLOCK: return match_unblock(x, y, a);
+        default: return match_empty(x, y, a);
+        }
+    }
+
+    // One search.  queue entries: cell | dir << 10; prev: 0xFFFF unvisited, 0xFFFE = None (an initial state).
+    BB_HD bool bfs(uint16_t* prev, uint16_t* q, int& qn, const Accept& a, bool ignore_blockers, int& finish) const {
+        int head = 0;
+        while (head < qn) {
+            const int st = q[head++];
+            const int ci = st & 1023, d = st >> 10;
+            const int x = ci % c.W, y = ci / c.W;
+            const int e = cell(x, y);
+            if (accept(a, x, y, e)) { finish = ci; return true; }
+            if (!seen(x, y)) continue;
+            if (!is_none(e)) {
+                const int t = e_type(e);
+                if (t == T_WALL) continue;
+                if (t == T_DOOR) { if (e_state(e) != S_OPEN) continue; }
+                else if (!ignore_blockers) continue;
+            }
+            const int nd[4] = {d, d ^ 1, 3 - d, d ^ 2};          // (di,dj), (dj,di), (-dj,-di), (-di,-dj)
+            for (int k = 0; k < 4; ++k) {
+                const int nx = x + dir_dx(nd[k]), ny = y + dir_dy(nd[k]);
+                if (!in_grid(nx, ny)) continue;                   // (never happens: the border is wall)
+                const int ni = ny * c.W + nx;
+                if (prev[ni] != 0xFFFF) continue;
+                prev[ni] = (uint16_t)ci;
+                q[qn++] = (uint16_t)(ni | nd[k] << 10);
+            }
+        }
+        return false;
+    }
+
+    struct Path { bool found; bool nonempty; int len; int nx, ny; int fxp, fyp; bool with_blockers; };
+
+    BB_HD Path shortest_path(const Accept& a, bool try_with_blockers) const {          // :772-806
+        Path p = {};
+        const int cells = c.W * c.H;
+        for (int i = 0; i < cells; ++i) w.prev1[i] = 0xFFFF;
+        const int start = h.ay * c.W + h.ax;
+        int qn1 = 0, finish = -1;
+        w.prev1[start] = 0xFFFE;
+        w.q1[qn1++] = (uint16_t)(start | h.dir << 10);
+        int len = 0, next = -1;
+        bool found = bfs(w.prev1, w.q1, qn1, a, false, finish);
+        if (found) {
+            for (int v = finish; w.prev1[v] != 0xFFFE; v = w.prev1[v]) { ++len; next = v; }
+        } else if (try_with_blockers) {
+            p.with_blockers = true;
+            for (int i = 0; i < cells; ++i) w.prev2[i] = 0xFFFF;
+            int qn2 = 0;
+            for (int i = 0; i < qn1; ++i) {                        // every position the first search reached, dir (1,0)
+                const int ci = w.q1[i] & 1023;
+                w.prev2[ci] = 0xFFFE;
+                w.q2[qn2++] = (uint16_t)ci;
+            }
+            found = bfs(w.prev2, w.q2, qn2, a, true, finish);
+            if (found) {
+                int v = finish;
+                for (; w.prev2[v] != 0xFFFE; v = w.prev2[v]) { ++len; next = v; }
+                int len1 = 0, next1 = -1;
+                for (; w.prev1[v] != 0xFFFE; v = w.prev1[v]) { ++len1; next1 = v; }
+                len += len1;
+                if (len1) next = next1;
+            }
+        }
+        p.found = found;
+        if (found) {
+            p.len = len; p.nonempty = len > 0;
+            p.fxp = finish % c.W; p.fyp = finish / c.W;
+            if (len) { p.nx = next % c.W; p.ny = next / c.W; }
+        }
+        return p;
+    }
+    BB_HD static Accept acc_pos(int x, int y) { Accept a = {}; a.kind = ACC_POS; a.x = x; a.y = y; return a; }
+
+    BB_HD bool find_drop_pos(bool has_except, int ex, int ey, int& ox, int& oy) const { // :808-898
+        Accept a = {};
+        a.has_except = has_except; a.ex = ex; a.ey = ey;
+        const int kinds[4] = {ACC_UNBLOCK, ACC_EMPTY, ACC_UNBLOCK, ACC_EMPTY};
+        for (int k = 0; k < 4; ++k) {
+            a.kind = kinds[k];
+            Path p = shortest_path(a, k >= 2);
+            if (p.found) { ox = p.fxp; oy = p.fyp; return true; }
+        }
+        return false;
+    }
+
+    BB_HD int closest_wall_or_door(int dx, int dy) const {                             // :697-708
+        // positions h.a + d*(+-right_vec) stay inside the 7x7 view for d <= 3 (agent at view column 3)
+        for (int d = 1; d <= 3; ++d) {
+            const int t = e_type(cell(h.ax + d * dx, h.ay + d * dy));
+            if (t == T_DOOR || t == T_WALL) return d;
+        }
+        return 3;
+    }
+
+    // ---- descriptors ------------------------------------------------------------------------------------------
+    // ObjDesc('key', colour).find_matching_objs(env): x-major scan of the whole grid (verifier.py:96-161)
+    BB_HD Subgoal go_keys(int color) {
+        Subgoal g = mk(SG_GONEXT);
+        g.dtype = DT_KEYS;
+        for (int x = 0; x < c.W; ++x)
+            for (int y = 0; y < c.H; ++y) {
+                const int e = cell(x, y);
+                if (e_type(e) == T_KEY && e_color(e) == color) {
+                    if (g.nkeys >= BOT_KEYS) { die(DEAD_CAPACITY); return g; }
+                    g.keys[g.nkeys][0] = (uint8_t)(I[i_index(c, x, y)] - 2);
+                    g.keys[g.nkeys][1] = (uint8_t)x; g.keys[g.nkeys][2] = (uint8_t)y;
+                    ++g.nkeys;
+                }
+            }
+        return g;
+    }
+
+    // Bot._find_obj_pos: closest visible object of a descriptor.  obj_set keeps its episode-start order while
+    // obj_poss is rebuilt (shorter) on every drop action, and the reference indexes both with the same i
+    // (IndexError swallowed, :649-653) -- reproduced as is.
+    BB_HD bool find_obj_pos(const Subgoal& g, bool adjacent, int& obj, int& ox, int& oy) {
+        uint8_t set_list[MAX_OBJ], poss[MAX_OBJ][2];
+        int n_set = 0, n_poss = 0;
+        if (g.dtype == DT_KEYS) {
+            n_set = n_poss = g.nkeys;
+            for (int i = 0; i < n_set; ++i) { set_list[i] = g.keys[i][0]; poss[i][0] = g.keys[i][1]; poss[i][1] = g.keys[i][2]; }
+        } else {
+            const uint64_t set = prog->set[g.a >> 1][g.a & 1];
+            uint16_t key_s[MAX_OBJ], key_p[MAX_OBJ];
+            for (uint64_t m = set; m; m &= m - 1) {
+                const int o = __builtin_ctzll(m);
+                {   // obj_set: order of the scan at reset
+                    const uint16_t k = (uint16_t)(s.ipos[o][0] << 8 | s.ipos[o][1]);
+                    int j = n_set++;
+                    for (; j > 0 && key_s[j - 1] > k; --j) { key_s[j] = key_s[j - 1]; set_list[j] = set_list[j - 1]; }
+                    key_s[j] = k; set_list[j] = (uint8_t)o;
+                }
+                if (obj_in_grid(o) || (stale >> o & 1)) {   // obj_poss: still recorded since the last refresh
+                    const uint16_t k = (uint16_t)(pos[2 * o] << 8 | pos[2 * o + 1]);
+                    int j = n_poss++;
+                    for (; j > 0 && key_p[j - 1] > k; --j) { key_p[j] = key_p[j - 1]; poss[j][0] = poss[j - 1][0]; poss[j][1] = poss[j - 1][1]; }
+                    key_p[j] = k; poss[j][0] = pos[2 * o]; poss[j][1] = pos[2 * o + 1];
+                }
+            }
+        }
+        // ObjDesc(type=None, colour='grey') also matches every WALL cell (bonus_levels.py PickupDist; walls are grey):
+        // the walls sit in obj_set / obj_poss in scan order with the objects, and the first visible wall the search
+        // cannot reach (a corner) trips the reference's assertion.  Rare, so the merged lists are streamed.
+        const bool walls = g.dtype == DT_DESC && prog->desc[g.a >> 1][g.a & 1].type == 0 &&
+                           prog->desc[g.a >> 1][g.a & 1].color == C_GREY;
+        if (walls) return find_obj_pos_with_walls(prog->set[g.a >> 1][g.a & 1], adjacent, obj, ox, oy);
+        if (n_set == 0) { die(); return false; }                  // assert len(obj_desc.obj_set) > 0
+        int best = 999;
+        bool have = false;
+        for (int i = 0; i < n_set; ++i) {
+            if (set_list[i] == h.carry) continue;
+            if (i >= n_poss) continue;                             // IndexError -> pass
+            const int px = poss[i][0], py = poss[i][1];
+            if (!seen(px, py)) continue;
+            Path p = shortest_path(acc_pos(px, py), true);
+            if (!p.found) { die(); return false; }                 // assert shortest_path_to_obj is not None
+            int d = p.len;
+            if (p.with_blockers) d = p.len + (carrying() ? 7 : 4);
+            if (d == 0) d = adjacent ? 3 : 2;
+            if (adjacent && d == 1) d = 3;
+            if (d < best) { best = d; have = true; obj = set_list[i]; ox = px; oy = py; }
+        }
+        return have;
+    }
+
+    // next entry of obj_set (which = 0, episode-start positions) / obj_poss (which = 1, recorded positions) at or after
+    // x-major scan index `cur`, walls included.  Returns false at the end; `o` = object or NONE8 for a wall.
+    BB_HD bool next_with_walls(uint64_t set, int which, int& cur, int& o, int& x, int& y) const {
+        for (; cur < c.W * c.H; ++cur) {
+            x = cur / c.H; y = cur % c.H;
+            if (e_type(cell(x, y)) == T_WALL) { o = NONE8; ++cur; return true; }
+            for (uint64_t m = set; m; m &= m - 1) {
+                const int k = __builtin_ctzll(m);
+                const bool hit = which == 0 ? (s.ipos[k][0] == x && s.ipos[k][1] == y)
+                                            : ((obj_in_grid(k) || (stale >> k & 1)) && pos[2 * k] == x && pos[2 * k + 1] == y);
+                if (hit) { o = k; ++cur; return true; }
+            }
+        }
+        return false;
+    }
+    BB_HD bool find_obj_pos_with_walls(uint64_t set, bool adjacent, int& obj, int& ox, int& oy) {
+        int cs = 0, cp = 0, best = 999;
+        bool have = false;
+        for (;;) {
+            int so, sx, sy, po, px, py;
+            if (!next_with_walls(set, 0, cs, so, sx, sy)) break;
+            const bool has_pos = next_with_walls(set, 1, cp, po, px, py);      // both cursors advance with i
+            if (so != NONE8 && so == h.carry) continue;
+            if (!has_pos) continue;                                            // IndexError -> pass
+            if (!seen(px, py)) continue;
+            Path p = shortest_path(acc_pos(px, py), true);
+            if (!p.found) { die(); return false; }
+            int d = p.len;
+            if (p.with_blockers) d = p.len + (carrying() ? 7 : 4);
+            if (d == 0) d = adjacent ? 3 : 2;
+            if (adjacent && d == 1) d = 3;
+            if (d < best) { best = d; have = true; obj = so; ox = px; oy = py; }
+        }
+        return have;
+    }
+
+    // ---- subgoals -----------------------------------------------------------------------------------------------
+    BB_HD void plan_undo(int action) {                                                  // :109-137
+        if (action == A_FORWARD) {
+            if (s.prev_ax != h.ax || s.prev_ay != h.ay) push(go_pos(h.ax, h.ay));
+        } else if (action == A_LEFT) {
+            push(go_pos(h.ax + rx(), h.ay + ry()));
+        } else if (action == A_RIGHT) {
+            push(go_pos(h.ax - rx(), h.ay - ry()));
+        } else if (action == A_DROP && s.prev_carry != h.carry) {
+            const int t = e_type(cell(fx(), fy()));
+            if (!(t == T_KEY || t == T_BOX || t == T_BALL)) { die(); return; }
+            push(mk(SG_PICKUP));
+        } else if (action == A_PICKUP && s.prev_carry != h.carry) {
+            push(mk(SG_DROP));
+        } else if (action == A_TOGGLE) {
+            const int e = cell(fx(), fy());
+            if (e_type(e) == T_DOOR) {
+                if (s.door_was_open == 2) { die(); return; }        // AttributeError: fwd_door_was_open
+                const int open = e_state(e) == S_OPEN;
+                if (s.door_was_open != open) push(mk(open ? SG_CLOSE : SG_OPEN));
+            }
+        }
+    }
+    BB_HD static bool is_move(int a) { return a == A_FORWARD || a == A_LEFT || a == A_RIGHT; }
+
+    BB_HD void after_action(const Subgoal g, int action) {      // replan_after_action; action < 0 = None
+        const bool none = action < 0;
+        switch (g.kind) {
+        case SG_CLOSE:
+            if (none || action == A_TOGGLE) pop();
+            else if (is_move(action)) plan_undo(action);
+            break;
+        case SG_OPEN:
+            if (none || action == A_TOGGLE) {
+                pop();
+                if (g.reason == RS_UNLOCK) {
+                    int dx = 0, dy = 0;
+                    const bool ok = find_drop_pos(false, 0, 0, dx, dy);
+                    push(mk(SG_DROP));
+                    push(go_maybe(ok, dx, dy));
+                }
+            } else plan_undo(action);
+            break;
+        case SG_DROP:
+            if (none || action == A_DROP) pop();
+            else if (is_move(action)) plan_undo(action);
+            break;
+        case SG_PICKUP:
+            if (none || action == A_PICKUP) pop();
+            else if (action == A_LEFT || action == A_RIGHT) plan_undo(action);
+            break;
+        case SG_GONEXT:
+            if (action == A_PICKUP || action == A_DROP || action == A_TOGGLE) plan_undo(action);
+            break;
+        default: break;
+        }
+    }
+    BB_HD static bool exploratory(const Subgoal& g) {
+        return g.kind == SG_EXPLORE || (g.kind == SG_GONEXT && g.reason == RS_EXPLORE);
+    }
+
+    BB_HD bool got_key_for(int door_e) const {
+        if (!carrying()) return false;
+        const int ce = app[h.carry];
+        return e_type(ce) == T_KEY && e_color(ce) == e_color(door_e);
+    }
+
+    // replan_before_action: returns an action, or -1 when the stack changed and replanning continues
+    BB_HD int before_open(const Subgoal g) {                                           // :170-233
+        const int fe = cell(fx(), fy());
+        if (e_type(fe) != T_DOOR) { die(); return -1; }
+        if (e_state(fe) == S_LOCKED && !got_key_for(fe)) {
+            Subgoal keys = go_keys(e_color(fe));
+            if (raised) return -1;
+            if (carrying()) {
+                pop();
+                int dx = 0, dy = 0;
+                const bool ok = find_drop_pos(false, 0, 0, dx, dy);
+                push(mk(SG_PICKUP));
+                push(go_maybe(ok, dx, dy));
+                push(mk(SG_OPEN));
+                push(go_pos(fx(), fy()));
+                push(mk(SG_PICKUP));
+                push(keys);
+                push(mk(SG_DROP));
+                push(go_maybe(ok, dx, dy));
+            } else {
+                pop();
+                push(mk(SG_OPEN));
+                push(go_pos(fx(), fy()));
+                push(mk(SG_PICKUP));
+                push(keys);
+            }
+            return -1;
+        }
+        if (e_state(fe) == S_OPEN) { push(mk(SG_CLOSE)); return -1; }
+        if (e_state(fe) == S_LOCKED && g.reason == RS_NONE) { pop(); push(mk(SG_OPEN, RS_UNLOCK)); return -1; }
+        return A_TOGGLE;
+    }
+
+    BB_HD int before_gonext(const Subgoal g) {                                         // :295-442
+        int tobj = -1, tx = 0, ty = 0;
+        if (g.dtype == DT_DESC || g.dtype == DT_KEYS) {
+            if (!find_obj_pos(g, g.reason == RS_PUTNEXT, tobj, tx, ty)) {
+                if (raised) return -1;
+                push(mk(SG_EXPLORE));
+                return -1;
+            }
+            if (tobj == NONE8) tobj = -1;                           // a wall "object" (grey type-less descriptor)
+        } else if (g.dtype == DT_OBJ) {
+            tobj = g.a; tx = pos[2 * tobj]; ty = pos[2 * tobj + 1];
+        } else if (g.dtype == DT_POS) {
+            tx = (int8_t)g.a; ty = (int8_t)g.b;
+        } else { die(); return -1; }                                // tuple(None)
+
+        if (g.reason == RS_OPEN && tobj >= 0) {
+            const int te = app_now(tobj);
+            if (e_type(te) == T_DOOR && e_state(te) == S_LOCKED) {
+                if (!carrying()) {
+                    Subgoal keys = go_keys(e_color(te));
+                    if (raised) return -1;
+                    pop();
+                    push(go_obj(tobj, RS_OPEN));
+                    push(mk(SG_PICKUP));
+                    push(keys);
+                    return -1;
+                }
+            }
+        }
+        const int px = h.ax, py = h.ay, fxx = fx(), fyy = fy();
+        const int fe = cell(fxx, fyy);
+        const int dist = (tx > px ? tx - px : px - tx) + (ty > py ? ty - py : py - ty);
+        if (dist == (g.reason == RS_PUTNEXT ? 1 : 0)) {
+            if (is_none(fe) || open_door(fe)) return A_FORWARD;
+            int e = cell(px + rx(), py + ry());
+            if (is_none(e) || open_door(e)) return A_RIGHT;
+            e = cell(px - rx(), py - ry());
+            if (is_none(e) || open_door(e)) return A_LEFT;
+            return A_LEFT;
+        }
+        if (g.reason == RS_PUTNEXT) {
+            const int dfw = (tx > fxx ? tx - fxx : fxx - tx) + (ty > fyy ? ty - fyy : fyy - ty);
+            if (dfw == 1) {
+                if (is_none(fe)) { pop(); return -1; }
+                if (open_door(fe)) { push(go_pos(fxx + 2 * dir_dx(h.dir), fyy + 2 * dir_dy(h.dir))); return -1; }
+            }
+        } else if (tx == fxx && ty == fyy) { pop(); return -1; }
+
+        Path p = shortest_path(acc_pos(tx, ty), false);
+        if (!p.nonempty) p = shortest_path(acc_pos(tx, ty), true);
+        if (!p.nonempty) { push(mk(SG_EXPLORE)); return -1; }
+
+        if (p.nx == fxx && p.ny == fyy) {
+            if (!is_none(fe)) {
+                if (e_type(fe) == T_DOOR) {
+                    if (e_state(fe) == S_LOCKED) { die(); return -1; }       // assert not is_locked
+                    if (e_state(fe) != S_OPEN) { push(mk(SG_OPEN)); return -1; }
+                    return A_FORWARD;
+                }
+                if (carrying()) {
+                    int cx = 0, cy = 0, bx = 0, by = 0;
+                    const bool okc = find_drop_pos(false, 0, 0, cx, cy);
+                    // _find_drop_pos(drop_pos_cur): `except_pos and ...` -- None means no exclusion
+                    const bool okb = find_drop_pos(okc, cx, cy, bx, by);
+                    push(mk(SG_PICKUP));
+                    push(go_maybe(okc, cx, cy));
+                    push(mk(SG_DROP));
+                    push(go_maybe(okb, bx, by));
+                    push(mk(SG_PICKUP));
+                    push(go_pos(fxx, fyy));
+                    push(mk(SG_DROP));
+                    push(go_maybe(okc, cx, cy));
+                    return -1;
+                }
+                int dx = 0, dy = 0;
+                const bool ok = find_drop_pos(false, 0, 0, dx, dy);
+                push(mk(SG_DROP));
+                push(go_maybe(ok, dx, dy));
+                push(mk(SG_PICKUP));
+                return -1;
+            }
+            return A_FORWARD;
+        }
+        if (p.nx - px == rx() && p.ny - py == ry()) return A_RIGHT;
+        if (p.nx - px == -rx() && p.ny - py == -ry()) return A_LEFT;
+        const int dr = closest_wall_or_door(rx(), ry()), dl = closest_wall_or_door(-rx(), -ry());
+        return dl > dr ? A_LEFT : A_RIGHT;
+    }
+    // appearance of object o as it is NOW (a door's state lives in the E plane)
+    BB_HD int app_now(int o) const {
+        if (obj_in_grid(o)) return cell(pos[2 * o], pos[2 * o + 1]);
+        return app[o];
+    }
+
+    BB_HD int before_explore() {                                                       // :453-497
+        Accept a = {};
+        a.kind = ACC_UNSEEN;
+        Path p = shortest_path(a, true);
+        if (p.found) { push(go_pos(p.fxp, p.fyp, RS_EXPLORE)); return -1; }
+        a.kind = ACC_DOOR_UNLOCKED;
+        p = shortest_path(a, true);
+        if (!p.found) { a.kind = ACC_DOOR; p = shortest_path(a, true); }
+        if (p.found) {
+            const int de = cell(p.fxp, p.fyp);
+            const int o = I[i_index(c, p.fxp, p.fyp)] - 2;
+            const bool keep = e_state(de) == S_LOCKED && got_key_for(de);
+            pop();
+            push(mk(SG_OPEN, keep ? RS_KEEPKEY : RS_NONE));
+            push(go_obj(o, RS_OPEN));
+            return -1;
+        }
+        die();                                                       // assert False, "nothing left to explore"
+        return -1;
+    }
+
+    BB_HD int before_action(const Subgoal g) {
+        const int fe = cell(fx(), fy());
+        switch (g.kind) {
+        case SG_CLOSE:                                              // :141-145
+            if (e_type(fe) != T_DOOR || e_state(fe) != S_OPEN) { die(); return -1; }
+            return A_TOGGLE;
+        case SG_OPEN: return before_open(g);
+        case SG_DROP:                                               // :252-255
+            if (!carrying() || !is_none(fe)) { die(); return -1; }
+            return A_DROP;
+        case SG_PICKUP:                                             // :266-268
+            if (carrying()) { die(); return -1; }
+            return A_PICKUP;
+        case SG_GONEXT: return before_gonext(g);
+        default: return before_explore();
+        }
+    }
+
+    // ---- Bot ------------------------------------------------------------------------------------------------------
+    BB_HD void process_instr_leaf(int leaf) {                                          // :900-924
+        const int k = prog->kind[leaf];
+        if (k == L_GOTO) {
+            push(go_desc(2 * leaf));
+        } else if (k == L_OPEN) {
+            push(mk(SG_OPEN));
+            push(go_desc(2 * leaf, RS_OPEN));
+        } else if (k == L_PICKUP) {
+            push(mk(SG_DROP));
+            push(mk(SG_PICKUP));
+            push(go_desc(2 * leaf));
+        } else if (k == L_PUTNEXT) {
+            push(mk(SG_DROP));
+            push(go_desc(2 * leaf + 1, RS_PUTNEXT));
+            push(mk(SG_PICKUP));
+            push(go_desc(2 * leaf));
+        } else die();
+    }
+    // a side is one ActionInstr or And(first, second): And pushes b then a (:926-929)
+    BB_HD void process_side(int base, int n) {
+        if (n == 2) process_instr_leaf(base + 1);
+        process_instr_leaf(base);
+    }
+    BB_HD void init() {                                                                // Bot.__init__
+        for (int y = 0; y < MAX_W; ++y) s.vis[y] = 0;
+        for (int o = 0; o < c.maxo; ++o) { s.ipos[o][0] = pos[2 * o]; s.ipos[o][1] = pos[2 * o + 1]; }
+        s.sp = 0; s.dead = DEAD_NO;
+        s.prev_ax = s.prev_ay = 0; s.prev_carry = NONE8; s.door_was_open = 2; s.prev_fwd_type = 0;
+        const int root = prog->root;
+        if (root == R_ACTION || root == R_AND) process_side(0, prog->n_a);
+        else if (root == R_BEFORE) { process_side(2, prog->n_b); process_side(0, prog->n_a); }      // b then a
+        else { process_side(0, prog->n_a); process_side(2, prog->n_b); }                            // After: a then b
+    }
+
+    BB_HD void process_obs() {                                                         // :658-687
+        uint32_t opq[VIEW], vis[VIEW];
+        for (int vj = 0; vj < VIEW; ++vj) {
+            uint32_t o = 0;
+            for (int vi = 0; vi < VIEW; ++vi) {
+                int x, y; view_to_world(h.ax, h.ay, h.dir, vi, vj, x, y);
+                if (e_opaque(cell(x, y))) o |= 1u << vi;
+            }
+            opq[vj] = o;
+        }
+        process_vis_rows(opq, vis);
+        for (int vj = 0; vj < VIEW; ++vj)
+            for (int vi = 0; vi < VIEW; ++vi) {
+                if (!(vis[vj] >> vi & 1)) continue;
+                int x, y; view_to_world(h.ax, h.ay, h.dir, vi, vj, x, y);
+                if (in_grid(x, y)) s.vis[y] |= 1u << x;
+            }
+    }
+
+    // Bot.replan(action_taken).  action_taken < 0 = None.  Returns the suggested action or BOT_DEAD.
+    BB_HD int replan(int action_taken) {
+        if (s.dead) return BOT_DEAD;
+        process_obs();
+        if (action_taken == A_TOGGLE && s.prev_fwd_type == T_BOX) { die(); return BOT_DEAD; }   // DisappearedBoxError
+        if (s.sp) after_action(s.stack[s.sp - 1], action_taken);
+        if (raised) return BOT_DEAD;
+        while (s.sp && exploratory(s.stack[s.sp - 1])) pop();
+        int suggested = -1;
+        int iters = 0;
+        while (s.sp) {
+            suggested = before_action(s.stack[s.sp - 1]);
+            if (raised) return BOT_DEAD;
+            if (suggested >= 0) break;
+            if (++iters > BOT_MAX_ITERS) { die(); return BOT_DEAD; }
+        }
+        if (!s.sp) suggested = A_DONE;
+        // _remember_current_state (:689-695)
+        s.prev_ax = h.ax; s.prev_ay = h.ay; s.prev_carry = h.carry;
+        const int fe = cell(fx(), fy());
+        if (e_type(fe) == T_DOOR) s.door_was_open = e_state(fe) == S_OPEN;
+        s.prev_fwd_type = is_none(fe) ? 0 : (uint8_t)e_type(fe);
+        return suggested;
+    }
+};
+
+// One decision for one env.  `first` = first decision of the episode (fresh Bot, action_taken = None).
+BB_HD int bot_decide(const LevelCfg& c, const uint8_t* rec, const Hot& h, uint64_t stale, BotState& s, BotWork& w, bool first,
+                     int action_taken) {
+    Bot b(c, rec, h, stale, s, w);
+    if (first) { b.init(); action_taken = -1; if (b.raised) return BOT_DEAD; }
+    return b.replan(action_taken);
+}
+
+}  // namespace bbai

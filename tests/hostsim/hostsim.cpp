@@ -6,6 +6,7 @@
 #include "../../babyai_amd/csrc/bbai_types.hpp"
 #include "../../babyai_amd/csrc/bbai_gen.hpp"
 #include "../../babyai_amd/csrc/bbai_step.hpp"
+#include "../../babyai_amd/csrc/bbai_bot.hpp"
 #include "../../babyai_amd/csrc/bbai_seed.hpp"
 
 using namespace bbai;
@@ -75,6 +76,17 @@ int hs_step(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int ac
 
 void hs_observe(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, uint8_t* out) {
     observe_env(*cfg, rec, *hot, out);
+}
+
+// ---- the expert (bbai_bot.hpp) -------------------------------------------------------------------------------
+int hs_bot_state_bytes(void) { return (int)sizeof(BotState); }
+
+// One Bot.replan decision; `first` != 0 starts a fresh Bot (new episode).  action_taken < 0 = None.
+// Returns the suggested action, or 255 once the bot is dead (state->dead says why).
+int hs_bot_decide(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, const uint64_t* stale, uint8_t* state, int first,
+                  int action_taken) {
+    static thread_local BotWork work;
+    return bot_decide(*cfg, rec, *hot, *stale, *(BotState*)state, work, first != 0, action_taken);
 }
 
 }  // extern "C"
