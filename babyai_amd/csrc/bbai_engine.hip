@@ -32,6 +32,7 @@
 #include "bbai_types.hpp"
 #include "bbai_gen.hpp"
 #include "bbai_step.hpp"
+#include "bbai_bot.hpp"
 #include "bbai_seed.hpp"
 
 using namespace bbai;
@@ -91,7 +92,8 @@ struct bbai_env {
     Hot* next_hot;        // [D][n]
     uint8_t* pending;     // [3][n]  per window buffer: slots consumed by env in the window (0 = not in the window)
     uint8_t* first_slot;  // [3][n]  first slot the env consumed in the window
-    int32_t* win_list;    // [3][n]  unique envs of the window (when it was not a reset-everything window)
+    int32_t* win_list;    // [3][B*n] envs consumed in the window, one entry per (tick, finished env); an env that
+                          //          finishes again within the window is marked -1 (every env may finish on every tick)
     uint32_t* win_count;  // [3][16]
     int win_all[3];       // window contained a reset() of every env: refill iterates all envs
     int32_t* reset_list;  // [n]     envs finished by the current step (k_step -> k_consume / k_tokens)
@@ -108,6 +110,10 @@ struct bbai_env {
     uint8_t* lut;         // [2][256]
     int n_tiles;
     bool seeded, live;
+    BotState* bot_state;  // [n]        the expert's per-env plan (bbai_bot_act; allocated on first use)
+    BotWork* bot_work;    // [bot_threads] BFS scratch per resident thread
+    int64_t bot_threads;
+    uint64_t* bot_stats;  // [2] decisions that ended in a dead bot: by the reference's rules / by our capacity limits
 };
 
 // ------------------------------------------------------------------------------------------
@@ -449,6 +455,28 @@ __global__ void k_sync_prog(LevelCfg c, int64_t n, int64_t first, int64_t count,
     vheads[env] = vhead_pack(*p);
 }
 
+// The reference's expert for every env (babyai/bot.py Bot.replan): lane = env, grid-stride over the batch with one BFS
+// scratch block per resident thread.  A new episode (step_count == 0) starts a fresh Bot.
+__global__ __launch_bounds__(64) void k_bot(LevelCfg c, int64_t n, const uint8_t* __restrict__ recs, const Hot* __restrict__ hots,
+                                            const uint64_t* __restrict__ stales, BotState* __restrict__ states,
+                                            BotWork* __restrict__ works, const uint8_t* __restrict__ prev_actions,
+                                            uint8_t* __restrict__ out, unsigned long long* __restrict__ stats) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    BotWork& w = works[tid];
+    for (int64_t i = tid; i < n; i += nthreads) {
+        const Hot h = hots[i];
+        if (h.frozen) { out[i] = A_DONE; continue; }
+        const bool first = h.step == 0;
+        const int taken = (prev_actions && !first) ? prev_actions[i] : -1;
+        BotState& st = states[i];
+        const bool was_dead = !first && st.dead;
+        const int a = bot_decide(c, recs + i * (int64_t)c.rec_bytes, h, stales[i], st, w, first, taken);
+        out[i] = (uint8_t)a;
+        if (a == BOT_DEAD && !was_dead) atomicAdd(&stats[st.dead == DEAD_CAPACITY ? 1 : 0], 1ull);
+    }
+}
+
 __global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, Hot* __restrict__ next_hots, uint64_t* __restrict__ stales, int depth) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -635,7 +663,7 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->next_hot, D * (size_t)n_envs * sizeof(Hot));
     alloc((void**)&e->pending, 3 * (size_t)n_envs);
     alloc((void**)&e->first_slot, 3 * (size_t)n_envs);
-    alloc((void**)&e->win_list, 3 * (size_t)n_envs * 4);
+    alloc((void**)&e->win_list, 3 * (size_t)e->period * (size_t)n_envs * 4);
     alloc((void**)&e->win_count, 3 * 64);
     alloc((void**)&e->reset_list, (size_t)n_envs * 4);
     alloc((void**)&e->counters, 128);
@@ -687,6 +715,8 @@ void bbai_destroy(bbai_env* e) {
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->ev_consumed) (void)hipEventDestroy(e->ev_consumed);
     for (int k = 0; k < 3; ++k) if (e->ev_refill[k]) (void)hipEventDestroy(e->ev_refill[k]);
+    void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats};
+    for (void* p : bot_ptrs) if (p) (void)hipFree(p);
     void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_list, e->win_count, e->reset_list, e->counters,
                     e->total_resets, e->atlas, e->lut};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -718,7 +748,7 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
     hipLaunchKernelGGL(k_consume, dim3((unsigned)std::min<int64_t>((hint + 3) / 4, 8192)), dim3(256), 0, s, e->cfg, e->n, e->rec,
                        e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, e->reset_list, e->counters + 16 * e->step_parity, all,
                        e->total_resets, D, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n,
-                       e->win_list + (size_t)wb * e->n, e->win_count + 16 * wb, pos, image, dirs,
+                       e->win_list + (size_t)wb * e->period * e->n, e->win_count + 16 * wb, pos, image, dirs,
                        e->counters + 16 * (e->step_parity ^ 1));
     if (e->tokens)
         hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n, e->rec,
@@ -733,7 +763,7 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
         HIP_TRY(hipEventRecord(e->ev_consumed, s));
         HIP_TRY(hipStreamWaitEvent(e->side, e->ev_consumed, 0));
         hipLaunchKernelGGL(k_pregen, dim3(pregen_grid(rh)), dim3(64), 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt,
-                           e->mti, e->win_list + (size_t)wb * e->n, e->win_count + 16 * wb, wall, D,
+                           e->mti, e->win_list + (size_t)wb * e->period * e->n, e->win_count + 16 * wb, wall, D,
                            e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n, e->total_resets + 1);
         HIP_TRY(hipEventRecord(e->ev_refill[wb], e->side));
         HIP_TRY(hipGetLastError());
@@ -888,6 +918,36 @@ int bbai_get_programs(bbai_env* e, int64_t first, int64_t count, uint8_t* prog) 
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy2D(prog, sizeof(Prog), e->rec + first * e->cfg.rec_bytes + e->cfg.off_prog, (size_t)e->cfg.rec_bytes,
                         sizeof(Prog), (size_t)count, hipMemcpyDeviceToHost));
+    return BBAI_OK;
+}
+
+int bbai_bot_act(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions, void* stream) {
+    if (!e || !actions) ARG_FAIL("null handle or output buffer");
+    if (!e->live) { snprintf(g_err, sizeof(g_err), "bot_act before reset"); return BBAI_ERR_STATE; }
+    ON_DEVICE(e->device);
+    if (!e->bot_state) {
+        e->bot_threads = std::min<int64_t>((e->n + 63) / 64 * 64, 256 * 8 * 64);     // 8 waves per CU resident
+        HIP_TRY(hipMalloc((void**)&e->bot_state, (size_t)e->n * sizeof(BotState)));
+        HIP_TRY(hipMalloc((void**)&e->bot_work, (size_t)e->bot_threads * sizeof(BotWork)));
+        HIP_TRY(hipMalloc((void**)&e->bot_stats, 16));
+        HIP_TRY(hipMemset(e->bot_state, 0, (size_t)e->n * sizeof(BotState)));
+        HIP_TRY(hipMemset(e->bot_stats, 0, 16));
+    }
+    hipLaunchKernelGGL(k_bot, dim3((unsigned)(e->bot_threads / 64)), dim3(64), 0, (hipStream_t)stream, e->cfg, e->n, e->rec, e->hot,
+                       e->stale, e->bot_state, e->bot_work, prev_actions, actions, (unsigned long long*)e->bot_stats);
+    HIP_TRY(hipGetLastError());
+    return BBAI_OK;
+}
+
+int bbai_bot_stats(bbai_env* e, uint64_t* gave_up, uint64_t* capacity) {
+    if (!e || !gave_up || !capacity) ARG_FAIL("null pointer");
+    ON_DEVICE(e->device);
+    *gave_up = *capacity = 0;
+    if (!e->bot_stats) return BBAI_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long v[2] = {0, 0};
+    HIP_TRY(hipMemcpy(v, e->bot_stats, 16, hipMemcpyDeviceToHost));
+    *gave_up = v[0]; *capacity = v[1];
     return BBAI_OK;
 }
 

@@ -64,6 +64,8 @@ def load_library():
     lib.bbai_get_programs.argtypes = [P, I64, I64, P]
     lib.bbai_reset_count.argtypes = [P, P]
     lib.bbai_generator_failures.argtypes = [P, P]
+    lib.bbai_bot_act.argtypes = [P, P, P, P]
+    lib.bbai_bot_stats.argtypes = [P, P, P]
     _lib = lib
     return lib
 
@@ -71,7 +73,7 @@ def load_library():
 EXPORTED_SYMBOLS = (
     "bbai_version", "bbai_last_error", "bbai_fill_layout", "bbai_create", "bbai_destroy", "bbai_seed",
     "bbai_reset", "bbai_step", "bbai_set_atlas", "bbai_render", "bbai_set_token_buffer", "bbai_export_state", "bbai_import_state",
-    "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures",
+    "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures", "bbai_bot_act", "bbai_bot_stats",
 )
 
 
@@ -278,6 +280,34 @@ class BatchedBabyAIEnv(object):
                 self.instr = self.torch.zeros((self.num_envs, TOK_MAX), dtype=self.torch.uint8, device=self.device)
             _check(self.lib, self.lib.bbai_set_token_buffer(self.handle, self.instr.data_ptr()), "bbai_set_token_buffer")
         return self.instr
+
+    BOT_GAVE_UP = 255
+
+    def bot_actions(self, prev_actions=None, out=None):
+        """One decision of the reference's expert (babyai/bot.py Bot.replan) for every env, on the device:
+        uint8[N] suggested actions, BOT_GAVE_UP (255) where the reference bot would have raised.  `prev_actions` = the
+        actions the envs were really stepped with since the last call (advising mode), None = the suggestions."""
+        torch = self.torch
+        if out is None:
+            if getattr(self, "_bot_out", None) is None:
+                self._bot_out = torch.zeros((self.num_envs,), dtype=torch.uint8, device=self.device)
+            out = self._bot_out
+        prev_ptr = None
+        if prev_actions is not None:
+            if not isinstance(prev_actions, torch.Tensor):
+                prev_actions = torch.as_tensor(np.asarray(prev_actions), device=self.device)
+            prev_actions = prev_actions.to(device=self.device, dtype=torch.uint8).contiguous()
+            if prev_actions.numel() != self.num_envs:
+                raise ValueError("need %d previous actions" % self.num_envs)
+            self._bot_prev = prev_actions        # keep alive until the launch is consumed
+            prev_ptr = prev_actions.data_ptr()
+        _check(self.lib, self.lib.bbai_bot_act(self.handle, prev_ptr, out.data_ptr(), self._stream()), "bbai_bot_act")
+        return out
+
+    def bot_stats(self):
+        a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _check(self.lib, self.lib.bbai_bot_stats(self.handle, ctypes.byref(a), ctypes.byref(b)), "bbai_bot_stats")
+        return {"gave_up": int(a.value), "capacity": int(b.value)}
 
     def reset_count(self):
         v = ctypes.c_uint64(0)

@@ -96,6 +96,18 @@ int bbai_import_state(bbai_env* env, int64_t first, int64_t count, const uint8_t
                       const uint8_t* hot_host, const uint64_t* stale_host);
 int bbai_get_programs(bbai_env* env, int64_t first, int64_t count, uint8_t* prog_host /* 112 B each */);
 
+/* The reference's GOFAI expert for every env: one `Bot.replan(action_taken)` decision each
+ * (babyai/bot.py:547-597; callers babyai/utils/agent.py:139-146 BotAgent.act, scripts/make_agent_demos.py:93-107).
+ * `prev_actions_dev` = the action each env was actually stepped with since the previous call (advising mode,
+ * bot.py:88-98), or NULL = "the suggestion was taken" (replan(None)).  An env whose episode has just started
+ * (step_count == 0) gets a fresh Bot.  `actions_dev[i]` = suggested action 0..6, or 255 where the reference bot would
+ * have raised (assertion / DisappearedBoxError / endless replanning); it stays 255 until the episode ends.
+ * Decision-for-decision parity with the reference bot: tests/test_hostsim_bot.py, tests/golden/bot/. */
+int bbai_bot_act(bbai_env* env, const uint8_t* prev_actions_dev, uint8_t* actions_dev, void* stream);
+/* Bots that gave up so far: by the reference's own rules / because a fixed-size structure of this port overflowed
+ * (subgoal stack 48, same-colour keys 5) -- the second is expected to be 0 except where the reference replans for ever. */
+int bbai_bot_stats(bbai_env* env, uint64_t* gave_up, uint64_t* capacity);
+
 /* Number of level generations (resets) performed so far, all envs. */
 int bbai_reset_count(bbai_env* env, uint64_t* out);
 

@@ -596,3 +596,126 @@ def test_c1_plumbing_config_on_the_engine(gpu):
             env.reset()
     env.close()
     assert h.hexdigest() == C1_DIGEST
+
+
+BOT_LEVELS = ["GoToLocal", "PickupLoc", "PutNextLocal", "GoTo", "Open", "Unlock", "UnblockPickup", "GoToImpUnlock", "PickupDist",
+              "KeyCorridorS4R3", "BlockedUnlockPickup", "UnlockToUnlock", "SynthSeq", "MiniBossLevel", "BossLevel",
+              "TestLotsOfBlockers", "MoveTwoAcrossS8N9", "KeyInBox"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", BOT_LEVELS)
+@pytest.mark.parametrize("mode", ["pure", "advised"])
+def test_bot_decisions_on_the_engine_match_reference(gpu, level, mode):
+    """bbai_bot_act (k_bot) against the decisions recorded from the reference's babyai/bot.py (tests/golden/bot/,
+    tools/gen_golden_bot.py): every suggestion of every env, through auto-resets, 255 where the reference bot raised."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "bot", level + ".npz")) as f:
+        g = {k: f[k] for k in f.files}
+    suggest, action, done = g[mode + "_suggest"], g[mode + "_action"], g[mode + "_done"]
+    n_steps, n = suggest.shape
+    env = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=int(g["seed_base"]))
+    env.reset()
+    prev = None
+    for t in range(n_steps):
+        got = env.bot_actions(prev).cpu().numpy().astype(np.int16)
+        got[got == 255] = -1
+        assert np.array_equal(got, suggest[t].astype(np.int16)), (level, mode, t, got, suggest[t])
+        prev = torch.as_tensor(action[t], device=gpu)
+        _, _, d, _ = env.step(prev)
+        assert np.array_equal(d.cpu().numpy(), done[t]), (level, mode, t)
+    stats = env.bot_stats()
+    assert stats["capacity"] == 0 or level == "UnlockToUnlock"
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level,n,steps", [("BossLevel", 384, 260), ("MiniBossLevel", 512, 200), ("PutNextS7N4", 256, 120)])
+def test_bot_device_equals_host_build(gpu, level, n, steps):
+    """Many more seeds than the golden fixtures hold: the device expert against the host build of the same header
+    (which tests/test_hostsim_bot.py pins to the reference), decision for decision, with the bot driving."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from babyai_amd.levels import make_cfg
+    from hostsim_util import HostBot, HostEnv
+    base = 31000
+    env = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=base)
+    env.reset()
+    hosts = [HostEnv(make_cfg(level), base + i) for i in range(n)]
+    bots = []
+    for h in hosts:
+        h.reset()
+        bots.append(HostBot(h))
+    first = [True] * n
+    rng = np.random.RandomState(5)
+    prev = None
+    last = [None] * n
+    episodes = successes = 0
+    for t in range(steps):
+        got = env.bot_actions(prev).cpu().numpy()
+        act = np.zeros(n, np.uint8)
+        for i in range(n):
+            a = bots[i].decide(first[i], last[i])
+            first[i] = False
+            assert got[i] == (255 if a is None else a), (level, i, t, got[i], a)
+            if a is None or rng.rand() < 0.05:
+                a = int(rng.randint(0, 7))
+            act[i] = a
+        prev = torch.as_tensor(act, device=gpu)
+        _, r, d, _ = env.step(prev)
+        d = d.cpu().numpy()
+        r = r.cpu().numpy()
+        for i in range(n):
+            _, hr, hd = hosts[i].step(int(act[i]))
+            assert bool(hd) == bool(d[i]) and np.float32(hr) == r[i]
+            last[i] = int(act[i])
+            if hd:
+                episodes += 1
+                successes += hr > 0
+                hosts[i].reset()
+                first[i], last[i] = True, None
+    assert episodes > n // 4 and successes > 0.8 * episodes, (episodes, successes)
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lookahead", [None, "2"])
+def test_very_short_episodes_every_window_tick(gpu, lookahead, monkeypatch):
+    """Expert-driven GoToObjS4: episodes of 1-4 steps, so roughly a third of the batch finishes on EVERY step and an env
+    finishes several times within one look-ahead window (regression: the window's refill list must hold one entry
+    per (tick, finished env), not one per env).  Every env against the host build, bot and env in lockstep."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from babyai_amd.levels import make_cfg
+    from hostsim_util import HostBot, HostEnv
+    if lookahead:
+        monkeypatch.setenv("BBAI_LOOKAHEAD", lookahead)
+    level, n, base = "GoToObjS4", 768, 52000
+    env = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=base)
+    env.reset()
+    hosts = [HostEnv(make_cfg(level), base + i) for i in range(n)]
+    bots = []
+    for h in hosts:
+        h.reset()
+        bots.append(HostBot(h))
+    first = [True] * n
+    resets = 0
+    for t in range(72):
+        got = env.bot_actions(None).cpu().numpy()
+        for i in range(n):
+            assert got[i] == bots[i].decide(first[i], None), (i, t)
+            first[i] = False
+        obs, r, d, _ = env.step(torch.as_tensor(got, device=gpu))
+        img, r, d = obs["image"].cpu().numpy(), r.cpu().numpy(), d.cpu().numpy()
+        for i in range(n):
+            himg, hr, hd = hosts[i].step(int(got[i]))
+            assert bool(hd) == bool(d[i]) and np.float32(hr) == r[i], (i, t)
+            if hd:
+                himg = hosts[i].reset()
+                first[i] = True
+                resets += 1
+            assert np.array_equal(img[i], himg), (i, t)
+    assert resets > 72 * n // 5
+    assert env.generator_failures() == 0
+    env.close()
