@@ -29,7 +29,7 @@
 namespace bbai {
 
 constexpr int BOT_STACK = 48;       // subgoal stack depth (overflow => dead, counted)
-constexpr int BOT_KEYS = 5;         // same-colour keys a key descriptor can list (overflow => dead, counted)
+constexpr int BOT_KEYS = 12;        // same-colour keys a key descriptor can list (overflow => dead, counted)
 constexpr int BOT_MAX_CELLS = MAX_W * MAX_W;
 constexpr int BOT_MAX_ITERS = 1000; // replanning rounds per decision (the reference would spin for ever)
 constexpr int BOT_DEAD = 0xFF;      // action value reported for a dead bot
@@ -39,14 +39,14 @@ enum : uint8_t { RS_NONE = 0, RS_UNLOCK, RS_KEEPKEY, RS_PUTNEXT, RS_EXPLORE, RS_
 enum : uint8_t { DT_NONE = 0, DT_DESC, DT_KEYS, DT_OBJ, DT_POS };
 enum : uint8_t { DEAD_NO = 0, DEAD_REFERENCE = 1, DEAD_CAPACITY = 2 };   // 2: our fixed-size structures overflowed
 
-struct Subgoal {            // 24 bytes
+struct Subgoal {            // 32 bytes
     uint8_t kind, reason, dtype;
     uint8_t a, b;           // DT_DESC: a = 2*leaf+slot; DT_OBJ: a = object; DT_POS: (a, b) = (x, y) as int8
     uint8_t nkeys;          // DT_KEYS: frozen obj_set / obj_poss of ObjDesc('key', colour)
-    uint8_t keys[BOT_KEYS][3];
-    uint8_t pad[3];
+    uint16_t keys[BOT_KEYS];// object << 10 | x << 5 | y
+    uint8_t pad[2];
 };
-static_assert(sizeof(Subgoal) == 24, "Subgoal layout");
+static_assert(sizeof(Subgoal) == 32, "Subgoal layout");
 
 struct BotState {
     uint32_t vis[MAX_W];            // vis[y] bit x : Bot.vis_mask
@@ -267,9 +267,7 @@ struct Bot {
                 const int e = cell(x, y);
                 if (e_type(e) == T_KEY && e_color(e) == color) {
                     if (g.nkeys >= BOT_KEYS) { die(DEAD_CAPACITY); return g; }
-                    g.keys[g.nkeys][0] = (uint8_t)(I[i_index(c, x, y)] - 2);
-                    g.keys[g.nkeys][1] = (uint8_t)x; g.keys[g.nkeys][2] = (uint8_t)y;
-                    ++g.nkeys;
+                    g.keys[g.nkeys++] = (uint16_t)((I[i_index(c, x, y)] - 2) << 10 | x << 5 | y);
                 }
             }
         return g;
@@ -283,7 +281,9 @@ struct Bot {
         int n_set = 0, n_poss = 0;
         if (g.dtype == DT_KEYS) {
             n_set = n_poss = g.nkeys;
-            for (int i = 0; i < n_set; ++i) { set_list[i] = g.keys[i][0]; poss[i][0] = g.keys[i][1]; poss[i][1] = g.keys[i][2]; }
+            for (int i = 0; i < n_set; ++i) {
+                set_list[i] = (uint8_t)(g.keys[i] >> 10); poss[i][0] = (g.keys[i] >> 5) & 31; poss[i][1] = g.keys[i] & 31;
+            }
         } else {
             const uint64_t set = prog->set[g.a >> 1][g.a & 1];
             uint16_t key_s[MAX_OBJ], key_p[MAX_OBJ];

@@ -105,7 +105,7 @@ int bbai_get_programs(bbai_env* env, int64_t first, int64_t count, uint8_t* prog
  * Decision-for-decision parity with the reference bot: tests/test_hostsim_bot.py, tests/golden/bot/. */
 int bbai_bot_act(bbai_env* env, const uint8_t* prev_actions_dev, uint8_t* actions_dev, void* stream);
 /* Bots that gave up so far: by the reference's own rules / because a fixed-size structure of this port overflowed
- * (subgoal stack 48, same-colour keys 5) -- the second is expected to be 0 except where the reference replans for ever. */
+ * (subgoal stack 48, same-colour keys 12) -- the second is expected to be 0 except where the reference replans for ever. */
 int bbai_bot_stats(bbai_env* env, uint64_t* gave_up, uint64_t* capacity);
 
 /* Number of level generations (resets) performed so far, all envs. */

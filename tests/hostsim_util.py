@@ -99,5 +99,5 @@ class HostBot(object):
 
     @property
     def dead_reason(self):
-        off = 4 * 25 + 2 * 48 + 24 * 48 + 1
+        off = 4 * 25 + 2 * 48 + 32 * 48 + 1
         return int(self.state[off])

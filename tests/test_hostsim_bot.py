@@ -57,3 +57,65 @@ def test_bot_decisions_match_reference(path, mode):
     # A death by capacity (subgoal stack full) that the reference shares is the reference bot replanning for ever
     # (2 s decision budget in tools/gen_golden_bot.py): only UnlockToUnlock does that.
     assert capacity == 0 or "UnlockToUnlock" in path
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("level,n_envs,steps", [("BossLevel", 24, 300), ("SynthSeq", 16, 200), ("KeyCorridorS6R3", 8, 250)])
+def test_bot_differential_against_live_reference(level, n_envs, steps):
+    """Fresh seeds (not in the fixtures), the reference's Bot running live next to the host build (build container only)."""
+    from oracle import refenv
+    if not refenv.have_reference():
+        pytest.skip("reference tree not present")
+    import signal
+    refenv.import_reference()
+    from babyai.bot import Bot
+    from babyai.levels import level_dict
+
+    class Timeout(BaseException):
+        pass
+
+    def on_alarm(signum, frame):
+        raise Timeout()
+
+    rng = np.random.RandomState(len(level))
+    checked = 0
+    for i in range(n_envs):
+        seed = 880000 + 37 * i
+        ref = level_dict[level]()
+        if hasattr(ref, "locked_room"):
+            ref.locked_room = None
+        ref.seed(seed)
+        ref.reset()
+        env = HostEnv(make_cfg(level), seed)
+        env.reset()
+        rbot, hbot = Bot(ref), HostBot(env)
+        first, last = True, None
+        for t in range(steps):
+            try:
+                signal.signal(signal.SIGALRM, on_alarm)
+                signal.setitimer(signal.ITIMER_REAL, 3.0)
+                try:
+                    want = int(rbot.replan(last))
+                finally:
+                    signal.setitimer(signal.ITIMER_REAL, 0)
+            except BaseException as exc:
+                if isinstance(exc, KeyboardInterrupt):
+                    raise
+                want = None
+            got = hbot.decide(first, last)
+            first = False
+            assert got == want, (level, seed, t, got, want)
+            checked += 1
+            if want is None:
+                break
+            a = want if rng.rand() > 0.08 else int(rng.randint(0, 7))
+            last = a
+            _, r, d, _ = ref.step(a)
+            _, hr, hd = env.step(a)
+            assert bool(d) == bool(hd) and np.float32(r) == hr
+            if d:
+                ref.reset()
+                env.reset()
+                rbot, hbot = Bot(ref), HostBot(env)
+                first, last = True, None
+    assert checked > n_envs * steps // 2
