@@ -236,7 +236,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(LevelCfg c, int64_t n, uint
             uint64_t stale = stales[env];
             float reward;
             VProg vp; vp.head = vheads[env]; vp.sets = vsets + env; vp.stride = n;
-            bool done = step_env(c, rec, vp, h, stale, actions[env], reward);
+            bool done = step_env_cmd(c, rec, vp, h, stale, actions[env], reward);
             if (done && !auto_reset) h.frozen = 1;
             want_reset = done && auto_reset;
             hots[env] = h;

@@ -193,6 +193,15 @@ BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, ui
     return done;
 }
 
+// Not a MiniGrid action: "env.reset() for THIS env, now" -- what a ParallelEnv worker does on a `reset` command
+// (babyai/rl/utils/penv.py:12-14) and what make_agent_demos.py:84-88 does after a bot crash.  The episode ends with
+// done = 1, reward = 0 and (auto-reset) the next observation is the first one of the env's next level.
+constexpr int A_RESET_ENV = 7;
+BB_HD bool step_env_cmd(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, float& reward) {
+    if (action == A_RESET_ENV) { reward = 0.0f; return true; }
+    return step_env(c, rec, vp, h, stale, action, reward);
+}
+
 // bonus_levels.py:821-829: right after reset (and after the first observation was produced) the object is taken
 // off the grid and put in the agent's hands; its recorded position stays behind (stale), exactly as if picked up.
 BB_HD void apply_start_carry(const LevelCfg& c, uint8_t* rec, Hot& h, uint64_t& stale, int obj) {

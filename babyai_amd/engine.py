@@ -282,6 +282,7 @@ class BatchedBabyAIEnv(object):
         return self.instr
 
     BOT_GAVE_UP = 255
+    RESET_ENV = 7          # step() "action": abandon the episode of that env (include/bbai.h BBAI_ACTION_RESET_ENV)
 
     def bot_actions(self, prev_actions=None, out=None):
         """One decision of the reference's expert (babyai/bot.py Bot.replan) for every env, on the device:

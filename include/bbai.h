@@ -73,7 +73,11 @@ int bbai_reset(bbai_env* env, uint8_t* image_dev, uint8_t* dir_dev, void* stream
  *                     is reset in the same call and image/dir hold the NEXT episode's first obs,
  *                     while reward/done are the terminal step's.
  *   auto_reset == 0 : ManyEnvs semantics (babyai/evaluate.py:73-81): a finished env is frozen and
- *                     keeps re-emitting its last (obs, reward, done) until bbai_reset. */
+ *                     keeps re-emitting its last (obs, reward, done) until bbai_reset.
+ * actions_dev[i] is 0..6 (MiniGridEnv.Actions), or BBAI_ACTION_RESET_ENV = "env.reset() for this env now": the
+ * episode is abandoned with done = 1, reward = 0 and handled like any finished env above (a ParallelEnv worker's
+ * `reset` command, penv.py:12-14; scripts/make_agent_demos.py:84-88 after a bot crash). */
+#define BBAI_ACTION_RESET_ENV 7
 int bbai_step(bbai_env* env, const uint8_t* actions_dev, uint8_t* image_dev, uint8_t* dir_dev,
               float* reward_dev, uint8_t* done_dev, int auto_reset, void* stream);
 

@@ -71,7 +71,7 @@ int hs_step(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int ac
     uint64_t sets[8];
     for (int k = 0; k < 8; ++k) sets[k] = p->set[k >> 1][k & 1];
     VProg vp; vp.head = vhead_pack(*p); vp.sets = sets; vp.stride = 1;
-    return step_env(*cfg, rec, vp, *hot, *stale, action, *reward) ? 1 : 0;
+    return step_env_cmd(*cfg, rec, vp, *hot, *stale, action, *reward) ? 1 : 0;
 }
 
 void hs_observe(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, uint8_t* out) {

@@ -719,3 +719,54 @@ def test_very_short_episodes_every_window_tick(gpu, lookahead, monkeypatch):
     assert resets > 72 * n // 5
     assert env.generator_failures() == 0
     env.close()
+
+
+@pytest.mark.gpu
+def test_per_env_reset_command(gpu):
+    """Action 7 = env.reset() for that env only (a ParallelEnv worker's `reset` command): done, reward 0, and the
+    next observation is the first one of the env's next level -- against oracle envs reset individually."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    n = 96
+    env = BatchedBabyAIEnv("BabyAI-PickupLoc-v0", n, device=gpu, seeds=77)
+    refs = _oracle_envs("PickupLoc", [77 + i for i in range(n)])
+    env.reset()
+    ro = [e.reset() for e in refs]
+    rng = np.random.RandomState(3)
+    for t in range(120):
+        a = rng.randint(0, 7, size=n).astype(np.uint8)
+        a[rng.rand(n) < 0.07] = env.RESET_ENV
+        obs, r, d, _ = env.step(torch.as_tensor(a, device=gpu))
+        img, r, d = obs["image"].cpu().numpy(), r.cpu().numpy(), d.cpu().numpy()
+        for i in range(n):
+            if a[i] == env.RESET_ENV:
+                o, rr, dd = refs[i].reset(), 0.0, True
+            else:
+                o, rr, dd, _ = refs[i].step(int(a[i]))
+                if dd:
+                    o = refs[i].reset()
+            assert np.array_equal(img[i], o["image"]) and np.float32(rr) == r[i] and bool(dd) == bool(d[i]), (i, t)
+            assert obs["mission"][i] == o["mission"]
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", ["GoToLocal", "PutNextLocal", "PickupDist", "BossLevel", "UnlockToUnlock"])
+def test_generate_demos_matches_reference_script(gpu, level):
+    """babyai_amd.demos.generate_demos vs demonstrations made by the reference's own loop (scripts/make_agent_demos.py:
+    71-137 with BotAgent; tools/gen_golden_bot.py demos): same missions, actions, directions and images, including the
+    streams where the reference bot crashed or failed first and the script moved on to the stream's next level."""
+    import hashlib
+    from babyai_amd.demos import generate_demos
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "demos", "bot_demos.npz")) as f:
+        g = {k[len(level) + 1:]: f[k] for k in f.files if k.startswith(level + "_")}
+    n = len(g["length"])
+    demos = generate_demos("BabyAI-%s-v0" % level, n, int(g["seed"]), device=gpu, batch=32)
+    ends = np.cumsum(g["length"])
+    for k, (mission, images, directions, actions) in enumerate(demos):
+        lo, hi = ends[k] - g["length"][k], ends[k]
+        assert mission == str(g["mission"][k]), (level, k)
+        assert list(actions) == list(g["actions"][lo:hi]), (level, k)
+        assert list(directions) == list(g["directions"][lo:hi]), (level, k)
+        assert images.dtype == np.uint8 and images.shape == (hi - lo, 7, 7, 3)
+        assert hashlib.sha256(images.tobytes()).hexdigest() == str(g["image_sha"][k]), (level, k)

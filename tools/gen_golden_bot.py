@@ -104,7 +104,71 @@ def trace(name):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), level=name, seed_base=SEED_BASE, **out)
 
 
+DEMO_PLAN = [("GoToLocal", 24, 100), ("PutNextLocal", 12, 7), ("PickupDist", 80, 300), ("BossLevel", 6, 41),
+             ("UnlockToUnlock", 4, 9)]
+
+
+def demos():
+    """scripts/make_agent_demos.py:71-137 generate_demos with BotAgent, `--on-exception warn`: demo k = first episode of
+    stream seed + k the bot solves; a crash or a failed mission means env.reset() on the same stream."""
+    import hashlib
+    out = {}
+    for name, n_episodes, seed in DEMO_PLAN:
+        env = level_dict[name]()
+        if hasattr(env, "locked_room"):
+            env.locked_room = None
+        result = []
+        just_crashed = False
+        retries = 0
+        while len(result) < n_episodes:
+            if just_crashed:
+                obs = None
+                retries += 1
+            else:
+                env.seed(seed + len(result))
+                if hasattr(env, "locked_room"):
+                    env.locked_room = None
+            obs = env.reset()
+            bot = Bot(env)
+            mission, images, directions, actions = obs["mission"], [], [], []
+            done, reward = False, 0
+            try:
+                while not done:
+                    signal.signal(signal.SIGALRM, _on_alarm)
+                    signal.setitimer(signal.ITIMER_REAL, 2.0)
+                    try:
+                        action = int(bot.replan())
+                    finally:
+                        signal.setitimer(signal.ITIMER_REAL, 0)
+                    new_obs, reward, done, _ = env.step(action)
+                    actions.append(action)
+                    images.append(obs["image"])
+                    directions.append(obs["direction"])
+                    obs = new_obs
+                if reward > 0:
+                    result.append((mission, np.array(images), directions, actions))
+                    just_crashed = False
+                if reward == 0:
+                    just_crashed = True
+            except BaseException as exc:
+                if isinstance(exc, KeyboardInterrupt):
+                    raise
+                just_crashed = True
+                continue
+        out[name + "_mission"] = np.array([d[0] for d in result]).astype(str)
+        out[name + "_length"] = np.array([len(d[3]) for d in result], np.int32)
+        out[name + "_actions"] = np.concatenate([np.array(d[3], np.uint8) for d in result])
+        out[name + "_directions"] = np.concatenate([np.array(d[2], np.uint8) for d in result])
+        out[name + "_image_sha"] = np.array([hashlib.sha256(d[1].tobytes()).hexdigest() for d in result]).astype(str)
+        out[name + "_seed"] = seed
+        print("%-16s demos=%d retries=%d mean_len=%.1f" % (name, n_episodes, retries, out[name + "_length"].mean()), flush=True)
+    np.savez_compressed(os.path.join(OUT, "..", "demos", "bot_demos.npz"), **out)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:2] == ["demos"]:
+        demos()
+        sys.exit(0)
     names = sys.argv[1:] or sorted(level_dict)
     for n in names:
         trace(n)
