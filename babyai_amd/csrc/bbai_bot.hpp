@@ -19,9 +19,11 @@
 //   Bot._check_erroneous_box_opening                  :941-949
 //   ObjDesc.find_matching_objs (key descriptors)      babyai/levels/verifier.py:96-161
 //
-// BFS note: the reference appends every neighbour to a FIFO and discards already-visited positions when they are
+// BFS notes: (1) the reference appends every neighbour to a FIFO and discards already-visited positions when they are
 // popped; since the first entry queued for a position is also the first popped, marking positions when they are
 // QUEUED visits the same positions in the same order with the same predecessors, and bounds the queue by W*H.
+// (2) every search of one decision runs on the same grid from the same state, so two resumable search trees per
+// decision (see `search`) replace the reference's one-or-two searches per query.
 #pragma once
 #include "bbai_types.hpp"
 #include "bbai_step.hpp"
@@ -59,9 +61,14 @@ struct BotState {
     uint8_t pad;
 };
 
-struct BotWork {                    // BFS scratch (two searches alive at once in _shortest_path)
-    uint16_t prev1[BOT_MAX_CELLS], q1[BOT_MAX_CELLS];
-    uint16_t prev2[BOT_MAX_CELLS], q2[BOT_MAX_CELLS];
+// BFS scratch: four uint16 arrays of BOT_MAX_CELLS (predecessors + queue, two searches alive at once in
+// _shortest_path) behind a strided view, so the kernel can choose the layout (k_bot: contiguous per thread).
+constexpr int BOT_WORK_WORDS = 4 * BOT_MAX_CELLS;
+enum { WK_PREV1 = 0, WK_Q1 = 1, WK_PREV2 = 2, WK_Q2 = 3 };
+struct BotWork {
+    uint16_t* base;
+    int stride;
+    BB_HD uint16_t& at(int arr, int i) const { return base[(int64_t)(arr * BOT_MAX_CELLS + i) * stride]; }
 };
 
 struct Bot {
@@ -70,12 +77,12 @@ struct Bot {
     const Hot& h;
     uint64_t stale;
     BotState& s;
-    BotWork& w;
+    BotWork w;
     const uint8_t *E, *I, *app, *pos;
     const Prog* prog;
     bool raised;
 
-    BB_HD Bot(const LevelCfg& c_, const uint8_t* rec_, const Hot& h_, uint64_t stale_, BotState& s_, BotWork& w_)
+    BB_HD Bot(const LevelCfg& c_, const uint8_t* rec_, const Hot& h_, uint64_t stale_, BotState& s_, const BotWork& w_)
         : c(c_), rec(rec_), h(h_), stale(stale_), s(s_), w(w_), raised(false) {
         E = rec; I = rec + c.off_I; app = rec + c.off_app; pos = rec + c.off_pos;
         prog = (const Prog*)(rec + c.off_prog);
@@ -164,70 +171,101 @@ struct Bot {
         }
     }
 
-    // One search.  queue entries: cell | dir << 10; prev: 0xFFFF unvisited, 0xFFFE = None (an initial state).
-    BB_HD bool bfs(uint16_t* prev, uint16_t* q, int& qn, const Accept& a, bool ignore_blockers, int& finish) const {
-        int head = 0;
-        while (head < qn) {
-            const int st = q[head++];
-            const int ci = st & 1023, d = st >> 10;
-            const int x = ci % c.W, y = ci / c.W;
-            const int e = cell(x, y);
-            if (accept(a, x, y, e)) { finish = ci; return true; }
-            if (!seen(x, y)) continue;
-            if (!is_none(e)) {
-                const int t = e_type(e);
-                if (t == T_WALL) continue;
-                if (t == T_DOOR) { if (e_state(e) != S_OPEN) continue; }
-                else if (!ignore_blockers) continue;
-            }
-            const int nd[4] = {d, d ^ 1, 3 - d, d ^ 2};          // (di,dj), (dj,di), (-dj,-di), (-di,-dj)
-            for (int k = 0; k < 4; ++k) {
-                const int nx = x + dir_dx(nd[k]), ny = y + dir_dy(nd[k]);
-                if (!in_grid(nx, ny)) continue;                   // (never happens: the border is wall)
-                const int ni = ny * c.W + nx;
-                if (prev[ni] != 0xFFFF) continue;
-                prev[ni] = (uint16_t)ci;
-                q[qn++] = (uint16_t)(ni | nd[k] << 10);
-            }
+    // The searches of one decision share their work.  Which positions a search pops, in which order and with which
+    // predecessor does not depend on the acceptance test (the reference merely stops at the first accepted position
+    // it pops), and the env does not change inside Bot.replan.  So each of the two searches of _shortest_path (from the
+    // agent / from everything the first one reached, through blockers) is kept as ONE resumable tree per decision:
+    // a query first looks through the positions already popped, in pop order, then keeps popping until the test
+    // accepts.  Queue entries: cell | dir << 10; prev: 0xFFFF not queued, 0xFFFE = None (an initial state).
+    mutable int head1 = 0, qn1 = -1, head2 = 0, qn2 = -1;          // qn < 0: search not started in this decision
+
+    BB_HD void expand(int prev, int q, int& qn, int st, bool ignore_blockers) const {
+        const int ci = st & 1023, d = st >> 10;
+        const int x = ci % c.W, y = ci / c.W;
+        const int e = cell(x, y);
+        if (!seen(x, y)) return;
+        if (!is_none(e)) {
+            const int t = e_type(e);
+            if (t == T_WALL) return;
+            if (t == T_DOOR) { if (e_state(e) != S_OPEN) return; }
+            else if (!ignore_blockers) return;
         }
-        return false;
+        const int nd[4] = {d, d ^ 1, 3 - d, d ^ 2};              // (di,dj), (dj,di), (-dj,-di), (-di,-dj)
+        for (int k = 0; k < 4; ++k) {
+            const int nx = x + dir_dx(nd[k]), ny = y + dir_dy(nd[k]);
+            if (!in_grid(nx, ny)) continue;                       // (never happens: the border is wall)
+            const int ni = ny * c.W + nx;
+            if (w.at(prev, ni) != 0xFFFF) continue;
+            w.at(prev, ni) = (uint16_t)ci;
+            w.at(q, qn++) = (uint16_t)(ni | nd[k] << 10);
+        }
+    }
+    // first position in pop order that the test accepts, -1 if the search ends without one
+    BB_HD int search(int prev, int q, int& head, int& qn, const Accept& a, bool ignore_blockers) const {
+        if (a.kind == ACC_POS) {                                  // queued already => it will be popped and accepted
+            if (!in_grid(a.x, a.y)) { while (head < qn) expand(prev, q, qn, w.at(q, head++), ignore_blockers); return -1; }
+            const int target = a.y * c.W + a.x;
+            while (w.at(prev, target) == 0xFFFF && head < qn) expand(prev, q, qn, w.at(q, head++), ignore_blockers);
+            return w.at(prev, target) != 0xFFFF ? target : -1;
+        }
+        for (int i = 0; i < head; ++i) {
+            const int ci = w.at(q, i) & 1023;
+            if (accept(a, ci % c.W, ci / c.W, cell(ci % c.W, ci / c.W))) return ci;
+        }
+        while (head < qn) {
+            const int st = w.at(q, head);
+            const int ci = st & 1023;
+            if (accept(a, ci % c.W, ci / c.W, cell(ci % c.W, ci / c.W))) return ci;     // stays at the head for later queries
+            expand(prev, q, qn, st, ignore_blockers);
+            ++head;
+        }
+        return -1;
+    }
+    BB_HD void start1() const {
+        if (qn1 >= 0) return;
+        const int cells = c.W * c.H;
+        for (int i = 0; i < cells; ++i) w.at(WK_PREV1, i) = 0xFFFF;
+        const int start = h.ay * c.W + h.ax;
+        head1 = qn1 = 0;
+        w.at(WK_PREV1, start) = 0xFFFE;
+        w.at(WK_Q1, qn1++) = (uint16_t)(start | h.dir << 10);
+    }
+    BB_HD void start2() const {                                    // needs search 1 complete (it is: its query just failed)
+        if (qn2 >= 0) return;
+        const int cells = c.W * c.H;
+        for (int i = 0; i < cells; ++i) w.at(WK_PREV2, i) = 0xFFFF;
+        head2 = qn2 = 0;
+        for (int i = 0; i < qn1; ++i) {                            // every position search 1 reached, direction (1,0)
+            const int ci = w.at(WK_Q1, i) & 1023;
+            w.at(WK_PREV2, ci) = 0xFFFE;
+            w.at(WK_Q2, qn2++) = (uint16_t)ci;
+        }
     }
 
     struct Path { bool found; bool nonempty; int len; int nx, ny; int fxp, fyp; bool with_blockers; };
 
     BB_HD Path shortest_path(const Accept& a, bool try_with_blockers) const {          // :772-806
         Path p = {};
-        const int cells = c.W * c.H;
-        for (int i = 0; i < cells; ++i) w.prev1[i] = 0xFFFF;
-        const int start = h.ay * c.W + h.ax;
-        int qn1 = 0, finish = -1;
-        w.prev1[start] = 0xFFFE;
-        w.q1[qn1++] = (uint16_t)(start | h.dir << 10);
+        start1();
         int len = 0, next = -1;
-        bool found = bfs(w.prev1, w.q1, qn1, a, false, finish);
-        if (found) {
-            for (int v = finish; w.prev1[v] != 0xFFFE; v = w.prev1[v]) { ++len; next = v; }
+        int finish = search(WK_PREV1, WK_Q1, head1, qn1, a, false);
+        if (finish >= 0) {
+            for (int v = finish; w.at(WK_PREV1, v) != 0xFFFE; v = w.at(WK_PREV1, v)) { ++len; next = v; }
         } else if (try_with_blockers) {
             p.with_blockers = true;
-            for (int i = 0; i < cells; ++i) w.prev2[i] = 0xFFFF;
-            int qn2 = 0;
-            for (int i = 0; i < qn1; ++i) {                        // every position the first search reached, dir (1,0)
-                const int ci = w.q1[i] & 1023;
-                w.prev2[ci] = 0xFFFE;
-                w.q2[qn2++] = (uint16_t)ci;
-            }
-            found = bfs(w.prev2, w.q2, qn2, a, true, finish);
-            if (found) {
+            start2();
+            finish = search(WK_PREV2, WK_Q2, head2, qn2, a, true);
+            if (finish >= 0) {
                 int v = finish;
-                for (; w.prev2[v] != 0xFFFE; v = w.prev2[v]) { ++len; next = v; }
+                for (; w.at(WK_PREV2, v) != 0xFFFE; v = w.at(WK_PREV2, v)) { ++len; next = v; }
                 int len1 = 0, next1 = -1;
-                for (; w.prev1[v] != 0xFFFE; v = w.prev1[v]) { ++len1; next1 = v; }
+                for (; w.at(WK_PREV1, v) != 0xFFFE; v = w.at(WK_PREV1, v)) { ++len1; next1 = v; }
                 len += len1;
                 if (len1) next = next1;
             }
         }
-        p.found = found;
-        if (found) {
+        p.found = finish >= 0;
+        if (p.found) {
             p.len = len; p.nonempty = len > 0;
             p.fxp = finish % c.W; p.fyp = finish / c.W;
             if (len) { p.nx = next % c.W; p.ny = next / c.W; }
@@ -678,7 +716,7 @@ struct Bot {
 };
 
 // One decision for one env.  `first` = first decision of the episode (fresh Bot, action_taken = None).
-BB_HD int bot_decide(const LevelCfg& c, const uint8_t* rec, const Hot& h, uint64_t stale, BotState& s, BotWork& w, bool first,
+BB_HD int bot_decide(const LevelCfg& c, const uint8_t* rec, const Hot& h, uint64_t stale, BotState& s, const BotWork& w, bool first,
                      int action_taken) {
     Bot b(c, rec, h, stale, s, w);
     if (first) { b.init(); action_taken = -1; if (b.raised) return BOT_DEAD; }

@@ -111,7 +111,7 @@ struct bbai_env {
     int n_tiles;
     bool seeded, live;
     BotState* bot_state;  // [n]        the expert's per-env plan (bbai_bot_act; allocated on first use)
-    BotWork* bot_work;    // [bot_threads] BFS scratch per resident thread
+    uint16_t* bot_work;   // [bot_threads][BOT_WORK_WORDS] BFS scratch per resident thread
     int64_t bot_threads;
     uint64_t* bot_stats;  // [2] decisions that ended in a dead bot: by the reference's rules / by our capacity limits
 };
@@ -459,11 +459,15 @@ __global__ void k_sync_prog(LevelCfg c, int64_t n, int64_t first, int64_t count,
 // scratch block per resident thread.  A new episode (step_count == 0) starts a fresh Bot.
 __global__ __launch_bounds__(64) void k_bot(LevelCfg c, int64_t n, const uint8_t* __restrict__ recs, const Hot* __restrict__ hots,
                                             const uint64_t* __restrict__ stales, BotState* __restrict__ states,
-                                            BotWork* __restrict__ works, const uint8_t* __restrict__ prev_actions,
+                                            uint16_t* __restrict__ works, const uint8_t* __restrict__ prev_actions,
                                             uint8_t* __restrict__ out, unsigned long long* __restrict__ stats) {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-    BotWork& w = works[tid];
+    BotWork w;
+    // per-thread contiguous scratch: measured faster than lane-interleaving it (BossLevel 262144 envs 12.8 vs 17.6 ms per
+    // decision batch) -- the lanes' searches diverge at once, so an interleaved line holds one useful 2-byte element
+    w.base = works + tid * BOT_WORK_WORDS;
+    w.stride = 1;
     for (int64_t i = tid; i < n; i += nthreads) {
         const Hot h = hots[i];
         if (h.frozen) { out[i] = A_DONE; continue; }
@@ -928,7 +932,7 @@ int bbai_bot_act(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions, voi
     if (!e->bot_state) {
         e->bot_threads = std::min<int64_t>((e->n + 63) / 64 * 64, 256 * 8 * 64);     // 8 waves per CU resident
         HIP_TRY(hipMalloc((void**)&e->bot_state, (size_t)e->n * sizeof(BotState)));
-        HIP_TRY(hipMalloc((void**)&e->bot_work, (size_t)e->bot_threads * sizeof(BotWork)));
+        HIP_TRY(hipMalloc((void**)&e->bot_work, (size_t)e->bot_threads * BOT_WORK_WORDS * sizeof(uint16_t)));
         HIP_TRY(hipMalloc((void**)&e->bot_stats, 16));
         HIP_TRY(hipMemset(e->bot_state, 0, (size_t)e->n * sizeof(BotState)));
         HIP_TRY(hipMemset(e->bot_stats, 0, 16));

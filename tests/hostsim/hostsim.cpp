@@ -85,7 +85,8 @@ int hs_bot_state_bytes(void) { return (int)sizeof(BotState); }
 // Returns the suggested action, or 255 once the bot is dead (state->dead says why).
 int hs_bot_decide(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, const uint64_t* stale, uint8_t* state, int first,
                   int action_taken) {
-    static thread_local BotWork work;
+    static thread_local uint16_t buf[BOT_WORK_WORDS];
+    BotWork work; work.base = buf; work.stride = 1;
     return bot_decide(*cfg, rec, *hot, *stale, *(BotState*)state, work, first != 0, action_taken);
 }
 
