@@ -25,39 +25,44 @@ def _generate_batch(env_name, seed, n, device, filter_steps, pack, max_steps, de
     import torch
     env = BatchedBabyAIEnv(env_name, n, device=device, seeds=[seed + k for k in range(n)], auto_reset=True)
     obs = env.reset()
-    missions = [obs["mission"][i] for i in range(n)]
-    images = [[] for _ in range(n)]
-    directions = [[] for _ in range(n)]
-    actions = [[] for _ in range(n)]
-    open_ = np.ones(n, dtype=bool)                 # streams still looking for their first solved episode
+    missions = list(obs["mission"])
+    # whole-batch history, one row per step; an episode is the slice [ep_start[i], t] of column i
+    hist_img, hist_dir, hist_act = [], [], []
+    ep_start = np.zeros(n, dtype=np.int64)
+    span = np.full((n, 2), -1, dtype=np.int64)     # [first, last] step of the stream's first solved episode
+    open_ = np.ones(n, dtype=bool)                 # streams still looking for it
     budget = max_steps if max_steps is not None else 64 * env.max_steps_bound
-    for _ in range(budget):
+    reset_cmd = torch.full((n,), env.RESET_ENV, dtype=torch.uint8, device=env.device)
+    for t in range(budget):
         if not open_.any():
             break
-        img = obs["image"].cpu().numpy()
-        dirs = obs["direction"].cpu().numpy()
+        hist_img.append(obs["image"].cpu().numpy())
+        hist_dir.append(obs["direction"].cpu().numpy())
         act = env.bot_actions(None)
-        crashed = (act == env.BOT_GAVE_UP)
-        act = torch.where(crashed, torch.full_like(act, env.RESET_ENV), act)
+        crashed = act == env.BOT_GAVE_UP
+        act = torch.where(crashed, reset_cmd, act)          # bot crash: env.reset() on the same stream
         obs, reward, done, _ = env.step(act)
-        act_h, crashed_h = act.cpu().numpy(), crashed.cpu().numpy()
+        hist_act.append(act.cpu().numpy())
+        crashed_h = crashed.cpu().numpy()
         reward_h, done_h = reward.cpu().numpy(), done.cpu().numpy().astype(bool)
-        fresh = None
-        for i in np.nonzero(open_)[0]:
-            if not crashed_h[i]:
-                images[i].append(img[i])
-                directions[i].append(int(dirs[i]))
-                actions[i].append(int(act_h[i]))
-            if done_h[i]:
-                if not crashed_h[i] and reward_h[i] > 0 and (filter_steps == 0 or len(images[i]) <= filter_steps):
-                    stack = np.array(images[i])
-                    demos[offset + i] = (missions[i], pack(stack) if pack else stack, directions[i], actions[i])
-                    open_[i] = False
-                else:                               # "mission failed" / bot crash: next level of the same stream
-                    if fresh is None:
-                        fresh = obs["mission"]
-                    missions[i] = fresh[i]
-                    images[i], directions[i], actions[i] = [], [], []
+        length = t - ep_start + 1
+        solved = open_ & done_h & ~crashed_h & (reward_h > 0)
+        if filter_steps:
+            solved &= length <= filter_steps
+        span[solved, 0], span[solved, 1] = ep_start[solved], t
+        open_ &= ~solved
+        again = open_ & done_h                               # "mission failed" / crash: next level of the same stream
+        if again.any():
+            fresh = obs["mission"]
+            for i in np.nonzero(again)[0]:
+                missions[i] = fresh[i]
+        ep_start[done_h] = t + 1
     env.close()
     if open_.any():
         raise RuntimeError("no solvable episode found for %d stream(s) within the step budget" % int(open_.sum()))
+    img, dirs, acts = np.stack(hist_img), np.stack(hist_dir), np.stack(hist_act)
+    for i in range(n):
+        lo, hi = span[i, 0], span[i, 1] + 1
+        stack = np.ascontiguousarray(img[lo:hi, i])
+        demos[offset + i] = (missions[i], pack(stack) if pack else stack,
+                             [int(v) for v in dirs[lo:hi, i]], [int(v) for v in acts[lo:hi, i]])

@@ -127,3 +127,25 @@ def test_config_sizes_oracle_spots(gpu, level, n):
     if level != "GoTo":
         assert env.reset_count() > n       # every env crossed at least one auto-reset on average
     env.close()
+
+
+@pytest.mark.gpu
+def test_expert_solves_every_episode_at_scale(gpu):
+    """Size-independent property of the expert (bbai_bot_act) on 262 144 BossLevel envs: with the bot choosing every
+    action every finished episode is a success, no bot gives up, no capacity limit is hit, no generator failure."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    n = 262144
+    env = BatchedBabyAIEnv("BabyAI-BossLevel-v0", n, device=gpu, seeds=9_000_000)
+    env.reset()
+    episodes = torch.zeros((), dtype=torch.int64, device=gpu)
+    solved = torch.zeros((), dtype=torch.int64, device=gpu)
+    for t in range(48):
+        a = env.bot_actions(None)
+        assert int((a == env.BOT_GAVE_UP).sum()) == 0
+        _, r, d, _ = env.step(a)
+        episodes += d.sum()
+        solved += (r > 0).sum()
+    assert int(episodes) > n // 8 and int(solved) == int(episodes)
+    assert env.bot_stats() == {"gave_up": 0, "capacity": 0} and env.generator_failures() == 0
+    env.close()
