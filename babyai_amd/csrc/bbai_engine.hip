@@ -457,7 +457,8 @@ __global__ void k_sync_prog(LevelCfg c, int64_t n, int64_t first, int64_t count,
 
 // The reference's expert for every env (babyai/bot.py Bot.replan): lane = env, grid-stride over the batch with one BFS
 // scratch block per resident thread.  A new episode (step_count == 0) starts a fresh Bot.
-__global__ __launch_bounds__(64) void k_bot(LevelCfg c, int64_t n, const uint8_t* __restrict__ recs, const Hot* __restrict__ hots,
+template <int WAVES_PER_SIMD>
+__global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_bot(LevelCfg c, int64_t n, const uint8_t* __restrict__ recs, const Hot* __restrict__ hots,
                                             const uint64_t* __restrict__ stales, BotState* __restrict__ states,
                                             uint16_t* __restrict__ works, const uint8_t* __restrict__ prev_actions,
                                             uint8_t* __restrict__ out, unsigned long long* __restrict__ stats) {
@@ -937,8 +938,21 @@ int bbai_bot_act(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions, voi
         HIP_TRY(hipMemset(e->bot_state, 0, (size_t)e->n * sizeof(BotState)));
         HIP_TRY(hipMemset(e->bot_stats, 0, 16));
     }
-    hipLaunchKernelGGL(k_bot, dim3((unsigned)(e->bot_threads / 64)), dim3(64), 0, (hipStream_t)stream, e->cfg, e->n, e->rec, e->hot,
-                       e->stale, e->bot_state, e->bot_work, prev_actions, actions, (unsigned long long*)e->bot_stats);
+    {
+        // Occupancy target, measured (profiles/r01/bot_bench.jsonl): the fully inlined expert wants ~400
+        // registers; capping it at 256 (2 waves/SIMD, spills to scratch) is +35 % on maze levels (BossLevel 1M envs 22.8 ->
+        // 17.0 ms) and -10 % on single rooms, 128 registers (4 waves/SIMD) loses everywhere, real calls instead of inlining too.
+        const bool maze = e->cfg.num_rows * e->cfg.num_cols > 1;
+        const dim3 grid((unsigned)(e->bot_threads / 64)), block(64);
+        hipStream_t s = (hipStream_t)stream;
+        unsigned long long* stats = (unsigned long long*)e->bot_stats;
+        if (maze)
+            hipLaunchKernelGGL(k_bot<2>, grid, block, 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_work,
+                               prev_actions, actions, stats);
+        else
+            hipLaunchKernelGGL(k_bot<1>, grid, block, 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_work,
+                               prev_actions, actions, stats);
+    }
     HIP_TRY(hipGetLastError());
     return BBAI_OK;
 }
