@@ -930,13 +930,20 @@ int bbai_bot_act(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions, voi
     if (!e || !actions) ARG_FAIL("null handle or output buffer");
     if (!e->live) { snprintf(g_err, sizeof(g_err), "bot_act before reset"); return BBAI_ERR_STATE; }
     ON_DEVICE(e->device);
-    if (!e->bot_state) {
-        e->bot_threads = std::min<int64_t>((e->n + 63) / 64 * 64, 256 * 8 * 64);     // 8 waves per CU resident
-        HIP_TRY(hipMalloc((void**)&e->bot_state, (size_t)e->n * sizeof(BotState)));
-        HIP_TRY(hipMalloc((void**)&e->bot_work, (size_t)e->bot_threads * BOT_WORK_WORDS * sizeof(uint16_t)));
-        HIP_TRY(hipMalloc((void**)&e->bot_stats, 16));
-        HIP_TRY(hipMemset(e->bot_state, 0, (size_t)e->n * sizeof(BotState)));
-        HIP_TRY(hipMemset(e->bot_stats, 0, 16));
+    if (!e->bot_state) {                                   // first use: all three buffers or none
+        const int64_t threads = std::min<int64_t>((e->n + 63) / 64 * 64, 256 * 8 * 64);
+        void *st = nullptr, *wk = nullptr, *ss = nullptr;
+        hipError_t err = hipMalloc(&st, (size_t)e->n * sizeof(BotState));
+        if (err == hipSuccess) err = hipMalloc(&wk, (size_t)threads * BOT_WORK_WORDS * sizeof(uint16_t));
+        if (err == hipSuccess) err = hipMalloc(&ss, 16);
+        if (err == hipSuccess) err = hipMemset(st, 0, (size_t)e->n * sizeof(BotState));
+        if (err == hipSuccess) err = hipMemset(ss, 0, 16);
+        if (err != hipSuccess) {
+            (void)hipFree(st); (void)hipFree(wk); (void)hipFree(ss);
+            snprintf(g_err, sizeof(g_err), "bot_act: allocating the expert's state failed: %s", hipGetErrorString(err));
+            return BBAI_ERR_NOMEM;
+        }
+        e->bot_state = (BotState*)st; e->bot_work = (uint16_t*)wk; e->bot_stats = (uint64_t*)ss; e->bot_threads = threads;
     }
     {
         // Occupancy target, measured (profiles/r01/bot_bench.jsonl): the fully inlined expert wants ~400

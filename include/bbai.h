@@ -106,7 +106,9 @@ int bbai_get_programs(bbai_env* env, int64_t first, int64_t count, uint8_t* prog
  * bot.py:88-98), or NULL = "the suggestion was taken" (replan(None)).  An env whose episode has just started
  * (step_count == 0) gets a fresh Bot.  `actions_dev[i]` = suggested action 0..6, or 255 where the reference bot would
  * have raised (assertion / DisappearedBoxError / endless replanning); it stays 255 until the episode ends.
- * Decision-for-decision parity with the reference bot: tests/test_hostsim_bot.py, tests/golden/bot/. */
+ * Decision-for-decision parity with the reference bot: tests/test_hostsim_bot.py, tests/golden/bot/.
+ * The expert's plan lives in the handle (allocated on first use, ~1.7 KB per env) and is not part of
+ * bbai_export_state / bbai_import_state: import states at episode boundaries when the expert is in use. */
 int bbai_bot_act(bbai_env* env, const uint8_t* prev_actions_dev, uint8_t* actions_dev, void* stream);
 /* Bots that gave up so far: by the reference's own rules / because a fixed-size structure of this port overflowed
  * (subgoal stack 48, same-colour keys 12) -- the second is expected to be 0 except where the reference replans for ever. */

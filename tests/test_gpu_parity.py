@@ -770,3 +770,43 @@ def test_generate_demos_matches_reference_script(gpu, level):
         assert list(directions) == list(g["directions"][lo:hi]), (level, k)
         assert images.dtype == np.uint8 and images.shape == (hi - lo, 7, 7, 3)
         assert hashlib.sha256(images.tobytes()).hexdigest() == str(g["image_sha"][k]), (level, k)
+
+
+@pytest.mark.gpu
+def test_bot_device_equals_host_build_on_every_level(gpu):
+    """All 105 levels: k_bot against the host build of bbai_bot.hpp (which tests/test_hostsim_bot.py pins to the
+    reference on every level), bot-driven with 6 % random actions so the undo logic runs too."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from babyai_amd.levels import LEVELS, make_cfg
+    from hostsim_util import HostBot, HostEnv
+    n, steps = 24, 48
+    rng = np.random.RandomState(11)
+    for level in sorted(LEVELS):
+        env = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=61000)
+        env.reset()
+        hosts = [HostEnv(make_cfg(level), 61000 + i) for i in range(n)]
+        bots = []
+        for h in hosts:
+            h.reset()
+            bots.append(HostBot(h))
+        first, last, prev = [True] * n, [None] * n, None
+        for t in range(steps):
+            got = env.bot_actions(prev).cpu().numpy()
+            act = np.zeros(n, np.uint8)
+            for i in range(n):
+                a = bots[i].decide(first[i], last[i])
+                first[i] = False
+                assert got[i] == (255 if a is None else a), (level, i, t, got[i], a)
+                act[i] = a if (a is not None and rng.rand() > 0.06) else rng.randint(0, 7)
+            prev = torch.as_tensor(act, device=gpu)
+            _, _, d, _ = env.step(prev)
+            d = d.cpu().numpy()
+            for i in range(n):
+                _, _, hd = hosts[i].step(int(act[i]))
+                assert bool(hd) == bool(d[i]), (level, i, t)
+                last[i] = int(act[i])
+                if hd:
+                    hosts[i].reset()
+                    first[i], last[i] = True, None
+        env.close()
