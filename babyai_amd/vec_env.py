@@ -215,6 +215,13 @@ class SingleEnv(object):
         self.step_count += 1
         return self._one(obs), float(reward[0]), bool(done[0]), {}
 
+    def bot_action(self, action_taken=None):
+        """`Bot(env).replan(action_taken)` (babyai/bot.py:547-597): the expert's suggestion for the current state, or
+        None where the reference bot would raise.  Call once per step (the expert keeps its plan in the engine)."""
+        prev = None if action_taken is None else np.array([int(action_taken)], dtype=np.uint8)
+        a = int(self.engine.bot_actions(prev)[0])
+        return None if a == self.engine.BOT_GAVE_UP else a
+
     def close(self):
         self.engine.close()
 

@@ -514,6 +514,13 @@ def test_single_env_protocol(gpu):
             assert env.agent_pos == tuple(ref.agent_pos) and env.agent_dir == ref.agent_dir
             if d:
                 break
+    # the expert through the single-env protocol: solves the episode, like `Bot(env).replan()` in scripts/enjoy.py
+    env.seed(5)
+    env.reset()
+    reward, done = 0.0, False
+    while not done:
+        _, reward, done, _ = env.step(env.bot_action())
+    assert reward > 0
     twin = SingleEnv("BabyAI-PickupLoc-v0", device=gpu, seed=5)
     env.seed(5)
     env.reset(), twin.reset()
