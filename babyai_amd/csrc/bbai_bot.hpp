@@ -30,7 +30,7 @@
 
 namespace bbai {
 
-constexpr int BOT_STACK = 48;       // subgoal stack depth (overflow => dead, counted)
+constexpr int BOT_STACK = 48;       // default subgoal stack depth (overflow => dead, counted); BBAI_BOT_STACK raises it
 constexpr int BOT_KEYS = 12;        // same-colour keys a key descriptor can list (overflow => dead, counted)
 constexpr int BOT_MAX_CELLS = MAX_W * MAX_W;
 constexpr int BOT_MAX_ITERS = 1000; // replanning rounds per decision (the reference would spin for ever)
@@ -53,13 +53,15 @@ static_assert(sizeof(Subgoal) == 32, "Subgoal layout");
 struct BotState {
     uint32_t vis[MAX_W];            // vis[y] bit x : Bot.vis_mask
     uint8_t ipos[MAX_OBJ][2];       // object positions when the episode started (order of ObjDesc.obj_set)
-    Subgoal stack[BOT_STACK];
-    uint8_t sp, dead;
+    uint16_t sp;                    // subgoal stack: `cap` entries of 32 bytes stored BEHIND this struct
+    uint8_t dead, pad0;
     uint8_t prev_ax, prev_ay, prev_carry;
     uint8_t door_was_open;          // 0 / 1, 2 = attribute never set
     uint8_t prev_fwd_type;          // T_* of prev_fwd_cell, 0 = None
     uint8_t pad;
 };
+static_assert(sizeof(BotState) % 4 == 0, "the subgoal stack follows the state");
+BB_HD size_t bot_state_bytes(int stack_cap) { return sizeof(BotState) + (size_t)stack_cap * sizeof(Subgoal); }
 
 // BFS scratch: four uint16 arrays of BOT_MAX_CELLS (predecessors + queue, two searches alive at once in
 // _shortest_path) behind a strided view, so the kernel can choose the layout (k_bot: contiguous per thread).
@@ -77,13 +79,15 @@ struct Bot {
     const Hot& h;
     uint64_t stale;
     BotState& s;
+    Subgoal* stk;                   // s's stack (behind the struct)
+    int cap;
     BotWork w;
     const uint8_t *E, *I, *app, *pos;
     const Prog* prog;
     bool raised;
 
-    BB_HD Bot(const LevelCfg& c_, const uint8_t* rec_, const Hot& h_, uint64_t stale_, BotState& s_, const BotWork& w_)
-        : c(c_), rec(rec_), h(h_), stale(stale_), s(s_), w(w_), raised(false) {
+    BB_HD Bot(const LevelCfg& c_, const uint8_t* rec_, const Hot& h_, uint64_t stale_, BotState& s_, int cap_, const BotWork& w_)
+        : c(c_), rec(rec_), h(h_), stale(stale_), s(s_), stk((Subgoal*)(&s_ + 1)), cap(cap_), w(w_), raised(false) {
         E = rec; I = rec + c.off_I; app = rec + c.off_app; pos = rec + c.off_pos;
         prog = (const Prog*)(rec + c.off_prog);
     }
@@ -106,8 +110,8 @@ struct Bot {
     }
 
     BB_HD void push(const Subgoal& g) {
-        if (s.sp >= BOT_STACK) { die(DEAD_CAPACITY); return; }
-        s.stack[s.sp++] = g;
+        if (s.sp >= cap) { die(DEAD_CAPACITY); return; }
+        stk[s.sp++] = g;
     }
     BB_HD void pop() { if (s.sp) --s.sp; }
     BB_HD static Subgoal mk(int kind, int reason = RS_NONE) {
@@ -694,13 +698,13 @@ struct Bot {
         if (s.dead) return BOT_DEAD;
         process_obs();
         if (action_taken == A_TOGGLE && s.prev_fwd_type == T_BOX) { die(); return BOT_DEAD; }   // DisappearedBoxError
-        if (s.sp) after_action(s.stack[s.sp - 1], action_taken);
+        if (s.sp) after_action(stk[s.sp - 1], action_taken);
         if (raised) return BOT_DEAD;
-        while (s.sp && exploratory(s.stack[s.sp - 1])) pop();
+        while (s.sp && exploratory(stk[s.sp - 1])) pop();
         int suggested = -1;
         int iters = 0;
         while (s.sp) {
-            suggested = before_action(s.stack[s.sp - 1]);
+            suggested = before_action(stk[s.sp - 1]);
             if (raised) return BOT_DEAD;
             if (suggested >= 0) break;
             if (++iters > BOT_MAX_ITERS) { die(); return BOT_DEAD; }
@@ -716,9 +720,9 @@ struct Bot {
 };
 
 // One decision for one env.  `first` = first decision of the episode (fresh Bot, action_taken = None).
-BB_HD int bot_decide(const LevelCfg& c, const uint8_t* rec, const Hot& h, uint64_t stale, BotState& s, const BotWork& w, bool first,
-                     int action_taken) {
-    Bot b(c, rec, h, stale, s, w);
+BB_HD int bot_decide(const LevelCfg& c, const uint8_t* rec, const Hot& h, uint64_t stale, BotState& s, int stack_cap, const BotWork& w,
+                     bool first, int action_taken) {
+    Bot b(c, rec, h, stale, s, stack_cap, w);
     if (first) { b.init(); action_taken = -1; if (b.raised) return BOT_DEAD; }
     return b.replan(action_taken);
 }

@@ -110,7 +110,8 @@ struct bbai_env {
     uint8_t* lut;         // [2][256]
     int n_tiles;
     bool seeded, live;
-    BotState* bot_state;  // [n]        the expert's per-env plan (bbai_bot_act; allocated on first use)
+    uint8_t* bot_state;   // [n][bot_state_bytes(bot_stack)] the expert's per-env plan (bbai_bot_act; allocated on first use)
+    int bot_stack;        // subgoal stack capacity per env (BBAI_BOT_STACK, default 48)
     uint16_t* bot_work;   // [bot_threads][BOT_WORK_WORDS] BFS scratch per resident thread
     int64_t bot_threads;
     uint64_t* bot_stats;  // [2] decisions that ended in a dead bot: by the reference's rules / by our capacity limits
@@ -459,7 +460,7 @@ __global__ void k_sync_prog(LevelCfg c, int64_t n, int64_t first, int64_t count,
 // scratch block per resident thread.  A new episode (step_count == 0) starts a fresh Bot.
 template <int WAVES_PER_SIMD>
 __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_bot(LevelCfg c, int64_t n, const uint8_t* __restrict__ recs, const Hot* __restrict__ hots,
-                                            const uint64_t* __restrict__ stales, BotState* __restrict__ states,
+                                            const uint64_t* __restrict__ stales, uint8_t* __restrict__ states, int stack_cap,
                                             uint16_t* __restrict__ works, const uint8_t* __restrict__ prev_actions,
                                             uint8_t* __restrict__ out, unsigned long long* __restrict__ stats) {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -474,9 +475,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_bot(LevelCfg c, int64_t 
         if (h.frozen) { out[i] = A_DONE; continue; }
         const bool first = h.step == 0;
         const int taken = (prev_actions && !first) ? prev_actions[i] : -1;
-        BotState& st = states[i];
+        BotState& st = *(BotState*)(states + i * (int64_t)bot_state_bytes(stack_cap));
         const bool was_dead = !first && st.dead;
-        const int a = bot_decide(c, recs + i * (int64_t)c.rec_bytes, h, stales[i], st, w, first, taken);
+        const int a = bot_decide(c, recs + i * (int64_t)c.rec_bytes, h, stales[i], st, stack_cap, w, first, taken);
         out[i] = (uint8_t)a;
         if (a == BOT_DEAD && !was_dead) atomicAdd(&stats[st.dead == DEAD_CAPACITY ? 1 : 0], 1ull);
     }
@@ -933,17 +934,24 @@ int bbai_bot_act(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions, voi
     if (!e->bot_state) {                                   // first use: all three buffers or none
         const int64_t threads = std::min<int64_t>((e->n + 63) / 64 * 64, 256 * 8 * 64);
         void *st = nullptr, *wk = nullptr, *ss = nullptr;
-        hipError_t err = hipMalloc(&st, (size_t)e->n * sizeof(BotState));
+        // Subgoal stack depth per env.  The reference's list is unbounded; 48 covers every plan that makes progress (the
+        // rare bot that loops without progress grows its stack until max_steps and fails the episode -- here it gives up
+        // when the stack is full, counted in bbai_bot_stats().capacity).  Raise it to follow such a bot further.
+        const char* ev = getenv("BBAI_BOT_STACK");
+        const int cap = ev ? std::max(8, std::min(atoi(ev), 4096)) : BOT_STACK;
+        const size_t sbytes = bot_state_bytes(cap);
+        hipError_t err = hipMalloc(&st, (size_t)e->n * sbytes);
         if (err == hipSuccess) err = hipMalloc(&wk, (size_t)threads * BOT_WORK_WORDS * sizeof(uint16_t));
         if (err == hipSuccess) err = hipMalloc(&ss, 16);
-        if (err == hipSuccess) err = hipMemset(st, 0, (size_t)e->n * sizeof(BotState));
+        if (err == hipSuccess) err = hipMemset(st, 0, (size_t)e->n * sbytes);
         if (err == hipSuccess) err = hipMemset(ss, 0, 16);
         if (err != hipSuccess) {
             (void)hipFree(st); (void)hipFree(wk); (void)hipFree(ss);
             snprintf(g_err, sizeof(g_err), "bot_act: allocating the expert's state failed: %s", hipGetErrorString(err));
             return BBAI_ERR_NOMEM;
         }
-        e->bot_state = (BotState*)st; e->bot_work = (uint16_t*)wk; e->bot_stats = (uint64_t*)ss; e->bot_threads = threads;
+        e->bot_stack = cap;
+        e->bot_state = (uint8_t*)st; e->bot_work = (uint16_t*)wk; e->bot_stats = (uint64_t*)ss; e->bot_threads = threads;
     }
     {
         // Occupancy target, measured (profiles/r01/bot_bench.jsonl): the fully inlined expert wants ~400
@@ -954,10 +962,10 @@ int bbai_bot_act(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions, voi
         hipStream_t s = (hipStream_t)stream;
         unsigned long long* stats = (unsigned long long*)e->bot_stats;
         if (maze)
-            hipLaunchKernelGGL(k_bot<2>, grid, block, 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_work,
+            hipLaunchKernelGGL(k_bot<2>, grid, block, 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
                                prev_actions, actions, stats);
         else
-            hipLaunchKernelGGL(k_bot<1>, grid, block, 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_work,
+            hipLaunchKernelGGL(k_bot<1>, grid, block, 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
                                prev_actions, actions, stats);
     }
     HIP_TRY(hipGetLastError());

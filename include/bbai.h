@@ -111,7 +111,10 @@ int bbai_get_programs(bbai_env* env, int64_t first, int64_t count, uint8_t* prog
  * bbai_export_state / bbai_import_state: import states at episode boundaries when the expert is in use. */
 int bbai_bot_act(bbai_env* env, const uint8_t* prev_actions_dev, uint8_t* actions_dev, void* stream);
 /* Bots that gave up so far: by the reference's own rules / because a fixed-size structure of this port overflowed
- * (subgoal stack 48, same-colour keys 12) -- the second is expected to be 0 except where the reference replans for ever. */
+ * (subgoal stack, 48 entries unless the environment variable BBAI_BOT_STACK says otherwise when the expert is first
+ * used; same-colour keys 12).  The reference's stack is an unbounded list: a bot that replans for ever inside one
+ * decision, or loops without progress across steps until max_steps, overflows here instead (observed: UnlockToUnlock,
+ * 1 in 1024 MiniBossLevel missions); those episodes fail in the reference too. */
 int bbai_bot_stats(bbai_env* env, uint64_t* gave_up, uint64_t* capacity);
 
 /* Number of level generations (resets) performed so far, all envs. */

@@ -79,15 +79,17 @@ void hs_observe(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, uint8_t
 }
 
 // ---- the expert (bbai_bot.hpp) -------------------------------------------------------------------------------
-int hs_bot_state_bytes(void) { return (int)sizeof(BotState); }
+int hs_bot_state_bytes(int stack_cap) { return (int)bot_state_bytes(stack_cap); }
+int hs_bot_dead_reason(const uint8_t* state) { return ((const BotState*)state)->dead; }
+int hs_bot_stack_depth(const uint8_t* state) { return ((const BotState*)state)->sp; }
 
 // One Bot.replan decision; `first` != 0 starts a fresh Bot (new episode).  action_taken < 0 = None.
 // Returns the suggested action, or 255 once the bot is dead (state->dead says why).
-int hs_bot_decide(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, const uint64_t* stale, uint8_t* state, int first,
-                  int action_taken) {
+int hs_bot_decide(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, const uint64_t* stale, uint8_t* state, int stack_cap,
+                  int first, int action_taken) {
     static thread_local uint16_t buf[BOT_WORK_WORDS];
     BotWork work; work.base = buf; work.stride = 1;
-    return bot_decide(*cfg, rec, *hot, *stale, *(BotState*)state, work, first != 0, action_taken);
+    return bot_decide(*cfg, rec, *hot, *stale, *(BotState*)state, stack_cap, work, first != 0, action_taken);
 }
 
 }  // extern "C"

@@ -26,7 +26,9 @@ def lib():
         L.hs_observe.argtypes = [P, P, P, P]
         L.hs_fill_layout.argtypes = [P]
         L.hs_start_carry.argtypes = [P, P, P, P]
-        L.hs_bot_decide.argtypes = [P, P, P, P, P, ctypes.c_int, ctypes.c_int]
+        L.hs_bot_decide.argtypes = [P, P, P, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.hs_bot_dead_reason.argtypes = [P]
+        L.hs_bot_stack_depth.argtypes = [P]
         _lib = L
     return _lib
 
@@ -86,18 +88,23 @@ class HostEnv(object):
 class HostBot(object):
     """The expert of babyai_amd/csrc/bbai_bot.hpp on one HostEnv (host build of the same header)."""
 
-    def __init__(self, env):
+    def __init__(self, env, stack_cap=48):
         self.env = env
-        self.state = np.zeros(env.L.hs_bot_state_bytes(), np.uint8)
+        self.stack_cap = stack_cap
+        self.state = np.zeros(env.L.hs_bot_state_bytes(stack_cap), np.uint8)
 
     def decide(self, first, action_taken=None):
         """Bot.replan(action_taken): suggested action, or None once the bot gave up (bot.py raises)."""
         e = self.env
         a = e.L.hs_bot_decide(ctypes.byref(e.cfg), e.rec.ctypes.data, e.hot.ctypes.data, ctypes.byref(e.stale),
-                              self.state.ctypes.data, 1 if first else 0, -1 if action_taken is None else int(action_taken))
+                              self.state.ctypes.data, self.stack_cap, 1 if first else 0,
+                              -1 if action_taken is None else int(action_taken))
         return None if a == 255 else a
 
     @property
     def dead_reason(self):
-        off = 4 * 25 + 2 * 48 + 32 * 48 + 1
-        return int(self.state[off])
+        return int(self.env.L.hs_bot_dead_reason(self.state.ctypes.data))
+
+    @property
+    def stack_depth(self):
+        return int(self.env.L.hs_bot_stack_depth(self.state.ctypes.data))

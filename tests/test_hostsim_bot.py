@@ -119,3 +119,43 @@ def test_bot_differential_against_live_reference(level, n_envs, steps):
                 rbot, hbot = Bot(ref), HostBot(env)
                 first, last = True, None
     assert checked > n_envs * steps // 2
+
+
+def test_stack_capacity_is_the_one_documented_divergence():
+    """MiniBossLevel, `Level(seed=520)`: the reference bot enters an unproductive loop that grows its subgoal stack by
+    about four entries every five steps and keeps acting until max_steps (episode failed, reward 0).  With the default
+    48-entry stack the port reports 'gave up' (reason = capacity) at step 63, where the reference's stack reaches 52;
+    with a deeper stack (BBAI_BOT_STACK / stack_cap) it follows the reference to the end of the episode.
+    Either way the episode fails; demonstrations (first SOLVED episode per stream) are unaffected."""
+    level, seed = "MiniBossLevel", 520
+    env = HostEnv(make_cfg(level), seed)
+    env.reset()
+    bot = HostBot(env)                      # default capacity
+    deep_env = HostEnv(make_cfg(level), seed)
+    deep_env.reset()
+    deep = HostBot(deep_env, stack_cap=1024)
+    ref = rbot = None
+    from oracle import refenv
+    if refenv.have_reference():
+        refenv.import_reference()
+        from babyai.bot import Bot
+        from babyai.levels import level_dict
+        ref = level_dict[level](seed=seed)
+        rbot = Bot(ref)
+    first, t, done, reward, deepest = True, 0, False, 0.0, 0
+    while not done:
+        b = deep.decide(first, None)
+        assert b is not None, t
+        deepest = max(deepest, deep.stack_depth)
+        if t <= 63:
+            a = bot.decide(first, None)
+            assert (a == b) if t < 63 else (a is None and bot.dead_reason == 2), t
+            if t < 63:
+                env.step(a)
+        if rbot is not None:
+            assert int(rbot.replan()) == b and len(rbot.stack) == deep.stack_depth, t
+            ref.step(b)
+        first = False
+        _, reward, done = deep_env.step(b)
+        t += 1
+    assert reward == 0 and t == deep_env.max_steps and deepest > 48
