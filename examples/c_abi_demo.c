@@ -2,7 +2,7 @@
  *
  *   gcc -std=c99 -O2 examples/c_abi_demo.c -Iinclude -I/opt/rocm/include -Lbabyai_amd -lbbai_hip -L/opt/rocm/lib -lamdhip64 \
  *       -Wl,-rpath,$PWD/babyai_amd -Wl,-rpath,/opt/rocm/lib -o /tmp/c_abi_demo
- *   /tmp/c_abi_demo            # 4096 GoToLocal envs, 200 random steps, prints a state digest
+ *   /tmp/c_abi_demo            # 4096 GoToLocal envs, 200 random steps + 100 expert-chosen steps, prints a state digest
  *
  * GoToLocal = Level_GoToLocal(room_size=8, num_dists=8) of babyai/levels/iclr19_levels.py:105-124.
  */
@@ -51,6 +51,20 @@ int main(void) {
         if (hipMemcpy(host_done, done, n, hipMemcpyDeviceToHost)) return 2;
         for (int64_t i = 0; i < n; ++i) { reward_sum += host_reward[i]; episodes += host_done[i]; }
     }
+    /* second phase: the reference's expert (babyai/bot.py) chooses the actions, on the device */
+    long expert_episodes = 0, expert_solved = 0;
+    for (int t = 0; t < 100; ++t) {
+        CHECK(bbai_bot_act(env, NULL /* replan(None): the suggestion is what we step with */, actions, NULL));
+        CHECK(bbai_step(env, actions, image, dir, reward, done, 1, NULL));
+        if (hipMemcpy(host_reward, reward, n * sizeof(float), hipMemcpyDeviceToHost)) return 2;
+        if (hipMemcpy(host_done, done, n, hipMemcpyDeviceToHost)) return 2;
+        for (int64_t i = 0; i < n; ++i) { expert_episodes += host_done[i]; expert_solved += host_reward[i] > 0.0f; }
+    }
+    episodes += expert_episodes;
+    uint64_t gave_up = 0, capacity = 0;
+    CHECK(bbai_bot_stats(env, &gave_up, &capacity));
+    printf("expert: episodes=%ld solved=%ld gave_up=%llu capacity=%llu\n", expert_episodes, expert_solved,
+           (unsigned long long)gave_up, (unsigned long long)capacity);
     uint64_t resets = 0, failures = 0;
     CHECK(bbai_reset_count(env, &resets));
     CHECK(bbai_generator_failures(env, &failures));
@@ -58,7 +72,7 @@ int main(void) {
     if (hipMemcpy(host_image, image, n * BBAI_OBS_BYTES, hipMemcpyDeviceToHost)) return 2;
     uint64_t digest = 1469598103934665603ull;
     for (int64_t i = 0; i < n * BBAI_OBS_BYTES; ++i) digest = (digest ^ host_image[i]) * 1099511628211ull;
-    printf("envs=%lld steps=200 episodes_finished=%ld resets=%llu generator_failures=%llu reward_sum=%.6f obs_digest=%016llx\n",
+    printf("envs=%lld steps=300 episodes_finished=%ld resets=%llu generator_failures=%llu reward_sum=%.6f obs_digest=%016llx\n",
            (long long)n, episodes, (unsigned long long)resets, (unsigned long long)failures, reward_sum, (unsigned long long)digest);
     bbai_destroy(env);
     return (resets == (uint64_t)n + (uint64_t)episodes && failures == 0) ? 0 : 3;

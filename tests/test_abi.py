@@ -96,6 +96,12 @@ def test_c_abi_demo_runs_without_python_or_torch(gpu, tmp_path):
             lcg = (lcg * 1664525 + 1013904223) & 0xFFFFFFFF
             a[i] = (lcg >> 24) % 7
         env.step(torch.as_tensor(a, device=gpu))
+    solved = episodes = 0
+    for t in range(100):                       # second phase of the demo: the device expert drives
+        _, r, d, _ = env.step(env.bot_actions(None))
+        solved += int((r > 0).sum())
+        episodes += int(d.sum())
+    assert ("expert: episodes=%d solved=%d gave_up=0 capacity=0" % (episodes, solved)) in out and solved == episodes, out
     torch.cuda.synchronize()
     digest = 1469598103934665603
     for b in env.image.cpu().numpy().reshape(-1):
