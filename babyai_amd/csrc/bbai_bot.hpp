@@ -59,6 +59,7 @@ struct BotState {
     uint8_t door_was_open;          // 0 / 1, 2 = attribute never set
     uint8_t prev_fwd_type;          // T_* of prev_fwd_cell, 0 = None
     uint8_t pad;
+    uint16_t next_step;             // step_count at which the next decision of THIS plan is expected
 };
 static_assert(sizeof(BotState) % 4 == 0, "the subgoal stack follows the state");
 BB_HD size_t bot_state_bytes(int stack_cap) { return sizeof(BotState) + (size_t)stack_cap * sizeof(Subgoal); }
@@ -719,10 +720,16 @@ struct Bot {
     }
 };
 
-// One decision for one env.  `first` = first decision of the episode (fresh Bot, action_taken = None).
+// One decision for one env.  A fresh Bot (`Bot(env)`, action_taken = None) is started when the caller says so, when
+// the episode has just begun (step_count == 0), and when the expert was not consulted on the previous step of this
+// episode (so it can be switched on in the middle of an episode, like constructing `Bot(env)` there).  A Bot started
+// mid-episode orders each descriptor's obj_set by the objects' positions at that moment; the reference uses their
+// positions at reset, which differ only if a described object was carried somewhere else before.
 BB_HD int bot_decide(const LevelCfg& c, const uint8_t* rec, const Hot& h, uint64_t stale, BotState& s, int stack_cap, const BotWork& w,
                      bool first, int action_taken) {
     Bot b(c, rec, h, stale, s, stack_cap, w);
+    first = first || h.step == 0 || s.next_step != h.step;
+    s.next_step = (uint16_t)(h.step + 1);
     if (first) { b.init(); action_taken = -1; if (b.raised) return BOT_DEAD; }
     return b.replan(action_taken);
 }

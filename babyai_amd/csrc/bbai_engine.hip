@@ -473,9 +473,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_bot(LevelCfg c, int64_t 
     for (int64_t i = tid; i < n; i += nthreads) {
         const Hot h = hots[i];
         if (h.frozen) { out[i] = A_DONE; continue; }
-        const bool first = h.step == 0;
-        const int taken = (prev_actions && !first) ? prev_actions[i] : -1;
         BotState& st = *(BotState*)(states + i * (int64_t)bot_state_bytes(stack_cap));
+        const bool first = h.step == 0 || st.next_step != h.step;       // (bot_decide applies the same rule)
+        const int taken = (prev_actions && !first) ? prev_actions[i] : -1;
         const bool was_dead = !first && st.dead;
         const int a = bot_decide(c, recs + i * (int64_t)c.rec_bytes, h, stales[i], st, stack_cap, w, first, taken);
         out[i] = (uint8_t)a;

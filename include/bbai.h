@@ -104,7 +104,7 @@ int bbai_get_programs(bbai_env* env, int64_t first, int64_t count, uint8_t* prog
  * (babyai/bot.py:547-597; callers babyai/utils/agent.py:139-146 BotAgent.act, scripts/make_agent_demos.py:93-107).
  * `prev_actions_dev` = the action each env was actually stepped with since the previous call (advising mode,
  * bot.py:88-98), or NULL = "the suggestion was taken" (replan(None)).  An env whose episode has just started
- * (step_count == 0) gets a fresh Bot.  `actions_dev[i]` = suggested action 0..6, or 255 where the reference bot would
+ * (step_count == 0), or whose expert was not consulted on the previous step, gets a fresh Bot (= `Bot(env)` there).  `actions_dev[i]` = suggested action 0..6, or 255 where the reference bot would
  * have raised (assertion / DisappearedBoxError / endless replanning); it stays 255 until the episode ends.
  * Decision-for-decision parity with the reference bot: tests/test_hostsim_bot.py, tests/golden/bot/.
  * The expert's plan lives in the handle (allocated on first use, ~1.7 KB per env) and is not part of

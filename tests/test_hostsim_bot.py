@@ -159,3 +159,50 @@ def test_stack_capacity_is_the_one_documented_divergence():
         _, reward, done = deep_env.step(b)
         t += 1
     assert reward == 0 and t == deep_env.max_steps and deepest > 48
+
+
+@pytest.mark.parametrize("level", ["GoToLocal", "PickupLoc", "GoTo", "Unlock"])
+def test_expert_switched_on_mid_episode(level):
+    """`Bot(env)` constructed in the middle of an episode (after random steps) vs the port, which starts a fresh plan by
+    itself when it was not consulted on the previous step.  Only turn/forward noise before the switch, so that no
+    described object has moved (see bot_decide)."""
+    from oracle import refenv
+    if not refenv.have_reference():
+        pytest.skip("reference tree not present")
+    refenv.import_reference()
+    from babyai.bot import Bot
+    from babyai.levels import level_dict
+    rng = np.random.RandomState(3)
+    for k in range(6):
+        seed = 990000 + k
+        ref = level_dict[level]()
+        ref.seed(seed)
+        ref.reset()
+        env = HostEnv(make_cfg(level), seed)
+        env.reset()
+        hbot = HostBot(env)
+        for _ in range(2):                                   # two switch-on points per mission
+            done = False
+            for t in range(int(rng.randint(3, 12))):
+                a = int(rng.choice([0, 1, 2]))
+                _, _, d, _ = ref.step(a)
+                env.step(a)
+                if d:
+                    done = True
+                    break
+            if done:
+                break
+            rbot = Bot(ref)
+            last = None
+            for t in range(40):
+                want = int(rbot.replan(last))
+                got = hbot.decide(False, last)               # no `first` flag: the port notices by itself
+                assert got == want, (level, seed, t)
+                last = want
+                _, _, d, _ = ref.step(want)
+                env.step(want)
+                if d or t == 12:
+                    done = d
+                    break
+            if done:
+                break
