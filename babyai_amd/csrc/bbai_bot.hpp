@@ -71,7 +71,8 @@ enum { WK_PREV1 = 0, WK_Q1 = 1, WK_PREV2 = 2, WK_Q2 = 3 };
 struct BotWork {
     uint16_t* base;
     int stride;
-    BB_HD uint16_t& at(int arr, int i) const { return base[(int64_t)(arr * BOT_MAX_CELLS + i) * stride]; }
+    int cells;                      // W * H of the level: the four arrays are packed to the grid actually in use
+    BB_HD uint16_t& at(int arr, int i) const { return base[(int64_t)(arr * cells + i) * stride]; }
 };
 
 struct Bot {

@@ -468,7 +468,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_bot(LevelCfg c, int64_t 
     BotWork w;
     // per-thread contiguous scratch: measured faster than lane-interleaving it (BossLevel 262144 envs 12.8 vs 17.6 ms per
     // decision batch) -- the lanes' searches diverge at once, so an interleaved line holds one useful 2-byte element
-    w.base = works + tid * BOT_WORK_WORDS;
+    w.cells = c.W * c.H;                                    // 64 cells (512 B of scratch) for an 8x8 room, 484 for a 3x3 maze
+    w.base = works + tid * (int64_t)(4 * w.cells);
     w.stride = 1;
     for (int64_t i = tid; i < n; i += nthreads) {
         const Hot h = hots[i];

@@ -88,7 +88,7 @@ int hs_bot_stack_depth(const uint8_t* state) { return ((const BotState*)state)->
 int hs_bot_decide(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, const uint64_t* stale, uint8_t* state, int stack_cap,
                   int first, int action_taken) {
     static thread_local uint16_t buf[BOT_WORK_WORDS];
-    BotWork work; work.base = buf; work.stride = 1;
+    BotWork work; work.base = buf; work.stride = 1; work.cells = cfg->W * cfg->H;
     return bot_decide(*cfg, rec, *hot, *stale, *(BotState*)state, stack_cap, work, first != 0, action_taken);
 }
 
