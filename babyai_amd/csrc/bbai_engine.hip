@@ -310,7 +310,8 @@ struct WaveCtx {
     __device__ __forceinline__ bool any(bool p) const { return __ballot(p) != 0ull; }
 };
 
-__global__ __launch_bounds__(64) void k_pregen(LevelCfg c, int64_t n, uint8_t* __restrict__ next_recs,
+template <int KIND>
+__global__ __launch_bounds__(64, KIND == K_BONUS ? 4 : 1) void k_pregen(LevelCfg c, int64_t n, uint8_t* __restrict__ next_recs,
                                                Hot* __restrict__ next_hots, uint32_t* __restrict__ mts,
                                                int32_t* __restrict__ mtis, const int32_t* __restrict__ win_list,
                                                const uint32_t* __restrict__ win_count, int all, int depth,
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(64) void k_pregen(LevelCfg c, int64_t n, uint8_t* _
         for (int j = 0; j < cnt; ++j) {
             __syncthreads();
             Gen<WaveCtx> g(WaveCtx(), c, w, mti, last_locked);
-            const int max_steps = g.generate();
+            const int max_steps = g.template generate_kind<KIND>();
             mti = g.mti;
             last_locked = g.last_locked;
             __syncthreads();
@@ -730,6 +731,22 @@ void bbai_destroy(bbai_env* e) {
     delete e;
 }
 
+// k_pregen is instantiated per level family so that a launch carries only that family's mission code
+static void launch_pregen(const bbai_env* e, unsigned grid, const int32_t* win_list, const uint32_t* win_count, int all,
+                          uint8_t* pending, const uint8_t* first_slot) {
+    unsigned long long* fails = (unsigned long long*)(e->total_resets + 1);
+    const dim3 g(grid), b(64);
+    if (e->cfg.kind == K_LEVELGEN)
+        hipLaunchKernelGGL(k_pregen<K_LEVELGEN>, g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
+                           win_count, all, e->depth, pending, first_slot, fails);
+    else if (e->cfg.kind == K_BONUS)
+        hipLaunchKernelGGL(k_pregen<K_BONUS>, g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
+                           win_count, all, e->depth, pending, first_slot, fails);
+    else
+        hipLaunchKernelGGL(k_pregen<K_GOTO>, g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
+                           win_count, all, e->depth, pending, first_slot, fails);
+}
+
 static unsigned pregen_grid(int64_t count_hint) {
     // one single-wave workgroup per env, capped at 256 CUs x 32 wave slots
     int64_t g = std::min<int64_t>(count_hint, 256 * 32);
@@ -769,9 +786,8 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
         const int64_t rh = wall ? e->n : std::max<int64_t>((int64_t)B * (e->n / 64), 64);
         HIP_TRY(hipEventRecord(e->ev_consumed, s));
         HIP_TRY(hipStreamWaitEvent(e->side, e->ev_consumed, 0));
-        hipLaunchKernelGGL(k_pregen, dim3(pregen_grid(rh)), dim3(64), 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt,
-                           e->mti, e->win_list + (size_t)wb * e->period * e->n, e->win_count + 16 * wb, wall, D,
-                           e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n, e->total_resets + 1);
+        launch_pregen(e, pregen_grid(rh), e->win_list + (size_t)wb * e->period * e->n, e->win_count + 16 * wb, wall,
+                      e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n);
         HIP_TRY(hipEventRecord(e->ev_refill[wb], e->side));
         HIP_TRY(hipGetLastError());
     }
@@ -804,8 +820,7 @@ int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
     // fill every env's look-ahead ring with the first D levels of its stream (slot order == stream order)
     HIP_TRY(hipMemsetAsync(e->pending, e->depth, (size_t)n, e->side));
     HIP_TRY(hipMemsetAsync(e->first_slot, 0, (size_t)n, e->side));
-    hipLaunchKernelGGL(k_pregen, dim3(pregen_grid(n)), dim3(64), 0, e->side, e->cfg, n, e->next_rec, e->next_hot, e->mt, e->mti,
-                       e->win_list, e->win_count, 1, e->depth, e->pending, e->first_slot, e->total_resets + 1);
+    launch_pregen(e, pregen_grid(n), e->win_list, e->win_count, 1, e->pending, e->first_slot);
     HIP_TRY(hipGetLastError());
     for (int k = 0; k < 3; ++k) HIP_TRY(hipEventRecord(e->ev_refill[k], e->side));
     HIP_TRY(hipMemsetAsync(e->win_count, 0, 3 * 64, e->side));

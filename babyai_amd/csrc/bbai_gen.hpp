@@ -1140,6 +1140,11 @@ struct Gen {
     // RoomGridLevel._gen_grid: retry until a mission is generated and validated.
     // Returns max_steps (levelgen.py:42-45).
     BB_HD int generate() {
+        return cfg.kind == K_LEVELGEN ? generate_kind<K_LEVELGEN>() : cfg.kind == K_BONUS ? generate_kind<K_BONUS>() : generate_kind<K_GOTO>();
+    }
+    // KIND is the level family (cfg.kind): a kernel instantiated per family carries only that family's mission code
+    template <int KIND>
+    BB_HD int generate_kind() {
         if constexpr (ctx_profiles<Ctx>::value) t_last = ctx.now();
         gave_up = false;
         for (int attempts = 0;; ++attempts) {
@@ -1149,7 +1154,10 @@ struct Gen {
             if (attempts >= 200000) { gave_up = true; break; }
             count(PH_ATTEMPTS);
             build_rooms();
-            bool ok = cfg.kind == K_LEVELGEN ? mission_levelgen() : cfg.kind == K_BONUS ? mission_bonus() : mission_goto();
+            bool ok;
+            if constexpr (KIND == K_LEVELGEN) ok = mission_levelgen();
+            else if constexpr (KIND == K_BONUS) ok = mission_bonus();
+            else ok = mission_goto();
             tick(PH_INSTR);
             bool v = ok && validate();
             tick(PH_VALIDATE);
