@@ -7,7 +7,7 @@
 //                  orientation; the 147-byte encodings of a block's 256 envs are staged in LDS and
 //                  written back as one contiguous, dword-coalesced span.  Finished envs are
 //                  compacted into the reset list with one wave-aggregated atomic per wave.
-//   k_pregen       wave = env: the NEXT levels of an env's MT19937 stream are generated wave-uniformly
+//   k_pregen<F>    (one instantiation per level family F) wave = env: the NEXT levels of an env's MT19937 stream are generated wave-uniformly
 //                  with the whole working set in LDS (bbai_gen.hpp) into the env's look-ahead ring.
 //                  step() draws no randomness, so an env's level sequence is a pure function of
 //                  its seed: generation runs ahead of need on a second HIP stream, one launch per
@@ -19,7 +19,10 @@
 //   k_render       RGBImgPartialObsWrapper as a pure tile-atlas gather: atlas + per-cell tile ids
 //                  in LDS, 16 bytes per lane per store, a wave writes 1 KiB of contiguous pixels.
 //
-// Reference semantics: see bbai_step.hpp / bbai_gen.hpp headers for file:line citations.
+//   k_bot<W>       lane = env: one decision of the reference's GOFAI expert (babyai/bot.py) per env, W = occupancy target
+//                  (bbai_bot.hpp); only launched by bbai_bot_act.
+//
+// Reference semantics: see bbai_step.hpp / bbai_gen.hpp / bbai_bot.hpp headers for file:line citations.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
