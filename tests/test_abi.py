@@ -110,3 +110,20 @@ def test_c_abi_demo_runs_without_python_or_torch(gpu, tmp_path):
         digest = ((digest ^ int(b)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert ("obs_digest=%016x" % digest) in out, out
     env.close()
+
+
+def test_product_never_touches_the_oracle_or_the_reference():
+    """oracle/ is test infrastructure: nothing under babyai_amd/ may import it or read /root/reference, and bench.py may
+    only reach it inside the cpu_baseline leg."""
+    import re
+    pkg = os.path.join(ROOT, "babyai_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
+                assert not re.search(r"""["']/root/reference""", text), f          # (citations in comments are fine)
+                assert not re.search(r"""["'][^"']*hostsim""", text), f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle import", bench)]
+    assert len(uses) == 1 and "cpu_baseline" in bench[uses[0]:uses[0] + 40]
