@@ -123,7 +123,8 @@ def test_product_never_touches_the_oracle_or_the_reference():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
                 assert not re.search(r"""["']/root/reference""", text), f          # (citations in comments are fine)
-                assert not re.search(r"""["'][^"']*hostsim""", text), f
+                if f.endswith(".py"):
+                    assert "hostsim" not in text, f
     bench = open(os.path.join(ROOT, "bench.py")).read()
     uses = [m.start() for m in re.finditer(r"from oracle import", bench)]
     assert len(uses) == 1 and "cpu_baseline" in bench[uses[0]:uses[0] + 40]
