@@ -27,8 +27,6 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
-#include <thread>
-#include <vector>
 #include <algorithm>
 
 #include "../../include/bbai.h"
@@ -97,7 +95,7 @@ struct bbai_env {
     uint8_t* first_slot;  // [3][n]  first slot the env consumed in the window
     int32_t* win_list;    // [3][B*n] envs consumed in the window, one entry per (tick, finished env); an env that
                           //          finishes again within the window is marked -1 (every env may finish on every tick)
-    uint32_t* win_count;  // [3][16]
+    uint32_t* win_count;  // [3][WIN_STRIDE]: [1 + pos] = finished envs of tick `pos` of the window
     int win_all[3];       // window contained a reset() of every env: refill iterates all envs
     int32_t* reset_list;  // [n]     envs finished by the current step (k_step -> k_consume / k_tokens)
     uint32_t* counters;   // [2][16] [p][0] = reset list length; ping-pong by step parity so that k_consume can zero the
@@ -108,6 +106,10 @@ struct bbai_env {
     uint8_t* tokens;      // optional caller-owned [n][72] mission token buffer kept current on resets
     hipStream_t side;     // look-ahead generation stream
     hipEvent_t ev_consumed, ev_refill[3];
+    hipStream_t last_stream;   // the caller's stream of the previous call; a handle follows ONE stream at a time: when the
+    bool have_stream;          // caller switches, the new stream is ordered behind the old one's work (adopt_stream)
+    hipEvent_t ev_switch;
+    int pregen_cap;       // BBAI_PREGEN_BLOCKS: upper bound on resident look-ahead workgroups (experiments)
     int64_t tick;         // number of consume_and_refill calls so far
     uint8_t* atlas;       // [n_tiles][192]
     uint8_t* lut;         // [2][256]
@@ -124,6 +126,8 @@ struct bbai_env {
 // k_step
 // ------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int MAX_PERIOD = 32;          // refill period B (ticks per look-ahead refill); ring depth D = 2B
+constexpr int WIN_STRIDE = 64;          // uint32 per window-count block (1 + MAX_PERIOD used)
 constexpr int STEP_BLOCK = 256;
 constexpr int OBS_PAD = 148;           // LDS row per env (bytes), dword multiple
 
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(LevelCfg c, int64_t n, uint
                                                      const uint32_t* __restrict__ vheads, const uint64_t* __restrict__ vsets,
                                                      const uint8_t* __restrict__ actions, uint8_t* __restrict__ image,
                                                      uint8_t* __restrict__ dirs, float* __restrict__ rewards,
-                                                     uint8_t* __restrict__ dones, int auto_reset,
+                                                     double* __restrict__ rewards64, uint8_t* __restrict__ dones, int auto_reset,
                                                      int32_t* __restrict__ reset_list, uint32_t* __restrict__ counters) {
     __shared__ __attribute__((aligned(16))) uint8_t s_obs[STEP_BLOCK * OBS_PAD];
     const int64_t env0 = (int64_t)blockIdx.x * STEP_BLOCK;
@@ -238,20 +242,27 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(LevelCfg c, int64_t n, uint
         uint8_t* rec = recs + env * (int64_t)c.rec_bytes;
         if (!h.frozen) {
             uint64_t stale = stales[env];
-            float reward;
+            double reward;
             VProg vp; vp.head = vheads[env]; vp.sets = vsets + env; vp.stride = n;
             bool done = step_env_cmd(c, rec, vp, h, stale, actions[env], reward);
             if (done && !auto_reset) h.frozen = 1;
             want_reset = done && auto_reset;
             hots[env] = h;
             stales[env] = stale;
-            rewards[env] = reward;
+            rewards[env] = (float)reward;
+            if (rewards64) rewards64[env] = reward;        // the reference's Python float, bit for bit (levelgen.py:59-61)
             dones[env] = done ? 1 : 0;
             dirs[env] = h.dir;
             observe_lane_lds(c, rec, h, s_obs + threadIdx.x * OBS_PAD);
         }
         // frozen envs keep re-emitting their last outputs: copy them through LDS unchanged
         else {
+            if (h.frozen == 2 && auto_reset) {      // level the generator gave up on (last-resort guard): skip to the next one
+                rewards[env] = 0.0f;
+                if (rewards64) rewards64[env] = 0.0;
+                dones[env] = 1;
+                want_reset = true;
+            }
             const uint8_t* src = image + env * OBS_BYTES;
             for (int b = 0; b < OBS_BYTES; ++b) s_obs[threadIdx.x * OBS_PAD + b] = src[b];
         }
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(64, KIND == K_BONUS ? 4 : 1) void k_pregen(LevelCfg
     int64_t count = n;
     if (!all) {                                          // window list = concatenated per-tick lists
         count = 0;
-        for (int j = 0; j < 8; ++j) count += (int64_t)win_count[1 + j];
+        for (int j = 0; j < MAX_PERIOD; ++j) count += (int64_t)win_count[1 + j];
     }
     const int lane = threadIdx.x;
     for (int64_t it = blockIdx.x; it < count; it += gridDim.x) {
@@ -488,6 +499,15 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_bot(LevelCfg c, int64_t 
     }
 }
 
+// env.seed(s) for every env: lane = env.  Each lane writes its own 624-word state (2496-byte pitch): a wave's 64 open
+// lines stay in L2 until they are full, so HBM sees each state line once.
+__global__ __launch_bounds__(64) void k_seed(int64_t n, const uint64_t* __restrict__ seeds, uint32_t* __restrict__ mts, int32_t* __restrict__ mtis) {
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    seed_env(seeds[i], mts + i * MT_N);
+    mtis[i] = MT_N;                               // output index 624: the first draw twists (RandomState.seed leaves pos = N)
+}
+
 __global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, Hot* __restrict__ next_hots, uint64_t* __restrict__ stales, int depth) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -603,7 +623,7 @@ __global__ __launch_bounds__(64) void k_tokens(LevelCfg c, int64_t n, const uint
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-int bbai_version(void) { return 100; }
+int bbai_version(void) { return 200; }
 const char* bbai_last_error(void) { return g_err; }
 
 int bbai_fill_layout(bbai_level_cfg* cfg) {
@@ -661,12 +681,18 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->vhead, (size_t)n_envs * 4);
     alloc((void**)&e->vset, (size_t)n_envs * 8 * 8);
     {
-        const char* ev = getenv("BBAI_LOOKAHEAD");       // refill period B (ticks per refill); ring depth D = 2B
-        // default: the longest period (8, 4, 2 ticks per refill) whose 2B-slot ring stays under 4 GiB
-        // (1M BossLevel envs -> 2; 131072 GoTo envs -> 8)
-        const size_t slot_bytes = (size_t)n_envs * c.rec_bytes, cap = (size_t)4 << 30;
-        int b = ev ? atoi(ev) : (slot_bytes * 16 <= cap ? 8 : slot_bytes * 8 <= cap ? 4 : 2);
-        e->period = b < 1 ? 1 : (b > 8 ? 8 : b);
+        // Refill period B (ticks per look-ahead refill, BBAI_LOOKAHEAD); ring depth D = 2B.  One k_pregen launch per
+        // window lasts as long as its slowest level (hundreds of microseconds to milliseconds: rejection sampling has a
+        // heavy tail) and has to land within one window, so B ticks of the step path must outlast it or the step stream
+        // waits: default = the longest period of 32, 16, 8, 4, 2 whose ring fits BBAI_RING_GIB (default 16 GiB of the
+        // 288 GB).  (131072 GoTo envs -> 32; 1M BossLevel envs -> 4.)
+        const char* ev = getenv("BBAI_LOOKAHEAD");
+        const char* gv = getenv("BBAI_RING_GIB");
+        const size_t slot_bytes = (size_t)n_envs * c.rec_bytes, cap = (size_t)(gv ? std::max(1, atoi(gv)) : 16) << 30;
+        int b = 2;
+        if (ev) b = atoi(ev);
+        else for (int cand = MAX_PERIOD; cand >= 2; cand >>= 1) if (slot_bytes * 2 * (size_t)cand <= cap) { b = cand; break; }
+        e->period = b < 1 ? 1 : (b > MAX_PERIOD ? MAX_PERIOD : b);
         e->depth = 2 * e->period;
     }
     const size_t D = (size_t)e->depth;
@@ -675,7 +701,7 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->pending, 3 * (size_t)n_envs);
     alloc((void**)&e->first_slot, 3 * (size_t)n_envs);
     alloc((void**)&e->win_list, 3 * (size_t)e->period * (size_t)n_envs * 4);
-    alloc((void**)&e->win_count, 3 * 64);
+    alloc((void**)&e->win_count, 3 * WIN_STRIDE * 4);
     alloc((void**)&e->reset_list, (size_t)n_envs * 4);
     alloc((void**)&e->counters, 128);
     alloc((void**)&e->total_resets, 16);
@@ -702,7 +728,7 @@ static int create_finish(bbai_env* e) {
     HIP_TRY(hipMemset(e->next_rec, 0, D * (size_t)n_envs * c.rec_bytes));
     HIP_TRY(hipMemset(e->pending, 0, 3 * (size_t)n_envs));
     HIP_TRY(hipMemset(e->first_slot, 0, 3 * (size_t)n_envs));
-    HIP_TRY(hipMemset(e->win_count, 0, 3 * 64));
+    HIP_TRY(hipMemset(e->win_count, 0, 3 * WIN_STRIDE * 4));
     HIP_TRY(hipMemset(e->vhead, 0, (size_t)n_envs * 4));
     HIP_TRY(hipMemset(e->vset, 0, (size_t)n_envs * 64));
     HIP_TRY(hipMemset(e->counters, 0, 128));
@@ -710,9 +736,15 @@ static int create_finish(bbai_env* e) {
     {
         int lo = 0, hi = 0;     // look-ahead generation should get wave slots as soon as any free up
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIP_TRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, hi));
+        const char* pv = getenv("BBAI_PREGEN_PRIORITY");     // 1 (default): highest priority, 0: default priority
+        HIP_TRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, (pv && atoi(pv) == 0) ? lo : hi));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_consumed, hipEventDisableTiming));
         for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreateWithFlags(&e->ev_refill[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_switch, hipEventDisableTiming));
+    }
+    {
+        const char* ev = getenv("BBAI_PREGEN_BLOCKS");
+        e->pregen_cap = ev ? std::max(64, atoi(ev)) : 256 * 32;
     }
     return BBAI_OK;
 }
@@ -725,6 +757,7 @@ void bbai_destroy(bbai_env* e) {
     (void)hipDeviceSynchronize();
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->ev_consumed) (void)hipEventDestroy(e->ev_consumed);
+    if (e->ev_switch) (void)hipEventDestroy(e->ev_switch);
     for (int k = 0; k < 3; ++k) if (e->ev_refill[k]) (void)hipEventDestroy(e->ev_refill[k]);
     void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
@@ -750,10 +783,23 @@ static void launch_pregen(const bbai_env* e, unsigned grid, const int32_t* win_l
                            win_count, all, e->depth, pending, first_slot, fails);
 }
 
-static unsigned pregen_grid(int64_t count_hint) {
+static unsigned pregen_grid(const bbai_env* e, int64_t count_hint) {
     // one single-wave workgroup per env, capped at 256 CUs x 32 wave slots
-    int64_t g = std::min<int64_t>(count_hint, 256 * 32);
+    int64_t g = std::min<int64_t>(count_hint, e->pregen_cap);
     return (unsigned)std::max<int64_t>(g, 1);
+}
+
+// A handle's launches are ordered by ONE caller stream at a time (plus the private look-ahead stream, which is tied to
+// it by events).  A caller that comes back on a different stream gets that stream ordered behind everything the handle
+// enqueued on the previous one -- correct, but it serialises the two streams at that point.
+static int adopt_stream(bbai_env* e, hipStream_t s) {
+    if (e->have_stream && e->last_stream != s) {
+        HIP_TRY(hipEventRecord(e->ev_switch, e->last_stream));
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_switch, 0));
+    }
+    e->last_stream = s;
+    e->have_stream = true;
+    return BBAI_OK;
 }
 
 // main stream: slots -> live state (+ first obs); side stream: refill the consumed slots.
@@ -767,7 +813,7 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
         // wait for that refill; its buffer becomes the one window w+1 will use, so clear its count.
         const int ob = (int)((w + 1) % 3);
         HIP_TRY(hipStreamWaitEvent(s, e->ev_refill[ob], 0));
-        HIP_TRY(hipMemsetAsync(e->win_count + 16 * ob, 0, 64, s));
+        HIP_TRY(hipMemsetAsync(e->win_count + WIN_STRIDE * ob, 0, WIN_STRIDE * 4, s));
         e->win_all[ob] = 0;
     }
     if (all) e->win_all[wb] = 1;
@@ -775,7 +821,7 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
     hipLaunchKernelGGL(k_consume, dim3((unsigned)std::min<int64_t>((hint + 3) / 4, 8192)), dim3(256), 0, s, e->cfg, e->n, e->rec,
                        e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, e->reset_list, e->counters + 16 * e->step_parity, all,
                        e->total_resets, D, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n,
-                       e->win_list + (size_t)wb * e->period * e->n, e->win_count + 16 * wb, pos, image, dirs,
+                       e->win_list + (size_t)wb * e->period * e->n, e->win_count + WIN_STRIDE * wb, pos, image, dirs,
                        e->counters + 16 * (e->step_parity ^ 1));
     if (e->tokens)
         hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n, e->rec,
@@ -789,7 +835,7 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
         const int64_t rh = wall ? e->n : std::max<int64_t>((int64_t)B * (e->n / 64), 64);
         HIP_TRY(hipEventRecord(e->ev_consumed, s));
         HIP_TRY(hipStreamWaitEvent(e->side, e->ev_consumed, 0));
-        launch_pregen(e, pregen_grid(rh), e->win_list + (size_t)wb * e->period * e->n, e->win_count + 16 * wb, wall,
+        launch_pregen(e, pregen_grid(e, rh), e->win_list + (size_t)wb * e->period * e->n, e->win_count + WIN_STRIDE * wb, wall,
                       e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n);
         HIP_TRY(hipEventRecord(e->ev_refill[wb], e->side));
         HIP_TRY(hipGetLastError());
@@ -801,34 +847,27 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
 int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
     if (!e || !seeds || n != e->n) { snprintf(g_err, sizeof(g_err), "seed: need exactly n_envs seeds"); return BBAI_ERR_ARG; }
     ON_DEVICE(e->device);
-    const int64_t chunk = 65536;
-    std::vector<uint32_t> buf((size_t)std::min<int64_t>(chunk, n) * MT_N);
-    unsigned hw = std::thread::hardware_concurrency();
-    int nthreads = (int)std::max(1u, std::min(hw ? hw : 1u, 64u));
-    for (int64_t base = 0; base < n; base += chunk) {
-        int64_t cnt = std::min<int64_t>(chunk, n - base);
-        std::vector<std::thread> th;
-        for (int t = 0; t < nthreads; ++t)
-            th.emplace_back([&, t]() {
-                for (int64_t i = t; i < cnt; i += nthreads) seed_env(seeds[base + i], buf.data() + (size_t)i * MT_N);
-            });
-        for (auto& x : th) x.join();
-        HIP_TRY(hipMemcpy(e->mt + base * MT_N, buf.data(), (size_t)cnt * MT_N * 4, hipMemcpyHostToDevice));
-    }
-    // output index 624: the first draw twists (RandomState.seed leaves pos = N)
-    std::vector<int32_t> idx((size_t)n, MT_N);
-    HIP_TRY(hipMemcpy(e->mti, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipDeviceSynchronize());             // nothing of an earlier run may still be in flight on either stream
+    // 8 bytes per env cross PCIe; sha512 + init_by_array run per lane (k_seed).  The seeds are parked in the reset list +
+    // window list area (n * 4 * (1 + 3B) bytes >= 8 n), which nothing reads before the first reset.
+    uint64_t* seeds_dev = (uint64_t*)e->win_list;
+    HIP_TRY(hipMemcpy(seeds_dev, seeds, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_seed, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, e->side, n, seeds_dev, e->mt, e->mti);
     hipLaunchKernelGGL(k_init_hot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->side, n, e->hot, e->next_hot, e->stale, e->depth);
-    // fill every env's look-ahead ring with the first D levels of its stream (slot order == stream order)
+    // fill every env's look-ahead ring with the first D levels of its stream (slot order == stream order).  ALL THREE
+    // window buffers start clean: a re-seed may land in the middle of a window that was using buffer 1 or 2.
+    HIP_TRY(hipMemsetAsync(e->pending, 0, 3 * (size_t)n, e->side));
+    HIP_TRY(hipMemsetAsync(e->first_slot, 0, 3 * (size_t)n, e->side));
     HIP_TRY(hipMemsetAsync(e->pending, e->depth, (size_t)n, e->side));
-    HIP_TRY(hipMemsetAsync(e->first_slot, 0, (size_t)n, e->side));
-    launch_pregen(e, pregen_grid(n), e->win_list, e->win_count, 1, e->pending, e->first_slot);
+    launch_pregen(e, pregen_grid(e, n), e->win_list, e->win_count, 1, e->pending, e->first_slot);
     HIP_TRY(hipGetLastError());
     for (int k = 0; k < 3; ++k) HIP_TRY(hipEventRecord(e->ev_refill[k], e->side));
-    HIP_TRY(hipMemsetAsync(e->win_count, 0, 3 * 64, e->side));
+    HIP_TRY(hipMemsetAsync(e->win_count, 0, 3 * WIN_STRIDE * 4, e->side));
+    HIP_TRY(hipMemsetAsync(e->counters, 0, 128, e->side));
     e->win_all[0] = e->win_all[1] = e->win_all[2] = 0;
     e->tick = 0;
+    e->step_parity = 0;
+    e->next_counter_clean = true;
     HIP_TRY(hipDeviceSynchronize());
     e->seeded = true;
     e->live = false;
@@ -840,14 +879,16 @@ int bbai_reset(bbai_env* e, uint8_t* image, uint8_t* dirs, void* stream) {
     if (!e->seeded) { snprintf(g_err, sizeof(g_err), "reset before seed"); return BBAI_ERR_STATE; }
     ON_DEVICE(e->device);
     hipStream_t s = (hipStream_t)stream;
-    int rc = consume_and_refill(e, s, image, dirs, 1);
+    int rc = adopt_stream(e, s);
+    if (rc != BBAI_OK) return rc;
+    rc = consume_and_refill(e, s, image, dirs, 1);
     if (rc != BBAI_OK) return rc;
     e->live = true;
     return BBAI_OK;
 }
 
-int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, uint8_t* dones,
-              int auto_reset, void* stream) {
+int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64,
+              uint8_t* dones, int auto_reset, void* stream) {
     if (!e || !actions || !image || !dirs || !rewards || !dones) ARG_FAIL("null handle or buffer");
     if (!e->live) { snprintf(g_err, sizeof(g_err), "step before reset"); return BBAI_ERR_STATE; }
     if (auto_reset && !e->seeded) {     // live through import_state only: there is no level stream to reset from
@@ -856,12 +897,13 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
     }
     ON_DEVICE(e->device);
     hipStream_t s = (hipStream_t)stream;
+    { int rc = adopt_stream(e, s); if (rc != BBAI_OK) return rc; }
     int32_t* list = e->reset_list;
     uint32_t* counter = e->counters + 16 * e->step_parity;
     if (!e->next_counter_clean) HIP_TRY(hipMemsetAsync(counter, 0, 4, s));   // (k_consume of the previous step zeroes it)
     e->next_counter_clean = false;
     hipLaunchKernelGGL(k_step, dim3((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), dim3(STEP_BLOCK), 0, s, e->cfg, e->n,
-                       e->rec, e->hot, e->stale, e->vhead, e->vset, actions, image, dirs, rewards, dones, auto_reset, list, counter);
+                       e->rec, e->hot, e->stale, e->vhead, e->vset, actions, image, dirs, rewards, rewards64, dones, auto_reset, list, counter);
     HIP_TRY(hipGetLastError());
     // the number of finished envs is only known on the device: fixed grids, device-side count
     if (auto_reset) return consume_and_refill(e, s, image, dirs, 0);
@@ -888,6 +930,7 @@ int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream
     // point and keeps wave slots turning over for the look-ahead stream.
     const int gpb = 8;
     unsigned grid = (unsigned)((groups + gpb - 1) / gpb);
+    { int rc = adopt_stream(e, (hipStream_t)stream); if (rc != BBAI_OK) return rc; }
     hipLaunchKernelGGL(k_render, dim3(grid), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut,
                        e->n_tiles);
     HIP_TRY(hipGetLastError());
@@ -937,6 +980,94 @@ int bbai_import_state(bbai_env* e, int64_t first, int64_t count, const uint8_t* 
     return BBAI_OK;
 }
 
+// ---- checkpoint: EVERYTHING an auto-resetting batch needs to continue bit-identically in another handle --------------
+// live records / hot / stale, the MT19937 streams, the look-ahead ring and its window bookkeeping, counters, and the
+// expert's plans when the expert has been used.  Blob = header + the device arrays in a fixed order.
+struct CkptHeader {
+    uint64_t magic; int32_t version, period; int64_t n; LevelCfg cfg; int32_t depth, step_parity, next_counter_clean, seeded, live;
+    int32_t win_all[3]; int32_t bot_stack; int64_t tick; int64_t bot_threads;
+};
+struct Seg { void* p; size_t bytes; };
+static int ckpt_segments(const bbai_env* e, Seg* out) {
+    const size_t n = (size_t)e->n, D = (size_t)e->depth, B = (size_t)e->period, rb = (size_t)e->cfg.rec_bytes;
+    int k = 0;
+    out[k++] = {e->rec, n * rb}; out[k++] = {e->hot, n * sizeof(Hot)}; out[k++] = {e->stale, n * 8};
+    out[k++] = {e->mt, n * MT_N * 4}; out[k++] = {e->mti, n * 4}; out[k++] = {e->vhead, n * 4}; out[k++] = {e->vset, n * 64};
+    out[k++] = {e->next_rec, D * n * rb}; out[k++] = {e->next_hot, D * n * sizeof(Hot)};
+    out[k++] = {e->pending, 3 * n}; out[k++] = {e->first_slot, 3 * n}; out[k++] = {e->win_list, 3 * B * n * 4};
+    out[k++] = {e->win_count, 3 * WIN_STRIDE * 4}; out[k++] = {e->reset_list, n * 4}; out[k++] = {e->counters, 128};
+    out[k++] = {e->total_resets, 16};
+    if (e->bot_state) { out[k++] = {e->bot_state, n * bot_state_bytes(e->bot_stack)}; out[k++] = {e->bot_stats, 16}; }
+    return k;
+}
+
+int64_t bbai_checkpoint_bytes(bbai_env* e) {
+    if (!e) return -1;
+    Seg seg[24];
+    const int k = ckpt_segments(e, seg);
+    size_t total = sizeof(CkptHeader);
+    for (int i = 0; i < k; ++i) total += seg[i].bytes;
+    return (int64_t)total;
+}
+
+int bbai_checkpoint_save(bbai_env* e, void* host_buf, int64_t bytes) {
+    if (!e || !host_buf || bytes != bbai_checkpoint_bytes(e)) ARG_FAIL("null pointer or buffer size != bbai_checkpoint_bytes()");
+    ON_DEVICE(e->device);
+    HIP_TRY(hipDeviceSynchronize());             // both streams idle: the ring and the window lists are at rest
+    CkptHeader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = 0x42424149434b5054ull; h.version = 1; h.period = e->period; h.n = e->n; h.cfg = e->cfg; h.depth = e->depth;
+    h.step_parity = e->step_parity; h.next_counter_clean = e->next_counter_clean; h.seeded = e->seeded; h.live = e->live;
+    for (int i = 0; i < 3; ++i) h.win_all[i] = e->win_all[i];
+    h.bot_stack = e->bot_state ? e->bot_stack : 0; h.tick = e->tick; h.bot_threads = e->bot_threads;
+    uint8_t* dst = (uint8_t*)host_buf;
+    memcpy(dst, &h, sizeof(h)); dst += sizeof(h);
+    Seg seg[24];
+    const int k = ckpt_segments(e, seg);
+    for (int i = 0; i < k; ++i) { HIP_TRY(hipMemcpy(dst, seg[i].p, seg[i].bytes, hipMemcpyDeviceToHost)); dst += seg[i].bytes; }
+    return BBAI_OK;
+}
+
+static int bot_alloc(bbai_env* e, int cap);
+
+int bbai_checkpoint_load(bbai_env* e, const void* host_buf, int64_t bytes) {
+    if (!e || !host_buf || bytes < (int64_t)sizeof(CkptHeader)) ARG_FAIL("null pointer or short buffer");
+    CkptHeader h;
+    memcpy(&h, host_buf, sizeof(h));
+    if (h.magic != 0x42424149434b5054ull || h.version != 1) ARG_FAIL("not a bbai checkpoint");
+    if (h.n != e->n || memcmp(&h.cfg, &e->cfg, sizeof(LevelCfg)) != 0 || h.depth != e->depth || h.period != e->period)
+        ARG_FAIL("checkpoint was taken from a different level / batch size / look-ahead depth (BBAI_LOOKAHEAD)");
+    ON_DEVICE(e->device);
+    HIP_TRY(hipDeviceSynchronize());
+    if (h.bot_stack && (!e->bot_state || e->bot_stack != h.bot_stack)) {
+        if (e->bot_state) ARG_FAIL("the handle's expert uses a different stack capacity (BBAI_BOT_STACK)");
+        int rc = bot_alloc(e, h.bot_stack);
+        if (rc != BBAI_OK) return rc;
+    }
+    const bool had_bot = e->bot_state != nullptr;
+    if (!h.bot_stack && had_bot) {               // checkpoint without expert state: every env gets a fresh Bot
+        HIP_TRY(hipMemset(e->bot_state, 0, (size_t)e->n * bot_state_bytes(e->bot_stack)));
+        HIP_TRY(hipMemset(e->bot_stats, 0, 16));
+    }
+    uint8_t* keep_state = e->bot_state;
+    if (!h.bot_stack) e->bot_state = nullptr;    // (segment list follows the checkpoint's contents)
+    Seg seg[24];
+    const int k = ckpt_segments(e, seg);
+    e->bot_state = keep_state;
+    size_t total = sizeof(CkptHeader);
+    for (int i = 0; i < k; ++i) total += seg[i].bytes;
+    if ((int64_t)total != bytes) ARG_FAIL("checkpoint size does not match this handle");
+    const uint8_t* src = (const uint8_t*)host_buf + sizeof(CkptHeader);
+    for (int i = 0; i < k; ++i) { HIP_TRY(hipMemcpy(seg[i].p, src, seg[i].bytes, hipMemcpyHostToDevice)); src += seg[i].bytes; }
+    e->step_parity = h.step_parity; e->next_counter_clean = h.next_counter_clean != 0; e->seeded = h.seeded != 0; e->live = h.live != 0;
+    for (int i = 0; i < 3; ++i) e->win_all[i] = h.win_all[i];
+    e->tick = h.tick;
+    // the refill events of the saved run completed before the save: re-record them on the (idle) look-ahead stream
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventRecord(e->ev_refill[i], e->side));
+    HIP_TRY(hipDeviceSynchronize());
+    return BBAI_OK;
+}
+
 int bbai_get_programs(bbai_env* e, int64_t first, int64_t count, uint8_t* prog) {
     if (!e || !prog || first < 0 || count < 0 || first + count > e->n) ARG_FAIL("null pointer or env range out of bounds");
     ON_DEVICE(e->device);
@@ -946,31 +1077,36 @@ int bbai_get_programs(bbai_env* e, int64_t first, int64_t count, uint8_t* prog) 
     return BBAI_OK;
 }
 
+static int bot_alloc(bbai_env* e, int cap) {             // the expert's state: all three buffers or none
+    const int64_t threads = std::min<int64_t>((e->n + 63) / 64 * 64, 256 * 8 * 64);
+    void *st = nullptr, *wk = nullptr, *ss = nullptr;
+    const size_t sbytes = bot_state_bytes(cap);
+    hipError_t err = hipMalloc(&st, (size_t)e->n * sbytes);
+    if (err == hipSuccess) err = hipMalloc(&wk, (size_t)threads * BOT_WORK_WORDS * sizeof(uint16_t));
+    if (err == hipSuccess) err = hipMalloc(&ss, 16);
+    if (err == hipSuccess) err = hipMemset(st, 0, (size_t)e->n * sbytes);
+    if (err == hipSuccess) err = hipMemset(ss, 0, 16);
+    if (err != hipSuccess) {
+        (void)hipFree(st); (void)hipFree(wk); (void)hipFree(ss);
+        snprintf(g_err, sizeof(g_err), "allocating the expert's state failed: %s", hipGetErrorString(err));
+        return BBAI_ERR_NOMEM;
+    }
+    e->bot_stack = cap;
+    e->bot_state = (uint8_t*)st; e->bot_work = (uint16_t*)wk; e->bot_stats = (uint64_t*)ss; e->bot_threads = threads;
+    return BBAI_OK;
+}
+
 int bbai_bot_act(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions, void* stream) {
     if (!e || !actions) ARG_FAIL("null handle or output buffer");
     if (!e->live) { snprintf(g_err, sizeof(g_err), "bot_act before reset"); return BBAI_ERR_STATE; }
     ON_DEVICE(e->device);
-    if (!e->bot_state) {                                   // first use: all three buffers or none
-        const int64_t threads = std::min<int64_t>((e->n + 63) / 64 * 64, 256 * 8 * 64);
-        void *st = nullptr, *wk = nullptr, *ss = nullptr;
+    if (!e->bot_state) {                                   // first use
         // Subgoal stack depth per env.  The reference's list is unbounded; 48 covers every plan that makes progress (the
         // rare bot that loops without progress grows its stack until max_steps and fails the episode -- here it gives up
         // when the stack is full, counted in bbai_bot_stats().capacity).  Raise it to follow such a bot further.
         const char* ev = getenv("BBAI_BOT_STACK");
-        const int cap = ev ? std::max(8, std::min(atoi(ev), 4096)) : BOT_STACK;
-        const size_t sbytes = bot_state_bytes(cap);
-        hipError_t err = hipMalloc(&st, (size_t)e->n * sbytes);
-        if (err == hipSuccess) err = hipMalloc(&wk, (size_t)threads * BOT_WORK_WORDS * sizeof(uint16_t));
-        if (err == hipSuccess) err = hipMalloc(&ss, 16);
-        if (err == hipSuccess) err = hipMemset(st, 0, (size_t)e->n * sbytes);
-        if (err == hipSuccess) err = hipMemset(ss, 0, 16);
-        if (err != hipSuccess) {
-            (void)hipFree(st); (void)hipFree(wk); (void)hipFree(ss);
-            snprintf(g_err, sizeof(g_err), "bot_act: allocating the expert's state failed: %s", hipGetErrorString(err));
-            return BBAI_ERR_NOMEM;
-        }
-        e->bot_stack = cap;
-        e->bot_state = (uint8_t*)st; e->bot_work = (uint16_t*)wk; e->bot_stats = (uint64_t*)ss; e->bot_threads = threads;
+        int rc = bot_alloc(e, ev ? std::max(8, std::min(atoi(ev), 4096)) : BOT_STACK);
+        if (rc != BBAI_OK) return rc;
     }
     {
         // Occupancy target, measured (profiles/r01/bot_bench.jsonl): the fully inlined expert wants ~400
@@ -979,6 +1115,7 @@ int bbai_bot_act(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions, voi
         const bool maze = e->cfg.num_rows * e->cfg.num_cols > 1;
         const dim3 grid((unsigned)(e->bot_threads / 64)), block(64);
         hipStream_t s = (hipStream_t)stream;
+        { int rc = adopt_stream(e, s); if (rc != BBAI_OK) return rc; }
         unsigned long long* stats = (unsigned long long*)e->bot_stats;
         if (maze)
             hipLaunchKernelGGL(k_bot<2>, grid, block, 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,

@@ -78,6 +78,8 @@ BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale
         return (r.prog.strict(leaf) && h.carry != NONE8) ? V_FAILURE : V_CONTINUE;
     }
     // L_PUTNEXT
+    // strict: a pickup action while holding something fails the instruction (verifier.py:398-401)
+    if (r.prog.strict(leaf) && action == A_PICKUP && h.carry != NONE8) return V_FAILURE;
     if (action != A_DROP) return V_CONTINUE;
     if (pre == NONE8 || !(set0 >> pre & 1)) return V_CONTINUE;
     if (h.carry == pre) return V_CONTINUE;          // drop failed: cur_pos == (-1,-1)
@@ -112,26 +114,33 @@ BB_HD int verify_root(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale
     const int b2 = before ? 2 : 0, n2 = before ? p->n_b() : p->n_a(), s2 = before ? 3 : 1;
     if (!(h.vstate & 1)) {
         int st = verify_side(c, r, h, stale, b1, n1, s1, action);
-        if (st != V_SUCCESS) return st;
+        if (st == V_FAILURE) return st;
+        if (st != V_SUCCESS) {
+            // strict Seq: completing the second part first fails (verifier.py:466-469,507-510); the probe IS a verify()
+            // of the second part, with its side effects (preCarrying, And progress bits)
+            if (p->strict_seq() && verify_side(c, r, h, stale, b2, n2, s2, action) == V_SUCCESS) return V_FAILURE;
+            return st;
+        }
         h.vstate |= 1;
     }
     return verify_side(c, r, h, stale, b2, n2, s2, action);
 }
 
-// reward = 1 - 0.9 * (step_count / max_steps) in float64, no FMA contraction, then f32.
-BB_HD float success_reward(int step, int max_steps) {
+// reward = 1 - 0.9 * (step_count / max_steps) in float64 (MiniGridEnv._reward, returned as a Python float at
+// levelgen.py:59-61), no FMA contraction.  The f64 value crosses the ABI as is; the f32 output is its rounding.
+BB_HD double success_reward(int step, int max_steps) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double q = __ddiv_rn((double)step, (double)max_steps);
-    return (float)__dsub_rn(1.0, __dmul_rn(0.9, q));
+    return __dsub_rn(1.0, __dmul_rn(0.9, q));
 #else
     volatile double q = (double)step / (double)max_steps;
     volatile double m = 0.9 * q;
-    return (float)(1.0 - m);
+    return 1.0 - m;
 #endif
 }
 
 // MiniGridEnv.step + RoomGridLevel.step for one env.  Returns done; reward by reference.
-BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, float& reward) {
+BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, double& reward) {
     EnvRef r = env_ref(c, rec, vp);
     h.step = (uint16_t)(h.step + 1);
     const int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
@@ -187,7 +196,7 @@ BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, ui
     if (action == A_DROP) stale = 0;
     const int status = verify_root(c, r, h, stale, action);
     bool done = h.step >= h.max_steps;
-    reward = 0.0f;
+    reward = 0.0;
     if (status == V_SUCCESS) { done = true; reward = success_reward(h.step, h.max_steps); }
     else if (status == V_FAILURE) done = true;      // levelgen.py:62-64
     return done;
@@ -197,8 +206,8 @@ BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, ui
 // (babyai/rl/utils/penv.py:12-14) and what make_agent_demos.py:84-88 does after a bot crash.  The episode ends with
 // done = 1, reward = 0 and (auto-reset) the next observation is the first one of the env's next level.
 constexpr int A_RESET_ENV = 7;
-BB_HD bool step_env_cmd(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, float& reward) {
-    if (action == A_RESET_ENV) { reward = 0.0f; return true; }
+BB_HD bool step_env_cmd(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, double& reward) {
+    if (action == A_RESET_ENV) { reward = 0.0; return true; }
     return step_env(c, rec, vp, h, stale, action, reward);
 }
 

@@ -87,7 +87,8 @@ struct Prog {               // 112 bytes
     uint8_t kind[4];        // L_* ; leaves 0,1 = side A (two => And), leaves 2,3 = side B
     uint8_t root;           // R_*
     uint8_t n_a, n_b;       // leaves on each side
-    uint8_t strict;         // bit k: leaf k verifies in strict mode (verifier.py:270-272,343-346)
+    uint8_t strict;         // bit k < 4: leaf k verifies in strict mode (verifier.py:270-272,343-346,398-401);
+                            // bit 4: the Before/After root is strict (verifier.py:466-469,507-510)
     uint8_t start_carry;    // NONE8, or the object the agent holds right after reset (bonus_levels.py:821-829)
     uint8_t pad[7];
 };
@@ -99,7 +100,7 @@ static_assert(sizeof(Prog) == 112, "Prog layout");
 BB_HD uint32_t vhead_pack(const Prog& p) {
     return (uint32_t)p.root | ((uint32_t)p.n_a << 2) | ((uint32_t)p.n_b << 4) | ((uint32_t)p.kind[0] << 8) |
            ((uint32_t)p.kind[1] << 11) | ((uint32_t)p.kind[2] << 14) | ((uint32_t)p.kind[3] << 17) |
-           ((uint32_t)(p.strict & 15) << 20);
+           ((uint32_t)(p.strict & 31) << 20);
 }
 struct VProg {
     uint32_t head;
@@ -110,6 +111,7 @@ struct VProg {
     BB_HD int n_b() const { return (head >> 4) & 3; }
     BB_HD int kind(int leaf) const { return (head >> (8 + 3 * leaf)) & 7; }
     BB_HD bool strict(int leaf) const { return (head >> (20 + leaf)) & 1; }
+    BB_HD bool strict_seq() const { return (head >> 24) & 1; }
     BB_HD uint64_t set(int leaf, int slot) const { return sets[(int64_t)(2 * leaf + slot) * stride]; }
 };
 

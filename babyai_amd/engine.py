@@ -55,13 +55,17 @@ def load_library():
     lib.bbai_destroy.restype = None
     lib.bbai_seed.argtypes = [P, P, I64]
     lib.bbai_reset.argtypes = [P, P, P, P]
-    lib.bbai_step.argtypes = [P, P, P, P, P, P, I32, P]
+    lib.bbai_step.argtypes = [P, P, P, P, P, P, P, I32, P]
     lib.bbai_set_atlas.argtypes = [P, P, I32, P]
     lib.bbai_render.argtypes = [P, P, P, P]
     lib.bbai_set_token_buffer.argtypes = [P, P]
     lib.bbai_export_state.argtypes = [P, I64, I64, P, P, P]
     lib.bbai_import_state.argtypes = [P, I64, I64, P, P, P]
     lib.bbai_get_programs.argtypes = [P, I64, I64, P]
+    lib.bbai_checkpoint_bytes.argtypes = [P]
+    lib.bbai_checkpoint_bytes.restype = I64
+    lib.bbai_checkpoint_save.argtypes = [P, P, I64]
+    lib.bbai_checkpoint_load.argtypes = [P, P, I64]
     lib.bbai_reset_count.argtypes = [P, P]
     lib.bbai_generator_failures.argtypes = [P, P]
     lib.bbai_bot_act.argtypes = [P, P, P, P]
@@ -74,6 +78,7 @@ EXPORTED_SYMBOLS = (
     "bbai_version", "bbai_last_error", "bbai_fill_layout", "bbai_create", "bbai_destroy", "bbai_seed",
     "bbai_reset", "bbai_step", "bbai_set_atlas", "bbai_render", "bbai_set_token_buffer", "bbai_export_state", "bbai_import_state",
     "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures", "bbai_bot_act", "bbai_bot_stats",
+    "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load",
 )
 
 
@@ -155,6 +160,8 @@ class BatchedBabyAIEnv(object):
             self.image = torch.zeros((n, 7, 7, 3), dtype=torch.uint8, device=self.device)
             self.direction = torch.zeros((n,), dtype=torch.uint8, device=self.device)
             self.reward = torch.zeros((n,), dtype=torch.float32, device=self.device)
+            # the reference's own return value: a Python float = float64 (levelgen.py:59-61); `reward` is its f32 rounding
+            self.reward64 = torch.zeros((n,), dtype=torch.float64, device=self.device)
             self.done = torch.zeros((n,), dtype=torch.uint8, device=self.device)
             self.pixels = None
             if self.pixel:
@@ -228,7 +235,8 @@ class BatchedBabyAIEnv(object):
         self._actions = actions     # keep alive until the launch is consumed
         ev = self._ev_begin()
         _check(self.lib, self.lib.bbai_step(self.handle, actions.data_ptr(), self.image.data_ptr(),
-                                             self.direction.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
+                                             self.direction.data_ptr(), self.reward.data_ptr(), self.reward64.data_ptr(),
+                                             self.done.data_ptr(),
                                              1 if self.auto_reset else 0, self._stream()), "bbai_step")
         self._ev_end("step", ev)
         return self._obs(), self.reward, self.done, {}
@@ -271,6 +279,22 @@ class BatchedBabyAIEnv(object):
         assert rec.shape == (count, self.cfg.rec_bytes) and hot.shape == (count, 16) and stale.shape == (count,)
         _check(self.lib, self.lib.bbai_import_state(self.handle, first, count, rec.ctypes.data, hot.ctypes.data,
                                                      stale.ctypes.data), "bbai_import_state")
+
+    def save_checkpoint(self):
+        """The whole batch as one host blob (np.uint8): live state, RNG streams, look-ahead ring, window bookkeeping,
+        counters, the expert's plans -- everything `load_checkpoint` needs to continue bit-identically."""
+        nbytes = int(self.lib.bbai_checkpoint_bytes(self.handle))
+        blob = np.empty(nbytes, dtype=np.uint8)
+        _check(self.lib, self.lib.bbai_checkpoint_save(self.handle, blob.ctypes.data, nbytes), "bbai_checkpoint_save")
+        return blob
+
+    def load_checkpoint(self, blob):
+        """Continue a saved run in this handle (same level, batch size and look-ahead depth).  The current observation
+        is not part of the blob: callers that need it keep `image` / `direction` next to it (or step once)."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        _check(self.lib, self.lib.bbai_checkpoint_load(self.handle, blob.ctypes.data, blob.size), "bbai_checkpoint_load")
+        if getattr(self, "instr", None) is not None:        # refill the caller-owned token rows from the loaded programs
+            _check(self.lib, self.lib.bbai_set_token_buffer(self.handle, self.instr.data_ptr()), "bbai_set_token_buffer")
 
     def enable_instr_tokens(self):
         """Keep `self.instr` (uint8[N, 72] on the device) filled with the mission token ids of the current

@@ -1,62 +1,75 @@
-"""`batch_evaluate` on the batched engine -- the evaluation driver of the reference
-(babyai/evaluate.py:85-140) with its `gym.make` loop + `ManyEnvs` replaced by `BatchedManyEnvs`.
+"""Device-resident evaluation of a policy on a BabyAI level.
 
-Same signature and the same `logs` dict (num_frames_per_episode, return_per_episode, seed_per_episode,
-optionally observations/actions per episode), so scripts/evaluate.py-style callers can switch by import.
-The agent contract is the reference's: `agent.act_batch(many_obs)['action']` (babyai/utils/agent.py:51-72)
-and `agent.analyze_feedback(reward, done)`.
+What it computes is what the reference's evaluation driver logs (`batch_evaluate`, babyai/evaluate.py:85-140: per episode
+the number of frames, the return and the seed, episode k seeded with `seed + k`, finished envs frozen until everybody is
+done, evaluate.py:73-81) -- but not how: the reference walks 256 Python envs per round and re-derives the bookkeeping on
+the host every frame.  Here ALL episodes are one batch of engine envs (ManyEnvs semantics = `auto_reset=False`), the policy
+sees device tensors, returns / frame counts are reduced on the device as the frames go by, and the host reads them back
+once per chunk.  Returns are accumulated from the float64 rewards, as evaluate.py:128 does.
+
+    logs = evaluate_policy(policy, "BabyAI-GoToLocal-v0", seed=10**9, episodes=100_000)
+
+`policy(obs, t)` gets `obs = {"image": uint8 tensor [N,7,7,3] (or [N,56,56,3]), "direction": uint8 [N], "instr": uint8
+[N,72] mission token ids}` and returns an integer tensor [N] of actions on the same device.  A reference-style agent
+(`act_batch(list_of_obs_dicts)` / `analyze_feedback`, babyai/utils/agent.py:51-84) plugs in through `AgentPolicy`,
+at the price of one host round trip per frame; callers that want the reference's driver itself can also run it unchanged
+on `vec_env.BatchedManyEnvs`.
 """
 import numpy as np
 
-from .vec_env import BatchedManyEnvs
+from .engine import BatchedBabyAIEnv
 
 
-def batch_evaluate(agent, env_name, seed, episodes, return_obss_actions=False, pixel=False, device="cuda:0"):
-    num_envs = min(256, episodes)
-    env = BatchedManyEnvs(env_name, num_envs, device=device, pixel=pixel)
+class AgentPolicy(object):
+    """Adapter: a reference-style agent as a tensor policy (host round trip per frame)."""
 
-    logs = {
-        "num_frames_per_episode": [],
-        "return_per_episode": [],
-        "observations_per_episode": [],
-        "actions_per_episode": [],
-        "seed_per_episode": [],
-    }
+    def __init__(self, agent, env):
+        from .vec_env import ObsList
+        self._agent, self._env, self._ObsList = agent, env, ObsList
 
-    for i in range((episodes + num_envs - 1) // num_envs):
-        seeds = range(seed + i * num_envs, seed + (i + 1) * num_envs)
-        env.seed(seeds)
-        many_obs = env.reset()
+    def __call__(self, obs, t):
+        env = self._env
+        many = self._ObsList(obs["image"].cpu().numpy(), obs["direction"].cpu().numpy(), env._missions, env.pixel)
+        action = self._agent.act_batch(many)["action"]
+        return env.torch.as_tensor(np.asarray([int(a) for a in action], dtype=np.uint8), device=env.device)
 
-        cur_num_frames = 0
-        num_frames = np.zeros((num_envs,), dtype='int64')
-        returns = np.zeros((num_envs,))
-        already_done = np.zeros((num_envs,), dtype='bool')
-        if return_obss_actions:
-            obss = [[] for _ in range(num_envs)]
-            actions = [[] for _ in range(num_envs)]
-        while (num_frames == 0).any():
-            action = agent.act_batch(many_obs)['action']
-            if return_obss_actions:
-                for k in range(num_envs):
-                    if not already_done[k]:
-                        obss[k].append(many_obs[k])
-                        actions[k].append(int(action[k]))
-            many_obs, reward, done, _ = env.step(np.asarray([int(a) for a in action]))
-            agent.analyze_feedback(reward, done)
-            done = np.array(done)
-            just_done = done & (~already_done)
-            returns += np.array(reward) * just_done
-            cur_num_frames += 1
-            num_frames[just_done] = cur_num_frames
-            already_done[done] = True
+    def feedback(self, reward64, done):
+        self._agent.analyze_feedback(tuple(float(r) for r in reward64.cpu().numpy()),
+                                     tuple(bool(d) for d in done.cpu().numpy()))
 
-        logs["num_frames_per_episode"].extend(list(num_frames))
-        logs["return_per_episode"].extend(list(returns))
-        logs["seed_per_episode"].extend(list(seeds))
-        if return_obss_actions:
-            logs["observations_per_episode"].extend(obss)
-            logs["actions_per_episode"].extend(actions)
 
-    env.close()
+def evaluate_policy(policy, env_name, seed, episodes, pixel=False, device="cuda:0", chunk=262144, poll_every=16,
+                    agent=None):
+    """Run `episodes` episodes (seeds seed .. seed+episodes-1) to completion; returns the reference's `logs` dict
+    (num_frames_per_episode, return_per_episode, seed_per_episode).  `agent`: wrap a reference-style agent instead of a
+    tensor policy.  `poll_every`: frames between two host checks of "is everybody done" (frozen envs cost nothing)."""
+    import torch
+    logs = {"num_frames_per_episode": [], "return_per_episode": [], "seed_per_episode": []}
+    for first in range(0, episodes, chunk):
+        n = min(chunk, episodes - first)
+        env = BatchedBabyAIEnv(env_name, n, device=device, pixel=pixel, auto_reset=False)
+        env.seed(np.arange(first, first + n, dtype=np.uint64) + np.uint64(seed))
+        instr = env.enable_instr_tokens()
+        obs = env.reset()
+        pol = AgentPolicy(agent, env) if agent is not None else policy
+        frames = torch.zeros(n, dtype=torch.int64, device=env.device)      # 0 = still running
+        returns = torch.zeros(n, dtype=torch.float64, device=env.device)
+        t = 0
+        while True:
+            t += 1
+            action = pol({"image": obs["image"], "direction": obs["direction"], "instr": instr}, t)
+            obs, _, done, _ = env.step(action)
+            if agent is not None:
+                pol.feedback(env.reward64, done)
+            just = (done != 0) & (frames == 0)
+            returns += env.reward64 * just
+            frames = torch.where(just, torch.full_like(frames, t), frames)
+            # every episode ends by max_steps at the latest; poll the device only now and then before that
+            every = 1 if agent is not None else poll_every        # (a stateful agent must not see extra frames)
+            if t >= env.max_steps_bound or (t % every == 0 and bool((frames != 0).all())):
+                break
+        logs["num_frames_per_episode"].extend(frames.cpu().tolist())
+        logs["return_per_episode"].extend(returns.cpu().tolist())
+        logs["seed_per_episode"].extend(range(seed + first, seed + first + n))
+        env.close()
     return logs

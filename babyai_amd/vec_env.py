@@ -97,8 +97,8 @@ class _VecBase(object):
     def step(self, actions):
         if hasattr(actions, "cpu") and not hasattr(actions, "data_ptr"):
             actions = np.asarray(actions)
-        obs, reward, done, _ = self.engine.step(actions)
-        reward = reward.cpu().numpy()
+        obs, _, done, _ = self.engine.step(actions)
+        reward = self.engine.reward64.cpu().numpy()      # Python floats, as the reference returns them (levelgen.py:59-61)
         done = done.cpu().numpy().astype(bool)
         n = self.num_envs
         # the reference returns zip(*results): four tuples (obs...), (reward...), (done...), (info...)
@@ -211,9 +211,9 @@ class SingleEnv(object):
         return self._one(self.engine.reset())
 
     def step(self, action):
-        obs, reward, done, _ = self.engine.step(np.array([int(action)], dtype=np.uint8))
+        obs, _, done, _ = self.engine.step(np.array([int(action)], dtype=np.uint8))
         self.step_count += 1
-        return self._one(obs), float(reward[0]), bool(done[0]), {}
+        return self._one(obs), float(self.engine.reward64[0]), bool(done[0]), {}
 
     def bot_action(self, action_taken=None):
         """`Bot(env).replan(action_taken)` (babyai/bot.py:547-597): the expert's suggestion for the current state, or

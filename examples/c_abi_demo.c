@@ -46,7 +46,7 @@ int main(void) {
     for (int t = 0; t < 200; ++t) {
         for (int64_t i = 0; i < n; ++i) { lcg = lcg * 1664525u + 1013904223u; host_actions[i] = (uint8_t)((lcg >> 24) % 7); }
         if (hipMemcpy(actions, host_actions, n, hipMemcpyHostToDevice)) return 2;
-        CHECK(bbai_step(env, actions, image, dir, reward, done, 1 /* auto-reset */, NULL));
+        CHECK(bbai_step(env, actions, image, dir, reward, NULL /* no f64 rewards */, done, 1 /* auto-reset */, NULL));
         if (hipMemcpy(host_reward, reward, n * sizeof(float), hipMemcpyDeviceToHost)) return 2;
         if (hipMemcpy(host_done, done, n, hipMemcpyDeviceToHost)) return 2;
         for (int64_t i = 0; i < n; ++i) { reward_sum += host_reward[i]; episodes += host_done[i]; }
@@ -55,7 +55,7 @@ int main(void) {
     long expert_episodes = 0, expert_solved = 0;
     for (int t = 0; t < 100; ++t) {
         CHECK(bbai_bot_act(env, NULL /* replan(None): the suggestion is what we step with */, actions, NULL));
-        CHECK(bbai_step(env, actions, image, dir, reward, done, 1, NULL));
+        CHECK(bbai_step(env, actions, image, dir, reward, NULL, done, 1, NULL));
         if (hipMemcpy(host_reward, reward, n * sizeof(float), hipMemcpyDeviceToHost)) return 2;
         if (hipMemcpy(host_done, done, n, hipMemcpyDeviceToHost)) return 2;
         for (int64_t i = 0; i < n; ++i) { expert_episodes += host_done[i]; expert_solved += host_reward[i] > 0.0f; }

@@ -7,7 +7,9 @@
  * data_ptr() of torch tensors on the handle's device); launches are asynchronous on
  * the caller's hipStream_t (passed as void*; NULL = default stream).  No exceptions
  * cross the boundary: every call returns 0 or a negative bbai_status.  One handle per
- * device; a handle is not thread-safe.
+ * device; a handle is not thread-safe and follows ONE caller stream at a time: a call that arrives
+ * on a different stream than the previous one is ordered (by an event) behind everything the handle
+ * enqueued on the previous stream.
  */
 #ifndef BBAI_H
 #define BBAI_H
@@ -60,7 +62,8 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
 void bbai_destroy(bbai_env* env);
 
 /* env.seed(s) for every env (scripts/train_rl.py:59, babyai/evaluate.py:67-68,105-106):
- * seeds_host[i] -> gym-style sha512 -> MT19937 init_by_array, uploaded to HBM. */
+ * seeds_host[i] (8 bytes per env cross PCIe) -> gym-style sha512 -> MT19937 init_by_array, per lane on the device;
+ * then the first levels of every env's stream are generated ahead of need.  Synchronous. */
 int bbai_seed(bbai_env* env, const uint64_t* seeds_host, int64_t n);
 
 /* env.reset() for every env (babyai/levels/levelgen.py:35-47; ParallelEnv.reset
@@ -76,10 +79,13 @@ int bbai_reset(bbai_env* env, uint8_t* image_dev, uint8_t* dir_dev, void* stream
  *                     keeps re-emitting its last (obs, reward, done) until bbai_reset.
  * actions_dev[i] is 0..6 (MiniGridEnv.Actions), or BBAI_ACTION_RESET_ENV = "env.reset() for this env now": the
  * episode is abandoned with done = 1, reward = 0 and handled like any finished env above (a ParallelEnv worker's
- * `reset` command, penv.py:12-14; scripts/make_agent_demos.py:84-88 after a bot crash). */
+ * `reset` command, penv.py:12-14; scripts/make_agent_demos.py:84-88 after a bot crash).
+ * reward_dev[i]   = float32 rounding of the reward (what babyai/rl/algos/base.py:162-167 makes of it);
+ * reward64_dev[i] = the reference's own return value: MiniGridEnv._reward() as a Python float (levelgen.py:59-61),
+ *                   bit for bit (what babyai/evaluate.py:128 accumulates).  May be NULL. */
 #define BBAI_ACTION_RESET_ENV 7
 int bbai_step(bbai_env* env, const uint8_t* actions_dev, uint8_t* image_dev, uint8_t* dir_dev,
-              float* reward_dev, uint8_t* done_dev, int auto_reset, void* stream);
+              float* reward_dev, double* reward64_dev, uint8_t* done_dev, int auto_reset, void* stream);
 
 /* RGBImgPartialObsWrapper.observation (gym_minigrid.wrappers; used at babyai/evaluate.py:91-92,
  * scripts/train_rl.py:57-58): encoded obs uint8[N][147] -> pixels uint8[N][56][56][3].
@@ -99,6 +105,15 @@ int bbai_export_state(bbai_env* env, int64_t first, int64_t count, uint8_t* rec_
 int bbai_import_state(bbai_env* env, int64_t first, int64_t count, const uint8_t* rec_host,
                       const uint8_t* hot_host, const uint64_t* stale_host);
 int bbai_get_programs(bbai_env* env, int64_t first, int64_t count, uint8_t* prog_host /* 112 B each */);
+
+/* Checkpoint / resume of a whole batch (the reference checkpoints only its model, babyai/utils/model.py:29-32; an
+ * auto-resetting env batch additionally needs its RNG streams): the blob holds the live state, every env's MT19937
+ * stream, the look-ahead ring with its window bookkeeping, the counters and -- when bbai_bot_act has been used -- the
+ * expert's plans.  Loading it into a fresh handle of the same level, batch size and BBAI_LOOKAHEAD continues the run
+ * bit-identically, auto-resets included (tests/test_gpu_parity.py::test_checkpoint_resume_*).  Synchronous, host buffers. */
+int64_t bbai_checkpoint_bytes(bbai_env* env);
+int bbai_checkpoint_save(bbai_env* env, void* host_buf, int64_t bytes);
+int bbai_checkpoint_load(bbai_env* env, const void* host_buf, int64_t bytes);
 
 /* The reference's GOFAI expert for every env: one `Bot.replan(action_taken)` decision each
  * (babyai/bot.py:547-597; callers babyai/utils/agent.py:139-146 BotAgent.act, scripts/make_agent_demos.py:93-107).

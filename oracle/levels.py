@@ -24,7 +24,8 @@ What follows which reference code (all under /root/reference/babyai/levels/):
   GoToOracle.gen_mission           iclr19_levels.py:40-63, 75-124, 224-257
   BonusOracle.gen_*                bonus_levels.py (line ranges in each method's docstring)
   FixedLayoutOracle.lay_*          test_levels.py (line ranges in each method's docstring)
-BABYAI_DONE_ACTIONS (verifier.py:17) and SeqInstr-level `strict` (unused by any level) are not restated.
+BABYAI_DONE_ACTIONS (verifier.py:17) is not restated; PutNext / Before / After `strict` (no registered level sets them)
+are, and are checked against the reference's verifier classes in tests/test_strict_modes.py.
 """
 import os
 import sys
@@ -163,6 +164,8 @@ class Clause(object):
                 return 'failure'          # verifier.py:343-346
             return 'continue'
         # putnext
+        if self.strict and action == A.pickup and env.carrying:
+            return 'failure'              # verifier.py:398-401
         if action != A.drop:
             return 'continue'
         for o in self.d1.objs:
@@ -175,8 +178,8 @@ class Combo(object):
     """Two sub-instructions joined by 'and' / 'before' / 'after'."""
     JOIN = {'and': ' and ', 'before': ', then ', 'after': ' after you '}
 
-    def __init__(self, how, a, b):
-        self.how, self.a, self.b = how, a, b
+    def __init__(self, how, a, b, strict=False):
+        self.how, self.a, self.b, self.strict = how, a, b, strict
 
     def navs(self):
         return self.a.navs() + self.b.navs()
@@ -209,8 +212,14 @@ class Combo(object):
         first, second = (self.a, self.b) if self.how == 'before' else (self.b, self.a)
         if not getattr(self, '_first_done', False):
             st = first.verify(action)
+            if st == 'failure':
+                return 'failure'
             if st != 'success':
-                return 'failure' if st == 'failure' else 'continue'
+                # strict: completing the second part first fails the mission (verifier.py:466-469,507-510); the
+                # probe is a real verify() of the second part, side effects included
+                if self.strict and second.verify(action) == 'success':
+                    return 'failure'
+                return 'continue'
             self._first_done = True
         st = second.verify(action)
         return st if st in ('success', 'failure') else 'continue'

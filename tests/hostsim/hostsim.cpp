@@ -66,12 +66,18 @@ int hs_start_carry(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale)
     return 1;
 }
 
-int hs_step(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int action, float* reward) {
+int hs_step64(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int action, double* reward) {
     const Prog* p = (const Prog*)(rec + cfg->off_prog);
     uint64_t sets[8];
     for (int k = 0; k < 8; ++k) sets[k] = p->set[k >> 1][k & 1];
     VProg vp; vp.head = vhead_pack(*p); vp.sets = sets; vp.stride = 1;
     return step_env_cmd(*cfg, rec, vp, *hot, *stale, action, *reward) ? 1 : 0;
+}
+int hs_step(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int action, float* reward) {
+    double r = 0.0;
+    const int d = hs_step64(cfg, rec, hot, stale, action, &r);
+    *reward = (float)r;
+    return d;
 }
 
 void hs_observe(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, uint8_t* out) {

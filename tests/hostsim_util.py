@@ -23,6 +23,7 @@ def lib():
         L.hs_seed.argtypes = [ctypes.c_uint64, P]
         L.hs_generate.argtypes = [P, P, P, P, P]
         L.hs_step.argtypes = [P, P, P, P, ctypes.c_int, P]
+        L.hs_step64.argtypes = [P, P, P, P, ctypes.c_int, P]
         L.hs_observe.argtypes = [P, P, P, P]
         L.hs_fill_layout.argtypes = [P]
         L.hs_start_carry.argtypes = [P, P, P, P]
@@ -62,9 +63,10 @@ class HostEnv(object):
         return self.out.reshape(7, 7, 3).copy()
 
     def step(self, action):
-        rew = ctypes.c_float(0)
-        d = self.L.hs_step(ctypes.byref(self.cfg), self.rec.ctypes.data, self.hot.ctypes.data,
-                           ctypes.byref(self.stale), int(action), ctypes.byref(rew))
+        rew = ctypes.c_double(0)
+        d = self.L.hs_step64(ctypes.byref(self.cfg), self.rec.ctypes.data, self.hot.ctypes.data,
+                             ctypes.byref(self.stale), int(action), ctypes.byref(rew))
+        self.last_reward64 = rew.value            # the f64 the kernel core computes; the f32 output is its rounding
         return self.observe(), np.float32(rew.value), bool(d)
 
     @property

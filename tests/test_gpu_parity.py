@@ -52,6 +52,8 @@ def test_golden_trace(gpu, path):
         obs, reward, done, _ = env.step(actions[t])
         torch.cuda.synchronize()
         assert np.array_equal(reward.cpu().numpy().view(np.uint32), g["reward"][t].view(np.uint32)), "reward bits t=%d" % t
+        # the reference's own return value (a Python float, levelgen.py:59-61), bit for bit
+        assert np.array_equal(env.reward64.cpu().numpy().view(np.uint64), g["reward64"][t].view(np.uint64)), "f64 reward bits t=%d" % t
         assert np.array_equal(done.cpu().numpy(), g["done"][t]), "done t=%d" % t
         check_obs(t + 1, obs)
     env.close()
@@ -122,7 +124,7 @@ def test_parallel_env_adapter_vs_oracle(gpu, level, pixel):
                 o = e.reset()
             robs[i] = o
             rr.append((r, d))
-        assert [np.float32(x[0]) for x in rr] == [np.float32(x) for x in reward]
+        assert [float(x[0]) for x in rr] == list(reward) and all(type(x) is float for x in reward)     # f64, as the reference
         assert [bool(x[1]) for x in rr] == list(done)
     venv.close()
 
@@ -355,11 +357,12 @@ class _ScriptedAgent(object):
 
 @pytest.mark.gpu
 def test_batch_evaluate_matches_reference_driver(gpu):
-    """babyai_amd.evaluate.batch_evaluate vs the reference's evaluation loop (babyai/evaluate.py:85-140) run over
-    oracle envs with the ManyEnvs freeze-after-done rule (evaluate.py:73-81): identical logs."""
-    from babyai_amd.evaluate import batch_evaluate
+    """babyai_amd.evaluate.evaluate_policy (device-resident bookkeeping, a reference-style agent plugged in) vs the
+    reference's evaluation loop (babyai/evaluate.py:85-140) restated over oracle envs with the ManyEnvs freeze-after-done
+    rule (evaluate.py:73-81): identical logs, float64 returns included."""
+    from babyai_amd.evaluate import evaluate_policy
     name, seed, episodes = "BabyAI-GoToLocal-v0", 31, 20
-    logs = batch_evaluate(_ScriptedAgent(), name, seed, episodes, device=gpu)
+    logs = evaluate_policy(None, name, seed, episodes, device=gpu, agent=_ScriptedAgent())
     # reference driver restated over oracle envs
     envs = _oracle_envs("GoToLocal", [0] * episodes)
     agent = _ScriptedAgent()
@@ -386,8 +389,30 @@ def test_batch_evaluate_matches_reference_driver(gpu):
         num_frames[just] = cur
         already[done] = True
     assert list(logs["num_frames_per_episode"]) == list(num_frames)
-    assert np.array_equal(np.float32(logs["return_per_episode"]), np.float32(returns))
+    assert list(logs["return_per_episode"]) == list(returns)          # float64, bit for bit
     assert list(logs["seed_per_episode"]) == list(range(seed, seed + episodes))
+
+
+@pytest.mark.gpu
+def test_evaluate_policy_tensor_path(gpu):
+    """The tensor path of evaluate_policy (no host hop per frame, polling every 16 frames) gives the same logs as the
+    per-frame agent path for the same decisions, on a batch that spans two chunks."""
+    import torch
+    from babyai_amd.evaluate import evaluate_policy
+
+    def policy(obs, t):
+        return ((obs["image"].to(torch.int64).sum(dim=(1, 2, 3)) * 13 // 5 + obs["direction"].to(torch.int64)) % 7).to(torch.uint8)
+
+    class Agent(object):
+        def act_batch(self, many_obs):
+            return {"action": np.array([(int(o["image"].astype(np.int64).sum()) * 13 // 5 + o["direction"]) % 7 for o in many_obs])}
+
+        def analyze_feedback(self, reward, done):
+            pass
+
+    a = evaluate_policy(policy, "BabyAI-PickupLoc-v0", 7, 300, device=gpu, chunk=256)
+    b = evaluate_policy(None, "BabyAI-PickupLoc-v0", 7, 300, device=gpu, chunk=256, agent=Agent())
+    assert a == b and len(a["return_per_episode"]) == 300 and min(a["num_frames_per_episode"]) >= 1
 
 
 @pytest.mark.gpu
@@ -817,3 +842,113 @@ def test_bot_device_equals_host_build_on_every_level(gpu):
                     hosts[i].reset()
                     first[i], last[i] = True, None
         env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level,lookahead,use_bot", [("GoToObjS4", "2", False), ("PickupLoc", None, False), ("GoToObjS4", None, True),
+                                                     ("MiniBossLevel", "4", True)])
+def test_checkpoint_resume_is_bit_identical(gpu, level, lookahead, use_bot, monkeypatch):
+    """bbai_checkpoint_save mid-rollout (at a tick that is not a window boundary), bbai_checkpoint_load into a FRESH
+    handle, and both continue through many auto-resets: every output of every later step is identical, the expert's
+    decisions included -- i.e. the blob carries the RNG streams, the look-ahead ring, the window bookkeeping and the
+    expert's plans, not just the live grids."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    if lookahead:
+        monkeypatch.setenv("BBAI_LOOKAHEAD", lookahead)
+    n = 512
+    a = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=4242)
+    a.reset()
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(5)
+    acts = torch.randint(0, 7, (200, n), dtype=torch.uint8, device=gpu, generator=gen)
+
+    def act(env, t):
+        if not use_bot:
+            return acts[t]
+        noise = acts[t] == 6                  # the expert, with 1/7 of the envs acting randomly
+        return torch.where(noise, acts[(t + 1) % 200], env.bot_actions(None))
+
+    prev = None
+    for t in range(37):                       # 37 is not a multiple of any refill period
+        prev = act(a, t).clone()
+        a.step(prev)
+    blob = a.save_checkpoint()
+    b = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu)      # never seeded: everything comes from the blob
+    b.load_checkpoint(blob)
+    resets0 = a.reset_count()
+    assert b.reset_count() == resets0
+    for t in range(37, 200):
+        xa, xb = act(a, t).clone(), act(b, t).clone()
+        assert torch.equal(xa, xb), t
+        oa, ra, da, _ = a.step(xa)
+        ob, rb, db, _ = b.step(xb)
+        torch.cuda.synchronize()
+        assert torch.equal(a.image, b.image) and torch.equal(a.direction, b.direction), t
+        assert torch.equal(a.reward64, b.reward64) and torch.equal(da, db), t
+        if t % 40 == 0:
+            assert a.missions() == b.missions()
+    assert a.reset_count() - resets0 > 2 * n // 3 and a.reset_count() == b.reset_count()
+    assert a.generator_failures() == 0
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lookahead,first_leg", [("2", 3), ("2", 5), ("4", 6), ("4", 9), ("8", 13), ("8", 21)])
+def test_reseed_in_the_middle_of_a_window(gpu, lookahead, first_leg, monkeypatch):
+    """seed() on an engine that stopped `first_leg` auto-reset steps into a run -- not a multiple of the refill period, so
+    the window in progress was using buffer 1 or 2 of the window bookkeeping -- must start a clean run: three and more
+    windows of the new run against the oracle (round-1 advisor finding: only buffer 0 used to be cleared)."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    monkeypatch.setenv("BBAI_LOOKAHEAD", lookahead)
+    n = 96
+    env = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=1)
+    env.reset()
+    rng = np.random.RandomState(first_leg)
+    for t in range(first_leg):
+        env.step(torch.as_tensor(rng.choice([0, 1, 2], size=n).astype(np.uint8), device=gpu))
+    assert env.reset_count() > n               # envs did finish in the first leg
+    env.seed(500)
+    refs = _oracle_envs("GoToObjS4", [500 + i for i in range(n)])
+    env.reset()
+    ro = [e.reset() for e in refs]
+    for t in range(5 * int(lookahead) + 7):
+        img = env.image.cpu().numpy()
+        for i in range(n):
+            assert np.array_equal(img[i], ro[i]["image"]), (lookahead, first_leg, t, i)
+        a = rng.choice([0, 1, 2], size=n).astype(np.uint8)
+        env.step(torch.as_tensor(a, device=gpu))
+        for i in range(n):
+            o, r, d, _ = refs[i].step(int(a[i]))
+            ro[i] = refs[i].reset() if d else o
+    env.close()
+
+
+@pytest.mark.gpu
+def test_caller_may_change_streams_between_calls(gpu):
+    """A handle follows one caller stream at a time; when the caller comes back on another stream the engine orders it
+    behind the work it enqueued on the previous one (include/bbai.h).  Alternating two streams per step, with no
+    synchronisation by the caller, must give the single-stream result."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    n = 4096
+    a = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=9, pixel=True)
+    b = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=9, pixel=True)
+    a.reset()
+    b.reset()
+    acts = torch.randint(0, 7, (96, n), dtype=torch.uint8, device=gpu)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=gpu), torch.cuda.Stream(device=gpu)]
+    for t in range(96):
+        a.step(acts[t])
+        with torch.cuda.stream(streams[t & 1]):
+            b.step(acts[t])
+    for s in streams:
+        s.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(a.image, b.image) and torch.equal(a.pixels, b.pixels) and torch.equal(a.reward64, b.reward64)
+    assert a.reset_count() == b.reset_count() > n
+    a.close()
+    b.close()

@@ -37,6 +37,7 @@ def test_core_replays_reference_trace(path):
                 break
             img, rew, done = sim.step(int(g["actions"][t, i]))
             assert rew.view(np.uint32) == g["reward"][t, i].view(np.uint32), (name, i, t)
+            assert np.float64(sim.last_reward64).view(np.uint64) == g["reward64"][t, i].view(np.uint64), (name, i, t)
             assert done == bool(g["done"][t, i]), (name, i, t)
             if done:
                 img = sim.reset()

@@ -39,6 +39,7 @@ def replay(g, n_envs=None, n_steps=None):
                 break
             o, r, d, _ = env.step(int(g["actions"][t, i]))
             assert np.float32(r).view(np.uint32) == g["reward"][t, i].view(np.uint32)
+            assert np.float64(r).view(np.uint64) == g["reward64"][t, i].view(np.uint64)
             assert bool(d) == bool(g["done"][t, i])
             if d:
                 o = env.reset()

@@ -143,6 +143,7 @@ def trace(name, n_envs, n_steps, pre_resets, n_pix, expert=False):
     image = np.zeros((n_steps + 1, n_envs, 7, 7, 3), np.uint8)
     direction = np.zeros((n_steps + 1, n_envs), np.uint8)
     reward = np.zeros((n_steps, n_envs), np.float32)
+    reward64 = np.zeros((n_steps, n_envs), np.float64)      # the Python float the reference returns, as is
     done = np.zeros((n_steps, n_envs), np.uint8)
     max_steps = np.zeros((n_steps + 1, n_envs), np.int32)
     pixels = np.zeros((n_steps + 1, n_pix, 56, 56, 3), np.uint8)
@@ -161,6 +162,7 @@ def trace(name, n_envs, n_steps, pre_resets, n_pix, expert=False):
                 actions[t, i] = drivers[i].act()
             o, r, d, _ = e.step(int(actions[t, i]))
             reward[t, i] = np.float32(r)
+            reward64[t, i] = r
             done[t, i] = d
             if d:
                 o = e.reset()
@@ -175,7 +177,7 @@ def trace(name, n_envs, n_steps, pre_resets, n_pix, expert=False):
     np.savez_compressed(
         out, level=name, seeds=seeds, actions=actions, pre_image=pre_image,
         pre_mission=np.array(pre_mission, dtype=object).astype(str) if pre_resets else np.zeros((0, n_envs), dtype=str),
-        image=image, direction=direction, reward=reward, done=done, max_steps=max_steps, pixels=pixels,
+        image=image, direction=direction, reward=reward, reward64=reward64, done=done, max_steps=max_steps, pixels=pixels,
         event_t=np.array([e[0] for e in events], np.int32), event_env=np.array([e[1] for e in events], np.int32),
         event_mission=np.array([e[2] for e in events]).astype(str))
     print('%-14s%s envs=%d steps=%d episodes_finished=%d success=%d -> %d KB' % (
