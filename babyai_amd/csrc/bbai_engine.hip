@@ -73,6 +73,8 @@ struct DeviceGuard {
     DeviceGuard guard_(dev);                                                                  \
     HIP_TRY((hipError_t)guard_.err)
 
+constexpr int PROF_RING = 256;          // event pairs per profiled kernel (bbai_profile)
+
 struct bbai_env {
     LevelCfg cfg;
     int64_t n;
@@ -110,6 +112,12 @@ struct bbai_env {
     bool have_stream;          // caller switches, the new stream is ordered behind the old one's work (adopt_stream)
     hipEvent_t ev_switch;
     int pregen_cap;       // BBAI_PREGEN_BLOCKS: upper bound on resident look-ahead workgroups (experiments)
+    // optional per-kernel timing (bbai_profile): HIP event pairs on the launch stream around k_step / k_consume / k_render
+    bool prof_on;
+    struct ProfSlot { hipEvent_t a, b; bool used; } prof[3][PROF_RING];
+    int prof_pos[3];
+    double prof_ms[3];
+    int64_t prof_n[3];
     int64_t tick;         // number of consume_and_refill calls so far
     uint8_t* atlas;       // [n_tiles][192]
     uint8_t* lut;         // [2][256]
@@ -758,6 +766,7 @@ void bbai_destroy(bbai_env* e) {
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->ev_consumed) (void)hipEventDestroy(e->ev_consumed);
     if (e->ev_switch) (void)hipEventDestroy(e->ev_switch);
+    for (int k = 0; k < 3; ++k) for (int i = 0; i < PROF_RING; ++i) if (e->prof[k][i].a) { (void)hipEventDestroy(e->prof[k][i].a); (void)hipEventDestroy(e->prof[k][i].b); }
     for (int k = 0; k < 3; ++k) if (e->ev_refill[k]) (void)hipEventDestroy(e->ev_refill[k]);
     void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
@@ -802,6 +811,32 @@ static int adopt_stream(bbai_env* e, hipStream_t s) {
     return BBAI_OK;
 }
 
+// bbai_profile: bracket a launch with an event pair (ring of PROF_RING pairs per kernel; a pair is folded into the sums
+// when its slot comes round again, i.e. long after it completed, or when the totals are read)
+static void prof_fold(bbai_env* e, int k, int i) {
+    bbai_env::ProfSlot& p = e->prof[k][i];
+    if (!p.used) return;
+    float ms = 0;
+    if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { e->prof_ms[k] += ms; e->prof_n[k]++; }
+    p.used = false;
+}
+struct ProfScope {
+    bbai_env* e; int k; hipStream_t s; int i;
+    ProfScope(bbai_env* e_, int k_, hipStream_t s_) : e(e_), k(k_), s(s_), i(-1) {
+        if (!e->prof_on) return;
+        i = e->prof_pos[k];
+        e->prof_pos[k] = (i + 1) % PROF_RING;
+        prof_fold(e, k, i);
+        if (!e->prof[k][i].a) { (void)hipEventCreate(&e->prof[k][i].a); (void)hipEventCreate(&e->prof[k][i].b); }
+        (void)hipEventRecord(e->prof[k][i].a, s);
+    }
+    ~ProfScope() {
+        if (i < 0) return;
+        (void)hipEventRecord(e->prof[k][i].b, s);
+        e->prof[k][i].used = true;
+    }
+};
+
 // main stream: slots -> live state (+ first obs); side stream: refill the consumed slots.
 static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_t* dirs, int all) {
     const int D = e->depth, B = e->period;
@@ -818,11 +853,14 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
     }
     if (all) e->win_all[wb] = 1;
     const int64_t hint = all ? e->n : std::max<int64_t>(e->n / 64, 64);
+    {
+    ProfScope prof_(e, 1, s);
     hipLaunchKernelGGL(k_consume, dim3((unsigned)std::min<int64_t>((hint + 3) / 4, 8192)), dim3(256), 0, s, e->cfg, e->n, e->rec,
                        e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, e->reset_list, e->counters + 16 * e->step_parity, all,
                        e->total_resets, D, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n,
                        e->win_list + (size_t)wb * e->period * e->n, e->win_count + WIN_STRIDE * wb, pos, image, dirs,
                        e->counters + 16 * (e->step_parity ^ 1));
+    }
     if (e->tokens)
         hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n, e->rec,
                            e->tokens, e->reset_list, e->counters + 16 * e->step_parity, all);
@@ -902,8 +940,11 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
     uint32_t* counter = e->counters + 16 * e->step_parity;
     if (!e->next_counter_clean) HIP_TRY(hipMemsetAsync(counter, 0, 4, s));   // (k_consume of the previous step zeroes it)
     e->next_counter_clean = false;
-    hipLaunchKernelGGL(k_step, dim3((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), dim3(STEP_BLOCK), 0, s, e->cfg, e->n,
-                       e->rec, e->hot, e->stale, e->vhead, e->vset, actions, image, dirs, rewards, rewards64, dones, auto_reset, list, counter);
+    {
+        ProfScope prof_(e, 0, s);
+        hipLaunchKernelGGL(k_step, dim3((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), dim3(STEP_BLOCK), 0, s, e->cfg, e->n,
+                           e->rec, e->hot, e->stale, e->vhead, e->vset, actions, image, dirs, rewards, rewards64, dones, auto_reset, list, counter);
+    }
     HIP_TRY(hipGetLastError());
     // the number of finished envs is only known on the device: fixed grids, device-side count
     if (auto_reset) return consume_and_refill(e, s, image, dirs, 0);
@@ -931,8 +972,11 @@ int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream
     const int gpb = 8;
     unsigned grid = (unsigned)((groups + gpb - 1) / gpb);
     { int rc = adopt_stream(e, (hipStream_t)stream); if (rc != BBAI_OK) return rc; }
-    hipLaunchKernelGGL(k_render, dim3(grid), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut,
-                       e->n_tiles);
+    {
+        ProfScope prof_(e, 2, (hipStream_t)stream);
+        hipLaunchKernelGGL(k_render, dim3(grid), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut,
+                           e->n_tiles);
+    }
     HIP_TRY(hipGetLastError());
     return BBAI_OK;
 }
@@ -1137,6 +1181,23 @@ int bbai_bot_stats(bbai_env* e, uint64_t* gave_up, uint64_t* capacity) {
     unsigned long long v[2] = {0, 0};
     HIP_TRY(hipMemcpy(v, e->bot_stats, 16, hipMemcpyDeviceToHost));
     *gave_up = v[0]; *capacity = v[1];
+    return BBAI_OK;
+}
+
+int bbai_profile(bbai_env* e, int enable) {
+    if (!e) ARG_FAIL("null handle");
+    e->prof_on = enable != 0;
+    if (enable) for (int k = 0; k < 3; ++k) { e->prof_ms[k] = 0; e->prof_n[k] = 0; for (int i = 0; i < PROF_RING; ++i) e->prof[k][i].used = false; }
+    return BBAI_OK;
+}
+
+int bbai_profile_read(bbai_env* e, double* ms_total /* [3] */, int64_t* launches /* [3] */) {
+    if (!e || !ms_total || !launches) ARG_FAIL("null pointer");
+    ON_DEVICE(e->device);
+    for (int k = 0; k < 3; ++k) {
+        for (int i = 0; i < PROF_RING; ++i) prof_fold(e, k, i);
+        ms_total[k] = e->prof_ms[k]; launches[k] = e->prof_n[k];
+    }
     return BBAI_OK;
 }
 

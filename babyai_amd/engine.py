@@ -62,6 +62,8 @@ def load_library():
     lib.bbai_export_state.argtypes = [P, I64, I64, P, P, P]
     lib.bbai_import_state.argtypes = [P, I64, I64, P, P, P]
     lib.bbai_get_programs.argtypes = [P, I64, I64, P]
+    lib.bbai_profile.argtypes = [P, I32]
+    lib.bbai_profile_read.argtypes = [P, P, P]
     lib.bbai_checkpoint_bytes.argtypes = [P]
     lib.bbai_checkpoint_bytes.restype = I64
     lib.bbai_checkpoint_save.argtypes = [P, P, I64]
@@ -78,7 +80,7 @@ EXPORTED_SYMBOLS = (
     "bbai_version", "bbai_last_error", "bbai_fill_layout", "bbai_create", "bbai_destroy", "bbai_seed",
     "bbai_reset", "bbai_step", "bbai_set_atlas", "bbai_render", "bbai_set_token_buffer", "bbai_export_state", "bbai_import_state",
     "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures", "bbai_bot_act", "bbai_bot_stats",
-    "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load",
+    "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load", "bbai_profile", "bbai_profile_read",
 )
 
 
@@ -333,6 +335,17 @@ class BatchedBabyAIEnv(object):
         a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
         _check(self.lib, self.lib.bbai_bot_stats(self.handle, ctypes.byref(a), ctypes.byref(b)), "bbai_bot_stats")
         return {"gave_up": int(a.value), "capacity": int(b.value)}
+
+    def profile(self, enable=True):
+        """Bracket every k_step / k_consume / k_render launch with HIP events on its launch stream (bench.py)."""
+        _check(self.lib, self.lib.bbai_profile(self.handle, 1 if enable else 0), "bbai_profile")
+
+    def profile_read(self):
+        """{kernel: (average ms per launch, launches)} since profile(True)."""
+        ms = (ctypes.c_double * 3)()
+        cnt = (ctypes.c_int64 * 3)()
+        _check(self.lib, self.lib.bbai_profile_read(self.handle, ms, cnt), "bbai_profile_read")
+        return {k: (ms[i] / cnt[i] if cnt[i] else None, int(cnt[i])) for i, k in enumerate(("k_step", "k_consume", "k_render"))}
 
     def reset_count(self):
         v = ctypes.c_uint64(0)

@@ -1,11 +1,14 @@
-"""Multi-GPU decomposition: one process per GPU, contiguous env shards, NO collective on the
-step path (envs never interact: SURVEY.md section 8e).  Env i's trajectory is a pure function of
-(seed_i, its actions), with seed_i = base + global index, so results do not depend on the
-number of shards (tests/test_gpu_parity.py::test_shard_independence checks this on one GPU).
+"""Multi-GPU decomposition and the measured rollout loop: one process per GPU, contiguous env shards, NO collective on
+the step path (envs never interact: SURVEY.md section 8e; the reference's only parallelism is one env per worker
+process, babyai/rl/utils/penv.py:28-52).  Env i's trajectory is a pure function of (seed_i, its actions) with seed_i =
+base + global index and actions keyed on the global index (action_stream.py), so results do not depend on the number of
+shards.  `bench.py` drives exactly the functions below; tests/test_distributed_shard.py runs the same functions under
+world_size-2 gloo on CPU over oracle envs, tests/test_gpu_multirank.py runs bench.py itself with 4 ranks on one GPU.
 
-The only collectives are (a) bench timing: barrier + max-over-ranks, (b) the OPTIONAL gather of
-encoded observations to rank 0 (torch.distributed.gather: RCCL over xGMI on GPUs, gloo on CPU).
+The only collectives are (a) timing: barrier + max-over-ranks, (b) sums of counters for the report, (c) the OPTIONAL
+gather of encoded observations to rank 0 (RCCL over xGMI on GPUs, gloo on CPU).
 """
+import os
 
 
 def shard_range(total_envs, world_size, rank):
@@ -22,6 +25,57 @@ def shard_seeds(seed_base, total_envs, world_size, rank):
     import numpy as np
     first, count = shard_range(total_envs, world_size, rank)
     return np.arange(first, first + count, dtype=np.uint64) + np.uint64(seed_base)
+
+
+class Ranks(object):
+    """The process group of a bench / rollout run (or a single process when WORLD_SIZE is 1 / unset)."""
+
+    def __init__(self, dist=None, reduce_device=None, sync=None):
+        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self.reduce_device = reduce_device
+        self._sync = sync or (lambda: None)
+
+    @classmethod
+    def from_env(cls, backend="nccl", share_device=False):
+        """torch.distributed.run contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  backend
+        "nccl" (= RCCL, one rank per GPU) or "gloo" (test rigs: ranks may share cuda:0 with share_device)."""
+        import torch
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = 0 if share_device else int(os.environ.get("LOCAL_RANK", "0"))
+        device = torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu")
+        if device.type == "cuda":
+            torch.cuda.set_device(device)
+        dist = None
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=device)
+            else:
+                dist.init_process_group(backend=backend)
+        sync = (lambda: torch.cuda.synchronize(device)) if device.type == "cuda" else None
+        r = cls(dist, device if (backend == "nccl" and device.type == "cuda") else torch.device("cpu"), sync)
+        r.device = device
+        return r
+
+    def barrier(self):
+        """Device idle on every rank: sync, barrier, sync (the bench contract's bracket)."""
+        self._sync()
+        if self.dist:
+            self.dist.barrier()
+        self._sync()
+
+    def max(self, value):
+        return max_over_ranks(value, self.dist, self.reduce_device)
+
+    def sum(self, value):
+        return sum_over_ranks(value, self.dist, self.reduce_device)
+
+    def close(self):
+        if self.dist:
+            self.dist.destroy_process_group()
 
 
 def max_over_ranks(value, dist=None, device=None):
@@ -53,3 +107,54 @@ def gather_to_rank0(tensor, dist):
         return torch.cat(parts, dim=0)
     dist.gather(tensor, gather_list=None, dst=0)
     return None
+
+
+def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None):
+    """The measured loop.  `actions`: uint8[warmup + blocks*steps, E] resident on the env's device.  `warmup` untimed
+    steps, then `blocks` timed blocks of EXACTLY `steps` steps, each bracketed by ranks.barrier() on both sides and
+    reduced with max over ranks.  `after_step(t)` (t = index into `actions`) runs inside the timed region (parity tap,
+    digests).  Returns the list of per-block seconds."""
+    import time
+    t = 0
+    for _ in range(warmup):
+        env.step(actions[t])
+        if after_step:
+            after_step(t)
+        t += 1
+    out = []
+    for _ in range(blocks):
+        ranks.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            env.step(actions[t])
+            if after_step:
+                after_step(t)
+            t += 1
+        ranks.barrier()
+        out.append(ranks.max(time.perf_counter() - t0))
+    return out
+
+
+class EnvDigest(object):
+    """Per-env running 64-bit digest of everything a step hands out (image, direction, float64 reward bits, done),
+    kept on the env's device with a handful of tensor ops per step.  Per-env, so the digests of the shards of a run
+    concatenate to the digests of the unsharded run -- the multi-rank equality check."""
+
+    def __init__(self, num_envs, device, obs_bytes):
+        import torch
+        g = torch.Generator(device="cpu")
+        g.manual_seed(20260924)
+        self.w = (torch.randint(-2 ** 62, 2 ** 62, (obs_bytes,), generator=g, dtype=torch.int64) | 1).to(device)
+        self.h = torch.zeros(num_envs, dtype=torch.int64, device=device)
+        self.torch = torch
+
+    def update(self, image, direction, reward64, done):
+        torch = self.torch
+        n = self.h.shape[0]
+        x = (image.reshape(n, -1).to(torch.int64) * self.w).sum(dim=1)
+        x = x + direction.to(torch.int64) * 0x5851F42D4C957F2D + done.to(torch.int64) * 0x14057B7EF767814F
+        x = x ^ reward64.contiguous().view(torch.int64)
+        self.h = (self.h ^ x) * (-0x61C8864680B583EB) + 0x2545F4914F6CDD1D       # odd multiplier: wraps mod 2^64
+
+    def numpy(self):
+        return self.h.cpu().numpy().view("uint64")

@@ -1,24 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the batched BabyAI hot path on MI355X.
 
-One "step" = one pass of the hot path over one batch: every env of the shard applies one
-action (transition + verifier), finished envs are regenerated on the device (auto-reset) and
-the observation is written (7x7x3 encoding, plus the 56x56x3 pixel render for the default
-BossLevel workload = BASELINE.json configs[4] on one GPU).  Actions are synthetic i.i.d.
-uniform over the 7 actions, resident in HBM before the timed region.
+One "step" = one pass of the hot path over one batch: every env of the shard applies one action (transition + verifier),
+finished envs are regenerated on the device (auto-reset) and the observation is written (7x7x3 encoding, plus the
+56x56x3 pixel render for the default BossLevel workload = BASELINE.json configs[4] on one GPU).  Actions are synthetic,
+i.i.d. uniform over the 7 actions from a counter-based generator keyed on (bench seed, step, global env index)
+(babyai_amd/action_stream.py), resident in HBM before the timed region.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Envs shard embarrassingly: rank r owns envs [r*E, (r+1)*E) with seeds base + global index; no
-collective on the step path (only the timing barrier / max-reduce).  scaling = weak
-(E envs per GPU fixed).
+What one run proves about itself (all in the one JSON line rank 0 prints):
+  * timing      W warmup steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize and max-reduced
+                over ranks, repeated until >= --min-seconds of timed work: `ms_per_step` / `value` come from the MEDIAN
+                block, `timing` holds min / median / max (box-to-box and run-to-run variance is ~10 %).
+  * roofline    the dominant kernel's algorithmic bytes / its HIP-event time on the launch stream, against the 8 TB/s
+                spec peak AND against what a plain 1-GiB fill / copy reaches on this box in this process
+                (`achievable`, `frac_of_achievable`).  `traffic` = HBM bytes per launch from the committed rocprofv3 PMC
+                passes, only while the kernel sources still hash to what was profiled (else null).
+  * parity      the outputs of the shard's first 1024 envs at EVERY timed step (image, direction, f64 reward bits, done;
+                pixels of the first 64) are tapped inside the timed region and re-derived afterwards by the CPU oracle
+                from the seeds and the action stream: `parity.mismatches` must be 0.
+  * cpu_baseline  the oracle on the usable host cores over the same seeds and action stream (a reported baseline).
+
+Envs shard embarrassingly (babyai_amd/shard.py): rank r owns global envs [r*E, (r+1)*E) with seeds base + global index;
+no collective on the step path.  scaling = weak (E envs per GPU fixed).
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -36,6 +49,47 @@ CONFIGS = {
 }
 
 
+def csrc_sha():
+    """Hash of the kernel sources: ties a PMC measurement to the code it was taken on."""
+    d = os.path.join(ROOT, "babyai_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode())
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def git_head():
+    try:
+        return subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
+
+
+def achievable_bandwidth(torch, dev):
+    """Plain fill and copy of 1 GiB on this box, in this process (GB/s of bytes moved)."""
+    n = 1 << 30
+    x = torch.empty(n, dtype=torch.uint8, device=dev).view(torch.int32)
+    y = torch.empty(n, dtype=torch.uint8, device=dev).view(torch.int32)
+
+    def timeit(fn, iters=12):
+        fn()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) / iters * 1e-3
+
+    fill = n / timeit(lambda: x.fill_(7)) / 1e9
+    copy = 2 * n / timeit(lambda: y.copy_(x)) / 1e9
+    del x, y
+    return {"fill_GBs": fill, "copy_GBs": copy, "bytes": n}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -44,61 +98,58 @@ def main():
     ap.add_argument("--envs", type=int, default=1048576, help="envs per GPU")
     ap.add_argument("--level", default="BossLevel")
     ap.add_argument("--no-pixel", action="store_true")
-    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=0, help="env i of the whole job is seeded with seed + i")
+    ap.add_argument("--action-seed", type=int, default=1234)
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
                     help="a BASELINE.json config by name (overrides --level/--envs/--no-pixel); default = C5 on one GPU")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step block until this much timed work")
+    ap.add_argument("--max-blocks", type=int, default=64)
+    ap.add_argument("--parity-envs", type=int, default=1024, help="first envs of every shard checked against the oracle (0 = off)")
+    ap.add_argument("--parity-pixel-envs", type=int, default=64)
+    ap.add_argument("--parity-budget", type=int, default=600000,
+                    help="oracle env-steps the parity check may cost: long runs check every step of fewer envs")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prewarm-seconds", type=float, default=1.0, help="untimed GPU activity before the warmup steps")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (test rigs: ranks may share a GPU)")
     ap.add_argument("--share-device", action="store_true", help="test rigs only: every rank uses cuda:0")
+    ap.add_argument("--dump-digest", default=None, help="write per-env output digests of this rank to <prefix>.rank<r>.npy")
     args = ap.parse_args()
     if args.config:
         cfgsel = CONFIGS[args.config]
         args.level, args.envs, args.no_pixel = cfgsel["level"], cfgsel["envs"], not cfgsel["pixel"]
 
+    import numpy as np
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.share_device:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=args.dist_backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU path)")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    from babyai_amd import shard
+    from babyai_amd.action_stream import actions_torch
+    ranks = shard.Ranks.from_env(args.dist_backend, args.share_device)
+    rank, world, dev = ranks.rank, ranks.world, ranks.device
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     import __graft_entry__
     if rank == 0:
         __graft_entry__.build()
-    if dist is not None:
-        dist.barrier()
+    ranks.barrier()
     from babyai_amd.engine import BatchedBabyAIEnv
 
     pixel = not args.no_pixel
     E = args.envs
+    total_envs = E * world
+    first, count = shard.shard_range(total_envs, world, rank)
+    assert count == E
     env = BatchedBabyAIEnv("BabyAI-%s-v0" % args.level, E, device=dev, pixel=pixel)
-    env.seed(args.seed + rank * E)
-    env.reset()
+    env.seed(shard.shard_seeds(args.seed, total_envs, world, rank))
     K, W = args.steps, args.warmup
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    actions = torch.randint(0, 7, (K + W, E), dtype=torch.uint8, device=dev, generator=gen)
-    torch.cuda.synchronize()
+
+    achievable = achievable_bandwidth(torch, dev) if rank == 0 else None
 
     # clock ramp: a cold GPU spends its first second or so below its sustained clocks; keep it busy with an
     # untimed fill stream before the (short) warmup so the timed region sees steady-state clocks
     if args.prewarm_seconds > 0:
+        import time
         scratch = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
         t_end = time.perf_counter() + args.prewarm_seconds
         while time.perf_counter() < t_end:
@@ -107,86 +158,182 @@ def main():
             torch.cuda.synchronize()
         del scratch
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    P = min(args.parity_envs, E)
+    if world > 1 and P:
+        P = max(min(128, E), P // world)      # every rank's host cores are shared by all ranks of the node
+    PP = min(args.parity_pixel_envs, P) if pixel else 0
+    digest = shard.EnvDigest(E, dev, 147) if args.dump_digest else None
 
-    for t in range(W):
-        env.step(actions[t])
+    def make_log(steps, with_initial, p, pp):
+        if not p:
+            return None
+        extra = 1 if with_initial else 0
+        lg = {"image": torch.zeros((steps + extra, p, 7, 7, 3), dtype=torch.uint8, device=dev),
+              "direction": torch.zeros((steps + extra, p), dtype=torch.uint8, device=dev),
+              "reward64": torch.zeros((steps, p), dtype=torch.float64, device=dev),
+              "done": torch.zeros((steps, p), dtype=torch.uint8, device=dev)}
+        if pp:
+            lg["pixels"] = torch.zeros((steps + extra, pp, 56, 56, 3), dtype=torch.uint8, device=dev)
+        return lg
+
+    def tap(lg, obs_row, row):
+        """the parity tap: one multi-tensor device copy inside the timed region"""
+        p = lg["done"].shape[1]
+        dst = [lg["image"][obs_row], lg["direction"][obs_row], lg["reward64"][row], lg["done"][row]]
+        src = [env.image[:p], env.direction[:p], env.reward64[:p], env.done[:p]]
+        if "pixels" in lg:
+            dst.append(lg["pixels"][obs_row])
+            src.append(env.pixels[:lg["pixels"].shape[1]])
+        torch._foreach_copy_(dst, src)
+
+    # phase 1: reset, W warmup steps and ONE K-step block; its time decides how many further blocks make --min-seconds
+    S1 = W + K
+    actions1 = actions_torch(args.action_seed, 0, S1, first, E, dev)        # resident before the timed region
+    log1 = make_log(S1, True, P, PP)
+    env.reset()
+    if log1 is not None:
+        log1["image"][0].copy_(env.image[:P])
+        log1["direction"][0].copy_(env.direction[:P])
+        if PP:
+            log1["pixels"][0].copy_(env.pixels[:PP])
+
+    def after1(t):
+        if log1 is not None:
+            tap(log1, t + 1, t)
+        if digest is not None:
+            digest.update(env.image, env.direction, env.reward64, env.done)
+
+    torch.cuda.synchronize()
+    blocks = shard.timed_blocks(env, actions1, W, K, 1, ranks, after1)
+    want = int(min(args.max_blocks, max(0, -(-args.min_seconds // blocks[0]))))
+    want = int(ranks.max(want))
+    # phase 2: `want` more blocks of exactly K steps; when there are any, the phase-1 block was only the probe
+    S2 = want * K
+    if P and (S1 + S2) * P > args.parity_budget:      # long run: every step of fewer envs
+        P = max(min(16, P), args.parity_budget // (S1 + S2))
+        PP = min(PP, P)
+    log2 = None
     resets0 = env.reset_count()
     env.kernel_events = []
-    barrier()
-    t0 = time.perf_counter()
-    for t in range(W, W + K):
-        env.step(actions[t])
-    barrier()
-    dt = time.perf_counter() - t0
-    resets = env.reset_count() - resets0
-    if dist is not None:
-        rdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
-        tt = torch.tensor([dt], device=rdev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        rr = torch.tensor([resets], device=rdev, dtype=torch.int64)
-        dist.all_reduce(rr)
-        resets = int(rr.item())
+    env.profile(True)              # per-kernel HIP event pairs on the launch stream (include/bbai.h bbai_profile)
+    if want:
+        actions2 = actions_torch(args.action_seed, S1, S1 + S2, first, E, dev)
+        log2 = make_log(S2, False, P, PP)
+
+        def after2(t):
+            if log2 is not None:
+                tap(log2, t, t)
+            if digest is not None:
+                digest.update(env.image, env.direction, env.reward64, env.done)
+
+        torch.cuda.synchronize()
+        blocks = shard.timed_blocks(env, actions2, 0, K, want, ranks, after2)
+    resets = ranks.sum(env.reset_count() - resets0)
+    S = S1 + S2
 
     # per-kernel-group durations from HIP events recorded on the launch stream
     sums = {}
     for tag, a, b in env.kernel_events:
         sums.setdefault(tag, []).append(a.elapsed_time(b))
-    avg_ms = {k: sum(v) / len(v) for k, v in sums.items()}
+    avg_ms = {k: sum(v) / len(v) for k, v in sums.items()} if sums else {}
+    if not avg_ms:                  # single-block run: events were not armed during it; re-measure a few steps untimed
+        env.kernel_events = []
+        env.profile(True)
+        for t in range(4):
+            env.step(actions1[t])
+        torch.cuda.synchronize()
+        for tag, a, b in env.kernel_events:
+            sums.setdefault(tag, []).append(a.elapsed_time(b))
+        avg_ms = {k: sum(v) / len(v) for k, v in sums.items()}
+    env.kernel_events = None
+    kernel_ms = {k: v[0] for k, v in env.profile_read().items() if v[0] is not None}
+    kernel_launches = {k: v[1] for k, v in env.profile_read().items() if v[0] is not None}
+    env.profile(False)
 
-    total_steps = K * E * world
-    value = total_steps / dt
+    bs = sorted(blocks)
+    med = bs[len(bs) // 2] if len(bs) % 2 else 0.5 * (bs[len(bs) // 2 - 1] + bs[len(bs) // 2])
+    value = K * E * world / med
     if pixel:
         dom, alg_bytes = "k_render", E * (147 + 9408)          # reads the encoding, writes the pixels
-        dom_ms = avg_ms["render"]
+        dom_ms = kernel_ms["k_render"]
         bytes_per_step = 9496
+        ceiling_key = "fill_GBs"                                # a pure store stream
     else:
         dom, alg_bytes = "k_step", E * 235
-        dom_ms = avg_ms["step"]
+        dom_ms = kernel_ms["k_step"]
         bytes_per_step = 235
+        ceiling_key = "copy_GBs"                                # reads and writes mixed
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
     # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate
     # runs; tools/gpu_profile.sh -> tools/summarize_profile.py -> profiles/pmc_latest.json).  Counters cannot be
-    # collected inside this process, so the committed summary is used when it was taken on this exact workload.
+    # collected inside this process: the committed summary is quoted with its provenance, and only while the kernel
+    # sources still hash to what was profiled on this exact workload.
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        if args.level == "BossLevel" and E == 1048576 and dom in pmc["kernels"]:
+        if pmc.get("level") == args.level and pmc.get("envs") == E and dom in pmc["kernels"]:
             kk = pmc["kernels"][dom]
-            traffic = kk["FETCH_SIZE"] + kk["WRITE_SIZE"]
+            traffic = {"bytes": kk["FETCH_SIZE"] + kk["WRITE_SIZE"], "fetch": kk["FETCH_SIZE"], "write": kk["WRITE_SIZE"],
+                       "source": "profiles/pmc_latest.json", "commit": pmc.get("commit"), "csrc_sha": pmc.get("csrc_sha"),
+                       "current": pmc.get("csrc_sha") == csrc_sha()}
+            if not traffic["current"]:
+                traffic["bytes"] = None         # kernels changed since the counters were taken
     except Exception:
         traffic = None
     out = {
         "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": med / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": "BabyAI-%s-v0 %s obs, %d envs/GPU, random actions, auto-reset" % (
             args.level, "56x56x3 pixel (RGBImgPartialObsWrapper)" if pixel else "7x7x3 encoded", E),
-            "envs_per_gpu": E, "total_envs": E * world, "resets_in_timed_region": resets,
-            "parallelism": "env-shards x%d, no collective" % world},
+            "envs_per_gpu": E, "total_envs": total_envs, "resets_in_timed_region": resets,
+            "parallelism": "env-shards x%d, no collective" % world,
+            "actions": "counter-based (action_seed %d, step, global env index), uniform over 7" % args.action_seed},
+        "timing": {"blocks": len(blocks), "steps_per_block": K, "block_ms": {"min": bs[0] * 1e3, "median": med * 1e3, "max": bs[-1] * 1e3},
+                   "timed_seconds": sum(blocks), "value_from": "median block", "value_at_min": K * E * world / bs[0],
+                   "value_at_max": K * E * world / bs[-1]},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic["bytes"] if traffic else None, "traffic_provenance": traffic,
+                     "achievable": achievable, "frac_of_achievable": (achieved / achievable[ceiling_key]) if achievable else None,
+                     "achievable_ceiling": ceiling_key,
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
                      "whole_step_alg_GBs": value / world * bytes_per_step / 1e9,
-                     "avg_ms": avg_ms},
-        "cpu_baseline": None,
+                     "kernel_avg_ms": kernel_ms, "kernel_launches": kernel_launches,
+                     "call_group_avg_ms": avg_ms},
+        "parity": None, "cpu_baseline": None,
+        "build": {"commit": git_head(), "csrc_sha": csrc_sha()},
     }
+    torch.cuda.synchronize()
+    if args.dump_digest:
+        np.save("%s.rank%d.npy" % (args.dump_digest, rank), digest.numpy())
+    # ---- outside the timed region: the oracle re-derives what the tap recorded --------------------------------------
+    if log1 is not None:
+        host = {k: np.concatenate([log1[k][:, :(PP if k == "pixels" else P)].cpu().numpy()]
+                                  + ([log2[k].cpu().numpy()] if log2 is not None else [])) for k in log1 if (k != "pixels" or PP)}
+        try:
+            from oracle import cpu_baseline
+            par = cpu_baseline.parity_replay(args.level, host, args.seed, args.action_seed, first, PP)
+        except Exception as exc:
+            par = {"error": repr(exc), "mismatches": -1}
+        bad = ranks.sum(par.get("mismatches", -1) if par.get("mismatches", -1) >= 0 else 1 << 20)
+        if rank == 0:
+            par["mismatches_all_ranks"] = bad
+            par["envs_all_ranks"] = P * world
+            par["steps_checked"] = "all %d steps of the run (warmup, probe block and the %d timed blocks)" % (S, len(blocks))
+            out["parity"] = par
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import cpu_baseline
-            out["cpu_baseline"] = cpu_baseline.run(args.level, pixel, args.cpu_baseline_seconds)
+            out["cpu_baseline"] = cpu_baseline.run(args.level, pixel, args.cpu_baseline_seconds, args.seed, args.action_seed)
         except Exception as exc:      # the baseline is a reported number, never the product path
             out["cpu_baseline"] = {"error": repr(exc)}
     if rank == 0:
         print(json.dumps(out))
     env.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
+    if rank == 0 and out["parity"] and out["parity"].get("mismatches_all_ranks", 0) != 0:
+        sys.exit(3)                     # a fast kernel whose results differ from the oracle's is not done
 
 
 if __name__ == "__main__":

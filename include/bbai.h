@@ -132,6 +132,12 @@ int bbai_bot_act(bbai_env* env, const uint8_t* prev_actions_dev, uint8_t* action
  * 1 in 1024 MiniBossLevel missions); those episodes fail in the reference too. */
 int bbai_bot_stats(bbai_env* env, uint64_t* gave_up, uint64_t* capacity);
 
+/* Per-kernel timing for measurements (bench.py's roofline): while enabled, every k_step / k_consume / k_render launch is
+ * bracketed by a HIP event pair ON THE STREAM IT IS LAUNCHED ON; bbai_profile_read returns the summed milliseconds and the
+ * launch counts in that order.  Enabling resets the totals.  Costs two event records per launch. */
+int bbai_profile(bbai_env* env, int enable);
+int bbai_profile_read(bbai_env* env, double* ms_total /* [3] */, int64_t* launches /* [3] */);
+
 /* Number of level generations (resets) performed so far, all envs. */
 int bbai_reset_count(bbai_env* env, uint64_t* out);
 

@@ -1,8 +1,14 @@
-"""CPU baseline leg of bench.py: the stand-alone oracle (oracle/levels.py, one Python env object per
-environment -- the reference's own execution model, babyai/rl/utils/penv.py:4-16) stepping the same
-workload (same level, random actions over all 7 actions, auto-reset, optional pixel wrapper) on the
-host cores of the box the bench runs on.  TEST/REPORTING INFRASTRUCTURE: a reported baseline
-(kind = "port"), never a product path."""
+"""CPU legs of bench.py, both built on the stand-alone oracle (oracle/levels.py, one Python env object per environment
+-- the reference's own execution model, babyai/rl/utils/penv.py:4-16).  TEST / REPORTING INFRASTRUCTURE: a reported
+baseline (kind = "port") and the in-run parity checker, never a product path.
+
+  run(...)            the same workload as the GPU leg (same level, same counter-based action stream keyed on the global
+                      env index, auto-reset, optional pixel wrapper) on the usable host cores: one env per process on every
+                      core + the single-core figure, with the parallel efficiency of the pool.
+  parity_replay(...)  re-steps the first envs of a shard from their seeds through the recorded steps of a bench run and
+                      compares EVERY output byte (image, direction, float64 reward bits, done, pixels) with what the
+                      engine produced inside the timed region.
+"""
 import multiprocessing as mp
 import os
 import sys
@@ -12,47 +18,144 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 
 
-def _worker(args):
-    level, pixel, seconds, seed = args
+def usable_cores():
+    """Cores this process may really use: the affinity mask, cut by a cgroup CPU quota when there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        quota = q / float(f.read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
+def _make(level, pixel, seed):
     if _ROOT not in sys.path:
         sys.path.insert(0, _ROOT)
-    import numpy as np
     from oracle import levels as olevels
     from gym_minigrid.wrappers import RGBImgPartialObsWrapper
     env = olevels.make_env(level)
-    env.seed(seed)
-    wrapped = RGBImgPartialObsWrapper(env) if pixel else env
+    env.seed(int(seed))
+    return env, (RGBImgPartialObsWrapper(env) if pixel else env)
+
+
+def _worker(args):
+    level, pixel, seconds, seed_base, action_seed, index = args
+    if _ROOT not in sys.path:
+        sys.path.insert(0, _ROOT)
+    from babyai_amd.action_stream import action_scalar
+    _, wrapped = _make(level, pixel, seed_base + index)
     wrapped.reset()
-    rng = np.random.RandomState(seed)
-    acts = rng.randint(0, 7, size=4096)
     steps = 0
     t0 = time.perf_counter()
     while True:
-        for a in acts:
-            _, _, done, _ = wrapped.step(int(a))
+        for _ in range(256):
+            _, _, done, _ = wrapped.step(action_scalar(action_seed, steps, index))
+            steps += 1
             if done:
                 wrapped.reset()
-        steps += len(acts)
         if time.perf_counter() - t0 >= seconds:
             break
     return steps, time.perf_counter() - t0
 
 
-def run(level="BossLevel", pixel=True, seconds=12.0):
-    cores = os.cpu_count() or 1
-    # one env-per-process on every host core (ParallelEnv's model), plus the single-core figure
-    one_steps, one_dt = _worker((level, pixel, min(4.0, seconds / 3), 0))
+def run(level="BossLevel", pixel=True, seconds=12.0, seed_base=0, action_seed=1234):
+    cores = usable_cores()
+    one_steps, one_dt = _worker((level, pixel, min(4.0, seconds / 3), seed_base, action_seed, 0))
     ctx = mp.get_context("fork")
     with ctx.Pool(cores) as pool:
-        res = pool.map(_worker, [(level, pixel, seconds, 1000 + i) for i in range(cores)])
+        res = pool.map(_worker, [(level, pixel, seconds, seed_base, action_seed, i) for i in range(cores)])
     total = sum(r[0] for r in res)
     wall = max(r[1] for r in res)
+    single = one_steps / one_dt
     return {
         "value": total / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
-        "sample": "oracle/levels.py BabyAI-%s-v0%s, %d procs x %.0f s random-action rollouts with auto-reset (%d steps)"
-                  % (level, " + RGBImgPartialObsWrapper" if pixel else "", cores, seconds, total),
-        "single_core_value": one_steps / one_dt,
+        "sample": "oracle/levels.py BabyAI-%s-v0%s: envs 0..%d of the GPU leg's batch (same seeds, same counter-based action "
+                  "stream), one process per usable core x %.0f s, auto-reset (%d steps)"
+                  % (level, " + RGBImgPartialObsWrapper" if pixel else "", cores - 1, seconds, total),
+        "single_core_value": single, "parallel_efficiency": (total / wall) / (cores * single),
+        "os_cpu_count": os.cpu_count(),
     }
+
+
+# ---- in-run parity --------------------------------------------------------------------------------------------------
+_LOG = None
+
+
+def _replay(args):
+    level, pixel_envs, seed_base, action_seed, first, lo, hi = args
+    import numpy as np
+    if _ROOT not in sys.path:
+        sys.path.insert(0, _ROOT)
+    from babyai_amd.action_stream import action_scalar
+    log = _LOG
+    steps = log["done"].shape[0]
+    bad, where = 0, None
+    for k in range(lo, hi):
+        env, wrapped = _make(level, k < pixel_envs, seed_base + first + k)
+        o = wrapped.reset()
+        enc = env.gen_obs() if k < pixel_envs else o
+
+        def check(t, o, enc, r, d):
+            nonlocal bad, where
+            ok = np.array_equal(enc["image"], log["image"][t + 1, k]) and int(enc["direction"]) == int(log["direction"][t + 1, k])
+            if t >= 0:
+                ok = ok and np.float64(r).view(np.uint64) == log["reward64"][t, k].view(np.uint64) and bool(d) == bool(log["done"][t, k])
+            if k < pixel_envs:
+                ok = ok and np.array_equal(o["image"], log["pixels"][t + 1, k])
+            if not ok:
+                bad += 1
+                if where is None:
+                    where = {"env": int(first + k), "step": int(t)}
+
+        check(-1, o, enc, 0.0, False)
+        for t in range(steps):
+            o, r, d, _ = wrapped.step(action_scalar(action_seed, t, first + k))
+            if d:
+                o = wrapped.reset()
+            enc = env.gen_obs() if k < pixel_envs else o
+            check(t, o, enc, r, d)
+    return bad, where
+
+
+def parity_replay(level, log, seed_base, action_seed, first, pixel_envs=0):
+    """log: dict of numpy arrays recorded by the bench: image uint8[S+1, P, 7,7,3] (index 0 = after reset()), direction
+    uint8[S+1, P], reward64 float64[S, P], done uint8[S, P], pixels uint8[S+1, pixel_envs, 56,56,3] -- the outputs of the
+    shard's first P envs at every step.  Returns {"envs", "steps", "mismatches", "first_mismatch", "seconds", "cores"}."""
+    global _LOG
+    _LOG = log
+    P = log["done"].shape[1]
+    cores = usable_cores()
+    t0 = time.perf_counter()
+    nchunk = min(P, cores * 4)
+    bounds = [P * c // nchunk for c in range(nchunk + 1)]
+    jobs = [(level, pixel_envs, seed_base, action_seed, first, bounds[c], bounds[c + 1]) for c in range(nchunk)]
+    ctx = mp.get_context("fork")
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_replay, jobs, chunksize=1)
+    _LOG = None
+    bad = sum(r[0] for r in res)
+    firsts = [r[1] for r in res if r[1] is not None]
+    return {"envs": P, "pixel_envs": int(pixel_envs), "steps": int(log["done"].shape[0]), "outputs": "image, direction, f64 reward bits, "
+            "done every step" + (", pixels of the first %d envs" % pixel_envs if pixel_envs else ""),
+            "mismatches": int(bad), "first_mismatch": firsts[0] if firsts else None,
+            "oracle": "oracle/levels.py", "seconds": time.perf_counter() - t0, "cores": cores}
 
 
 def c1(steps=10000, seed=0, use_reference=False):

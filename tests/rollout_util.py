@@ -79,6 +79,7 @@ class OracleTensorEnv(object):
             o, r, d, _ = e.step(int(a))
             if d:
                 o = e.reset()
-            obss.append(o); rewards.append(np.float32(r)); dones.append(d)
-        return (self._publish(obss), torch.as_tensor(np.array(rewards, dtype=np.float32)),
-                torch.as_tensor(np.array(dones, dtype=np.uint8)), {})
+            obss.append(o); rewards.append(r); dones.append(d)
+        self.reward64 = torch.as_tensor(np.array(rewards, dtype=np.float64))
+        self.done = torch.as_tensor(np.array(dones, dtype=np.uint8))
+        return (self._publish(obss), self.reward64.to(torch.float32), self.done, {})

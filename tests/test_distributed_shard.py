@@ -1,5 +1,7 @@
-"""N>1 host logic on CPU: world_size-2 gloo processes exercise the shard decomposition, the timing
-max-reduce and the optional observation gather (the step path itself has no collective)."""
+"""N>1 host logic on CPU: world_size-2 gloo processes run THE functions bench.py runs (babyai_amd/shard.py: shard
+ranges and seeds, the counter-based action stream keyed on the global env index, the barrier-bracketed timed blocks with
+max-over-ranks, the per-env output digests, the optional observation gather) over oracle envs, and the concatenated
+per-rank results must equal the unsharded run.  (The step path itself has no collective.)"""
 import os
 import socket
 
@@ -10,6 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from babyai_amd import shard
+from babyai_amd.action_stream import actions_numpy, actions_torch, action_scalar
 
 
 def test_shard_range_partitions():
@@ -25,38 +28,66 @@ def test_shard_range_partitions():
         shard.shard_range(8, 2, 2)
 
 
-def _worker(rank, world, port, total, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    seeds = shard.shard_seeds(1000, total, world, rank)
-    # a stand-in "observation" that is a pure function of the seed: shard-count independent
-    obs = torch.from_numpy((seeds[:, None] * np.arange(1, 5, dtype=np.uint64)[None, :] % 251).astype(np.uint8))
-    full = shard.gather_to_rank0(obs, dist)
-    t = shard.max_over_ranks(0.5 + rank, dist)
-    n = shard.sum_over_ranks(len(seeds), dist)
+def test_action_stream_is_one_function_of_seed_step_and_global_index():
+    a = actions_numpy(1234, 5, 1000, 4096)
+    assert np.array_equal(a, actions_torch(1234, 3, 8, 1000, 4096, "cpu")[2].numpy())
+    assert a.tolist() == [action_scalar(1234, 5, 1000 + i) for i in range(4096)]
+    # a shard sees the same actions whatever the number of ranks
+    assert np.array_equal(a[1024:2048], actions_numpy(1234, 5, 2024, 1024))
+    counts = np.bincount(actions_numpy(7, 0, 0, 700000), minlength=7)
+    assert counts.min() > 98500 and counts.max() < 101500 and len(counts) == 7
+
+
+LEVEL, TOTAL, W, K, BLOCKS, SEED, ASEED = "GoToObjS4", 24, 3, 8, 2, 700, 99
+
+
+def _rollout(ranks, first, count):
+    """What bench.py does with a shard, on the oracle-backed tensor env."""
+    from rollout_util import OracleTensorEnv
+    seeds = np.arange(first, first + count, dtype=np.uint64) + np.uint64(SEED)
+    env = OracleTensorEnv(LEVEL, seeds)
+    actions = actions_torch(ASEED, 0, W + K * BLOCKS, first, count, "cpu")
+    env.reset()
+    dig = shard.EnvDigest(count, "cpu", 147)
+    blocks = shard.timed_blocks(env, actions, W, K, BLOCKS, ranks,
+                                lambda t: dig.update(env.image, env.direction, env.reward64, env.done))
+    return env, dig, blocks
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    ranks = shard.Ranks.from_env("gloo")
+    assert (ranks.rank, ranks.world) == (rank, world)
+    first, count = shard.shard_range(TOTAL, world, rank)
+    assert np.array_equal(shard.shard_seeds(SEED, TOTAL, world, rank), np.arange(first, first + count, dtype=np.uint64) + np.uint64(SEED))
+    env, dig, blocks = _rollout(ranks, first, count)
+    full_img = shard.gather_to_rank0(env.image, ranks.dist)
+    full_dig = shard.gather_to_rank0(dig.h, ranks.dist)
+    t = ranks.max(0.5 + rank)
+    n = ranks.sum(count)
     if rank == 0:
-        q.put((full.numpy(), t, n))
-    dist.barrier()
-    dist.destroy_process_group()
+        q.put((full_img.numpy(), full_dig.numpy(), blocks, t, n))
+    ranks.barrier()
+    ranks.close()
 
 
-def test_two_rank_gloo_shards():
+def test_two_rank_gloo_shards_equal_the_unsharded_run():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    total, world = 64, 2
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    full, t, n = q.get(timeout=120)
+    full_img, full_dig, blocks, t, n = q.get(timeout=300)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
-    seeds = np.arange(total, dtype=np.uint64) + np.uint64(1000)
-    expect = (seeds[:, None] * np.arange(1, 5, dtype=np.uint64)[None, :] % 251).astype(np.uint8)
-    assert np.array_equal(full, expect)       # rank-ordered concatenation == unsharded result
-    assert t == 1.5                           # max over ranks
-    assert n == total
+    env, dig, _ = _rollout(shard.Ranks(), 0, TOTAL)
+    assert np.array_equal(full_img, env.image.numpy())          # rank-ordered concatenation == unsharded result
+    assert np.array_equal(full_dig, dig.h.numpy())              # ... at every step, every output (running digests)
+    assert len(blocks) == BLOCKS and all(b > 0 for b in blocks)
+    assert t == 1.5                                             # max over ranks
+    assert n == TOTAL

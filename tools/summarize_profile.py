@@ -19,7 +19,27 @@ for f in os.listdir(src):
 ks = os.path.join(src, "stats", "boss_kernel_stats.csv")
 if os.path.isfile(ks):
     shutil.copy(ks, os.path.join(dst, "rocprofv3_kernel_stats_boss_pixel_1M.csv"))
+def _csrc_sha():
+    import hashlib
+    d = os.path.join("babyai_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode())
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _git_head():
+    import subprocess
+    try:
+        return subprocess.check_output(["git", "rev-parse", "--short", "HEAD"]).decode().strip()
+    except Exception:
+        return None
+
+
 summary = {"workload": "BabyAI-BossLevel-v0 pixel, 1048576 envs, bench.py --steps 8 --warmup 2", "unit": "bytes per launch",
+           "level": "BossLevel", "envs": 1048576, "commit": _git_head(), "csrc_sha": _csrc_sha(), "profile_tag": tag,
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (kernel-trace only); counters are KB per "
                    "dispatch; steady-state = median over launches (the first k_pregen/k_consume launches cover all envs). "
                    "gfx950 FETCH_SIZE under-reports wide streaming reads by 2x (MI355X_MICROARCH.md); reported raw.",
