@@ -627,6 +627,31 @@ __global__ __launch_bounds__(64) void k_tokens(LevelCfg c, int64_t n, const uint
 }
 
 // ------------------------------------------------------------------------------------------
+// k_gae : generalised advantage estimation of a rollout, lane = env (babyai/rl/algos/base.py:196-202 as ONE reverse
+// scan per env instead of T passes of five tensor ops).  All buffers are env-major [P][T], the layout the reference
+// flattens its experiences to (base.py:207-232), so nothing is transposed afterwards.  float32 arithmetic in the
+// reference's operation order (python scalars multiply as float32; the file is built with -ffp-contract=off):
+//   delta = (r + (d * next_value) * next_mask) - v ;  adv = delta + ((d * lambda) * next_adv) * next_mask
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_gae(int64_t P, int T, const float* __restrict__ rewards, const float* __restrict__ values,
+                                            const float* __restrict__ masks, const float* __restrict__ last_mask,
+                                            const float* __restrict__ last_value, float d, float dl, float* __restrict__ adv,
+                                            float* __restrict__ ret) {
+    const int64_t p = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (p >= P) return;
+    const float* r = rewards + p * T; const float* v = values + p * T; const float* m = masks + p * T;
+    float next_value = last_value[p], next_mask = last_mask[p], next_adv = 0.0f;
+    for (int i = T - 1; i >= 0; --i) {
+        const float vi = v[i];
+        const float delta = (r[i] + (d * next_value) * next_mask) - vi;
+        const float a = delta + (dl * next_adv) * next_mask;
+        adv[p * T + i] = a;
+        ret[p * T + i] = vi + a;
+        next_value = vi; next_mask = m[i]; next_adv = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
 extern "C" {
@@ -1181,6 +1206,16 @@ int bbai_bot_stats(bbai_env* e, uint64_t* gave_up, uint64_t* capacity) {
     unsigned long long v[2] = {0, 0};
     HIP_TRY(hipMemcpy(v, e->bot_stats, 16, hipMemcpyDeviceToHost));
     *gave_up = v[0]; *capacity = v[1];
+    return BBAI_OK;
+}
+
+int bbai_gae(int64_t num_envs, int num_frames, const float* rewards, const float* values, const float* masks, const float* last_mask,
+             const float* last_value, double discount, double gae_lambda, float* advantage, float* returnn, void* stream) {
+    if (num_envs <= 0 || num_frames <= 0 || !rewards || !values || !masks || !last_mask || !last_value || !advantage || !returnn)
+        ARG_FAIL("null pointer or empty rollout");
+    hipLaunchKernelGGL(k_gae, dim3((unsigned)((num_envs + 63) / 64)), dim3(64), 0, (hipStream_t)stream, num_envs, num_frames, rewards, values,
+                       masks, last_mask, last_value, (float)discount, (float)(discount * gae_lambda), advantage, returnn);
+    HIP_TRY(hipGetLastError());
     return BBAI_OK;
 }
 

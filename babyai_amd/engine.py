@@ -62,6 +62,7 @@ def load_library():
     lib.bbai_export_state.argtypes = [P, I64, I64, P, P, P]
     lib.bbai_import_state.argtypes = [P, I64, I64, P, P, P]
     lib.bbai_get_programs.argtypes = [P, I64, I64, P]
+    lib.bbai_gae.argtypes = [I64, I32, P, P, P, P, P, ctypes.c_double, ctypes.c_double, P, P, P]
     lib.bbai_profile.argtypes = [P, I32]
     lib.bbai_profile_read.argtypes = [P, P, P]
     lib.bbai_checkpoint_bytes.argtypes = [P]
@@ -80,7 +81,7 @@ EXPORTED_SYMBOLS = (
     "bbai_version", "bbai_last_error", "bbai_fill_layout", "bbai_create", "bbai_destroy", "bbai_seed",
     "bbai_reset", "bbai_step", "bbai_set_atlas", "bbai_render", "bbai_set_token_buffer", "bbai_export_state", "bbai_import_state",
     "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures", "bbai_bot_act", "bbai_bot_stats",
-    "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load", "bbai_profile", "bbai_profile_read",
+    "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load", "bbai_profile", "bbai_profile_read", "bbai_gae",
 )
 
 
@@ -176,6 +177,7 @@ class BatchedBabyAIEnv(object):
         self._missions = None
         self.kernel_events = None      # bench.py: list of (tag, start_event, end_event) when enabled
         self.num_actions = 7
+        self.max_mission_tokens = min(TOK_MAX, missions.max_mission_tokens(self.cfg))
         self.max_steps_bound = 8 * self.cfg.room_size ** 2 * self.cfg.num_rows * self.cfg.num_cols
         if seeds is not None:
             self.seed(seeds)

@@ -70,3 +70,24 @@ def tokenize(mission):
     babyai/utils/format.py:64 `re.findall("([a-z]+)", mission.lower())`)."""
     import re
     return [WORD_TO_ID[w] for w in re.findall("([a-z]+)", mission.lower())]
+
+
+def max_mission_tokens(cfg):
+    """Upper bound on the token count of any mission of a level (so that a model can be fed a fixed instruction width,
+    no host synchronisation per frame): per descriptor article + colour + type (+ up to 4 location words); per leaf the
+    verb (go to / pick up / open / put ... next to); " and " inside a side, ", then " / " after you " between sides."""
+    kind = int(cfg.kind)
+    if kind == 2:                      # bonus scripts: hand-written missions, at most two leaves without locations
+        return 28
+    desc = 3 + (4 if (kind == 1 and cfg.locations) else 0)
+    leaf = {L_GOTO: 2 + desc, L_PICKUP: 2 + desc, L_OPEN: 1 + desc, L_PUTNEXT: 3 + 2 * desc}
+    if kind == 0:
+        return leaf[int(cfg.instr)]
+    kinds = [int(cfg.action_kinds[i]) + 1 for i in range(int(cfg.n_action_kinds))]      # AK_* -> L_*
+    one = max(leaf[k] for k in kinds)
+    instr = [int(cfg.instr_kinds[i]) for i in range(int(cfg.n_instr_kinds))]           # 0 action, 1 and, 2 seq
+    if 2 in instr:
+        return 4 * one + 2 + 2         # two And-pairs joined by " after you "
+    if 1 in instr:
+        return 2 * one + 1
+    return one

@@ -12,9 +12,9 @@ preprocessor below never leaves the GPU:
 
 `batch` quacks like `babyai.rl.DictList` (attribute access, len, integer/slice/tensor indexing), which is
 what `ACModel.forward` (babyai/model.py:217-273) and `BaseAlgo.collect_experiences` (base.py:131-188)
-touch.  The vocabulary is FIXED (the 32 baby-language words, babyai_amd/missions.py VOCAB) rather than
-first-seen order; `vocab_dict()` returns it in the reference's `Vocabulary.vocab` format
-(format.py:15-41) so a model can be trained and saved against it.
+touch.  The engine's ids are FIXED (the 32 baby-language words, babyai_amd/missions.py VOCAB); a reference vocabulary
+(`vocab.json`, ids in first-seen order, format.py:15-41) is honoured through a remap table on the device
+(`load_vocab`), and `save_vocab` / `vocab_dict()` write the reference's format.
 """
 from .missions import VOCAB, WORD_TO_ID
 
@@ -33,25 +33,69 @@ class TensorDict(dict):
         return TensorDict({k: v[index] for k, v in dict.items(self)})
 
 
+def remap_table(vocab, max_size=100):
+    """(lut, vocab'): lut[fixed id] = id in the reference vocabulary `vocab` ({word: id}, format.py:15-41); words it has
+    never seen get the next free ids, as `Vocabulary.__getitem__` hands them out (format.py:24-29), in VOCAB order."""
+    vocab = {str(k): int(v) for k, v in vocab.items()}
+    for w in VOCAB:
+        if w not in vocab:
+            if len(vocab) >= max_size:
+                raise ValueError("Maximum vocabulary capacity reached")
+            vocab[w] = len(vocab) + 1
+    return [0] + [vocab[w] for w in VOCAB], vocab
+
+
 class TensorObssPreprocessor(object):
-    def __init__(self, env, max_vocab=100):
+    """`vocab`: None = the fixed ids of missions.VOCAB; or a reference vocabulary -- the `vocab.json` a reference model was
+    trained with (`Vocabulary.save`, babyai/utils/format.py:31-35: {word: id} in first-seen order) as a path or dict.
+    Token ids then go through a 33-entry remap table ON THE DEVICE, so a reference-trained `ACModel` runs on the tensor
+    fast path with the ids it was trained on.  Words the loaded vocabulary has never seen get the next free ids, as
+    `Vocabulary.__getitem__` would hand them out (format.py:24-29), in missions.VOCAB order."""
+
+    def __init__(self, env, max_vocab=100, vocab=None):
         self.env = env
         self.tokens = env.enable_instr_tokens()
+        self.max_size = max_vocab
         self.obs_space = {"image": 147, "instr": max_vocab}     # same keys as ObssPreprocessor.obs_space
+        self.vocab = dict(WORD_TO_ID)
+        self.lut = None
+        self.width = int(getattr(env, "max_mission_tokens", self.tokens.shape[1]))
+        if vocab is not None:
+            self.load_vocab(vocab)
 
-    @staticmethod
-    def vocab_dict():
-        return dict(WORD_TO_ID)
+    def load_vocab(self, vocab):
+        import json
+        if not isinstance(vocab, dict):
+            with open(vocab) as f:
+                vocab = json.load(f)
+        lut, vocab = remap_table(vocab, self.max_size)          # fixed id (1..32) -> the loaded vocabulary's id; 0 = padding
+        torch = self.env.torch
+        self.lut = torch.as_tensor(lut, dtype=torch.int64, device=self.env.device)
+        self.vocab = vocab
+        return vocab
+
+    def save_vocab(self, path):
+        """The vocabulary in the reference's file format (format.py:31-35)."""
+        import json
+        with open(path, "w") as f:
+            json.dump(self.vocab, f)
+
+    def vocab_dict(self):
+        return dict(self.vocab)
 
     @staticmethod
     def words():
         return list(VOCAB)
 
-    def __call__(self, obs=None, device=None):
+    def __call__(self, obs=None, device=None, trim=True):
+        """trim=True pads to the longest mission of the batch like the reference (one device->host read of the length);
+        trim=False uses the level's fixed width (no synchronisation)."""
         torch = self.env.torch
         obs = obs if obs is not None else {"image": self.env.pixels if self.env.pixel else self.env.image}
         image = obs["image"].to(torch.float32)                  # RawImagePreprocessor: float image, no scaling
         tok = self.tokens
-        length = int((tok != 0).sum(dim=1).max().item())        # pad to the longest mission of the batch
-        instr = tok[:, :max(length, 1)].to(torch.int64)
+        width = max(int((tok != 0).sum(dim=1).max().item()), 1) if trim else self.width
+        instr = tok[:, :width].to(torch.int64)
+        if self.lut is not None:
+            instr = self.lut[instr]
         return TensorDict(image=image, instr=instr)

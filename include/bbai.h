@@ -132,6 +132,15 @@ int bbai_bot_act(bbai_env* env, const uint8_t* prev_actions_dev, uint8_t* action
  * 1 in 1024 MiniBossLevel missions); those episodes fail in the reference too. */
 int bbai_bot_stats(bbai_env* env, uint64_t* gave_up, uint64_t* capacity);
 
+/* Generalised advantage estimation of a rollout on the current device (the loop of babyai/rl/algos/base.py:196-202 as
+ * one reverse scan per env).  All buffers float32, env-major [num_envs][num_frames] (the order base.py:207-232 flattens
+ * experiences to); masks[p][i] = 1 - done before frame i, last_mask / last_value [num_envs] = the mask and the critic's
+ * value after the last frame.  Writes advantage and returnn = value + advantage.  float32 in the reference's operation
+ * order: bit-identical to its torch loop. */
+int bbai_gae(int64_t num_envs, int num_frames, const float* rewards_dev, const float* values_dev, const float* masks_dev,
+             const float* last_mask_dev, const float* last_value_dev, double discount, double gae_lambda,
+             float* advantage_dev, float* returnn_dev, void* stream);
+
 /* Per-kernel timing for measurements (bench.py's roofline): while enabled, every k_step / k_consume / k_render launch is
  * bracketed by a HIP event pair ON THE STREAM IT IS LAUNCHED ON; bbai_profile_read returns the summed milliseconds and the
  * launch counts in that order.  Enabling resets the totals.  Costs two event records per launch. */

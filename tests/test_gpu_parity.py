@@ -183,6 +183,20 @@ def test_device_mission_tokens(gpu, level):
     assert torch.equal(batch.image.to(torch.uint8), env.image)
     sub = batch[torch.arange(0, n, 2, device=gpu)]
     assert len(sub) == n // 2 and sub.instr.shape[0] == n // 2
+    # a reference vocabulary (ids in first-seen order, format.py:15-41) through the remap table on the device
+    words = list(reversed(pre.words()))[:20]
+    ref_vocab = {w: i + 1 for i, w in enumerate(words)}
+    pre2 = TensorObssPreprocessor(env, vocab=ref_vocab)
+    b2 = pre2(obs)
+    full = pre2.vocab_dict()
+    assert all(full[w] == ref_vocab[w] for w in ref_vocab) and sorted(full.values()) == list(range(1, 33))
+    got = b2.instr.cpu().numpy()
+    import re
+    for i in range(0, n, 7):
+        ids = [full[w] for w in re.findall("([a-z]+)", missions[i])]
+        assert list(got[i, :len(ids)]) == ids and not got[i, len(ids):].any()
+    fixed = pre2(obs, trim=False)                  # the level's fixed width: no host synchronisation
+    assert fixed.instr.shape == (n, env.max_mission_tokens) and torch.equal(fixed.instr[:, :longest], b2.instr)
     if level == "PutNextLocal":
         assert env.reset_count() > n
     env.close()
@@ -583,6 +597,34 @@ def test_device_rollout_engine_equals_oracle_rollout(gpu, level):
         done_total += l1["episodes_done"]
     assert done_total >= n // 2
     env.close()
+
+
+@pytest.mark.gpu
+def test_gae_kernel_equals_the_reference_loop(gpu):
+    """bbai_gae (one reverse scan per env, env-major buffers) vs the reference's loop (base.py:196-202) in torch float32
+    ops on [T, P] tensors: every advantage / return bit for bit, including masked episode boundaries."""
+    import torch
+    from babyai_amd.rollout import gae_env_major
+    g = torch.Generator(device="cpu")
+    g.manual_seed(3)
+    P, T, d, lam = 3001, 40, 0.99, 0.95
+    rewards = (torch.rand(T, P, generator=g) * 20 * (torch.rand(T, P, generator=g) < 0.1)).to(torch.float32)
+    values = torch.randn(T, P, generator=g)
+    masks = (torch.rand(T, P, generator=g) > 0.08).to(torch.float32)
+    last_mask = (torch.rand(P, generator=g) > 0.08).to(torch.float32)
+    last_value = torch.randn(P, generator=g)
+    adv = torch.zeros(T, P)
+    for i in reversed(range(T)):                   # base.py:196-202, verbatim semantics
+        next_mask = masks[i + 1] if i < T - 1 else last_mask
+        next_value = values[i + 1] if i < T - 1 else last_value
+        next_advantage = adv[i + 1] if i < T - 1 else 0
+        delta = rewards[i] + d * next_value * next_mask - values[i]
+        adv[i] = delta + d * lam * next_advantage * next_mask
+    dev = lambda x: x.t().contiguous().to(gpu)
+    a, r = torch.zeros(P, T, device=gpu), torch.zeros(P, T, device=gpu)
+    gae_env_major(dev(rewards), dev(values), dev(masks), last_mask.to(gpu), last_value.to(gpu), d, lam, a, r)
+    torch.cuda.synchronize()
+    assert torch.equal(a.cpu(), adv.t()) and torch.equal(r.cpu(), (values + adv).t())
 
 
 @pytest.mark.gpu

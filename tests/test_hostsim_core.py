@@ -92,3 +92,21 @@ def test_tables_agree():
             tg = kw.get("target", "redball" if kw.get("redball") else "dist")
             assert p["target"] == {"redball": 0, "dist": 1, "door": 2, "two_dists": 3, "locked_door": 4,
                                    "locked_room_obj": 5}[tg], name
+
+
+def test_max_mission_tokens_bounds_every_level():
+    """babyai_amd.missions.max_mission_tokens(cfg) -- the fixed instruction width DeviceRollout feeds the model -- is an
+    upper bound of the token count of generated missions on every registered level, and not a wild one."""
+    from babyai_amd.levels import LEVELS, make_cfg
+    from babyai_amd.missions import max_mission_tokens, tokenize
+    from hostsim_util import HostEnv
+    for name in sorted(LEVELS):
+        cfg = make_cfg(name)
+        bound = max_mission_tokens(cfg)
+        longest = 0
+        for seed in range(40):
+            h = HostEnv(cfg, 9000 + seed)
+            for _ in range(3):
+                h.reset()
+                longest = max(longest, len(tokenize(h.mission)))
+        assert longest <= bound <= 72, (name, longest, bound)
