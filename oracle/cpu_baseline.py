@@ -99,7 +99,7 @@ _LOG = None
 
 
 def _replay(args):
-    level, pixel_envs, seed_base, action_seed, first, lo, hi = args
+    level, pixel_envs, seed_base, action_seed, ids, lo, hi = args
     import numpy as np
     if _ROOT not in sys.path:
         sys.path.insert(0, _ROOT)
@@ -108,7 +108,8 @@ def _replay(args):
     steps = log["done"].shape[0]
     bad, where = 0, None
     for k in range(lo, hi):
-        env, wrapped = _make(level, k < pixel_envs, seed_base + first + k)
+        gid = int(ids[k])                                   # global env index: seed and action stream key
+        env, wrapped = _make(level, k < pixel_envs, seed_base + gid)
         o = wrapped.reset()
         enc = env.gen_obs() if k < pixel_envs else o
 
@@ -122,11 +123,11 @@ def _replay(args):
             if not ok:
                 bad += 1
                 if where is None:
-                    where = {"env": int(first + k), "step": int(t)}
+                    where = {"env": gid, "step": int(t)}
 
         check(-1, o, enc, 0.0, False)
         for t in range(steps):
-            o, r, d, _ = wrapped.step(action_scalar(action_seed, t, first + k))
+            o, r, d, _ = wrapped.step(action_scalar(action_seed, t, gid))
             if d:
                 o = wrapped.reset()
             enc = env.gen_obs() if k < pixel_envs else o
@@ -134,10 +135,10 @@ def _replay(args):
     return bad, where
 
 
-def parity_replay(level, log, seed_base, action_seed, first, pixel_envs=0):
+def parity_replay(level, log, seed_base, action_seed, first, pixel_envs=0, env_ids=None):
     """log: dict of numpy arrays recorded by the bench: image uint8[S+1, P, 7,7,3] (index 0 = after reset()), direction
     uint8[S+1, P], reward64 float64[S, P], done uint8[S, P], pixels uint8[S+1, pixel_envs, 56,56,3] -- the outputs of the
-    shard's first P envs at every step.  Returns {"envs", "steps", "mismatches", "first_mismatch", "seconds", "cores"}."""
+    shard's first P envs at every step (or of the global envs `env_ids`, in that order).  Returns {"envs", "steps", "mismatches", "first_mismatch", "seconds", "cores"}."""
     global _LOG
     _LOG = log
     P = log["done"].shape[1]
@@ -145,7 +146,9 @@ def parity_replay(level, log, seed_base, action_seed, first, pixel_envs=0):
     t0 = time.perf_counter()
     nchunk = min(P, cores * 4)
     bounds = [P * c // nchunk for c in range(nchunk + 1)]
-    jobs = [(level, pixel_envs, seed_base, action_seed, first, bounds[c], bounds[c + 1]) for c in range(nchunk)]
+    ids = [first + k for k in range(P)] if env_ids is None else [int(i) for i in env_ids]
+    assert len(ids) == P
+    jobs = [(level, pixel_envs, seed_base, action_seed, ids, bounds[c], bounds[c + 1]) for c in range(nchunk)]
     ctx = mp.get_context("fork")
     with ctx.Pool(cores) as pool:
         res = pool.map(_replay, jobs, chunksize=1)

@@ -149,3 +149,60 @@ def test_expert_solves_every_episode_at_scale(gpu):
     assert int(episodes) > n // 8 and int(solved) == int(episodes)
     assert env.bot_stats() == {"gave_up": 0, "capacity": 0} and env.generator_failures() == 0
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level,n,pixel,steps", [("GoToLocal", 65536, False, 160), ("PickupLoc", 262144, False, 160),
+                                                 ("GoTo", 131072, False, 640), ("BossLevel", N_FULL, True, 600)])
+def test_baseline_configs_1024_scattered_envs_vs_oracle(gpu, level, n, pixel, steps):
+    """Every BASELINE.json GPU config at its full per-GPU size: 1024 envs scattered over the whole batch (block and wave
+    boundaries, both ends, a pseudo-random spread), EVERY output of EVERY step -- image, direction, float64 reward bits,
+    done, and the pixels of 32 of them -- re-derived by the CPU oracle from the seeds and the counter-based action
+    stream in a process pool: >= 2 x max_steps steps for the single-room levels (every env crosses auto-resets), >= 600
+    steps for the mazes."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from babyai_amd.action_stream import actions_torch
+    from oracle import cpu_baseline
+    rng = np.random.RandomState(n % 9973)
+    ids = sorted(set([0, 1, 63, 64, 255, 256, 257, n // 2 - 1, n // 2, n - 257, n - 256, n - 65, n - 2, n - 1]
+                     + rng.randint(0, n, size=1400).tolist()))[:1024]
+    assert len(ids) == 1024
+    PP = 32 if pixel else 0
+    sel = torch.as_tensor(ids, device=gpu)
+    env = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, pixel=pixel, seeds=5000)
+    env.reset()
+    log = {"image": torch.zeros((steps + 1, 1024, 7, 7, 3), dtype=torch.uint8, device=gpu),
+           "direction": torch.zeros((steps + 1, 1024), dtype=torch.uint8, device=gpu),
+           "reward64": torch.zeros((steps, 1024), dtype=torch.float64, device=gpu),
+           "done": torch.zeros((steps, 1024), dtype=torch.uint8, device=gpu)}
+    if PP:
+        log["pixels"] = torch.zeros((steps + 1, PP, 56, 56, 3), dtype=torch.uint8, device=gpu)
+    log["image"][0] = env.image[sel]
+    log["direction"][0] = env.direction[sel]
+    if PP:
+        log["pixels"][0] = env.pixels[sel[:PP]]
+    chunk = 64
+    for t0 in range(0, steps, chunk):
+        acts = actions_torch(777, t0, min(steps, t0 + chunk), 0, n, gpu)
+        for k in range(acts.shape[0]):
+            t = t0 + k
+            env.step(acts[k])
+            log["image"][t + 1] = env.image[sel]
+            log["direction"][t + 1] = env.direction[sel]
+            log["reward64"][t] = env.reward64[sel]
+            log["done"][t] = env.done[sel]
+            if PP:
+                log["pixels"][t + 1] = env.pixels[sel[:PP]]
+    torch.cuda.synchronize()
+    finished = int(log["done"].sum())
+    host = {k: v.cpu().numpy() for k, v in log.items()}
+    resets = env.reset_count() - n
+    env.close()
+    res = cpu_baseline.parity_replay(level, host, 5000, 777, 0, PP, env_ids=ids)
+    assert res["mismatches"] == 0, res
+    assert res["envs"] == 1024 and res["steps"] == steps
+    if level in ("GoToLocal", "PickupLoc"):
+        assert finished >= 2 * 1024 and resets >= 2 * n          # everybody crossed auto-resets, twice on average
+    else:
+        assert finished >= 1024 // 2 if level == "GoTo" else finished > 100
