@@ -28,6 +28,26 @@
 #include "bbai_types.hpp"
 #include "bbai_step.hpp"
 
+// Optional phase timers of the expert (experiment builds only: -DBBAI_BOT_PROF, tools/bot_prof.sh): wave wall-clock ticks
+// per phase, added by the first active lane of a scope.  Expands to nothing in the product build.
+#if defined(BBAI_BOT_PROF) && defined(__HIP_DEVICE_COMPILE__)
+extern __device__ unsigned long long g_bot_prof[32];
+struct BotProfScope {
+    int ph; unsigned long long t0;
+    __device__ BotProfScope(int p) : ph(p), t0(wall_clock64()) {}
+    __device__ ~BotProfScope() {
+        const unsigned long long dt = wall_clock64() - t0;
+        const unsigned long long act = __ballot(1);
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) { atomicAdd(&g_bot_prof[ph], dt); atomicAdd(&g_bot_prof[16 + ph], 1ull); }
+    }
+};
+#define BOT_PROF(ph) BotProfScope bot_prof_scope_##ph(ph)
+#else
+#define BOT_PROF(ph)
+#endif
+enum { BP_DECIDE = 0, BP_OBS = 1, BP_AFTER = 2, BP_FIND_OBJ = 3, BP_PATH = 4, BP_SEARCH = 5, BP_ROWS = 6, BP_DROP_POS = 7, BP_BEFORE = 8,
+       BP_INIT = 9, BP_KEYS = 10 };
+
 namespace bbai {
 
 constexpr int BOT_STACK = 48;       // default subgoal stack depth (overflow => dead, counted); BBAI_BOT_STACK raises it
@@ -35,6 +55,7 @@ constexpr int BOT_KEYS = 12;        // same-colour keys a key descriptor can lis
 constexpr int BOT_MAX_CELLS = MAX_W * MAX_W;
 constexpr int BOT_MAX_ITERS = 1000; // replanning rounds per decision (the reference would spin for ever)
 constexpr int BOT_DEAD = 0xFF;      // action value reported for a dead bot
+constexpr int BOT_RING = 64;        // LDS ring of the first search's newest queue entries (k_bot)
 
 enum : uint8_t { SG_CLOSE = 0, SG_OPEN, SG_DROP, SG_PICKUP, SG_GONEXT, SG_EXPLORE };
 enum : uint8_t { RS_NONE = 0, RS_UNLOCK, RS_KEEPKEY, RS_PUTNEXT, RS_EXPLORE, RS_OPEN };
@@ -68,11 +89,28 @@ BB_HD size_t bot_state_bytes(int stack_cap) { return sizeof(BotState) + (size_t)
 // _shortest_path) behind a strided view, so the kernel can choose the layout (k_bot: contiguous per thread).
 constexpr int BOT_WORK_WORDS = 4 * BOT_MAX_CELLS;
 enum { WK_PREV1 = 0, WK_Q1 = 1, WK_PREV2 = 2, WK_Q2 = 3 };
+// Row bitmasks (bit x of row y) that turn the per-pop grid / visited look-ups of the searches into bit tests: what a
+// position may be expanded through (search 1: free cells and open doors; search 2: blockers too) and which positions a
+// search has queued.  The two of search 1 are the hot ones (k_bot keeps them in LDS, [row][lane]: conflict-free, H rows
+// each), search 2's live in slower memory (it only runs when search 1 failed).
+enum { R_EXP1 = 0, R_VIS1 = 1, R_FAST = 2, R_EXP2 = 2, R_VIS2 = 3, R_ALL = 4 };
 struct BotWork {
     uint16_t* base;
     int stride;
     int cells;                      // W * H of the level: the four arrays are packed to the grid actually in use
+    uint32_t* rows_fast;            // [R_FAST][rows_h] x rstride_fast
+    uint32_t* rows_slow;            // [R_ALL - R_FAST][MAX_W] x rstride_slow
+    int rstride_fast, rstride_slow, rows_h;
+    uint16_t* ring;                 // the newest `ring_size` (power of two) queue entries of search 1, entry i at
+    int ring_stride, ring_size;     // ring[(i & (ring_size - 1)) * ring_stride]; 0 = no ring (host).  A FIFO's live part is
+                                    // its frontier, which is short: the eager expansion pops from LDS instead of waiting
+                                    // for a dependent global load per position
+    int eager;                      // 1: run search 1 to exhaustion at the top of every decision, while the lanes of a wave are
+                                    // still together (queries then only look things up); 0: expand lazily inside the queries
     BB_HD uint16_t& at(int arr, int i) const { return base[(int64_t)(arr * cells + i) * stride]; }
+    BB_HD uint32_t& row(int arr, int y) const {
+        return arr < R_FAST ? rows_fast[(arr * rows_h + y) * rstride_fast] : rows_slow[(int64_t)((arr - R_FAST) * MAX_W + y) * rstride_slow];
+    }
 };
 
 struct Bot {
@@ -182,90 +220,128 @@ struct Bot {
     // it pops), and the env does not change inside Bot.replan.  So each of the two searches of _shortest_path (from the
     // agent / from everything the first one reached, through blockers) is kept as ONE resumable tree per decision:
     // a query first looks through the positions already popped, in pop order, then keeps popping until the test
-    // accepts.  Queue entries: cell | dir << 10; prev: 0xFFFF not queued, 0xFFFE = None (an initial state).
+    // accepts.  Queue entries: packed position | dir << 10; prev: predecessor (packed), 0xFFFE = None (an initial state).
     mutable int head1 = 0, qn1 = -1, head2 = 0, qn2 = -1;          // qn < 0: search not started in this decision
 
+    // (prev array: predecessor of every queued position, WRITTEN when it is queued and only read back along the path of
+    // an answer; "already queued" is the R_VIS row bit, "may be expanded" the R_EXP row bit)
+    // Positions travel through the searches PACKED as y << 5 | x (no division by the grid width per pop); the predecessor
+    // arrays are indexed y * W + x.
+    BB_HD static int pk(int x, int y) { return y << 5 | x; }
+    BB_HD int pidx(int p) const { return (p >> 5) * c.W + (p & 31); }
     BB_HD void expand(int prev, int q, int& qn, int st, bool ignore_blockers) const {
-        const int ci = st & 1023, d = st >> 10;
-        const int x = ci % c.W, y = ci / c.W;
-        const int e = cell(x, y);
-        if (!seen(x, y)) return;
-        if (!is_none(e)) {
-            const int t = e_type(e);
-            if (t == T_WALL) return;
-            if (t == T_DOOR) { if (e_state(e) != S_OPEN) return; }
-            else if (!ignore_blockers) return;
-        }
+        const int p = st & 1023, d = st >> 10;
+        const int x = p & 31, y = p >> 5;
+        // seen, and (empty | open door | with ignore_blockers: any object that is not a wall or a closed door)
+        if (!(w.row(ignore_blockers ? R_EXP2 : R_EXP1, y) >> x & 1)) return;
+        const int rv = ignore_blockers ? R_VIS2 : R_VIS1;
         const int nd[4] = {d, d ^ 1, 3 - d, d ^ 2};              // (di,dj), (dj,di), (-dj,-di), (-di,-dj)
         for (int k = 0; k < 4; ++k) {
             const int nx = x + dir_dx(nd[k]), ny = y + dir_dy(nd[k]);
             if (!in_grid(nx, ny)) continue;                       // (never happens: the border is wall)
-            const int ni = ny * c.W + nx;
-            if (w.at(prev, ni) != 0xFFFF) continue;
-            w.at(prev, ni) = (uint16_t)ci;
-            w.at(q, qn++) = (uint16_t)(ni | nd[k] << 10);
+            uint32_t& vr = w.row(rv, ny);
+            if (vr >> nx & 1) continue;
+            vr |= 1u << nx;
+            w.at(prev, ny * c.W + nx) = (uint16_t)p;
+            const uint16_t ent = (uint16_t)(pk(nx, ny) | nd[k] << 10);
+            if (w.ring_size && q == WK_Q1) w.ring[(qn & (w.ring_size - 1)) * w.ring_stride] = ent;
+            w.at(q, qn++) = ent;
         }
     }
-    // first position in pop order that the test accepts, -1 if the search ends without one
+    BB_HD int q1_get(int i, int qn) const {                       // entry i of search 1's queue (the ring holds the newest)
+        if (w.ring_size && qn - i <= w.ring_size) return w.ring[(i & (w.ring_size - 1)) * w.ring_stride];
+        return w.at(WK_Q1, i);
+    }
+    BB_HD bool queued(int rv, int p) const { return w.row(rv, p >> 5) >> (p & 31) & 1; }
+    // first position (packed) in pop order that the test accepts, -1 if the search ends without one
     BB_HD int search(int prev, int q, int& head, int& qn, const Accept& a, bool ignore_blockers) const {
+        BOT_PROF(BP_SEARCH);
+        const int rv = ignore_blockers ? R_VIS2 : R_VIS1;
         if (a.kind == ACC_POS) {                                  // queued already => it will be popped and accepted
             if (!in_grid(a.x, a.y)) { while (head < qn) expand(prev, q, qn, w.at(q, head++), ignore_blockers); return -1; }
-            const int target = a.y * c.W + a.x;
-            while (w.at(prev, target) == 0xFFFF && head < qn) expand(prev, q, qn, w.at(q, head++), ignore_blockers);
-            return w.at(prev, target) != 0xFFFF ? target : -1;
+            const int target = pk(a.x, a.y);
+            while (!queued(rv, target) && head < qn) expand(prev, q, qn, w.at(q, head++), ignore_blockers);
+            return queued(rv, target) ? target : -1;
         }
         for (int i = 0; i < head; ++i) {
-            const int ci = w.at(q, i) & 1023;
-            if (accept(a, ci % c.W, ci / c.W, cell(ci % c.W, ci / c.W))) return ci;
+            const int p = w.at(q, i) & 1023;
+            if (accept(a, p & 31, p >> 5, cell(p & 31, p >> 5))) return p;
         }
         while (head < qn) {
             const int st = w.at(q, head);
-            const int ci = st & 1023;
-            if (accept(a, ci % c.W, ci / c.W, cell(ci % c.W, ci / c.W))) return ci;     // stays at the head for later queries
+            const int p = st & 1023;
+            if (accept(a, p & 31, p >> 5, cell(p & 31, p >> 5))) return p;       // stays at the head for later queries
             expand(prev, q, qn, st, ignore_blockers);
             ++head;
         }
         return -1;
     }
+    // the row masks of this decision's searches: one pass over the grid instead of a cell + visibility look-up per pop
+    BB_HD void build_rows(bool second) const {
+        BOT_PROF(BP_ROWS);
+        // a grid row = W appearance bytes at a dword-aligned pitch: fetched as 7 independent dwords (25 cells + the margin's
+        // odd byte) and tested from registers -- no load waits on another
+        constexpr int LEAD = MARGIN & 3;
+        for (int y = 0; y < c.H; ++y) {
+            const uint32_t sv = s.vis[y];
+            const uint32_t* rp = (const uint32_t*)(E + (y + MARGIN) * c.ES + (MARGIN & ~3));
+            uint32_t d[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) d[k] = 4 * k < c.W + LEAD ? rp[k] : 0u;
+            uint32_t ex = 0;
+#pragma unroll
+            for (int x = 0; x < MAX_W; ++x) {
+                const int b = x + LEAD;
+                const int e = (d[b >> 2] >> (8 * (b & 3))) & 0xFF;
+                bool ok = is_none(e) || open_door(e);
+                if (second) { const int t = e_type(e); ok = ok || (t != T_WALL && t != T_DOOR); }
+                ex |= (uint32_t)ok << x;
+            }
+            ex &= sv;                                              // seen cells only (vis has no bits beyond the grid)
+            if (second) { w.row(R_EXP2, y) = ex; w.row(R_VIS2, y) = w.row(R_VIS1, y); }     // search 2 starts from all search 1 reached
+            else { w.row(R_EXP1, y) = ex; w.row(R_VIS1, y) = 0; }
+        }
+    }
     BB_HD void start1() const {
         if (qn1 >= 0) return;
-        const int cells = c.W * c.H;
-        for (int i = 0; i < cells; ++i) w.at(WK_PREV1, i) = 0xFFFF;
-        const int start = h.ay * c.W + h.ax;
+        build_rows(false);
+        const int start = pk(h.ax, h.ay);
         head1 = qn1 = 0;
-        w.at(WK_PREV1, start) = 0xFFFE;
+        w.row(R_VIS1, h.ay) |= 1u << h.ax;
+        w.at(WK_PREV1, pidx(start)) = 0xFFFE;
+        if (w.ring_size) w.ring[0] = (uint16_t)(start | h.dir << 10);
         w.at(WK_Q1, qn1++) = (uint16_t)(start | h.dir << 10);
     }
     BB_HD void start2() const {                                    // needs search 1 complete (it is: its query just failed)
         if (qn2 >= 0) return;
-        const int cells = c.W * c.H;
-        for (int i = 0; i < cells; ++i) w.at(WK_PREV2, i) = 0xFFFF;
+        build_rows(true);
         head2 = qn2 = 0;
         for (int i = 0; i < qn1; ++i) {                            // every position search 1 reached, direction (1,0)
-            const int ci = w.at(WK_Q1, i) & 1023;
-            w.at(WK_PREV2, ci) = 0xFFFE;
-            w.at(WK_Q2, qn2++) = (uint16_t)ci;
+            const int p = w.at(WK_Q1, i) & 1023;
+            w.at(WK_PREV2, pidx(p)) = 0xFFFE;
+            w.at(WK_Q2, qn2++) = (uint16_t)p;
         }
     }
 
     struct Path { bool found; bool nonempty; int len; int nx, ny; int fxp, fyp; bool with_blockers; };
 
     BB_HD Path shortest_path(const Accept& a, bool try_with_blockers) const {          // :772-806
+        BOT_PROF(BP_PATH);
         Path p = {};
         start1();
         int len = 0, next = -1;
         int finish = search(WK_PREV1, WK_Q1, head1, qn1, a, false);
         if (finish >= 0) {
-            for (int v = finish; w.at(WK_PREV1, v) != 0xFFFE; v = w.at(WK_PREV1, v)) { ++len; next = v; }
+            for (int v = finish, u; (u = w.at(WK_PREV1, pidx(v))) != 0xFFFE; v = u) { ++len; next = v; }
         } else if (try_with_blockers) {
             p.with_blockers = true;
             start2();
             finish = search(WK_PREV2, WK_Q2, head2, qn2, a, true);
             if (finish >= 0) {
-                int v = finish;
-                for (; w.at(WK_PREV2, v) != 0xFFFE; v = w.at(WK_PREV2, v)) { ++len; next = v; }
+                int v = finish, u;
+                for (; (u = w.at(WK_PREV2, pidx(v))) != 0xFFFE; v = u) { ++len; next = v; }
                 int len1 = 0, next1 = -1;
-                for (; w.at(WK_PREV1, v) != 0xFFFE; v = w.at(WK_PREV1, v)) { ++len1; next1 = v; }
+                for (; (u = w.at(WK_PREV1, pidx(v))) != 0xFFFE; v = u) { ++len1; next1 = v; }
                 len += len1;
                 if (len1) next = next1;
             }
@@ -273,14 +349,15 @@ struct Bot {
         p.found = finish >= 0;
         if (p.found) {
             p.len = len; p.nonempty = len > 0;
-            p.fxp = finish % c.W; p.fyp = finish / c.W;
-            if (len) { p.nx = next % c.W; p.ny = next / c.W; }
+            p.fxp = finish & 31; p.fyp = finish >> 5;
+            if (len) { p.nx = next & 31; p.ny = next >> 5; }
         }
         return p;
     }
     BB_HD static Accept acc_pos(int x, int y) { Accept a = {}; a.kind = ACC_POS; a.x = x; a.y = y; return a; }
 
     BB_HD bool find_drop_pos(bool has_except, int ex, int ey, int& ox, int& oy) const { // :808-898
+        BOT_PROF(BP_DROP_POS);
         Accept a = {};
         a.has_except = has_except; a.ex = ex; a.ey = ey;
         const int kinds[4] = {ACC_UNBLOCK, ACC_EMPTY, ACC_UNBLOCK, ACC_EMPTY};
@@ -304,6 +381,7 @@ struct Bot {
     // ---- descriptors ------------------------------------------------------------------------------------------
     // ObjDesc('key', colour).find_matching_objs(env): x-major scan of the whole grid (verifier.py:96-161)
     BB_HD Subgoal go_keys(int color) {
+        BOT_PROF(BP_KEYS);
         Subgoal g = mk(SG_GONEXT);
         g.dtype = DT_KEYS;
         for (int x = 0; x < c.W; ++x)
@@ -321,6 +399,7 @@ struct Bot {
     // obj_poss is rebuilt (shorter) on every drop action, and the reference indexes both with the same i
     // (IndexError swallowed, :649-653) -- reproduced as is.
     BB_HD bool find_obj_pos(const Subgoal& g, bool adjacent, int& obj, int& ox, int& oy) {
+        BOT_PROF(BP_FIND_OBJ);
         uint8_t set_list[MAX_OBJ], poss[MAX_OBJ][2];
         int n_set = 0, n_poss = 0;
         if (g.dtype == DT_KEYS) {
@@ -434,6 +513,7 @@ struct Bot {
     BB_HD static bool is_move(int a) { return a == A_FORWARD || a == A_LEFT || a == A_RIGHT; }
 
     BB_HD void after_action(const Subgoal g, int action) {      // replan_after_action; action < 0 = None
+        BOT_PROF(BP_AFTER);
         const bool none = action < 0;
         switch (g.kind) {
         case SG_CLOSE:
@@ -677,6 +757,7 @@ struct Bot {
     }
 
     BB_HD void process_obs() {                                                         // :658-687
+        BOT_PROF(BP_OBS);
         uint32_t opq[VIEW], vis[VIEW];
         for (int vj = 0; vj < VIEW; ++vj) {
             uint32_t o = 0;
@@ -699,6 +780,11 @@ struct Bot {
     BB_HD int replan(int action_taken) {
         if (s.dead) return BOT_DEAD;
         process_obs();
+        if (w.eager && s.sp) {              // same tree, same pop order: only WHEN it is expanded changes
+            BOT_PROF(BP_INIT);
+            start1();
+            while (head1 < qn1) { const int st = q1_get(head1, qn1); ++head1; expand(WK_PREV1, WK_Q1, qn1, st, false); }
+        }
         if (action_taken == A_TOGGLE && s.prev_fwd_type == T_BOX) { die(); return BOT_DEAD; }   // DisappearedBoxError
         if (s.sp) after_action(stk[s.sp - 1], action_taken);
         if (raised) return BOT_DEAD;
@@ -706,7 +792,7 @@ struct Bot {
         int suggested = -1;
         int iters = 0;
         while (s.sp) {
-            suggested = before_action(stk[s.sp - 1]);
+            { BOT_PROF(BP_BEFORE); suggested = before_action(stk[s.sp - 1]); }
             if (raised) return BOT_DEAD;
             if (suggested >= 0) break;
             if (++iters > BOT_MAX_ITERS) { die(); return BOT_DEAD; }
@@ -728,6 +814,7 @@ struct Bot {
 // positions at reset, which differ only if a described object was carried somewhere else before.
 BB_HD int bot_decide(const LevelCfg& c, const uint8_t* rec, const Hot& h, uint64_t stale, BotState& s, int stack_cap, const BotWork& w,
                      bool first, int action_taken) {
+    BOT_PROF(BP_DECIDE);
     Bot b(c, rec, h, stale, s, stack_cap, w);
     first = first || h.step == 0 || s.next_step != h.step;
     s.next_step = (uint16_t)(h.step + 1);

@@ -29,6 +29,9 @@
 #include <stdlib.h>
 #include <algorithm>
 
+#if defined(BBAI_BOT_PROF)
+__device__ unsigned long long g_bot_prof[32];        // experiment builds: phase timers of the expert (bbai_bot.hpp)
+#endif
 #include "../../include/bbai.h"
 #include "bbai_types.hpp"
 #include "bbai_gen.hpp"
@@ -126,6 +129,8 @@ struct bbai_env {
     uint8_t* bot_state;   // [n][bot_state_bytes(bot_stack)] the expert's per-env plan (bbai_bot_act; allocated on first use)
     int bot_stack;        // subgoal stack capacity per env (BBAI_BOT_STACK, default 48)
     uint16_t* bot_work;   // [bot_threads][BOT_WORK_WORDS] BFS scratch per resident thread
+    uint32_t* bot_rows;   // [bot_threads][2 * MAX_W] row masks of the second (through-blockers) search
+    int bot_eager;        // BBAI_BOT_EAGER (default 1): expand the first search tree at the top of every decision
     int64_t bot_threads;
     uint64_t* bot_stats;  // [2] decisions that ended in a dead bot: by the reference's rules / by our capacity limits
 };
@@ -484,11 +489,18 @@ __global__ void k_sync_prog(LevelCfg c, int64_t n, int64_t first, int64_t count,
 template <int WAVES_PER_SIMD>
 __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_bot(LevelCfg c, int64_t n, const uint8_t* __restrict__ recs, const Hot* __restrict__ hots,
                                             const uint64_t* __restrict__ stales, uint8_t* __restrict__ states, int stack_cap,
-                                            uint16_t* __restrict__ works, const uint8_t* __restrict__ prev_actions,
+                                            uint16_t* __restrict__ works, uint32_t* __restrict__ slow_rows, int eager, const uint8_t* __restrict__ prev_actions,
                                             uint8_t* __restrict__ out, unsigned long long* __restrict__ stats) {
+    // the searches' hot row masks (expandable / queued / seen), [row][lane] in LDS: every lane on its own bank
+    extern __shared__ uint32_t s_rows[];              // [R_FAST][H][64] row masks, then the queue ring uint16 [BOT_RING][64]
+    uint16_t* s_ring = (uint16_t*)(s_rows + R_FAST * c.H * 64);
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
     BotWork w;
+    w.eager = eager;
+    w.ring = s_ring + threadIdx.x; w.ring_stride = 64; w.ring_size = BOT_RING;
+    w.rows_fast = s_rows + threadIdx.x; w.rstride_fast = 64; w.rows_h = c.H;
+    w.rows_slow = slow_rows + tid * ((R_ALL - R_FAST) * MAX_W); w.rstride_slow = 1;
     // per-thread contiguous scratch: measured faster than lane-interleaving it (BossLevel 262144 envs 12.8 vs 17.6 ms per
     // decision batch) -- the lanes' searches diverge at once, so an interleaved line holds one useful 2-byte element
     w.cells = c.W * c.H;                                    // 64 cells (512 B of scratch) for an 8x8 room, 484 for a 3x3 maze
@@ -793,7 +805,7 @@ void bbai_destroy(bbai_env* e) {
     if (e->ev_switch) (void)hipEventDestroy(e->ev_switch);
     for (int k = 0; k < 3; ++k) for (int i = 0; i < PROF_RING; ++i) if (e->prof[k][i].a) { (void)hipEventDestroy(e->prof[k][i].a); (void)hipEventDestroy(e->prof[k][i].b); }
     for (int k = 0; k < 3; ++k) if (e->ev_refill[k]) (void)hipEventDestroy(e->ev_refill[k]);
-    void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats};
+    void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
     void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_list, e->win_count, e->reset_list, e->counters,
                     e->total_resets, e->atlas, e->lut};
@@ -1148,20 +1160,23 @@ int bbai_get_programs(bbai_env* e, int64_t first, int64_t count, uint8_t* prog) 
 
 static int bot_alloc(bbai_env* e, int cap) {             // the expert's state: all three buffers or none
     const int64_t threads = std::min<int64_t>((e->n + 63) / 64 * 64, 256 * 8 * 64);
-    void *st = nullptr, *wk = nullptr, *ss = nullptr;
+    void *st = nullptr, *wk = nullptr, *ss = nullptr, *rw = nullptr;
     const size_t sbytes = bot_state_bytes(cap);
     hipError_t err = hipMalloc(&st, (size_t)e->n * sbytes);
     if (err == hipSuccess) err = hipMalloc(&wk, (size_t)threads * BOT_WORK_WORDS * sizeof(uint16_t));
+    if (err == hipSuccess) err = hipMalloc(&rw, (size_t)threads * (R_ALL - R_FAST) * MAX_W * sizeof(uint32_t));
     if (err == hipSuccess) err = hipMalloc(&ss, 16);
     if (err == hipSuccess) err = hipMemset(st, 0, (size_t)e->n * sbytes);
     if (err == hipSuccess) err = hipMemset(ss, 0, 16);
     if (err != hipSuccess) {
-        (void)hipFree(st); (void)hipFree(wk); (void)hipFree(ss);
+        (void)hipFree(st); (void)hipFree(wk); (void)hipFree(ss); (void)hipFree(rw);
         snprintf(g_err, sizeof(g_err), "allocating the expert's state failed: %s", hipGetErrorString(err));
         return BBAI_ERR_NOMEM;
     }
     e->bot_stack = cap;
     e->bot_state = (uint8_t*)st; e->bot_work = (uint16_t*)wk; e->bot_stats = (uint64_t*)ss; e->bot_threads = threads;
+    e->bot_rows = (uint32_t*)rw;
+    { const char* ev = getenv("BBAI_BOT_EAGER"); e->bot_eager = ev ? atoi(ev) != 0 : 1; }
     return BBAI_OK;
 }
 
@@ -1186,16 +1201,26 @@ int bbai_bot_act(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions, voi
         hipStream_t s = (hipStream_t)stream;
         { int rc = adopt_stream(e, s); if (rc != BBAI_OK) return rc; }
         unsigned long long* stats = (unsigned long long*)e->bot_stats;
+        const size_t lds = (size_t)R_FAST * e->cfg.H * 64 * 4 + (size_t)BOT_RING * 64 * 2;     // BossLevel: 11.3 + 8 KB -> 8 waves per CU
         if (maze)
-            hipLaunchKernelGGL(k_bot<2>, grid, block, 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
-                               prev_actions, actions, stats);
+            hipLaunchKernelGGL(k_bot<2>, grid, block, lds, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
+                               e->bot_rows, e->bot_eager, prev_actions, actions, stats);
         else
-            hipLaunchKernelGGL(k_bot<1>, grid, block, 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
-                               prev_actions, actions, stats);
+            hipLaunchKernelGGL(k_bot<1>, grid, block, lds, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
+                               e->bot_rows, e->bot_eager, prev_actions, actions, stats);
     }
     HIP_TRY(hipGetLastError());
     return BBAI_OK;
 }
+
+#if defined(BBAI_BOT_PROF)
+int bbai_bot_prof_read(unsigned long long* out32, int reset) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_bot_prof), 32 * 8));
+    if (reset) { unsigned long long z[32] = {}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_bot_prof), z, sizeof(z))); }
+    return BBAI_OK;
+}
+#endif
 
 int bbai_bot_stats(bbai_env* e, uint64_t* gave_up, uint64_t* capacity) {
     if (!e || !gave_up || !capacity) ARG_FAIL("null pointer");

@@ -20,7 +20,7 @@ from .levels import make_cfg
 from . import missions
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbbai_hip.so")
+LIB_PATH = os.environ.get("BBAI_ENGINE_LIB") or os.path.join(_HERE, "libbbai_hip.so")      # (override: experiment builds)
 ATLAS_PATH = os.path.join(_HERE, "data", "tile_atlas_ts8.npz")
 
 OBS_BYTES = 147

@@ -91,10 +91,15 @@ int hs_bot_stack_depth(const uint8_t* state) { return ((const BotState*)state)->
 
 // One Bot.replan decision; `first` != 0 starts a fresh Bot (new episode).  action_taken < 0 = None.
 // Returns the suggested action, or 255 once the bot is dead (state->dead says why).
+static int g_bot_eager = 0;
+void hs_bot_set_eager(int on) { g_bot_eager = on; }
+
 int hs_bot_decide(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, const uint64_t* stale, uint8_t* state, int stack_cap,
                   int first, int action_taken) {
     static thread_local uint16_t buf[BOT_WORK_WORDS];
+    static thread_local uint32_t rows[R_ALL * MAX_W];
     BotWork work; work.base = buf; work.stride = 1; work.cells = cfg->W * cfg->H;
+    work.eager = g_bot_eager; static thread_local uint16_t ring[8]; work.ring = ring; work.ring_stride = 1; work.ring_size = 8;   /* tiny: the fall-back to the queue proper is exercised */ work.rows_fast = rows; work.rstride_fast = 1; work.rows_h = MAX_W; work.rows_slow = rows + R_FAST * MAX_W; work.rstride_slow = 1;
     return bot_decide(*cfg, rec, *hot, *stale, *(BotState*)state, stack_cap, work, first != 0, action_taken);
 }
 

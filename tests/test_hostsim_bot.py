@@ -49,9 +49,19 @@ def replay(path, mode):
     return mismatches, capacity
 
 
+@pytest.fixture(params=[0, 1], ids=["lazy-search", "eager-search"])
+def eager(request):
+    """The first search tree expanded inside the queries (0) or to exhaustion at the top of every decision (1, the
+    device default): same tree, same pop order, so the decisions must not change."""
+    from hostsim_util import lib
+    lib().hs_bot_set_eager(request.param)
+    yield request.param
+    lib().hs_bot_set_eager(0)
+
+
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
 @pytest.mark.parametrize("mode", ["pure", "advised"])
-def test_bot_decisions_match_reference(path, mode):
+def test_bot_decisions_match_reference(path, mode, eager):
     mismatches, capacity = replay(path, mode)
     assert not mismatches, mismatches[:3]
     # A death by capacity (subgoal stack full) that the reference shares is the reference bot replanning for ever
