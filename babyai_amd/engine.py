@@ -98,11 +98,24 @@ class Missions(object):
         self._env = env
         self._progs = None
         self._cache = {}
+        self._version = env._obs_version          # the step / reset this view belongs to
 
     def _fetch(self):
         if self._progs is None:
+            if self._version != self._env._obs_version:
+                # the programs in HBM have moved on (an auto-reset may have replaced this env's mission): refuse to hand
+                # out the NEXT episode's text for an observation of an earlier step
+                raise EngineError("mission view of an earlier step: index obs['mission'] before the next step()/reset(), "
+                                  "or take env.missions() when the observation is produced")
             self._progs = self._env.programs()
         return self._progs
+
+    def snapshot(self):
+        """Fetch the programs NOW (n x 112 bytes to the host): the view stays valid after later steps.  The list-of-dicts
+        adapters do this for every observation they hand out (the reference's collectors read missions of stored
+        observations many steps later, babyai/rl/algos/base.py:207-232)."""
+        self._fetch()
+        return self
 
     def __len__(self):
         return self._env.num_envs
@@ -175,6 +188,7 @@ class BatchedBabyAIEnv(object):
                 _check(self.lib, self.lib.bbai_set_atlas(self.handle, tiles.ctypes.data, tiles.shape[0],
                                                           lut.ctypes.data), "bbai_set_atlas")
         self._missions = None
+        self._obs_version = 0
         self.kernel_events = None      # bench.py: list of (tag, start_event, end_event) when enabled
         self.num_actions = 7
         self.max_mission_tokens = min(TOK_MAX, missions.max_mission_tokens(self.cfg))
@@ -220,6 +234,7 @@ class BatchedBabyAIEnv(object):
                                                    self._stream()), "bbai_render")
             self._ev_end("render", ev)
             img = self.pixels
+        self._obs_version += 1
         self._missions = Missions(self)
         return {"image": img, "direction": self.direction, "mission": self._missions}
 

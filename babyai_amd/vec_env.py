@@ -89,7 +89,8 @@ class _VecBase(object):
         return self.engine.seed(seeds)
 
     def _obs_list(self, obs):
-        return ObsList(obs["image"].cpu().numpy(), obs["direction"].cpu().numpy(), obs["mission"], self.pixel)
+        # everything an obs dict may be asked for later is copied out now: images, directions and the mission programs
+        return ObsList(obs["image"].cpu().numpy(), obs["direction"].cpu().numpy(), obs["mission"].snapshot(), self.pixel)
 
     def reset(self):
         return self._obs_list(self.engine.reset())

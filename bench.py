@@ -119,6 +119,14 @@ def main():
         cfgsel = CONFIGS[args.config]
         args.level, args.envs, args.no_pixel = cfgsel["level"], cfgsel["envs"], not cfgsel["pixel"]
 
+    # the CPU legs' worker pool is forked BEFORE the GPU runtime and the process group exist (oracle/cpu_baseline.py
+    # make_pool): it idles through the timed region and is only fed afterwards
+    pool = None
+    if args.parity_envs or not args.no_cpu_baseline:
+        from oracle import cpu_baseline            # outside the timed region: checker / reported baseline only
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        pool = cpu_baseline.make_pool(max(2, cpu_baseline.usable_cores() // local_world))
+
     import numpy as np
     import torch
     if not torch.cuda.is_available():
@@ -312,8 +320,7 @@ def main():
         host = {k: np.concatenate([log1[k][:, :(PP if k == "pixels" else P)].cpu().numpy()]
                                   + ([log2[k].cpu().numpy()] if log2 is not None else [])) for k in log1 if (k != "pixels" or PP)}
         try:
-            from oracle import cpu_baseline
-            par = cpu_baseline.parity_replay(args.level, host, args.seed, args.action_seed, first, PP)
+            par = cpu_baseline.parity_replay(args.level, host, args.seed, args.action_seed, first, PP, pool=pool)
         except Exception as exc:
             par = {"error": repr(exc), "mismatches": -1}
         bad = ranks.sum(par.get("mismatches", -1) if par.get("mismatches", -1) >= 0 else 1 << 20)
@@ -324,10 +331,11 @@ def main():
             out["parity"] = par
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            from oracle import cpu_baseline
-            out["cpu_baseline"] = cpu_baseline.run(args.level, pixel, args.cpu_baseline_seconds, args.seed, args.action_seed)
+            out["cpu_baseline"] = cpu_baseline.run(args.level, pixel, args.cpu_baseline_seconds, args.seed, args.action_seed, pool=pool)
         except Exception as exc:      # the baseline is a reported number, never the product path
             out["cpu_baseline"] = {"error": repr(exc)}
+    if pool is not None:
+        pool.terminate()
     if rank == 0:
         print(json.dumps(out))
     env.close()

@@ -45,6 +45,13 @@ def usable_cores():
     return n
 
 
+def make_pool(processes=None):
+    """A worker pool forked NOW.  bench.py calls this before it initialises the GPU runtime / the process group: forking a
+    process that already runs HIP and RCCL threads is asking for trouble, so the workers exist first and get their work
+    (pickled slices of the recorded outputs) later."""
+    return mp.get_context("fork").Pool(processes or usable_cores())
+
+
 def _make(level, pixel, seed):
     if _ROOT not in sys.path:
         sys.path.insert(0, _ROOT)
@@ -75,12 +82,17 @@ def _worker(args):
     return steps, time.perf_counter() - t0
 
 
-def run(level="BossLevel", pixel=True, seconds=12.0, seed_base=0, action_seed=1234):
+def run(level="BossLevel", pixel=True, seconds=12.0, seed_base=0, action_seed=1234, pool=None):
     cores = usable_cores()
-    one_steps, one_dt = _worker((level, pixel, min(4.0, seconds / 3), seed_base, action_seed, 0))
-    ctx = mp.get_context("fork")
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_worker, [(level, pixel, seconds, seed_base, action_seed, i) for i in range(cores)])
+    own = pool is None
+    if own:
+        pool = make_pool(cores)
+    try:
+        one_steps, one_dt = pool.apply(_worker, ((level, pixel, min(4.0, seconds / 3), seed_base, action_seed, 0),))
+        res = pool.map(_worker, [(level, pixel, seconds, seed_base, action_seed, i) for i in range(cores)], chunksize=1)
+    finally:
+        if own:
+            pool.terminate()
     total = sum(r[0] for r in res)
     wall = max(r[1] for r in res)
     single = one_steps / one_dt
@@ -95,19 +107,19 @@ def run(level="BossLevel", pixel=True, seconds=12.0, seed_base=0, action_seed=12
 
 
 # ---- in-run parity --------------------------------------------------------------------------------------------------
-_LOG = None
 
 
 def _replay(args):
-    level, pixel_envs, seed_base, action_seed, ids, lo, hi = args
+    """args carry a slice of the log: arrays [steps(+1), hi - lo, ...]; pix = how many of the slice's first envs have pixels"""
+    level, pix, seed_base, action_seed, ids, log = args
     import numpy as np
     if _ROOT not in sys.path:
         sys.path.insert(0, _ROOT)
     from babyai_amd.action_stream import action_scalar
-    log = _LOG
     steps = log["done"].shape[0]
+    pixel_envs = pix
     bad, where = 0, None
-    for k in range(lo, hi):
+    for k in range(len(ids)):
         gid = int(ids[k])                                   # global env index: seed and action stream key
         env, wrapped = _make(level, k < pixel_envs, seed_base + gid)
         o = wrapped.reset()
@@ -135,12 +147,10 @@ def _replay(args):
     return bad, where
 
 
-def parity_replay(level, log, seed_base, action_seed, first, pixel_envs=0, env_ids=None):
+def parity_replay(level, log, seed_base, action_seed, first, pixel_envs=0, env_ids=None, pool=None):
     """log: dict of numpy arrays recorded by the bench: image uint8[S+1, P, 7,7,3] (index 0 = after reset()), direction
     uint8[S+1, P], reward64 float64[S, P], done uint8[S, P], pixels uint8[S+1, pixel_envs, 56,56,3] -- the outputs of the
     shard's first P envs at every step (or of the global envs `env_ids`, in that order).  Returns {"envs", "steps", "mismatches", "first_mismatch", "seconds", "cores"}."""
-    global _LOG
-    _LOG = log
     P = log["done"].shape[1]
     cores = usable_cores()
     t0 = time.perf_counter()
@@ -148,11 +158,19 @@ def parity_replay(level, log, seed_base, action_seed, first, pixel_envs=0, env_i
     bounds = [P * c // nchunk for c in range(nchunk + 1)]
     ids = [first + k for k in range(P)] if env_ids is None else [int(i) for i in env_ids]
     assert len(ids) == P
-    jobs = [(level, pixel_envs, seed_base, action_seed, ids, bounds[c], bounds[c + 1]) for c in range(nchunk)]
-    ctx = mp.get_context("fork")
-    with ctx.Pool(cores) as pool:
+    jobs = []
+    for c in range(nchunk):
+        lo, hi = bounds[c], bounds[c + 1]
+        part = {k: (v[:, lo:hi] if k != "pixels" else v[:, lo:min(hi, pixel_envs)]) for k, v in log.items() if k != "pixels" or lo < pixel_envs}
+        jobs.append((level, max(0, min(hi, pixel_envs) - lo), seed_base, action_seed, ids[lo:hi], part))
+    own = pool is None
+    if own:
+        pool = make_pool(cores)
+    try:
         res = pool.map(_replay, jobs, chunksize=1)
-    _LOG = None
+    finally:
+        if own:
+            pool.terminate()
     bad = sum(r[0] for r in res)
     firsts = [r[1] for r in res if r[1] is not None]
     return {"envs": P, "pixel_envs": int(pixel_envs), "steps": int(log["done"].shape[0]), "outputs": "image, direction, f64 reward bits, "

@@ -994,3 +994,42 @@ def test_caller_may_change_streams_between_calls(gpu):
     assert a.reset_count() == b.reset_count() > n
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+def test_stored_observations_keep_their_missions(gpu):
+    """The reference's collectors keep the obs of every frame and read their missions at the end of the rollout
+    (base.py:146-147,207-232): an obs list handed out by the adapter must keep ITS episode's mission after the env has
+    auto-reset into another one (round-1 advisor finding), and a raw tensor-level view must refuse instead of lying."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv, EngineError
+    from babyai_amd.vec_env import BatchedParallelEnv
+    n = 48
+    venv = BatchedParallelEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=21)
+    refs = _oracle_envs("GoToObjS4", [21 + i for i in range(n)])
+    kept = [(venv.reset(), [e.reset()["mission"] for e in refs])]
+    rng = np.random.RandomState(2)
+    for t in range(40):
+        a = rng.choice([0, 1, 2], size=n)
+        obs, _, _, _ = venv.step(a)
+        want = []
+        for i, e in enumerate(refs):
+            o, r, d, _ = e.step(int(a[i]))
+            if d:
+                o = e.reset()
+            want.append(o["mission"])
+        kept.append((obs, want))
+    assert venv.engine.reset_count() > 3 * n
+    changed = 0
+    for obs, want in kept:                     # read only now, many resets later
+        got = [obs[i]["mission"] for i in range(n)]
+        assert got == want
+        changed += sum(g != w for g, w in zip(got, kept[-1][1]))
+    assert changed > n                         # the missions really did change over the rollout
+    venv.close()
+    env = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", 8, device=gpu, seeds=1)
+    old = env.reset()
+    env.step(torch.zeros(8, dtype=torch.uint8, device=gpu))
+    with pytest.raises(EngineError):
+        old["mission"][0]
+    env.close()
