@@ -639,6 +639,22 @@ __global__ __launch_bounds__(64) void k_tokens(LevelCfg c, int64_t n, const uint
 }
 
 // ------------------------------------------------------------------------------------------
+// k_tap : copy the outputs of the first `count` envs (and the pixels of the first `pix_count`) into log rows -- the parity
+// tap of bench.py as ONE launch inside the timed region (five small tensor copies cost more than a 65 536-env step).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tap(int64_t count, int64_t pix_count, const uint8_t* __restrict__ image, const uint8_t* __restrict__ dirs,
+                                             const double* __restrict__ rew64, const uint8_t* __restrict__ dones, const uint8_t* __restrict__ pixels,
+                                             uint8_t* __restrict__ image_out, uint8_t* __restrict__ dirs_out, double* __restrict__ rew64_out,
+                                             uint8_t* __restrict__ dones_out, uint8_t* __restrict__ pixels_out) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid; i < count * OBS_BYTES; i += nth) image_out[i] = image[i];
+    for (int64_t i = tid; i < count; i += nth) { dirs_out[i] = dirs[i]; dones_out[i] = dones[i]; rew64_out[i] = rew64[i]; }
+    const u32x4* src = (const u32x4*)pixels;
+    u32x4* dst = (u32x4*)pixels_out;
+    for (int64_t i = tid; i < pix_count * (PIX_BYTES / 16); i += nth) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------
 // k_gae : generalised advantage estimation of a rollout, lane = env (babyai/rl/algos/base.py:196-202 as ONE reverse
 // scan per env instead of T passes of five tensor ops).  All buffers are env-major [P][T], the layout the reference
 // flattens its experiences to (base.py:207-232), so nothing is transposed afterwards.  float32 arithmetic in the
@@ -1231,6 +1247,19 @@ int bbai_bot_stats(bbai_env* e, uint64_t* gave_up, uint64_t* capacity) {
     unsigned long long v[2] = {0, 0};
     HIP_TRY(hipMemcpy(v, e->bot_stats, 16, hipMemcpyDeviceToHost));
     *gave_up = v[0]; *capacity = v[1];
+    return BBAI_OK;
+}
+
+int bbai_tap(int64_t count, int64_t pix_count, const uint8_t* image, const uint8_t* dirs, const double* rew64, const uint8_t* dones,
+             const uint8_t* pixels, uint8_t* image_out, uint8_t* dirs_out, double* rew64_out, uint8_t* dones_out, uint8_t* pixels_out,
+             void* stream) {
+    if (count <= 0 || pix_count < 0 || !image || !dirs || !rew64 || !dones || !image_out || !dirs_out || !rew64_out || !dones_out ||
+        (pix_count && (!pixels || !pixels_out || ((uintptr_t)pixels & 15) || ((uintptr_t)pixels_out & 15))))
+        ARG_FAIL("null / misaligned pointer or empty tap");
+    const int64_t work = std::max<int64_t>(count * OBS_BYTES, pix_count * (PIX_BYTES / 16));
+    hipLaunchKernelGGL(k_tap, dim3((unsigned)std::min<int64_t>((work + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, count, pix_count,
+                       image, dirs, rew64, dones, pixels, image_out, dirs_out, rew64_out, dones_out, pixels_out);
+    HIP_TRY(hipGetLastError());
     return BBAI_OK;
 }
 

@@ -62,6 +62,7 @@ def load_library():
     lib.bbai_export_state.argtypes = [P, I64, I64, P, P, P]
     lib.bbai_import_state.argtypes = [P, I64, I64, P, P, P]
     lib.bbai_get_programs.argtypes = [P, I64, I64, P]
+    lib.bbai_tap.argtypes = [I64, I64, P, P, P, P, P, P, P, P, P, P, P]
     lib.bbai_gae.argtypes = [I64, I32, P, P, P, P, P, ctypes.c_double, ctypes.c_double, P, P, P]
     lib.bbai_profile.argtypes = [P, I32]
     lib.bbai_profile_read.argtypes = [P, P, P]
@@ -81,7 +82,7 @@ EXPORTED_SYMBOLS = (
     "bbai_version", "bbai_last_error", "bbai_fill_layout", "bbai_create", "bbai_destroy", "bbai_seed",
     "bbai_reset", "bbai_step", "bbai_set_atlas", "bbai_render", "bbai_set_token_buffer", "bbai_export_state", "bbai_import_state",
     "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures", "bbai_bot_act", "bbai_bot_stats",
-    "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load", "bbai_profile", "bbai_profile_read", "bbai_gae",
+    "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load", "bbai_profile", "bbai_profile_read", "bbai_gae", "bbai_tap",
 )
 
 
@@ -353,9 +354,23 @@ class BatchedBabyAIEnv(object):
         _check(self.lib, self.lib.bbai_bot_stats(self.handle, ctypes.byref(a), ctypes.byref(b)), "bbai_bot_stats")
         return {"gave_up": int(a.value), "capacity": int(b.value)}
 
+    def tap(self, image_out, dir_out, reward64_out, done_out, pixels_out=None):
+        """Copy the current outputs of the first len(done_out) envs (pixels of the first len(pixels_out)) into the given
+        log rows with one launch on the current stream (bench.py's in-run parity tap)."""
+        pp = 0 if pixels_out is None else int(pixels_out.shape[0])
+        _check(self.lib, self.lib.bbai_tap(int(done_out.shape[0]), pp, self.image.data_ptr(), self.direction.data_ptr(),
+                                           self.reward64.data_ptr(), self.done.data_ptr(),
+                                           self.pixels.data_ptr() if pp else None, image_out.data_ptr(), dir_out.data_ptr(),
+                                           reward64_out.data_ptr(), done_out.data_ptr(),
+                                           pixels_out.data_ptr() if pp else None, self._stream()), "bbai_tap")
+
     def profile(self, enable=True):
         """Bracket every k_step / k_consume / k_render launch with HIP events on its launch stream (bench.py)."""
         _check(self.lib, self.lib.bbai_profile(self.handle, 1 if enable else 0), "bbai_profile")
+
+    def profile_pause(self):
+        """Stop bracketing launches; the totals stay readable."""
+        _check(self.lib, self.lib.bbai_profile(self.handle, 0), "bbai_profile")
 
     def profile_read(self):
         """{kernel: (average ms per launch, launches)} since profile(True)."""

@@ -109,11 +109,11 @@ def gather_to_rank0(tensor, dist):
     return None
 
 
-def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None):
+def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None, after_block=None):
     """The measured loop.  `actions`: uint8[warmup + blocks*steps, E] resident on the env's device.  `warmup` untimed
     steps, then `blocks` timed blocks of EXACTLY `steps` steps, each bracketed by ranks.barrier() on both sides and
     reduced with max over ranks.  `after_step(t)` (t = index into `actions`) runs inside the timed region (parity tap,
-    digests).  Returns the list of per-block seconds."""
+    digests), `after_block(i)` between blocks (untimed).  Returns the list of per-block seconds."""
     import time
     t = 0
     for _ in range(warmup):
@@ -132,6 +132,8 @@ def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None):
             t += 1
         ranks.barrier()
         out.append(ranks.max(time.perf_counter() - t0))
+        if after_block:
+            after_block(len(out) - 1)
     return out
 
 

@@ -185,14 +185,9 @@ def main():
         return lg
 
     def tap(lg, obs_row, row):
-        """the parity tap: one multi-tensor device copy inside the timed region"""
-        p = lg["done"].shape[1]
-        dst = [lg["image"][obs_row], lg["direction"][obs_row], lg["reward64"][row], lg["done"][row]]
-        src = [env.image[:p], env.direction[:p], env.reward64[:p], env.done[:p]]
-        if "pixels" in lg:
-            dst.append(lg["pixels"][obs_row])
-            src.append(env.pixels[:lg["pixels"].shape[1]])
-        torch._foreach_copy_(dst, src)
+        """the parity tap: ONE small launch inside the timed region (include/bbai.h bbai_tap)"""
+        env.tap(lg["image"][obs_row], lg["direction"][obs_row], lg["reward64"][row], lg["done"][row],
+                lg["pixels"][obs_row] if "pixels" in lg else None)
 
     # phase 1: reset, W warmup steps and ONE K-step block; its time decides how many further blocks make --min-seconds
     S1 = W + K
@@ -222,7 +217,6 @@ def main():
         PP = min(PP, P)
     log2 = None
     resets0 = env.reset_count()
-    env.kernel_events = []
     env.profile(True)              # per-kernel HIP event pairs on the launch stream (include/bbai.h bbai_profile)
     if want:
         actions2 = actions_torch(args.action_seed, S1, S1 + S2, first, E, dev)
@@ -235,25 +229,19 @@ def main():
                 digest.update(env.image, env.direction, env.reward64, env.done)
 
         torch.cuda.synchronize()
-        blocks = shard.timed_blocks(env, actions2, 0, K, want, ranks, after2)
+        # the per-kernel event pairs ride along in the first of these blocks only (two event records per launch are
+        # not free at 65 536 envs); `value` comes from the median block
+        blocks = shard.timed_blocks(env, actions2, 0, K, want, ranks, after2,
+                                    after_block=lambda i: env.profile_pause() if i == 0 else None)
     resets = ranks.sum(env.reset_count() - resets0)
     S = S1 + S2
 
-    # per-kernel-group durations from HIP events recorded on the launch stream
-    sums = {}
-    for tag, a, b in env.kernel_events:
-        sums.setdefault(tag, []).append(a.elapsed_time(b))
-    avg_ms = {k: sum(v) / len(v) for k, v in sums.items()} if sums else {}
-    if not avg_ms:                  # single-block run: events were not armed during it; re-measure a few steps untimed
-        env.kernel_events = []
+    # per-kernel durations: HIP event pairs recorded by the engine on the launch stream around each launch (bbai_profile)
+    if not want:                    # single-block run: nothing was bracketed; time a few untimed steps
         env.profile(True)
         for t in range(4):
             env.step(actions1[t])
         torch.cuda.synchronize()
-        for tag, a, b in env.kernel_events:
-            sums.setdefault(tag, []).append(a.elapsed_time(b))
-        avg_ms = {k: sum(v) / len(v) for k, v in sums.items()}
-    env.kernel_events = None
     kernel_ms = {k: v[0] for k, v in env.profile_read().items() if v[0] is not None}
     kernel_launches = {k: v[1] for k, v in env.profile_read().items() if v[0] is not None}
     env.profile(False)
@@ -307,8 +295,7 @@ def main():
                      "achievable_ceiling": ceiling_key,
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
                      "whole_step_alg_GBs": value / world * bytes_per_step / 1e9,
-                     "kernel_avg_ms": kernel_ms, "kernel_launches": kernel_launches,
-                     "call_group_avg_ms": avg_ms},
+                     "kernel_avg_ms": kernel_ms, "kernel_launches": kernel_launches},
         "parity": None, "cpu_baseline": None,
         "build": {"commit": git_head(), "csrc_sha": csrc_sha()},
     }

@@ -48,7 +48,7 @@ def test_device_rollout_equals_reference_collect_experiences(level, scale):
     for it in range(3):                                    # state carries across rollouts (memory, masks, log tails)
         exps_ref, log_ref = algo.collect_experiences()
         exps, log = roll.collect_experiences()
-        exact = scale == 16.0      # the reference scales the float64 reward before the float32 cast: 1 ulp apart for 20
+        exact = True               # rewards are shaped from the float64 reward, like the reference: exact for any scale
         for f in FIELDS:
             a, b = getattr(exps_ref, f), getattr(exps, f)
             assert a.shape == b.shape and a.dtype == b.dtype, f
