@@ -883,6 +883,10 @@ def test_bot_device_equals_host_build_on_every_level(gpu):
                 if hd:
                     hosts[i].reset()
                     first[i], last[i] = True, None
+        # the port's one representable divergence (a 48-entry subgoal stack) is visible and agrees between the two builds
+        host_cap = sum(1 for b in bots if b.dead_reason == 2)
+        stats = env.bot_stats()
+        assert stats["capacity"] >= host_cap and (stats["capacity"] == 0 or level in ("UnlockToUnlock",)), (level, stats, host_cap)
         env.close()
 
 
