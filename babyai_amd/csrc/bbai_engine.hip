@@ -114,7 +114,6 @@ struct bbai_env {
     hipStream_t last_stream;   // the caller's stream of the previous call; a handle follows ONE stream at a time: when the
     bool have_stream;          // caller switches, the new stream is ordered behind the old one's work (adopt_stream)
     hipEvent_t ev_switch;
-    int render_group;     // BBAI_RENDER_GROUP: 8 (default) or 2, see bbai_render
     int pregen_cap;       // BBAI_PREGEN_BLOCKS: upper bound on resident look-ahead workgroups (experiments)
     // optional per-kernel timing (bbai_profile): HIP event pairs on the launch stream around k_step / k_consume / k_render
     bool prof_on;
@@ -546,6 +545,7 @@ __global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, Hot* __restrict__ 
 // k_render : encoded obs -> 56x56x3 pixels through the tile atlas
 // ------------------------------------------------------------------------------------------
 constexpr int RENDER_BLOCK = 256;
+constexpr int RENDER_GROUP = 8;                   // envs rendered per block iteration
 constexpr int CHUNKS_PER_ROW = PIX * 3 / 8;       // 21 eight-byte chunks per pixel row
 constexpr int VEC_PER_ENV = PIX_BYTES / 16;       // 588 sixteen-byte stores per env
 
@@ -558,7 +558,6 @@ __device__ __forceinline__ uint64_t render_chunk(const uint8_t* s_atlas, const u
     return *(const uint64_t*)(s_atlas + tile * TILE_BYTES + ty * 24 + part * 8);
 }
 
-template <int RENDER_GROUP>                       // envs rendered per block iteration (between two barriers)
 __global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_t* __restrict__ image,
                                                          uint8_t* __restrict__ pixels, const uint8_t* __restrict__ atlas,
                                                          const uint8_t* __restrict__ lut, int n_tiles) {
@@ -807,8 +806,6 @@ static int create_finish(bbai_env* e) {
     {
         const char* ev = getenv("BBAI_PREGEN_BLOCKS");
         e->pregen_cap = ev ? std::max(64, atoi(ev)) : 256 * 32;
-        const char* rv = getenv("BBAI_RENDER_GROUP");
-        e->render_group = (rv && atoi(rv) == 2) ? 2 : 8;
     }
     return BBAI_OK;
 }
@@ -1020,19 +1017,18 @@ int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream
     if (!e || !image || !pixels) ARG_FAIL("null handle or buffer");
     if (e->n_tiles <= 0) { snprintf(g_err, sizeof(g_err), "render before set_atlas"); return BBAI_ERR_STATE; }
     ON_DEVICE(e->device);
-    // Launch shape (tools/ubench_render.hip, profiles/r02/ubench_render*.jsonl): looped 16-byte store streams sit on a
-    // plateau below the one-shot fill whatever the arrangement.  Shape 8 = 8 envs per barrier pair, 8 groups (64 envs, 602 KB)
-    // per short-lived block; shape 2 = one 2-env group (18.8 KB) per one-shot block, each paying the 11 KB atlas load.
+    // 8 groups (64 envs) per block: short-lived blocks keep wave slots turning over for the look-ahead stream
+    int64_t groups = (e->n + RENDER_GROUP - 1) / RENDER_GROUP;
+    // Measured on MI355X (tools/ubench_store.hip, gpurun_out/sweep): looped 16-byte store streams top out at
+    // ~5.6-5.7 TB/s whatever the per-block span; 8 groups (64 envs, 602 KB) per short-lived block is the best
+    // point and keeps wave slots turning over for the look-ahead stream.
+    const int gpb = 8;
+    unsigned grid = (unsigned)((groups + gpb - 1) / gpb);
     { int rc = adopt_stream(e, (hipStream_t)stream); if (rc != BBAI_OK) return rc; }
-    ProfScope prof_(e, 2, (hipStream_t)stream);
-    if (e->render_group == 2) {
-        const int64_t groups = (e->n + 1) / 2;
-        hipLaunchKernelGGL(k_render<2>, dim3((unsigned)groups), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas,
-                           e->lut, e->n_tiles);
-    } else {
-        const int64_t groups = (e->n + 7) / 8;
-        hipLaunchKernelGGL(k_render<8>, dim3((unsigned)((groups + 7) / 8)), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, e->n, image, pixels,
-                           e->atlas, e->lut, e->n_tiles);
+    {
+        ProfScope prof_(e, 2, (hipStream_t)stream);
+        hipLaunchKernelGGL(k_render, dim3(grid), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut,
+                           e->n_tiles);
     }
     HIP_TRY(hipGetLastError());
     return BBAI_OK;
