@@ -649,6 +649,32 @@ def test_state_errors_are_reported_not_undefined(gpu):
     assert torch.equal(o1[0]["image"], o2[0]["image"]) and torch.equal(o1[1], o2[1]) and torch.equal(o1[2], o2[2])
     with pytest.raises(ValueError):
         env.step(torch.zeros(7, dtype=torch.uint8, device=gpu))
+    # checkpoints: a blob only loads into a handle of the same level, batch size and look-ahead depth
+    blob = donor.save_checkpoint()
+    other = BatchedBabyAIEnv("BabyAI-GoToLocal-v0", 16, device=gpu)
+    with pytest.raises(EngineError, match="different level / batch size"):
+        other.load_checkpoint(blob)
+    other.close()
+    other = BatchedBabyAIEnv("BabyAI-PickupLoc-v0", 8, device=gpu)
+    with pytest.raises(EngineError, match="different level / batch size"):
+        other.load_checkpoint(blob)
+    with pytest.raises(EngineError, match="not a bbai checkpoint"):
+        other.load_checkpoint(np.zeros(blob.size, np.uint8))
+    with pytest.raises(EngineError):
+        other.load_checkpoint(blob[:100])
+    other.close()
+    # the parity tap refuses misaligned pixel rows instead of issuing misaligned 16-byte accesses
+    pix = BatchedBabyAIEnv("BabyAI-GoToLocal-v0", 8, device=gpu, seeds=2, pixel=True)
+    pix.reset()
+    img, dr = torch.zeros((4, 7, 7, 3), dtype=torch.uint8, device=gpu), torch.zeros(4, dtype=torch.uint8, device=gpu)
+    rw, dn = torch.zeros(4, dtype=torch.float64, device=gpu), torch.zeros(4, dtype=torch.uint8, device=gpu)
+    raw = torch.zeros(2 * 9408 + 1, dtype=torch.uint8, device=gpu)
+    with pytest.raises(EngineError, match="misaligned"):
+        pix.tap(img, dr, rw, dn, raw[1:].view(2, 56, 56, 3))
+    pix.tap(img, dr, rw, dn, raw[:-1].view(2, 56, 56, 3))
+    torch.cuda.synchronize()
+    assert torch.equal(img, pix.image[:4]) and torch.equal(raw[:-1].view(2, 56, 56, 3), pix.pixels[:2])
+    pix.close()
     env.close(); donor.close()
 
 
