@@ -9,7 +9,7 @@
  * cross the boundary: every call returns 0 or a negative bbai_status.  One handle per
  * device; a handle is not thread-safe and follows ONE caller stream at a time: a call that arrives
  * on a different stream than the previous one is ordered (by an event) behind everything the handle
- * enqueued on the previous stream.
+ * enqueued on the previous stream (which must therefore still exist at that point).
  */
 #ifndef BBAI_H
 #define BBAI_H
@@ -110,7 +110,9 @@ int bbai_get_programs(bbai_env* env, int64_t first, int64_t count, uint8_t* prog
  * auto-resetting env batch additionally needs its RNG streams): the blob holds the live state, every env's MT19937
  * stream, the look-ahead ring with its window bookkeeping, the counters and -- when bbai_bot_act has been used -- the
  * expert's plans.  Loading it into a fresh handle of the same level, batch size and BBAI_LOOKAHEAD continues the run
- * bit-identically, auto-resets included (tests/test_gpu_parity.py::test_checkpoint_resume_*).  Synchronous, host buffers. */
+ * bit-identically, auto-resets included (tests/test_gpu_parity.py::test_checkpoint_resume_*).  Synchronous, host buffers.
+ * Caller-owned buffers are not part of the blob: keep the last observation next to it if it is needed before the next
+ * step, and register the token buffer again after a load (bbai_set_token_buffer refills every row of a live handle). */
 int64_t bbai_checkpoint_bytes(bbai_env* env);
 int bbai_checkpoint_save(bbai_env* env, void* host_buf, int64_t bytes);
 int bbai_checkpoint_load(bbai_env* env, const void* host_buf, int64_t bytes);
