@@ -269,7 +269,9 @@ def main():
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
         if pmc.get("level") == args.level and pmc.get("envs") == E and dom in pmc["kernels"]:
             kk = pmc["kernels"][dom]
-            traffic = {"bytes": kk["FETCH_SIZE"] + kk["WRITE_SIZE"], "fetch": kk["FETCH_SIZE"], "write": kk["WRITE_SIZE"],
+            fetch = kk.get("FETCH_SIZE_corrected", 2 * kk["FETCH_SIZE"])      # gfx950: FETCH_SIZE tallies 128-B requests as 64 B
+            traffic = {"bytes": fetch + kk["WRITE_SIZE"], "fetch_corrected": fetch, "fetch_raw": kk["FETCH_SIZE"], "write": kk["WRITE_SIZE"],
+                       "correction": "FETCH_SIZE x 2 (MI355X_MICROARCH.md, calibrated on k_render's known byte counts)",
                        "source": "profiles/pmc_latest.json", "commit": pmc.get("commit"), "csrc_sha": pmc.get("csrc_sha"),
                        "current": pmc.get("csrc_sha") == csrc_sha()}
             if not traffic["current"]:

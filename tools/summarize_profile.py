@@ -42,7 +42,9 @@ summary = {"workload": "BabyAI-BossLevel-v0 pixel, 1048576 envs, bench.py --step
            "level": "BossLevel", "envs": 1048576, "commit": _git_head(), "csrc_sha": _csrc_sha(), "profile_tag": tag,
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (kernel-trace only); counters are KB per "
                    "dispatch; steady-state = median over launches (the first k_pregen/k_consume launches cover all envs). "
-                   "gfx950 FETCH_SIZE under-reports wide streaming reads by 2x (MI355X_MICROARCH.md); reported raw.",
+                   "Correction per MI355X_MICROARCH.md (gfx950: FETCH_SIZE = TCC_EA0_RDREQ x 64 B tallies 128-B requests at half their "
+                   "size): FETCH_SIZE_corrected = 2 x FETCH_SIZE, calibrated on k_render (reads 1 048 576 x 147 B = 154.1 MB, writes "
+                   "1 048 576 x 9408 B = 9.865 GB exactly); WRITE_SIZE needs none.",
            "kernels": {}}
 lines = []
 for name, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
@@ -61,5 +63,8 @@ for name, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         summary["kernels"].setdefault(k, {})[key] = med * 1024.0
         lines.append("%-16s %-11s launches=%3d median=%14.1f KB  min=%14.1f  max=%14.1f" % (k, key, len(v), med, v[0], v[-1]))
 open(os.path.join(dst, "rocprofv3_pmc_hbm_boss_pixel_1M.txt"), "w").write(summary["note"] + "\n\n" + "\n".join(lines) + "\n")
+for v in summary["kernels"].values():
+    if "FETCH_SIZE" in v:
+        v["FETCH_SIZE_corrected"] = 2 * v["FETCH_SIZE"]
 json.dump(summary, open(os.path.join("profiles", "pmc_latest.json"), "w"), indent=1)
 print("\n".join(lines))
