@@ -301,6 +301,24 @@ def main():
         "parity": None, "cpu_baseline": None,
         "build": {"commit": git_head(), "csrc_sha": csrc_sha()},
     }
+    # the OPTIONAL gather of the encoded observations to rank 0 (north_star: "only an optional xGMI gather of obs to
+    # rank 0"): timed on its own, after the timed region -- it is not part of a step and not part of `value`
+    if world > 1:
+        try:
+            src = env.image if args.dist_backend == "nccl" else env.image.cpu()
+            shard.gather_to_rank0(src, ranks.dist)
+            ranks.barrier()
+            import time
+            t0 = time.perf_counter()
+            for _ in range(5):
+                shard.gather_to_rank0(src, ranks.dist)
+            ranks.barrier()
+            g_ms = ranks.max(time.perf_counter() - t0) / 5 * 1e3
+            out["obs_gather"] = {"ms": g_ms, "bytes_per_peer": int(env.image.numel()), "backend": args.dist_backend,
+                                 "GBs_into_rank0": env.image.numel() * (world - 1) / (g_ms * 1e-3) / 1e9,
+                                 "note": "encoded obs of every shard -> rank 0; optional, outside the step path"}
+        except Exception as exc:
+            out["obs_gather"] = {"error": repr(exc)}
     torch.cuda.synchronize()
     if args.dump_digest:
         np.save("%s.rank%d.npy" % (args.dump_digest, rank), digest.numpy())

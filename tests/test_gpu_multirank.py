@@ -52,6 +52,8 @@ def test_bench_four_ranks_on_one_gpu_equal_the_unsharded_run(gpu, tmp_path):
     parts = np.concatenate([np.load(str(tmp_path / "four") + ".rank%d.npy" % r) for r in range(4)])
     assert whole.shape == (16384,) and np.array_equal(whole, parts)
     assert one["config"]["resets_in_timed_region"] == four["config"]["resets_in_timed_region"] > 0
+    # the optional obs gather to rank 0 ran (over gloo here) and is reported outside `value`
+    assert four["obs_gather"]["ms"] > 0 and four["obs_gather"]["bytes_per_peer"] == 4096 * 147 and "obs_gather" not in one
 
 
 @pytest.mark.gpu
