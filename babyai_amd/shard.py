@@ -97,10 +97,16 @@ def sum_over_ranks(value, dist=None, device=None):
     return int(t.item())
 
 
-def gather_to_rank0(tensor, dist):
-    """Optional obs gather: equal-sized shards -> rank 0 gets the concatenation in rank order."""
+def gather_to_rank0(tensor, dist, via_all_gather=False):
+    """Optional obs gather: equal-sized shards -> rank 0 gets the concatenation in rank order.  `via_all_gather`: use the
+    all-gather collective (every rank receives; rank 0's copy is the gather) -- the one RCCL path every installation
+    exercises, for callers that must not risk a point-to-point based `gather` (bench.py)."""
     import torch
     world = dist.get_world_size()
+    if via_all_gather:
+        parts = [torch.empty_like(tensor) for _ in range(world)]
+        dist.all_gather(parts, tensor.contiguous())
+        return torch.cat(parts, dim=0) if dist.get_rank() == 0 else None
     if dist.get_rank() == 0:
         parts = [torch.empty_like(tensor) for _ in range(world)]
         dist.gather(tensor, gather_list=parts, dst=0)

@@ -306,17 +306,17 @@ def main():
     if world > 1:
         try:
             src = env.image if args.dist_backend == "nccl" else env.image.cpu()
-            shard.gather_to_rank0(src, ranks.dist)
+            shard.gather_to_rank0(src, ranks.dist, via_all_gather=True)
             ranks.barrier()
             import time
             t0 = time.perf_counter()
             for _ in range(5):
-                shard.gather_to_rank0(src, ranks.dist)
+                shard.gather_to_rank0(src, ranks.dist, via_all_gather=True)
             ranks.barrier()
             g_ms = ranks.max(time.perf_counter() - t0) / 5 * 1e3
             out["obs_gather"] = {"ms": g_ms, "bytes_per_peer": int(env.image.numel()), "backend": args.dist_backend,
                                  "GBs_into_rank0": env.image.numel() * (world - 1) / (g_ms * 1e-3) / 1e9,
-                                 "note": "encoded obs of every shard -> rank 0; optional, outside the step path"}
+                                 "note": "encoded obs of every shard -> rank 0 (as an all-gather: every rank receives); optional, outside the step path"}
         except Exception as exc:
             out["obs_gather"] = {"error": repr(exc)}
     torch.cuda.synchronize()

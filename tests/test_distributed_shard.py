@@ -62,7 +62,7 @@ def _worker(rank, world, port, q):
     assert np.array_equal(shard.shard_seeds(SEED, TOTAL, world, rank), np.arange(first, first + count, dtype=np.uint64) + np.uint64(SEED))
     env, dig, blocks = _rollout(ranks, first, count)
     full_img = shard.gather_to_rank0(env.image, ranks.dist)
-    full_dig = shard.gather_to_rank0(dig.h, ranks.dist)
+    full_dig = shard.gather_to_rank0(dig.h, ranks.dist, via_all_gather=True)
     t = ranks.max(0.5 + rank)
     n = ranks.sum(count)
     if rank == 0:
