@@ -329,10 +329,12 @@ def main():
         try:
             par = cpu_baseline.parity_replay(args.level, host, args.seed, args.action_seed, first, PP, pool=pool)
         except Exception as exc:
-            par = {"error": repr(exc), "mismatches": -1}
-        bad = ranks.sum(par.get("mismatches", -1) if par.get("mismatches", -1) >= 0 else 1 << 20)
+            par = {"error": repr(exc), "mismatches": None}          # the CHECKER broke: reported, not a parity verdict
+        bad = ranks.sum(par["mismatches"] or 0)
+        broken = ranks.sum(1 if par["mismatches"] is None else 0)
         if rank == 0:
             par["mismatches_all_ranks"] = bad
+            par["checker_errors_all_ranks"] = broken
             par["envs_all_ranks"] = P * world
             par["steps_checked"] = "all %d steps of the run (warmup, probe block and the %d timed blocks)" % (S, len(blocks))
             out["parity"] = par
@@ -347,7 +349,7 @@ def main():
         print(json.dumps(out))
     env.close()
     ranks.close()
-    if rank == 0 and out["parity"] and out["parity"].get("mismatches_all_ranks", 0) != 0:
+    if rank == 0 and out["parity"] and (out["parity"].get("mismatches_all_ranks") or 0) != 0:
         sys.exit(3)                     # a fast kernel whose results differ from the oracle's is not done
 
 

@@ -88,8 +88,9 @@ def run(level="BossLevel", pixel=True, seconds=12.0, seed_base=0, action_seed=12
     if own:
         pool = make_pool(cores)
     try:
-        one_steps, one_dt = pool.apply(_worker, ((level, pixel, min(4.0, seconds / 3), seed_base, action_seed, 0),))
-        res = pool.map(_worker, [(level, pixel, seconds, seed_base, action_seed, i) for i in range(cores)], chunksize=1)
+        # (time-outs: a worker that dies must cost the bench a field, not hang it)
+        one_steps, one_dt = pool.apply_async(_worker, ((level, pixel, min(4.0, seconds / 3), seed_base, action_seed, 0),)).get(timeout=120 + seconds)
+        res = pool.map_async(_worker, [(level, pixel, seconds, seed_base, action_seed, i) for i in range(cores)], chunksize=1).get(timeout=180 + 3 * seconds)
     finally:
         if own:
             pool.terminate()
@@ -167,7 +168,7 @@ def parity_replay(level, log, seed_base, action_seed, first, pixel_envs=0, env_i
     if own:
         pool = make_pool(cores)
     try:
-        res = pool.map(_replay, jobs, chunksize=1)
+        res = pool.map_async(_replay, jobs, chunksize=1).get(timeout=900)
     finally:
         if own:
             pool.terminate()
