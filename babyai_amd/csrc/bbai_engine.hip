@@ -17,7 +17,8 @@
 //                  view, first observation of the new episode.
 //   k_tokens       lane = env over the reset list: mission text as fixed-vocabulary token ids.
 //   k_render       RGBImgPartialObsWrapper as a pure tile-atlas gather: atlas + per-cell tile ids
-//                  in LDS, 16 bytes per lane per store, a wave writes 1 KiB of contiguous pixels.
+//                  in LDS, 16 bytes per lane per store, a wave writes 1 KiB of contiguous pixels; one 2/4/8-env group per
+//                  short-lived block (by batch size, bbai_render).
 //
 //   k_bot<W>       lane = env: one decision of the reference's GOFAI expert (babyai/bot.py) per env, W = occupancy target
 //                  (bbai_bot.hpp); only launched by bbai_bot_act.
@@ -114,6 +115,7 @@ struct bbai_env {
     hipStream_t last_stream;   // the caller's stream of the previous call; a handle follows ONE stream at a time: when the
     bool have_stream;          // caller switches, the new stream is ordered behind the old one's work (adopt_stream)
     hipEvent_t ev_switch;
+    int render_group;     // BBAI_RENDER_GROUP: 2, 4 or 8 envs per one-shot render block; anything else = by batch size (bbai_render)
     int pregen_cap;       // BBAI_PREGEN_BLOCKS: upper bound on resident look-ahead workgroups (experiments)
     // optional per-kernel timing (bbai_profile): HIP event pairs on the launch stream around k_step / k_consume / k_render
     bool prof_on;
@@ -545,7 +547,6 @@ __global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, Hot* __restrict__ 
 // k_render : encoded obs -> 56x56x3 pixels through the tile atlas
 // ------------------------------------------------------------------------------------------
 constexpr int RENDER_BLOCK = 256;
-constexpr int RENDER_GROUP = 8;                   // envs rendered per block iteration
 constexpr int CHUNKS_PER_ROW = PIX * 3 / 8;       // 21 eight-byte chunks per pixel row
 constexpr int VEC_PER_ENV = PIX_BYTES / 16;       // 588 sixteen-byte stores per env
 
@@ -558,6 +559,7 @@ __device__ __forceinline__ uint64_t render_chunk(const uint8_t* s_atlas, const u
     return *(const uint64_t*)(s_atlas + tile * TILE_BYTES + ty * 24 + part * 8);
 }
 
+template <int RENDER_GROUP>                       // envs rendered per block iteration (between two barriers)
 __global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_t* __restrict__ image,
                                                          uint8_t* __restrict__ pixels, const uint8_t* __restrict__ atlas,
                                                          const uint8_t* __restrict__ lut, int n_tiles) {
@@ -806,6 +808,8 @@ static int create_finish(bbai_env* e) {
     {
         const char* ev = getenv("BBAI_PREGEN_BLOCKS");
         e->pregen_cap = ev ? std::max(64, atoi(ev)) : 256 * 32;
+        const char* rv = getenv("BBAI_RENDER_GROUP");
+        e->render_group = rv ? atoi(rv) : 0;
     }
     return BBAI_OK;
 }
@@ -1017,19 +1021,19 @@ int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream
     if (!e || !image || !pixels) ARG_FAIL("null handle or buffer");
     if (e->n_tiles <= 0) { snprintf(g_err, sizeof(g_err), "render before set_atlas"); return BBAI_ERR_STATE; }
     ON_DEVICE(e->device);
-    // 8 groups (64 envs) per block: short-lived blocks keep wave slots turning over for the look-ahead stream
-    int64_t groups = (e->n + RENDER_GROUP - 1) / RENDER_GROUP;
-    // Measured on MI355X (tools/ubench_store.hip, gpurun_out/sweep): looped 16-byte store streams top out at
-    // ~5.6-5.7 TB/s whatever the per-block span; 8 groups (64 envs, 602 KB) per short-lived block is the best
-    // point and keeps wave slots turning over for the look-ahead stream.
-    const int gpb = 8;
-    unsigned grid = (unsigned)((groups + gpb - 1) / gpb);
+    // Launch shape: ONE G-env group (G x 9.4 KB of pixels) per one-shot 256-thread block, G = the smallest of 2, 4, 8 that
+    // keeps the grid at or below 262 144 blocks (131 072 .. 524 288 envs: 2; 1 048 576: 4).  Measured inside the real bench
+    // on fast and slow boxes (profiles/r02/render_shape_*.jsonl): against round 1's looped shape (8 envs per barrier pair,
+    // 64 envs per block) -9 % at 131 072 envs, -8 % at 524 288, -8..-10 % at 1 048 576 on the slow boxes and -1 % on the
+    // fast ones; every block pays the 11 KB atlas load into LDS (L2 hits), which is what keeps G = 1 from winning.
     { int rc = adopt_stream(e, (hipStream_t)stream); if (rc != BBAI_OK) return rc; }
-    {
-        ProfScope prof_(e, 2, (hipStream_t)stream);
-        hipLaunchKernelGGL(k_render, dim3(grid), dim3(RENDER_BLOCK), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut,
-                           e->n_tiles);
-    }
+    ProfScope prof_(e, 2, (hipStream_t)stream);
+    int G = e->render_group;
+    if (G != 2 && G != 4 && G != 8) G = e->n <= 2 * 262144 ? 2 : e->n <= 4 * 262144 ? 4 : 8;
+    const dim3 grid((unsigned)((e->n + G - 1) / G)), block(RENDER_BLOCK);
+    if (G == 2) hipLaunchKernelGGL(k_render<2>, grid, block, 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut, e->n_tiles);
+    else if (G == 4) hipLaunchKernelGGL(k_render<4>, grid, block, 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut, e->n_tiles);
+    else hipLaunchKernelGGL(k_render<8>, grid, block, 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut, e->n_tiles);
     HIP_TRY(hipGetLastError());
     return BBAI_OK;
 }

@@ -1063,3 +1063,32 @@ def test_stored_observations_keep_their_missions(gpu):
     with pytest.raises(EngineError):
         old["mission"][0]
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("group", ["2", "4", "8"])
+def test_render_launch_shapes_are_byte_identical(gpu, group, monkeypatch):
+    """bbai_render picks 2, 4 or 8 envs per one-shot block by batch size; every shape (forced here with BBAI_RENDER_GROUP on
+    a batch that is not a multiple of any of them) must produce the reference wrapper's pixels."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from gym_minigrid.wrappers import RGBImgPartialObsWrapper
+    monkeypatch.setenv("BBAI_RENDER_GROUP", group)
+    n = 1003
+    env = BatchedBabyAIEnv("BabyAI-PickupLoc-v0", n, device=gpu, pixel=True, seeds=40)
+    spots = [0, 1, 2, 3, 7, 8, 500, 501, n - 9, n - 8, n - 3, n - 2, n - 1]
+    refs = _oracle_envs("PickupLoc", [40 + i for i in spots])
+    wr = [RGBImgPartialObsWrapper(e) for e in refs]
+    obs = env.reset()
+    ro = [w.reset() for w in wr]
+    rng = np.random.RandomState(int(group))
+    for t in range(40):
+        pix = obs["image"][spots].cpu().numpy()
+        for k in range(len(spots)):
+            assert np.array_equal(pix[k], ro[k]["image"]), (group, spots[k], t)
+        a = rng.randint(0, 7, size=n).astype(np.uint8)
+        obs, _, _, _ = env.step(torch.as_tensor(a, device=gpu))
+        for k, i in enumerate(spots):
+            o, r, d, _ = wr[k].step(int(a[i]))
+            ro[k] = wr[k].reset() if d else o
+    env.close()
