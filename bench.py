@@ -267,8 +267,9 @@ def main():
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        if pmc.get("level") == args.level and pmc.get("envs") == E and dom in pmc["kernels"]:
-            kk = pmc["kernels"][dom]
+        key = next((k for k in pmc["kernels"] if k == dom or k.startswith(dom + "<")), None)      # k_render is a template
+        if pmc.get("level") == args.level and pmc.get("envs") == E and key:
+            kk = pmc["kernels"][key]
             fetch = kk.get("FETCH_SIZE_corrected", 2 * kk["FETCH_SIZE"])      # gfx950: FETCH_SIZE tallies 128-B requests as 64 B
             traffic = {"bytes": fetch + kk["WRITE_SIZE"], "fetch_corrected": fetch, "fetch_raw": kk["FETCH_SIZE"], "write": kk["WRITE_SIZE"],
                        "correction": "FETCH_SIZE x 2 (MI355X_MICROARCH.md, calibrated on k_render's known byte counts)",

@@ -38,6 +38,22 @@ def _git_head():
         return None
 
 
+# the --stats CSV reports MEANS, which the launches that overlap the seed-time generation skew (one 25 ms k_render among 546):
+# medians and percentiles of the steady state from the kernel trace of the same run
+kt = os.path.join(src, "stats", "boss_kernel_trace.csv")
+if os.path.isfile(kt):
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(kt)):
+        dur[r["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    with open(os.path.join(dst, "rocprofv3_kernel_trace_summary_boss_pixel_1M.txt"), "w") as f:
+        f.write("rocprofv3 --kernel-trace of the judged command (python bench.py --steps 20 --warmup 5), durations in microseconds per launch\n")
+        f.write("%-16s %6s %10s %10s %10s %10s %10s\n" % ("kernel", "calls", "median", "mean", "p10", "p90", "max"))
+        for k, v in sorted(dur.items()):
+            if not k.startswith("k_"):
+                continue
+            v = sorted(v)
+            f.write("%-16s %6d %10.1f %10.1f %10.1f %10.1f %10.1f\n" % (k, len(v), v[len(v) // 2], sum(v) / len(v), v[len(v) // 10], v[len(v) * 9 // 10], v[-1]))
+
 summary = {"workload": "BabyAI-BossLevel-v0 pixel, 1048576 envs, bench.py --steps 8 --warmup 2", "unit": "bytes per launch",
            "level": "BossLevel", "envs": 1048576, "commit": _git_head(), "csrc_sha": _csrc_sha(), "profile_tag": tag,
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (kernel-trace only); counters are KB per "
