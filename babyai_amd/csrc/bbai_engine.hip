@@ -17,8 +17,8 @@
 //                  view, first observation of the new episode.
 //   k_tokens       lane = env over the reset list: mission text as fixed-vocabulary token ids.
 //   k_render       RGBImgPartialObsWrapper as a pure tile-atlas gather: atlas + per-cell tile ids
-//                  in LDS, 16 bytes per lane per store, a wave writes 1 KiB of contiguous pixels; one 2/4/8-env group per
-//                  short-lived block (by batch size, bbai_render).
+//                  in LDS, 16 bytes per lane per store, a wave writes 1 KiB of contiguous pixels; one 2- or 8-env group per
+//                  one-shot block of 512 / 1024 threads (by batch size, bbai_render).
 //
 //   k_bot<W>       lane = env: one decision of the reference's GOFAI expert (babyai/bot.py) per env, W = occupancy target
 //                  (bbai_bot.hpp); only launched by bbai_bot_act.
@@ -115,6 +115,7 @@ struct bbai_env {
     hipStream_t last_stream;   // the caller's stream of the previous call; a handle follows ONE stream at a time: when the
     bool have_stream;          // caller switches, the new stream is ordered behind the old one's work (adopt_stream)
     hipEvent_t ev_switch;
+    int render_tpb;       // BBAI_RENDER_TPB: 256 / 512 / 1024 threads per render block; anything else = by batch size
     int render_group;     // BBAI_RENDER_GROUP: 2, 4 or 8 envs per one-shot render block; anything else = by batch size (bbai_render)
     int pregen_cap;       // BBAI_PREGEN_BLOCKS: upper bound on resident look-ahead workgroups (experiments)
     // optional per-kernel timing (bbai_profile): HIP event pairs on the launch stream around k_step / k_consume / k_render
@@ -546,7 +547,6 @@ __global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, Hot* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // k_render : encoded obs -> 56x56x3 pixels through the tile atlas
 // ------------------------------------------------------------------------------------------
-constexpr int RENDER_BLOCK = 256;
 constexpr int CHUNKS_PER_ROW = PIX * 3 / 8;       // 21 eight-byte chunks per pixel row
 constexpr int VEC_PER_ENV = PIX_BYTES / 16;       // 588 sixteen-byte stores per env
 
@@ -559,7 +559,7 @@ __device__ __forceinline__ uint64_t render_chunk(const uint8_t* s_atlas, const u
     return *(const uint64_t*)(s_atlas + tile * TILE_BYTES + ty * 24 + part * 8);
 }
 
-template <int RENDER_GROUP>                       // envs rendered per block iteration (between two barriers)
+template <int RENDER_GROUP, int RENDER_BLOCK>     // envs rendered per block iteration (between two barriers); threads per block
 __global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_t* __restrict__ image,
                                                          uint8_t* __restrict__ pixels, const uint8_t* __restrict__ atlas,
                                                          const uint8_t* __restrict__ lut, int n_tiles) {
@@ -810,6 +810,8 @@ static int create_finish(bbai_env* e) {
         e->pregen_cap = ev ? std::max(64, atoi(ev)) : 256 * 32;
         const char* rv = getenv("BBAI_RENDER_GROUP");
         e->render_group = rv ? atoi(rv) : 0;
+        const char* tv = getenv("BBAI_RENDER_TPB");
+        e->render_tpb = tv ? atoi(tv) : 0;
     }
     return BBAI_OK;
 }
@@ -1021,19 +1023,22 @@ int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream
     if (!e || !image || !pixels) ARG_FAIL("null handle or buffer");
     if (e->n_tiles <= 0) { snprintf(g_err, sizeof(g_err), "render before set_atlas"); return BBAI_ERR_STATE; }
     ON_DEVICE(e->device);
-    // Launch shape: ONE G-env group (G x 9.4 KB of pixels) per one-shot 256-thread block, G = the smallest of 2, 4, 8 that
-    // keeps the grid at or below 262 144 blocks (131 072 .. 524 288 envs: 2; 1 048 576: 4).  Measured inside the real bench
-    // on fast and slow boxes (profiles/r02/render_shape_*.jsonl): against round 1's looped shape (8 envs per barrier pair,
-    // 64 envs per block) -9 % at 131 072 envs, -8 % at 524 288, -8..-10 % at 1 048 576 on the slow boxes and -1 % on the
-    // fast ones; every block pays the 11 KB atlas load into LDS (L2 hits), which is what keeps G = 1 from winning.
+    // Launch shape: ONE G-env group (G x 9.4 KB of pixels) per one-shot block of T threads.  Chosen by wall-clock step time
+    // inside the real bench, shapes alternated within one lease, on fast and slow boxes (profiles/r02/render_shape_*.jsonl,
+    // render_tpb_*.jsonl): (T, G) = (1024, 8) from 786 432 envs up, (512, 2) below.  Against round 1's looped shape (256
+    // threads, 8 envs per barrier pair, 64 envs per block): 1 048 576 envs 1.80-1.85 vs 1.99-2.15 ms per step on the slow
+    // boxes, 131 072 envs 0.224 vs 0.267-0.282.  Every block pays the 11 KB atlas load into LDS (L2 hits).
+    // BBAI_RENDER_GROUP / BBAI_RENDER_TPB override (experiments).
     { int rc = adopt_stream(e, (hipStream_t)stream); if (rc != BBAI_OK) return rc; }
     ProfScope prof_(e, 2, (hipStream_t)stream);
-    int G = e->render_group;
-    if (G != 2 && G != 4 && G != 8) G = e->n <= 2 * 262144 ? 2 : e->n <= 4 * 262144 ? 4 : 8;
-    const dim3 grid((unsigned)((e->n + G - 1) / G)), block(RENDER_BLOCK);
-    if (G == 2) hipLaunchKernelGGL(k_render<2>, grid, block, 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut, e->n_tiles);
-    else if (G == 4) hipLaunchKernelGGL(k_render<4>, grid, block, 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut, e->n_tiles);
-    else hipLaunchKernelGGL(k_render<8>, grid, block, 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut, e->n_tiles);
+    const bool big = e->n >= 786432;
+    int G = e->render_group, T = e->render_tpb;
+    if (G != 2 && G != 4 && G != 8) G = big ? 8 : 2;
+    if (T != 256 && T != 512 && T != 1024) T = big ? 1024 : 512;
+    const dim3 grid((unsigned)((e->n + G - 1) / G));
+#define RENDER_LAUNCH(GG, TT) hipLaunchKernelGGL((k_render<GG, TT>), grid, dim3(TT), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut, e->n_tiles)
+#define RENDER_G(GG) do { if (T == 1024) RENDER_LAUNCH(GG, 1024); else if (T == 512) RENDER_LAUNCH(GG, 512); else RENDER_LAUNCH(GG, 256); } while (0)
+    if (G == 2) RENDER_G(2); else if (G == 4) RENDER_G(4); else RENDER_G(8);
     HIP_TRY(hipGetLastError());
     return BBAI_OK;
 }

@@ -1066,10 +1066,12 @@ def test_stored_observations_keep_their_missions(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("group", ["2", "4", "8"])
-def test_render_launch_shapes_are_byte_identical(gpu, group, monkeypatch):
-    """bbai_render picks 2, 4 or 8 envs per one-shot block by batch size; every shape (forced here with BBAI_RENDER_GROUP on
-    a batch that is not a multiple of any of them) must produce the reference wrapper's pixels."""
+@pytest.mark.parametrize("group,tpb", [("2", "512"), ("8", "1024"), ("4", "256"), ("2", "1024"), ("8", "512")])
+def test_render_launch_shapes_are_byte_identical(gpu, group, tpb, monkeypatch):
+    """bbai_render picks (envs per one-shot block, threads per block) by batch size -- (2, 512) or (8, 1024); these and the
+    other instantiated shapes (forced here with BBAI_RENDER_GROUP / BBAI_RENDER_TPB on a batch that is not a multiple of
+    any group size) must produce the reference wrapper's pixels."""
+    monkeypatch.setenv("BBAI_RENDER_TPB", tpb)
     import torch
     from babyai_amd.engine import BatchedBabyAIEnv
     from gym_minigrid.wrappers import RGBImgPartialObsWrapper
