@@ -358,6 +358,9 @@ class BatchedBabyAIEnv(object):
         """Copy the current outputs of the first len(done_out) envs (pixels of the first len(pixels_out)) into the given
         log rows with one launch on the current stream (bench.py's in-run parity tap)."""
         pp = 0 if pixels_out is None else int(pixels_out.shape[0])
+        if self.torch.cuda.current_device() != self.dev_index:      # handle-free entry point: launches on the CURRENT device
+            with self.torch.cuda.device(self.dev_index):
+                return self.tap(image_out, dir_out, reward64_out, done_out, pixels_out)
         _check(self.lib, self.lib.bbai_tap(int(done_out.shape[0]), pp, self.image.data_ptr(), self.direction.data_ptr(),
                                            self.reward64.data_ptr(), self.done.data_ptr(),
                                            self.pixels.data_ptr() if pp else None, image_out.data_ptr(), dir_out.data_ptr(),

@@ -41,10 +41,11 @@ def gae_env_major(rewards, values, masks, last_mask, last_value, discount, gae_l
         lib = load_library()
         for t in (rewards, values, masks, last_mask, last_value, advantage, returnn):
             assert t.is_contiguous() and t.dtype == torch.float32
-        stream = ctypes.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream)
-        _check(lib, lib.bbai_gae(P, T, rewards.data_ptr(), values.data_ptr(), masks.data_ptr(), last_mask.data_ptr(),
-                                 last_value.data_ptr(), float(discount), float(gae_lambda), advantage.data_ptr(),
-                                 returnn.data_ptr(), stream), "bbai_gae")
+        with torch.cuda.device(rewards.device):        # handle-free entry point: launches on the CURRENT device
+            stream = ctypes.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream)
+            _check(lib, lib.bbai_gae(P, T, rewards.data_ptr(), values.data_ptr(), masks.data_ptr(), last_mask.data_ptr(),
+                                     last_value.data_ptr(), float(discount), float(gae_lambda), advantage.data_ptr(),
+                                     returnn.data_ptr(), stream), "bbai_gae")
         return
     next_value, next_mask, next_adv = last_value, last_mask, 0
     for i in reversed(range(T)):

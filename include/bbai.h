@@ -137,7 +137,8 @@ int bbai_bot_stats(bbai_env* env, uint64_t* gave_up, uint64_t* capacity);
 /* Measurement aid: copy the outputs of the first `count` envs of a batch (image 147 B, direction, float64 reward, done) and
  * the pixel images of the first `pix_count` into caller-owned log rows with ONE launch on `stream` -- the in-run parity tap of
  * bench.py ("first 1024 envs of every shard, every step, all outputs").  pixels / pixels_out may be NULL when
- * pix_count is 0; both must be 16-byte aligned otherwise. */
+ * pix_count is 0; both must be 16-byte aligned otherwise.  bbai_tap and bbai_gae take no handle: like any HIP call
+ * without one they launch on the calling thread's CURRENT device, which must own `stream` and every pointer. */
 int bbai_tap(int64_t count, int64_t pix_count, const uint8_t* image_dev, const uint8_t* dir_dev, const double* reward64_dev,
              const uint8_t* done_dev, const uint8_t* pixels_dev, uint8_t* image_out, uint8_t* dir_out, double* reward64_out,
              uint8_t* done_out, uint8_t* pixels_out, void* stream);
