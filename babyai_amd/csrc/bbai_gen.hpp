@@ -48,6 +48,51 @@ template <class C> struct ctx_profiles<C, decltype((void)C::kProfile)> { static 
 enum : int { PH_BUILD = 0, PH_LOCK = 1, PH_CONNECT = 2, PH_DISTS = 3, PH_AGENT = 4, PH_REACH = 5, PH_INSTR = 6, PH_VALIDATE = 7,
              PH_ATTEMPTS = 8, PH_DRAWS = 9, PH_TWISTS = 10, PH_N = 11 };
 
+// MT19937 state transition (numpy legacy RandomState bit stream), the lanes of the context splitting each chunk.  Needed
+// once per 624 draws but reachable from every draw: NOT inlined -- as part of next_u32() it was copied to ~50 call sites of
+// the level generators (~2 KB each; k_pregen<LevelGen> 208 KB of code against a 64 KB instruction cache).
+BB_HD uint32_t mt_mix(uint32_t u, uint32_t v) {
+    uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
+    return (y >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
+}
+template <class Ctx>
+BB_HD void mt_twist_chunk(Ctx ctx, uint32_t* mt, int lo, int hi) {
+    // new[k] = src[k+397 mod] ^ mix(old[k], old[k+1]) for k in [lo,hi); reads complete
+    // before any write of the chunk (sync), so lanes never see half-updated inputs.
+    // (chunks are <= 227 long: 4 strided elements per lane cover them with 64 lanes)
+    uint32_t tmp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int k = lo + ctx.lane() + q * ctx.nlanes();
+        if (k < hi) {
+            int m = k + 397; if (m >= MT_N) m -= MT_N;
+            tmp[q] = mt[m] ^ mt_mix(mt[k], mt[k + 1 < MT_N ? k + 1 : 0]);
+        }
+    }
+    ctx.sync();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int k = lo + ctx.lane() + q * ctx.nlanes();
+        if (k < hi) mt[k] = tmp[q];
+    }
+    ctx.sync();
+}
+template <class Ctx>
+BB_COLD void mt_twist(Ctx ctx, uint32_t* mt) {
+    if (ctx.nlanes() == 1) {           // host: plain sequential generation
+        for (int k = 0; k < MT_N; ++k) {
+            int m = k + 397; if (m >= MT_N) m -= MT_N;
+            mt[k] = mt[m] ^ mt_mix(mt[k], mt[k + 1 < MT_N ? k + 1 : 0]);
+        }
+        return;
+    }
+    ctx.sync();
+    mt_twist_chunk(ctx, mt, 0, 227);      // uses old[k+397]
+    mt_twist_chunk(ctx, mt, 227, 454);    // uses new[k-227] from the first chunk
+    mt_twist_chunk(ctx, mt, 454, 623);    // uses new[k-227] from the second chunk
+    mt_twist_chunk(ctx, mt, 623, 624);    // uses new[396] and new[0]
+}
+
 template <class Ctx>
 struct Gen {
     Ctx ctx;
@@ -91,45 +136,7 @@ struct Gen {
     BB_HD int div_es(int v) const { return (int)(((uint32_t)v * inv_es) >> 16); }         // v < 2048
 
     // ---------------- MT19937 (numpy legacy RandomState bit stream) ----------------
-    BB_HD static uint32_t mix(uint32_t u, uint32_t v) {
-        uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
-        return (y >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
-    }
-    BB_HD void twist_chunk(int lo, int hi) {
-        // new[k] = src[k+397 mod] ^ mix(old[k], old[k+1]) for k in [lo,hi); reads complete
-        // before any write of the chunk (sync), so lanes never see half-updated inputs.
-        // (chunks are <= 227 long: 4 strided elements per lane cover them with 64 lanes)
-        uint32_t tmp[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int k = lo + ctx.lane() + q * ctx.nlanes();
-            if (k < hi) {
-                int m = k + 397; if (m >= MT_N) m -= MT_N;
-                tmp[q] = w.mt[m] ^ mix(w.mt[k], w.mt[k + 1 < MT_N ? k + 1 : 0]);
-            }
-        }
-        ctx.sync();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int k = lo + ctx.lane() + q * ctx.nlanes();
-            if (k < hi) w.mt[k] = tmp[q];
-        }
-        ctx.sync();
-    }
-    BB_HD void twist() {
-        if (ctx.nlanes() == 1) {           // host: plain sequential generation
-            for (int k = 0; k < MT_N; ++k) {
-                int m = k + 397; if (m >= MT_N) m -= MT_N;
-                w.mt[k] = w.mt[m] ^ mix(w.mt[k], w.mt[k + 1 < MT_N ? k + 1 : 0]);
-            }
-            return;
-        }
-        ctx.sync();
-        twist_chunk(0, 227);      // uses old[k+397]
-        twist_chunk(227, 454);    // uses new[k-227] from the first chunk
-        twist_chunk(454, 623);    // uses new[k-227] from the second chunk
-        twist_chunk(623, 624);    // uses new[396] and new[0]
-    }
+    BB_HD void twist() { mt_twist(ctx, w.mt); }
     BB_HD uint32_t next_u32() {
         if (mti >= MT_N) { twist(); mti = 0; count(PH_TWISTS); }
         count(PH_DRAWS);

@@ -21,8 +21,10 @@
 
 #if defined(__HIPCC__)
 #define BB_HD __host__ __device__ __forceinline__
+#define BB_COLD __host__ __device__ __attribute__((noinline))      // rare and large: ONE copy per kernel instead of one per call site
 #else
 #define BB_HD inline
+#define BB_COLD inline
 #endif
 
 namespace bbai {
