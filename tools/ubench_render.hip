@@ -113,6 +113,38 @@ __global__ __launch_bounds__(64 * WAVES) void k_wave(int64_t n, const uint8_t* _
     }
 }
 
+// one-shot<G, T, DIRECT>: ONE G-env group per block of T threads (the shipped k_render launch shape).  DIRECT = false: the
+// 11 KB atlas is copied into the block's LDS first (shipped); DIRECT = true: only the G x 49 tile ids go through LDS and
+// every lane reads its two 8-byte tile-row pieces straight from the global atlas (11 KB: resident in every CU's L1).
+template <int GROUP, int T, bool DIRECT>
+__global__ __launch_bounds__(T) void k_shot(int64_t n, const uint8_t* __restrict__ image, uint8_t* __restrict__ pixels,
+                                            const uint8_t* __restrict__ atlas, const uint8_t* __restrict__ lut) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_atlas[DIRECT ? 16 : N_TILES * TILE_BYTES];
+    __shared__ uint8_t s_lut[DIRECT ? 16 : 512];
+    __shared__ uint8_t s_tile[GROUP * 49 + 8];
+    if (!DIRECT) {
+        for (int k = threadIdx.x; k < N_TILES * TILE_BYTES / 8; k += T) ((uint64_t*)s_atlas)[k] = ((const uint64_t*)atlas)[k];
+        for (int k = threadIdx.x; k < 512; k += T) s_lut[k] = lut[k];
+        __syncthreads();
+    }
+    const int64_t env0 = (int64_t)blockIdx.x * GROUP;
+    const int ne = (int)(n - env0 < GROUP ? n - env0 : GROUP);
+    for (int c = threadIdx.x; c < ne * 49; c += T) {
+        const int e = c / 49, cell = c - e * 49;
+        const uint8_t* o = image + (env0 + e) * OBS_BYTES + cell * 3;
+        const int key = (cell == 27 ? 256 : 0) + (o[0] | (o[1] << 3) | (o[2] << 6));
+        s_tile[c] = DIRECT ? lut[key] : s_lut[key];
+    }
+    __syncthreads();
+    u32x4* out = (u32x4*)(pixels + env0 * PIX_BYTES);
+    const uint8_t* src = DIRECT ? atlas : s_atlas;
+    for (int q = threadIdx.x; q < ne * VEC_PER_ENV; q += T) {
+        const int e = q / VEC_PER_ENV, k = q - e * VEC_PER_ENV;
+        const uint8_t* t49 = s_tile + e * 49;
+        put<true>(out + q, render_chunk(src, t49, 2 * k), render_chunk(src, t49, 2 * k + 1));
+    }
+}
+
 __global__ void k_fill(u32x4* out, int64_t nvec) {       // one 4-KiB span per 256-thread block, no loop: the plain-fill shape
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (q < nvec) { u32x4 v = {1u, 2u, 3u, (uint32_t)q}; out[q] = v; }
@@ -178,6 +210,18 @@ int main(int argc, char** argv) {
         }
         printf("{\"shape\": \"plain fill, one 4 KiB span per block\", \"avg_ms\": %.4f, \"min_ms\": %.4f, \"TBs_at_avg\": %.3f}\n", sum / 5, best,
                n * 9408.0 / (sum / 5) / 1e9);
+    }
+#define SHOT_CASE(G, T, D) run("one-shot<" #G "," #T "> " #D, (int)((n + G - 1) / G), [&] { \
+    hipLaunchKernelGGL((k_shot<G, T, D>), dim3((unsigned)((n + G - 1) / G)), dim3(T), 0, 0, n, image, pix, atlas, lut); })
+    if (argc > 2) {          // tools/ubench_render <n> direct : the LDS-atlas one-shot shapes against atlas reads from L1
+        for (int rep = 0; rep < 2; ++rep) {
+            SHOT_CASE(8, 1024, false); SHOT_CASE(8, 1024, true);
+            SHOT_CASE(2, 512, false);  SHOT_CASE(2, 512, true);
+            SHOT_CASE(4, 512, true);   SHOT_CASE(4, 1024, true);
+            SHOT_CASE(1, 256, true);   SHOT_CASE(2, 256, true);  SHOT_CASE(1, 512, true); SHOT_CASE(4, 256, true);
+            SHOT_CASE(1, 256, false);  SHOT_CASE(16, 1024, true);
+        }
+        return 0;
     }
     BLOCK_CASE(8, false, false, g8 / 8);
     BLOCK_CASE(8, true, false, g8);               // one 8-env group per short-lived block
