@@ -145,6 +145,20 @@ __global__ __launch_bounds__(T) void k_shot(int64_t n, const uint8_t* __restrict
     }
 }
 
+// gather<T>: the plain-fill shape with the render's data: one-shot blocks of T threads, one 16-byte store per thread, NO LDS and
+// no barrier -- every lane looks its two tile ids up in a precomputed 49-byte tile plane (what k_step could emit) and reads
+// its two 8-byte tile-row pieces from the global atlas (L1).  Blocks are not aligned to envs.
+template <int T, bool NT>
+__global__ __launch_bounds__(T) void k_gather(int64_t n, const uint8_t* __restrict__ tiles, uint8_t* __restrict__ pixels,
+                                              const uint8_t* __restrict__ atlas) {
+    const int64_t q = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (q >= n * VEC_PER_ENV) return;
+    const int64_t e = q / VEC_PER_ENV;
+    const int k = (int)(q - e * VEC_PER_ENV);
+    const uint8_t* t49 = tiles + e * 49;
+    put<NT>((u32x4*)pixels + q, render_chunk(atlas, t49, 2 * k), render_chunk(atlas, t49, 2 * k + 1));
+}
+
 __global__ void k_fill(u32x4* out, int64_t nvec) {       // one 4-KiB span per 256-thread block, no loop: the plain-fill shape
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (q < nvec) { u32x4 v = {1u, 2u, 3u, (uint32_t)q}; out[q] = v; }
@@ -220,6 +234,9 @@ int main(int argc, char** argv) {
             SHOT_CASE(4, 512, true);   SHOT_CASE(4, 1024, true);
             SHOT_CASE(1, 256, true);   SHOT_CASE(2, 256, true);  SHOT_CASE(1, 512, true); SHOT_CASE(4, 256, true);
             SHOT_CASE(1, 256, false);  SHOT_CASE(16, 1024, true);
+#define GATHER_CASE(T, NT) run("gather<" #T "> nt=" #NT " (tile plane in, no LDS)", (int)((n * VEC_PER_ENV + T - 1) / T), [&] { \
+    hipLaunchKernelGGL((k_gather<T, NT>), dim3((unsigned)((n * VEC_PER_ENV + T - 1) / T)), dim3(T), 0, 0, n, tiles, pix, atlas); })
+            GATHER_CASE(256, true); GATHER_CASE(512, true); GATHER_CASE(1024, true); GATHER_CASE(64, true); GATHER_CASE(256, false);
         }
         return 0;
     }
