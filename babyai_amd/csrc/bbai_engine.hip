@@ -112,9 +112,10 @@ struct bbai_env {
     uint8_t* tokens;      // optional caller-owned [n][72] mission token buffer kept current on resets
     hipStream_t side;     // look-ahead generation stream
     hipEvent_t ev_consumed, ev_refill[3];
-    hipStream_t last_stream;   // the caller's stream of the previous call; a handle follows ONE stream at a time: when the
-    bool have_stream;          // caller switches, the new stream is ordered behind the old one's work (adopt_stream)
-    hipEvent_t ev_switch;
+    hipStream_t last_stream;   // the caller's stream of the previous call (compared, never used): a handle follows ONE stream
+    bool have_stream;          // at a time; a call on another stream waits for ev_switch = end of the previous call
+    hipEvent_t ev_switch;      // (enter_call / leave_call)
+    bool call_events;
     int render_tpb;       // BBAI_RENDER_TPB: 256 / 512 / 1024 threads per render block; anything else = by batch size
     int render_group;     // BBAI_RENDER_GROUP: 2, 4 or 8 envs per one-shot render block; anything else = by batch size (bbai_render)
     int pregen_cap;       // BBAI_PREGEN_BLOCKS: upper bound on resident look-ahead workgroups (experiments)
@@ -641,19 +642,30 @@ __global__ __launch_bounds__(64) void k_tokens(LevelCfg c, int64_t n, const uint
 }
 
 // ------------------------------------------------------------------------------------------
-// k_tap : copy the outputs of the first `count` envs (and the pixels of the first `pix_count`) into log rows -- the parity
+// k_tap : copy the outputs of `count` envs (and the pixels of the first `pix_count` of them) into log rows -- the parity
 // tap of bench.py as ONE launch inside the timed region (five small tensor copies cost more than a 65 536-env step).
+// ids == NULL: the first `count` envs; else env ids[k] -> log row k (any order, anywhere in the batch).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tap(int64_t count, int64_t pix_count, const uint8_t* __restrict__ image, const uint8_t* __restrict__ dirs,
-                                             const double* __restrict__ rew64, const uint8_t* __restrict__ dones, const uint8_t* __restrict__ pixels,
-                                             uint8_t* __restrict__ image_out, uint8_t* __restrict__ dirs_out, double* __restrict__ rew64_out,
-                                             uint8_t* __restrict__ dones_out, uint8_t* __restrict__ pixels_out) {
+__global__ __launch_bounds__(256) void k_tap(int64_t count, int64_t pix_count, const int64_t* __restrict__ ids, const uint8_t* __restrict__ image,
+                                             const uint8_t* __restrict__ dirs, const double* __restrict__ rew64, const uint8_t* __restrict__ dones,
+                                             const uint8_t* __restrict__ pixels, uint8_t* __restrict__ image_out, uint8_t* __restrict__ dirs_out,
+                                             double* __restrict__ rew64_out, uint8_t* __restrict__ dones_out, uint8_t* __restrict__ pixels_out) {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = tid; i < count * OBS_BYTES; i += nth) image_out[i] = image[i];
-    for (int64_t i = tid; i < count; i += nth) { dirs_out[i] = dirs[i]; dones_out[i] = dones[i]; rew64_out[i] = rew64[i]; }
+    for (int64_t i = tid; i < count * OBS_BYTES; i += nth) {
+        const int64_t k = i / OBS_BYTES, b = i - k * OBS_BYTES;
+        image_out[i] = image[(ids ? ids[k] : k) * OBS_BYTES + b];
+    }
+    for (int64_t i = tid; i < count; i += nth) {
+        const int64_t e = ids ? ids[i] : i;
+        dirs_out[i] = dirs[e]; dones_out[i] = dones[e]; rew64_out[i] = rew64[e];
+    }
+    constexpr int VEC = PIX_BYTES / 16;
     const u32x4* src = (const u32x4*)pixels;
     u32x4* dst = (u32x4*)pixels_out;
-    for (int64_t i = tid; i < pix_count * (PIX_BYTES / 16); i += nth) dst[i] = src[i];
+    for (int64_t i = tid; i < pix_count * VEC; i += nth) {
+        const int64_t k = i / VEC, v = i - k * VEC;
+        dst[i] = src[(ids ? ids[k] : k) * VEC + v];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -743,28 +755,42 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->mti, (size_t)n_envs * 4);
     alloc((void**)&e->vhead, (size_t)n_envs * 4);
     alloc((void**)&e->vset, (size_t)n_envs * 8 * 8);
+    alloc((void**)&e->pending, 3 * (size_t)n_envs);
+    alloc((void**)&e->first_slot, 3 * (size_t)n_envs);
+    alloc((void**)&e->win_count, 3 * WIN_STRIDE * 4);
     {
         // Refill period B (ticks per look-ahead refill, BBAI_LOOKAHEAD); ring depth D = 2B.  One k_pregen launch per
         // window lasts as long as its slowest level (hundreds of microseconds to milliseconds: rejection sampling has a
         // heavy tail) and has to land within one window, so B ticks of the step path must outlast it or the step stream
-        // waits: default = the longest period of 32, 16, 8, 4, 2 whose ring fits BBAI_RING_GIB (default 16 GiB of the
-        // 288 GB).  (131072 GoTo envs -> 32; 1M BossLevel envs -> 4.)
+        // waits: default = the longest period of 32, 16, 8, 4, 2 whose ring fits the cap.  The cap is BBAI_RING_GIB
+        // (default 16 GiB) but never more than a quarter of the memory that is FREE right now (several handles or ranks
+        // on one device, smaller parts), and an allocation that fails all the same is retried with half the period: a
+        // shorter period only costs speed, never correctness.  (131072 GoTo envs -> 32; 1M BossLevel envs -> 4.)
         const char* ev = getenv("BBAI_LOOKAHEAD");
         const char* gv = getenv("BBAI_RING_GIB");
-        const size_t slot_bytes = (size_t)n_envs * c.rec_bytes, cap = (size_t)(gv ? std::max(1, atoi(gv)) : 16) << 30;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)64 << 30;
+        const size_t slot_bytes = (size_t)n_envs * c.rec_bytes;
+        const size_t cap = std::min((size_t)(gv ? std::max(1, atoi(gv)) : 16) << 30, free_b / 4);
         int b = 2;
         if (ev) b = atoi(ev);
         else for (int cand = MAX_PERIOD; cand >= 2; cand >>= 1) if (slot_bytes * 2 * (size_t)cand <= cap) { b = cand; break; }
-        e->period = b < 1 ? 1 : (b > MAX_PERIOD ? MAX_PERIOD : b);
-        e->depth = 2 * e->period;
+        b = b < 1 ? 1 : (b > MAX_PERIOD ? MAX_PERIOD : b);
+        for (; err == hipSuccess; b >>= 1) {
+            e->period = b;
+            e->depth = 2 * b;
+            const size_t D = (size_t)e->depth;
+            hipError_t r1 = hipMalloc((void**)&e->next_rec, D * slot_bytes);
+            hipError_t r2 = r1 == hipSuccess ? hipMalloc((void**)&e->next_hot, D * (size_t)n_envs * sizeof(Hot)) : r1;
+            hipError_t r3 = r2 == hipSuccess ? hipMalloc((void**)&e->win_list, 3 * (size_t)b * (size_t)n_envs * 4) : r2;
+            if (r3 == hipSuccess) break;
+            (void)hipGetLastError();                       // clear the sticky out-of-memory error before retrying
+            if (e->next_rec) { (void)hipFree(e->next_rec); e->next_rec = nullptr; }
+            if (e->next_hot) { (void)hipFree(e->next_hot); e->next_hot = nullptr; }
+            if (e->win_list) { (void)hipFree(e->win_list); e->win_list = nullptr; }
+            if (b == 1 || ev) err = r3;                    // an explicit BBAI_LOOKAHEAD is a request, not a hint
+        }
     }
-    const size_t D = (size_t)e->depth;
-    alloc((void**)&e->next_rec, D * (size_t)n_envs * c.rec_bytes);
-    alloc((void**)&e->next_hot, D * (size_t)n_envs * sizeof(Hot));
-    alloc((void**)&e->pending, 3 * (size_t)n_envs);
-    alloc((void**)&e->first_slot, 3 * (size_t)n_envs);
-    alloc((void**)&e->win_list, 3 * (size_t)e->period * (size_t)n_envs * 4);
-    alloc((void**)&e->win_count, 3 * WIN_STRIDE * 4);
     alloc((void**)&e->reset_list, (size_t)n_envs * 4);
     alloc((void**)&e->counters, 128);
     alloc((void**)&e->total_resets, 16);
@@ -806,6 +832,8 @@ static int create_finish(bbai_env* e) {
         HIP_TRY(hipEventCreateWithFlags(&e->ev_switch, hipEventDisableTiming));
     }
     {
+        const char* cv = getenv("BBAI_CALL_EVENTS");
+        e->call_events = !(cv && atoi(cv) == 0);
         const char* ev = getenv("BBAI_PREGEN_BLOCKS");
         e->pregen_cap = ev ? std::max(64, atoi(ev)) : 256 * 32;
         const char* rv = getenv("BBAI_RENDER_GROUP");
@@ -858,15 +886,22 @@ static unsigned pregen_grid(const bbai_env* e, int64_t count_hint) {
 }
 
 // A handle's launches are ordered by ONE caller stream at a time (plus the private look-ahead stream, which is tied to
-// it by events).  A caller that comes back on a different stream gets that stream ordered behind everything the handle
-// enqueued on the previous one -- correct, but it serialises the two streams at that point.
-static int adopt_stream(bbai_env* e, hipStream_t s) {
+// it by events).  Every call that launches on the caller's stream ends by recording the handle's completion event
+// there (leave_call); a call that arrives on a DIFFERENT stream than the previous one first makes its stream wait for
+// that event (enter_call).  The previous stream itself is never touched again -- it may have been destroyed since --
+// and its pointer is only compared.  (BBAI_CALL_EVENTS=0: round 2's scheme, an event recorded on the previous stream
+// at the moment of the switch; kept for A/B measurements of the per-call record.)
+static int enter_call(bbai_env* e, hipStream_t s) {
     if (e->have_stream && e->last_stream != s) {
-        HIP_TRY(hipEventRecord(e->ev_switch, e->last_stream));
+        if (!e->call_events) HIP_TRY(hipEventRecord(e->ev_switch, e->last_stream));
         HIP_TRY(hipStreamWaitEvent(s, e->ev_switch, 0));
     }
     e->last_stream = s;
     e->have_stream = true;
+    return BBAI_OK;
+}
+static int leave_call(bbai_env* e, hipStream_t s) {
+    if (e->call_events) HIP_TRY(hipEventRecord(e->ev_switch, s));
     return BBAI_OK;
 }
 
@@ -976,12 +1011,12 @@ int bbai_reset(bbai_env* e, uint8_t* image, uint8_t* dirs, void* stream) {
     if (!e->seeded) { snprintf(g_err, sizeof(g_err), "reset before seed"); return BBAI_ERR_STATE; }
     ON_DEVICE(e->device);
     hipStream_t s = (hipStream_t)stream;
-    int rc = adopt_stream(e, s);
+    int rc = enter_call(e, s);
     if (rc != BBAI_OK) return rc;
     rc = consume_and_refill(e, s, image, dirs, 1);
     if (rc != BBAI_OK) return rc;
     e->live = true;
-    return BBAI_OK;
+    return leave_call(e, s);
 }
 
 int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64,
@@ -994,7 +1029,7 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
     }
     ON_DEVICE(e->device);
     hipStream_t s = (hipStream_t)stream;
-    { int rc = adopt_stream(e, s); if (rc != BBAI_OK) return rc; }
+    { int rc = enter_call(e, s); if (rc != BBAI_OK) return rc; }
     int32_t* list = e->reset_list;
     uint32_t* counter = e->counters + 16 * e->step_parity;
     if (!e->next_counter_clean) HIP_TRY(hipMemsetAsync(counter, 0, 4, s));   // (k_consume of the previous step zeroes it)
@@ -1006,8 +1041,8 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
     }
     HIP_TRY(hipGetLastError());
     // the number of finished envs is only known on the device: fixed grids, device-side count
-    if (auto_reset) return consume_and_refill(e, s, image, dirs, 0);
-    return BBAI_OK;
+    if (auto_reset) { int rc = consume_and_refill(e, s, image, dirs, 0); if (rc != BBAI_OK) return rc; }
+    return leave_call(e, s);
 }
 
 int bbai_set_atlas(bbai_env* e, const uint8_t* tiles, int n_tiles, const uint8_t* lut) {
@@ -1029,7 +1064,8 @@ int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream
     // threads, 8 envs per barrier pair, 64 envs per block): 1 048 576 envs 1.80-1.85 vs 1.99-2.15 ms per step on the slow
     // boxes, 131 072 envs 0.224 vs 0.267-0.282.  Every block pays the 11 KB atlas load into LDS (L2 hits).
     // BBAI_RENDER_GROUP / BBAI_RENDER_TPB override (experiments).
-    { int rc = adopt_stream(e, (hipStream_t)stream); if (rc != BBAI_OK) return rc; }
+    { int rc = enter_call(e, (hipStream_t)stream); if (rc != BBAI_OK) return rc; }
+    {
     ProfScope prof_(e, 2, (hipStream_t)stream);
     const bool big = e->n >= 786432;
     int G = e->render_group, T = e->render_tpb;
@@ -1039,8 +1075,9 @@ int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream
 #define RENDER_LAUNCH(GG, TT) hipLaunchKernelGGL((k_render<GG, TT>), grid, dim3(TT), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut, e->n_tiles)
 #define RENDER_G(GG) do { if (T == 1024) RENDER_LAUNCH(GG, 1024); else if (T == 512) RENDER_LAUNCH(GG, 512); else RENDER_LAUNCH(GG, 256); } while (0)
     if (G == 2) RENDER_G(2); else if (G == 4) RENDER_G(4); else RENDER_G(8);
+    }
     HIP_TRY(hipGetLastError());
-    return BBAI_OK;
+    return leave_call(e, (hipStream_t)stream);
 }
 
 // Register (or clear with NULL) a caller-owned uint8[n][72] device buffer that the engine keeps filled with the
@@ -1224,7 +1261,7 @@ int bbai_bot_act(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions, voi
         const bool maze = e->cfg.num_rows * e->cfg.num_cols > 1;
         const dim3 grid((unsigned)(e->bot_threads / 64)), block(64);
         hipStream_t s = (hipStream_t)stream;
-        { int rc = adopt_stream(e, s); if (rc != BBAI_OK) return rc; }
+        { int rc = enter_call(e, s); if (rc != BBAI_OK) return rc; }
         unsigned long long* stats = (unsigned long long*)e->bot_stats;
         const size_t lds = (size_t)R_FAST * e->cfg.H * 64 * 4 + (size_t)BOT_RING * 64 * 2;     // BossLevel: 11.3 + 8 KB -> 8 waves per CU
         if (maze)
@@ -1235,7 +1272,7 @@ int bbai_bot_act(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions, voi
                                e->bot_rows, e->bot_eager, prev_actions, actions, stats);
     }
     HIP_TRY(hipGetLastError());
-    return BBAI_OK;
+    return leave_call(e, (hipStream_t)stream);
 }
 
 #if defined(BBAI_BOT_PROF)
@@ -1259,17 +1296,30 @@ int bbai_bot_stats(bbai_env* e, uint64_t* gave_up, uint64_t* capacity) {
     return BBAI_OK;
 }
 
-int bbai_tap(int64_t count, int64_t pix_count, const uint8_t* image, const uint8_t* dirs, const double* rew64, const uint8_t* dones,
-             const uint8_t* pixels, uint8_t* image_out, uint8_t* dirs_out, double* rew64_out, uint8_t* dones_out, uint8_t* pixels_out,
-             void* stream) {
-    if (count <= 0 || pix_count < 0 || !image || !dirs || !rew64 || !dones || !image_out || !dirs_out || !rew64_out || !dones_out ||
+static int tap_launch(int64_t count, int64_t pix_count, const int64_t* ids, const uint8_t* image, const uint8_t* dirs, const double* rew64,
+                      const uint8_t* dones, const uint8_t* pixels, uint8_t* image_out, uint8_t* dirs_out, double* rew64_out, uint8_t* dones_out,
+                      uint8_t* pixels_out, void* stream) {
+    if (count <= 0 || pix_count < 0 || pix_count > count || !image || !dirs || !rew64 || !dones || !image_out || !dirs_out || !rew64_out || !dones_out ||
         (pix_count && (!pixels || !pixels_out || ((uintptr_t)pixels & 15) || ((uintptr_t)pixels_out & 15))))
         ARG_FAIL("null / misaligned pointer or empty tap");
     const int64_t work = std::max<int64_t>(count * OBS_BYTES, pix_count * (PIX_BYTES / 16));
-    hipLaunchKernelGGL(k_tap, dim3((unsigned)std::min<int64_t>((work + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, count, pix_count,
+    hipLaunchKernelGGL(k_tap, dim3((unsigned)std::min<int64_t>((work + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, count, pix_count, ids,
                        image, dirs, rew64, dones, pixels, image_out, dirs_out, rew64_out, dones_out, pixels_out);
     HIP_TRY(hipGetLastError());
     return BBAI_OK;
+}
+
+int bbai_tap(int64_t count, int64_t pix_count, const uint8_t* image, const uint8_t* dirs, const double* rew64, const uint8_t* dones,
+             const uint8_t* pixels, uint8_t* image_out, uint8_t* dirs_out, double* rew64_out, uint8_t* dones_out, uint8_t* pixels_out,
+             void* stream) {
+    return tap_launch(count, pix_count, nullptr, image, dirs, rew64, dones, pixels, image_out, dirs_out, rew64_out, dones_out, pixels_out, stream);
+}
+
+int bbai_tap_ids(int64_t count, int64_t pix_count, const int64_t* ids_dev, const uint8_t* image, const uint8_t* dirs, const double* rew64,
+                 const uint8_t* dones, const uint8_t* pixels, uint8_t* image_out, uint8_t* dirs_out, double* rew64_out, uint8_t* dones_out,
+                 uint8_t* pixels_out, void* stream) {
+    if (!ids_dev) ARG_FAIL("null id list");
+    return tap_launch(count, pix_count, ids_dev, image, dirs, rew64, dones, pixels, image_out, dirs_out, rew64_out, dones_out, pixels_out, stream);
 }
 
 int bbai_gae(int64_t num_envs, int num_frames, const float* rewards, const float* values, const float* masks, const float* last_mask,
@@ -1285,7 +1335,8 @@ int bbai_gae(int64_t num_envs, int num_frames, const float* rewards, const float
 int bbai_profile(bbai_env* e, int enable) {
     if (!e) ARG_FAIL("null handle");
     e->prof_on = enable != 0;
-    if (enable) for (int k = 0; k < 3; ++k) { e->prof_ms[k] = 0; e->prof_n[k] = 0; for (int i = 0; i < PROF_RING; ++i) e->prof[k][i].used = false; }
+    // 1: start from zero; 2: resume (totals kept: callers that bracket every other block of a run); 0: pause, totals readable
+    if (enable == 1) for (int k = 0; k < 3; ++k) { e->prof_ms[k] = 0; e->prof_n[k] = 0; for (int i = 0; i < PROF_RING; ++i) e->prof[k][i].used = false; }
     return BBAI_OK;
 }
 

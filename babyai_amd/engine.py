@@ -63,6 +63,7 @@ def load_library():
     lib.bbai_import_state.argtypes = [P, I64, I64, P, P, P]
     lib.bbai_get_programs.argtypes = [P, I64, I64, P]
     lib.bbai_tap.argtypes = [I64, I64, P, P, P, P, P, P, P, P, P, P, P]
+    lib.bbai_tap_ids.argtypes = [I64, I64, P, P, P, P, P, P, P, P, P, P, P, P]
     lib.bbai_gae.argtypes = [I64, I32, P, P, P, P, P, ctypes.c_double, ctypes.c_double, P, P, P]
     lib.bbai_profile.argtypes = [P, I32]
     lib.bbai_profile_read.argtypes = [P, P, P]
@@ -83,6 +84,7 @@ EXPORTED_SYMBOLS = (
     "bbai_reset", "bbai_step", "bbai_set_atlas", "bbai_render", "bbai_set_token_buffer", "bbai_export_state", "bbai_import_state",
     "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures", "bbai_bot_act", "bbai_bot_stats",
     "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load", "bbai_profile", "bbai_profile_read", "bbai_gae", "bbai_tap",
+    "bbai_tap_ids",
 )
 
 
@@ -148,9 +150,12 @@ class BatchedBabyAIEnv(object):
     pixel : apply RGBImgPartialObsWrapper semantics (obs image uint8[N,56,56,3])
     auto_reset : True = ParallelEnv protocol (penv.py:8-11); False = ManyEnvs protocol
                  (evaluate.py:73-81: finished envs freeze until reset())
+    validate_actions : check every step()'s actions on the device first and raise AssertionError("unknown action") like
+                 the reference (gym_minigrid MiniGridEnv.step) instead of treating bytes 8..255 as `done` (include/bbai.h);
+                 costs one reduction and a host synchronisation per step, so it is off by default
     """
 
-    def __init__(self, env_id, num_envs, device="cuda:0", seeds=None, pixel=False, auto_reset=True):
+    def __init__(self, env_id, num_envs, device="cuda:0", seeds=None, pixel=False, auto_reset=True, validate_actions=False):
         import torch
         self.torch = torch
         if os.environ.get("BABYAI_DONE_ACTIONS"):
@@ -168,6 +173,7 @@ class BatchedBabyAIEnv(object):
         self.dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.pixel = bool(pixel)
         self.auto_reset = bool(auto_reset)
+        self.validate_actions = bool(validate_actions)
         self.cfg = make_cfg(env_id)
         self.handle = ctypes.c_void_p()
         _check(self.lib, self.lib.bbai_create(ctypes.byref(self.cfg), self.num_envs, self.dev_index,
@@ -244,10 +250,18 @@ class BatchedBabyAIEnv(object):
                                               self._stream()), "bbai_reset")
         return self._obs()
 
-    def step(self, actions):
+    def step(self, actions, validate=None):
         torch = self.torch
         if not isinstance(actions, torch.Tensor):
-            actions = torch.as_tensor(np.asarray(actions), device=self.device)
+            actions = np.asarray(actions)
+            if actions.size and (int(actions.max()) > self.RESET_ENV or int(actions.min()) < 0):      # host data: checked for free
+                raise AssertionError("unknown action")
+            actions = torch.as_tensor(actions, device=self.device)
+        elif self.validate_actions if validate is None else validate:
+            # MiniGridEnv.step: `assert False, "unknown action"` (7 = RESET_ENV is this engine's per-env reset command)
+            lo, hi = (int(v) for v in torch.stack([actions.min(), actions.max()]).tolist())
+            if hi > self.RESET_ENV or lo < 0:
+                raise AssertionError("unknown action")
         if actions.dtype != torch.uint8 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
         if actions.numel() != self.num_envs:
@@ -354,22 +368,33 @@ class BatchedBabyAIEnv(object):
         _check(self.lib, self.lib.bbai_bot_stats(self.handle, ctypes.byref(a), ctypes.byref(b)), "bbai_bot_stats")
         return {"gave_up": int(a.value), "capacity": int(b.value)}
 
-    def tap(self, image_out, dir_out, reward64_out, done_out, pixels_out=None):
-        """Copy the current outputs of the first len(done_out) envs (pixels of the first len(pixels_out)) into the given
-        log rows with one launch on the current stream (bench.py's in-run parity tap)."""
+    def tap(self, image_out, dir_out, reward64_out, done_out, pixels_out=None, ids=None):
+        """Copy the current outputs of the first len(done_out) envs -- or of the envs `ids` (int64 device tensor, any order)
+        -- into the given log rows, and the pixels of the first len(pixels_out) of them, with one launch on the current
+        stream (bench.py's in-run parity tap)."""
         pp = 0 if pixels_out is None else int(pixels_out.shape[0])
         if self.torch.cuda.current_device() != self.dev_index:      # handle-free entry point: launches on the CURRENT device
             with self.torch.cuda.device(self.dev_index):
-                return self.tap(image_out, dir_out, reward64_out, done_out, pixels_out)
-        _check(self.lib, self.lib.bbai_tap(int(done_out.shape[0]), pp, self.image.data_ptr(), self.direction.data_ptr(),
-                                           self.reward64.data_ptr(), self.done.data_ptr(),
-                                           self.pixels.data_ptr() if pp else None, image_out.data_ptr(), dir_out.data_ptr(),
-                                           reward64_out.data_ptr(), done_out.data_ptr(),
-                                           pixels_out.data_ptr() if pp else None, self._stream()), "bbai_tap")
+                return self.tap(image_out, dir_out, reward64_out, done_out, pixels_out, ids)
+        count = int(done_out.shape[0])
+        src = (self.image.data_ptr(), self.direction.data_ptr(), self.reward64.data_ptr(), self.done.data_ptr(),
+               self.pixels.data_ptr() if pp else None)
+        dst = (image_out.data_ptr(), dir_out.data_ptr(), reward64_out.data_ptr(), done_out.data_ptr(),
+               pixels_out.data_ptr() if pp else None, self._stream())
+        if ids is None:
+            _check(self.lib, self.lib.bbai_tap(count, pp, *src, *dst), "bbai_tap")
+        else:
+            if ids.dtype != self.torch.int64 or ids.device != self.device or ids.numel() != count or not ids.is_contiguous():
+                raise ValueError("ids: contiguous int64[%d] on %s" % (count, self.device))
+            _check(self.lib, self.lib.bbai_tap_ids(count, pp, ids.data_ptr(), *src, *dst), "bbai_tap_ids")
 
     def profile(self, enable=True):
         """Bracket every k_step / k_consume / k_render launch with HIP events on its launch stream (bench.py)."""
         _check(self.lib, self.lib.bbai_profile(self.handle, 1 if enable else 0), "bbai_profile")
+
+    def profile_resume(self):
+        """Bracket launches again, adding to the totals kept since profile(True)."""
+        _check(self.lib, self.lib.bbai_profile(self.handle, 2), "bbai_profile")
 
     def profile_pause(self):
         """Stop bracketing launches; the totals stay readable."""

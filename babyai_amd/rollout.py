@@ -20,6 +20,10 @@ to the reference's own function by tests/test_rollout.py.  How it gets there is 
     roll = DeviceRollout(env, acmodel, num_frames_per_proc=40, discount=0.99, gae_lambda=0.99, reward_scale=20.)
     exps, logs = roll.collect_experiences()
 
+ALIASING: `exps.*` are VIEWS of the collector's persistent `[P, T]` buffers (the reference returns fresh transposed copies,
+base.py:207-232): the next `collect_experiences()` overwrites them in place.  A caller that keeps experiences across
+collections (asynchronous updates, replay or auxiliary buffers, debugging) passes `copy=True` and gets its own tensors.
+
 `acmodel(obs, memory)` follows babyai/model.py:217-273 ('dist' with sample() / log_prob(), 'value', 'memory';
 `.memory_size`).  `env` is any object with the tensor protocol of `BatchedBabyAIEnv` (`num_envs`, `device`, `reset()`,
 `step(uint8 actions)`, `enable_instr_tokens()`, optionally `reward64`); the collector holds no environment logic.
@@ -115,7 +119,9 @@ class DeviceRollout(object):
             return (self.reward_scale * r64).to(torch.float32) if r64 is not None else self.reward_scale * reward
         return reward
 
-    def collect_experiences(self):
+    def collect_experiences(self, copy=False):
+        """One rollout of T frames per env.  `copy=False`: `exps` aliases the collector's buffers until the next call (see
+        the module docstring); `copy=True`: every field is cloned, as the reference's fresh tensors are."""
         torch = self.torch
         T, P = self.num_frames_per_proc, self.num_procs
         for i in range(T):
@@ -155,6 +161,11 @@ class DeviceRollout(object):
         exps.advantage = self.advantages.reshape(-1)
         exps.returnn = self.returns.reshape(-1)
         exps.log_prob = self.log_probs.reshape(-1)
+        if copy:
+            obs = exps.obs
+            exps.obs = TensorDict(image=obs.image.clone(), instr=obs.instr.clone())
+            for k in ("memory", "mask", "action", "value", "reward", "advantage", "returnn", "log_prob"):
+                setattr(exps, k, getattr(exps, k).clone())
 
         # episode statistics: one readback, in the reference's (frame, env) append order
         idx = self.dones.reshape(-1).nonzero().reshape(-1)

@@ -27,6 +27,32 @@ def shard_seeds(seed_base, total_envs, world_size, rank):
     return np.arange(first, first + count, dtype=np.uint64) + np.uint64(seed_base)
 
 
+def scattered_ids(count, want, salt=0):
+    """`want` distinct local env indices of a shard of `count` envs, ascending: both ends, wave (64) and step-block (256)
+    boundaries at the start, the middle and the end, the rest spread pseudo-randomly (a fixed LCG, so every run and every
+    rank count picks the same envs for the same shard).  What the in-run parity tap of bench.py and the full-size GPU
+    test check against the oracle."""
+    want = min(int(want), int(count))
+    if want <= 0:
+        return []
+    n = int(count)
+    edges = [0, 1, 63, 64, 65, 255, 256, 257, n // 2 - 1, n // 2, n // 2 + 1, n - 257, n - 256, n - 255, n - 65, n - 64, n - 2, n - 1]
+    picked = []
+    seen = set()
+    for i in edges:
+        if 0 <= i < n and i not in seen and len(picked) < want:
+            seen.add(i)
+            picked.append(i)
+    x = (0x9E3779B97F4A7C15 ^ (n * 0x100000001B3) ^ (int(salt) * 0xD1B54A32D192ED03)) & 0xFFFFFFFFFFFFFFFF
+    while len(picked) < want:
+        x = (x * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        i = (x >> 20) % n
+        if i not in seen:
+            seen.add(i)
+            picked.append(i)
+    return sorted(picked)
+
+
 class Ranks(object):
     """The process group of a bench / rollout run (or a single process when WORLD_SIZE is 1 / unset)."""
 
@@ -73,6 +99,34 @@ class Ranks(object):
     def sum(self, value):
         return sum_over_ranks(value, self.dist, self.reduce_device)
 
+    def gather_objects(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] on every rank (one all_gather_object; [obj] in a single process)."""
+        if not self.dist:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def describe(self):
+        """What the LIVE process group looks like -- the answer to "did N ranks on N devices really take part?":
+        world size and backend as the group reports them, every rank's device (index, name, PCI bus id where the
+        runtime gives one, host pid), and the result of one all-reduce of ones on the reduce device (== world)."""
+        import torch
+        dev = getattr(self, "device", None)
+        mine = {"rank": self.rank, "pid": os.getpid(), "device": str(dev) if dev is not None else None,
+                "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}
+        if dev is not None and dev.type == "cuda":
+            props = torch.cuda.get_device_properties(dev)
+            mine["device_name"] = props.name
+            mine["pci_bus_id"] = getattr(props, "pci_bus_id", None)
+            mine["device_uuid"] = str(getattr(props, "uuid", "")) or None
+        ranks = self.gather_objects(mine)
+        ones = self.sum(1)
+        return {"world": self.world, "backend": self.dist.get_backend() if self.dist else None,
+                "device_ids": [r.get("device") for r in ranks],
+                "distinct_devices": len(set((r.get("device"), r.get("pci_bus_id"), r.get("device_uuid")) for r in ranks)),
+                "allreduce_of_ones": ones, "ranks": ranks}
+
     def close(self):
         if self.dist:
             self.dist.destroy_process_group()
@@ -115,11 +169,12 @@ def gather_to_rank0(tensor, dist, via_all_gather=False):
     return None
 
 
-def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None, after_block=None):
+def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None, after_block=None, before_block=None, local_out=None):
     """The measured loop.  `actions`: uint8[warmup + blocks*steps, E] resident on the env's device.  `warmup` untimed
     steps, then `blocks` timed blocks of EXACTLY `steps` steps, each bracketed by ranks.barrier() on both sides and
     reduced with max over ranks.  `after_step(t)` (t = index into `actions`) runs inside the timed region (parity tap,
-    digests), `after_block(i)` between blocks (untimed).  Returns the list of per-block seconds."""
+    digests), `before_block(i)` / `after_block(i)` between blocks (untimed).  Returns the list of per-block seconds (max over ranks);
+    `local_out` (a list) receives this rank's own per-block seconds."""
     import time
     t = 0
     for _ in range(warmup):
@@ -128,7 +183,9 @@ def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None, af
             after_step(t)
         t += 1
     out = []
-    for _ in range(blocks):
+    for b in range(blocks):
+        if before_block:
+            before_block(b)
         ranks.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -136,6 +193,9 @@ def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None, af
             if after_step:
                 after_step(t)
             t += 1
+        ranks._sync()
+        if local_out is not None:
+            local_out.append(time.perf_counter() - t0)       # this rank's own device went idle (before the barrier)
         ranks.barrier()
         out.append(ranks.max(time.perf_counter() - t0))
         if after_block:

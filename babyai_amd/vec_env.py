@@ -98,6 +98,12 @@ class _VecBase(object):
     def step(self, actions):
         if hasattr(actions, "cpu") and not hasattr(actions, "data_ptr"):
             actions = np.asarray(actions)
+        if not hasattr(actions, "data_ptr"):
+            # the reference's env asserts on anything outside MiniGridEnv.Actions (gym_minigrid step: "unknown action");
+            # these adapters speak the reference's protocol, so the engine's per-env reset command (7) is not an action here
+            a = np.asarray(actions)
+            if a.size and (int(a.max()) > 6 or int(a.min()) < 0):
+                raise AssertionError("unknown action")
         obs, _, done, _ = self.engine.step(actions)
         reward = self.engine.reward64.cpu().numpy()      # Python floats, as the reference returns them (levelgen.py:59-61)
         done = done.cpu().numpy().astype(bool)
@@ -212,6 +218,8 @@ class SingleEnv(object):
         return self._one(self.engine.reset())
 
     def step(self, action):
+        if not 0 <= int(action) <= 6:
+            raise AssertionError("unknown action")            # gym_minigrid MiniGridEnv.step
         obs, _, done, _ = self.engine.step(np.array([int(action)], dtype=np.uint8))
         self.step_count += 1
         return self._one(obs), float(self.engine.reward64[0]), bool(done[0]), {}

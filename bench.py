@@ -3,33 +3,49 @@
 
 One "step" = one pass of the hot path over one batch: every env of the shard applies one action (transition + verifier),
 finished envs are regenerated on the device (auto-reset) and the observation is written (7x7x3 encoding, plus the
-56x56x3 pixel render for the default BossLevel workload = BASELINE.json configs[4] on one GPU).  Actions are synthetic,
-i.i.d. uniform over the 7 actions from a counter-based generator keyed on (bench seed, step, global env index)
+56x56x3 pixel render for the default BossLevel workload = BASELINE.json configs[4]).  Actions are synthetic, i.i.d.
+uniform over the 7 actions from a counter-based generator keyed on (bench seed, step, global env index)
 (babyai_amd/action_stream.py), resident in HBM before the timed region.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 and no WORLD_SIZE in the environment the script LAUNCHES ITSELF as N ranks (torch.distributed.run, one rank
+per GPU, rendezvous on 127.0.0.1); under an external `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N ...` it joins that group.  Either way a run whose live process group is not exactly N ranks FAILS -- it never
+falls back to one rank.
+
+The workload is BASELINE.json's: 1 048 576 BossLevel envs with pixel observations IN TOTAL, sharded contiguously over the
+N GPUs (`scaling: "strong"`; 131 072 envs per GPU at N = 8).  `--weak` keeps 1 048 576 envs on EVERY GPU instead
+(`scaling: "weak"`); `--envs` sets the per-GPU count by hand.
 
 What one run proves about itself (all in the one JSON line rank 0 prints):
   * timing      W warmup steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize and max-reduced
-                over ranks, repeated until >= --min-seconds of timed work: `ms_per_step` / `value` come from the MEDIAN
-                block, `timing` holds min / median / max (box-to-box and run-to-run variance is ~10 %).
-  * roofline    the dominant kernel's algorithmic bytes / its HIP-event time on the launch stream, against the 8 TB/s
-                spec peak AND against what a plain 1-GiB fill / copy reaches on this box in this process
-                (`achievable`, `frac_of_achievable`).  `traffic` = HBM bytes per launch from the committed rocprofv3 PMC
-                passes, only while the kernel sources still hash to what was profiled (else null).
-  * parity      the outputs of the shard's first 1024 envs at EVERY timed step (image, direction, f64 reward bits, done;
-                pixels of the first 64) are tapped inside the timed region and re-derived afterwards by the CPU oracle
-                from the seeds and the action stream: `parity.mismatches` must be 0.
-  * cpu_baseline  the oracle on the usable host cores over the same seeds and action stream (a reported baseline).
+                over ranks, repeated until >= --min-seconds of timed work.  Blocks alternate between PLAIN (nothing but
+                the steps and the parity tap) and PROFILED (every kernel launch bracketed by a HIP event pair on its
+                launch stream).  `value` / `ms_per_step` = median plain block; `roofline` = the profiled blocks, whose own
+                median step time is reported next to it (`timing.profiled_block_ms`), so that the kernel times add up to
+                a step that was really measured and the cost of the event pairs is visible.
+  * rccl        the live process group: world size, backend, every rank's device, an all-reduce of ones, and every
+                rank's own ms per step (before the max-reduce).
+  * roofline    the dominant kernel's algorithmic bytes / its HIP-event time, against the 8 TB/s spec peak AND against
+                what a plain 1-GiB fill / copy reaches on this box in this process (`achievable`).  `traffic` = HBM bytes
+                per launch from the committed rocprofv3 PMC passes, only while the kernel sources still hash to what was
+                profiled (else null).
+  * parity      the outputs of 1024 envs SCATTERED over the shard (both ends, wave and block boundaries, a pseudo-random
+                spread: shard.scattered_ids) at EVERY step (image, direction, f64 reward bits, done; pixels of 64) are
+                tapped inside the timed region and re-derived afterwards by the CPU oracle from the seeds and the action
+                stream: `parity.mismatches_all_ranks` must be 0 (exit code 3 otherwise; 4 when the checker itself broke).
+  * cpu_baseline  the oracle on the usable host cores over the same seeds and action stream (rank 0; a reported
+                baseline), with the measured reference/port ratio of the build container when it is on file.
 
-Envs shard embarrassingly (babyai_amd/shard.py): rank r owns global envs [r*E, (r+1)*E) with seeds base + global index;
-no collective on the step path.  scaling = weak (E envs per GPU fixed).
+Envs shard embarrassingly (babyai_amd/shard.py): rank r owns a contiguous range of global envs with seeds base + global
+index; no collective on the step path.
 """
 import argparse
 import hashlib
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -37,15 +53,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (MI355X_MICROARCH.md)
+HEADLINE_ENVS = 1048576     # BASELINE.json: "1M parallel envs"
 
-# BASELINE.json configs (per-GPU env counts; C4/C5 are quoted on 8 GPUs with 131072 envs each, the default
-# bench runs C5's level and obs mode with all 1 048 576 envs on ONE GPU, which is the headline metric's shape)
+# BASELINE.json configs: level, obs mode and the TOTAL env count the config is quoted on.  C4 / C5 are quoted on
+# 8 GPUs (131072 envs each); the "-shard" names run that per-GPU shard size on however many GPUs are used (profiling
+# one GPU's share of the 8-GPU job on a 1-GPU box).
 CONFIGS = {
-    "C2": dict(level="GoToLocal", envs=65536, pixel=False),
-    "C3": dict(level="PickupLoc", envs=262144, pixel=False),
-    "C4": dict(level="GoTo", envs=131072, pixel=False),
-    "C5": dict(level="BossLevel", envs=131072, pixel=True),
-    "C5-1gpu": dict(level="BossLevel", envs=1048576, pixel=True),
+    "C2": dict(level="GoToLocal", total=65536, pixel=False),
+    "C3": dict(level="PickupLoc", total=262144, pixel=False),
+    "C4": dict(level="GoTo", total=1048576, pixel=False),
+    "C5": dict(level="BossLevel", total=1048576, pixel=True),
+    "C4-shard": dict(level="GoTo", per_gpu=131072, pixel=False),
+    "C5-shard": dict(level="BossLevel", per_gpu=131072, pixel=True),
 }
 
 
@@ -90,21 +109,23 @@ def achievable_bandwidth(torch, dev):
     return {"fill_GBs": fill, "copy_GBs": copy, "bytes": n}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--envs", type=int, default=1048576, help="envs per GPU")
+    ap.add_argument("--envs", type=int, default=None, help="envs PER GPU (default: --total-envs / --gpus)")
+    ap.add_argument("--total-envs", type=int, default=None, help="envs of the whole job (default 1048576 = the BASELINE metric)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: the single-GPU env count on EVERY GPU (default: the total is fixed)")
     ap.add_argument("--level", default="BossLevel")
     ap.add_argument("--no-pixel", action="store_true")
     ap.add_argument("--seed", type=int, default=0, help="env i of the whole job is seeded with seed + i")
     ap.add_argument("--action-seed", type=int, default=1234)
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
-                    help="a BASELINE.json config by name (overrides --level/--envs/--no-pixel); default = C5 on one GPU")
+                    help="a BASELINE.json config by name (overrides --level/--envs/--no-pixel); default = C5")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step block until this much timed work")
     ap.add_argument("--max-blocks", type=int, default=64)
-    ap.add_argument("--parity-envs", type=int, default=1024, help="first envs of every shard checked against the oracle (0 = off)")
+    ap.add_argument("--parity-envs", type=int, default=1024, help="envs of every shard, scattered over it, checked against the oracle (0 = off)")
     ap.add_argument("--parity-pixel-envs", type=int, default=64)
     ap.add_argument("--parity-budget", type=int, default=600000,
                     help="oracle env-steps the parity check may cost: long runs check every step of fewer envs")
@@ -114,28 +135,89 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (test rigs: ranks may share a GPU)")
     ap.add_argument("--share-device", action="store_true", help="test rigs only: every rank uses cuda:0")
     ap.add_argument("--dump-digest", default=None, help="write per-env output digests of this rank to <prefix>.rank<r>.npy")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    return args
+
+
+def resolve_workload(args):
+    """(level, pixel, envs per GPU, total envs, scaling) for this run."""
+    level, pixel = args.level, not args.no_pixel
+    total = args.total_envs
+    per_gpu = args.envs
     if args.config:
-        cfgsel = CONFIGS[args.config]
-        args.level, args.envs, args.no_pixel = cfgsel["level"], cfgsel["envs"], not cfgsel["pixel"]
+        c = CONFIGS[args.config]
+        level, pixel = c["level"], c["pixel"]
+        if "per_gpu" in c:
+            per_gpu = c["per_gpu"] if per_gpu is None else per_gpu
+        elif total is None:
+            total = c["total"]
+    if per_gpu is not None:                       # explicit per-GPU count: every GPU gets it
+        return level, pixel, per_gpu, per_gpu * args.gpus, "weak"
+    if total is None:
+        total = HEADLINE_ENVS
+    if args.weak:
+        return level, pixel, total, total * args.gpus, "weak"
+    if total % args.gpus:
+        raise SystemExit("bench.py: %d envs do not split evenly over %d GPUs" % (total, args.gpus))
+    return level, pixel, total // args.gpus, total, "strong"
+
+
+def self_launch(args):
+    """--gpus N > 1 outside a torch.distributed launch: become the launcher.  The child ranks inherit stdout, so rank 0's
+    JSON line is this process's JSON line; the exit code is the launcher's (non-zero if any rank failed)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), BBAI_BENCH_SELF_LAUNCHED="1")
+    sys.stderr.write("bench.py: launching %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    return subprocess.call(cmd, env=env, cwd=os.getcwd())
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; start with --nproc-per-node == --gpus "
+                         "(or run plain `python bench.py --gpus N`, which launches the ranks itself)" % (args.gpus, env_world))
+    level, pixel, E, total_envs, scaling = resolve_workload(args)
 
     # the CPU legs' worker pool is forked BEFORE the GPU runtime and the process group exist (oracle/cpu_baseline.py
-    # make_pool): it idles through the timed region and is only fed afterwards
+    # make_pool): it idles through the timed region and is only fed afterwards.  Rank 0 also runs the CPU baseline and
+    # gets the larger share of the node's cores; the other ranks keep two workers each for their parity replay.
     pool = None
+    pool_size = 0
     if args.parity_envs or not args.no_cpu_baseline:
         from oracle import cpu_baseline            # outside the timed region: checker / reported baseline only
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-        pool = cpu_baseline.make_pool(max(2, cpu_baseline.usable_cores() // local_world))
+        cores = cpu_baseline.usable_cores()
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            pool_size = max(2, cores - 2 * (local_world - 1))
+        else:
+            pool_size = 2
+        pool = cpu_baseline.make_pool(pool_size)
 
     import numpy as np
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU path)")
+    if not args.share_device and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", env_world)):
+        raise SystemExit("bench.py: %d ranks on this node but only %d GPUs visible (one rank per GPU; test rigs: --share-device "
+                         "--dist-backend gloo)" % (env_world, torch.cuda.device_count()))
     from babyai_amd import shard
     from babyai_amd.action_stream import actions_torch
     ranks = shard.Ranks.from_env(args.dist_backend, args.share_device)
     rank, world, dev = ranks.rank, ranks.world, ranks.device
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if world != args.gpus:
+        raise SystemExit("bench.py: the live process group has %d ranks, --gpus asked for %d" % (world, args.gpus))
+    group = ranks.describe()
+    if group["allreduce_of_ones"] != world or (not args.share_device and group["distinct_devices"] != world):
+        raise SystemExit("bench.py: process group check failed: %r" % (group,))
 
     import __graft_entry__
     if rank == 0:
@@ -143,12 +225,9 @@ def main():
     ranks.barrier()
     from babyai_amd.engine import BatchedBabyAIEnv
 
-    pixel = not args.no_pixel
-    E = args.envs
-    total_envs = E * world
     first, count = shard.shard_range(total_envs, world, rank)
     assert count == E
-    env = BatchedBabyAIEnv("BabyAI-%s-v0" % args.level, E, device=dev, pixel=pixel)
+    env = BatchedBabyAIEnv("BabyAI-%s-v0" % level, E, device=dev, pixel=pixel)
     env.seed(shard.shard_seeds(args.seed, total_envs, world, rank))
     K, W = args.steps, args.warmup
 
@@ -172,9 +251,19 @@ def main():
     PP = min(args.parity_pixel_envs, P) if pixel else 0
     digest = shard.EnvDigest(E, dev, 147) if args.dump_digest else None
 
-    def make_log(steps, with_initial, p, pp):
-        if not p:
+    # the tapped envs: scattered over the shard; the ones whose pixels are checked too come first in the log rows and
+    # are themselves a spread (both ends included)
+    def tap_ids(p, pp):
+        ids = shard.scattered_ids(E, p, salt=first)
+        head = [ids[(len(ids) - 1) * k // max(1, pp - 1)] for k in range(pp)] if pp else []
+        head = sorted(set(head))
+        rest = [i for i in ids if i not in set(head)]
+        return head + rest, len(head)
+
+    def make_log(steps, with_initial, ids, pp):
+        if not ids:
             return None
+        p = len(ids)
         extra = 1 if with_initial else 0
         lg = {"image": torch.zeros((steps + extra, p, 7, 7, 3), dtype=torch.uint8, device=dev),
               "direction": torch.zeros((steps + extra, p), dtype=torch.uint8, device=dev),
@@ -182,23 +271,25 @@ def main():
               "done": torch.zeros((steps, p), dtype=torch.uint8, device=dev)}
         if pp:
             lg["pixels"] = torch.zeros((steps + extra, pp, 56, 56, 3), dtype=torch.uint8, device=dev)
+        lg["ids"] = torch.as_tensor(ids, dtype=torch.int64, device=dev)
         return lg
 
     def tap(lg, obs_row, row):
-        """the parity tap: ONE small launch inside the timed region (include/bbai.h bbai_tap)"""
+        """the parity tap: ONE small launch inside the timed region (include/bbai.h bbai_tap_ids)"""
         env.tap(lg["image"][obs_row], lg["direction"][obs_row], lg["reward64"][row], lg["done"][row],
-                lg["pixels"][obs_row] if "pixels" in lg else None)
+                lg["pixels"][obs_row] if "pixels" in lg else None, ids=lg["ids"])
 
     # phase 1: reset, W warmup steps and ONE K-step block; its time decides how many further blocks make --min-seconds
     S1 = W + K
     actions1 = actions_torch(args.action_seed, 0, S1, first, E, dev)        # resident before the timed region
-    log1 = make_log(S1, True, P, PP)
+    ids1, PP1 = tap_ids(P, PP)
+    log1 = make_log(S1, True, ids1, PP1)
     env.reset()
     if log1 is not None:
-        log1["image"][0].copy_(env.image[:P])
-        log1["direction"][0].copy_(env.direction[:P])
-        if PP:
-            log1["pixels"][0].copy_(env.pixels[:PP])
+        log1["image"][0].copy_(env.image[log1["ids"]])
+        log1["direction"][0].copy_(env.direction[log1["ids"]])
+        if PP1:
+            log1["pixels"][0].copy_(env.pixels[log1["ids"][:PP1]])
 
     def after1(t):
         if log1 is not None:
@@ -210,17 +301,29 @@ def main():
     blocks = shard.timed_blocks(env, actions1, W, K, 1, ranks, after1)
     want = int(min(args.max_blocks, max(0, -(-args.min_seconds // blocks[0]))))
     want = int(ranks.max(want))
-    # phase 2: `want` more blocks of exactly K steps; when there are any, the phase-1 block was only the probe
+    if want == 1:
+        want = 2                                      # one plain and one profiled block at least
+    # phase 2: `want` more blocks of exactly K steps, alternately plain (even) and profiled (odd); when there are any, the
+    # phase-1 block was only the probe
     S2 = want * K
-    if P and (S1 + S2) * P > args.parity_budget:      # long run: every step of fewer envs
-        P = max(min(16, P), args.parity_budget // (S1 + S2))
-        PP = min(PP, P)
+    ids2, PP2, sel2 = ids1, PP1, None
+    if P and (S1 + S2) * P > args.parity_budget:      # long run: every step of FEWER envs in phase 2 -- a spread of phase 1's
+        P2 = max(min(16, P), args.parity_budget // (S1 + S2))
+        PP2 = min(PP1, P2)
+        pix_rows = sorted(set((PP1 - 1) * k // max(1, PP2 - 1) for k in range(PP2))) if PP2 else []
+        n_rest = len(ids1) - PP1
+        rest_rows = sorted(set(PP1 + (n_rest - 1) * k // max(1, P2 - len(pix_rows) - 1) for k in range(P2 - len(pix_rows)))) if n_rest > 0 else []
+        sel2 = pix_rows + rest_rows                    # rows of log1 that phase 2 keeps following (pixel rows first)
+        ids2, PP2 = [ids1[r] for r in sel2], len(pix_rows)
     log2 = None
     resets0 = env.reset_count()
-    env.profile(True)              # per-kernel HIP event pairs on the launch stream (include/bbai.h bbai_profile)
+    env.profile(True)              # per-kernel HIP event pairs on the launch stream (include/bbai.h bbai_profile) ...
+    env.profile_pause()            # ... in the odd blocks only
+    local_blocks = []
+    profiled = []
     if want:
         actions2 = actions_torch(args.action_seed, S1, S1 + S2, first, E, dev)
-        log2 = make_log(S2, False, P, PP)
+        log2 = make_log(S2, False, ids2, PP2)
 
         def after2(t):
             if log2 is not None:
@@ -228,15 +331,21 @@ def main():
             if digest is not None:
                 digest.update(env.image, env.direction, env.reward64, env.done)
 
+        def before_block(i):
+            if i % 2:
+                env.profile_resume()
+            else:
+                env.profile_pause()
+
         torch.cuda.synchronize()
-        # the per-kernel event pairs ride along in the first of these blocks only (two event records per launch are
-        # not free at 65 536 envs); `value` comes from the median block
-        blocks = shard.timed_blocks(env, actions2, 0, K, want, ranks, after2,
-                                    after_block=lambda i: env.profile_pause() if i == 0 else None)
+        all_blocks = shard.timed_blocks(env, actions2, 0, K, want, ranks, after2, before_block=before_block, local_out=local_blocks)
+        env.profile_pause()
+        blocks = all_blocks[0::2]
+        profiled = all_blocks[1::2]
+        local_blocks = local_blocks[0::2]
     resets = ranks.sum(env.reset_count() - resets0)
     S = S1 + S2
 
-    # per-kernel durations: HIP event pairs recorded by the engine on the launch stream around each launch (bbai_profile)
     if not want:                    # single-block run: nothing was bracketed; time a few untimed steps
         env.profile(True)
         for t in range(4):
@@ -246,9 +355,14 @@ def main():
     kernel_launches = {k: v[1] for k, v in env.profile_read().items() if v[0] is not None}
     env.profile(False)
 
+    def median(xs):
+        xs = sorted(xs)
+        return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
+
     bs = sorted(blocks)
-    med = bs[len(bs) // 2] if len(bs) % 2 else 0.5 * (bs[len(bs) // 2 - 1] + bs[len(bs) // 2])
+    med = median(blocks)
     value = K * E * world / med
+    per_rank_ms = ranks.gather_objects(median(local_blocks) / K * 1e3 if local_blocks else None)
     if pixel:
         dom, alg_bytes = "k_render", E * (147 + 9408)          # reads the encoding, writes the pixels
         dom_ms = kernel_ms["k_render"]
@@ -268,7 +382,7 @@ def main():
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
         key = next((k for k in pmc["kernels"] if k == dom or k.startswith(dom + "<")), None)      # k_render is a template
-        if pmc.get("level") == args.level and pmc.get("envs") == E and key:
+        if pmc.get("level") == level and pmc.get("envs") == E and key:
             kk = pmc["kernels"][key]
             fetch = kk.get("FETCH_SIZE_corrected", 2 * kk["FETCH_SIZE"])      # gfx950: FETCH_SIZE tallies 128-B requests as 64 B
             traffic = {"bytes": fetch + kk["WRITE_SIZE"], "fetch_corrected": fetch, "fetch_raw": kk["FETCH_SIZE"], "write": kk["WRITE_SIZE"],
@@ -279,18 +393,29 @@ def main():
                 traffic["bytes"] = None         # kernels changed since the counters were taken
     except Exception:
         traffic = None
+    prof_med = median(profiled) if profiled else None
     out = {
         "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": med / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": med / K * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "BabyAI-%s-v0 %s obs, %d envs/GPU, random actions, auto-reset" % (
-            args.level, "56x56x3 pixel (RGBImgPartialObsWrapper)" if pixel else "7x7x3 encoded", E),
+        "config": {"workload": "BabyAI-%s-v0 %s obs, %d envs in total = %d per GPU x %d, random actions, auto-reset" % (
+            level, "56x56x3 pixel (RGBImgPartialObsWrapper)" if pixel else "7x7x3 encoded", total_envs, E, world),
             "envs_per_gpu": E, "total_envs": total_envs, "resets_in_timed_region": resets,
             "parallelism": "env-shards x%d, no collective" % world,
             "actions": "counter-based (action_seed %d, step, global env index), uniform over 7" % args.action_seed},
+        "rccl": dict(group, per_rank_ms_per_step=per_rank_ms,
+                     per_rank_ms_per_step_min=min(per_rank_ms) if all(v is not None for v in per_rank_ms) else None,
+                     per_rank_ms_per_step_max=max(per_rank_ms) if all(v is not None for v in per_rank_ms) else None,
+                     launched_by="bench.py itself" if os.environ.get("BBAI_BENCH_SELF_LAUNCHED") else ("external launcher" if world > 1 else "single process")),
         "timing": {"blocks": len(blocks), "steps_per_block": K, "block_ms": {"min": bs[0] * 1e3, "median": med * 1e3, "max": bs[-1] * 1e3},
-                   "timed_seconds": sum(blocks), "value_from": "median block", "value_at_min": K * E * world / bs[0],
-                   "value_at_max": K * E * world / bs[-1]},
+                   "timed_seconds": sum(blocks) + sum(profiled), "value_from": "median plain block", "value_at_min": K * E * world / bs[0],
+                   "value_at_max": K * E * world / bs[-1],
+                   "profiled_blocks": len(profiled),
+                   "profiled_block_ms": {"min": min(profiled) * 1e3, "median": prof_med * 1e3, "max": max(profiled) * 1e3} if profiled else None,
+                   "profiled_ms_per_step": prof_med / K * 1e3 if profiled else None,
+                   "event_pairs_cost_us_per_step": (prof_med - med) / K * 1e6 if profiled else None,
+                   "note": "plain and profiled blocks alternate; kernel_avg_ms are the profiled blocks' launches and add up to (at most) "
+                           "profiled_ms_per_step"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic["bytes"] if traffic else None, "traffic_provenance": traffic,
@@ -298,7 +423,7 @@ def main():
                      "achievable_ceiling": ceiling_key,
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
                      "whole_step_alg_GBs": value / world * bytes_per_step / 1e9,
-                     "kernel_avg_ms": kernel_ms, "kernel_launches": kernel_launches},
+                     "kernel_avg_ms": kernel_ms, "kernel_launches": kernel_launches, "measured_on": "rank 0"},
         "parity": None, "cpu_baseline": None,
         "build": {"commit": git_head(), "csrc_sha": csrc_sha()},
     }
@@ -324,34 +449,51 @@ def main():
     if args.dump_digest:
         np.save("%s.rank%d.npy" % (args.dump_digest, rank), digest.numpy())
     # ---- outside the timed region: the oracle re-derives what the tap recorded --------------------------------------
+    exit_code = 0
     if log1 is not None:
-        host = {k: np.concatenate([log1[k][:, :(PP if k == "pixels" else P)].cpu().numpy()]
-                                  + ([log2[k].cpu().numpy()] if log2 is not None else [])) for k in log1 if (k != "pixels" or PP)}
         try:
-            par = cpu_baseline.parity_replay(args.level, host, args.seed, args.action_seed, first, PP, pool=pool)
+            host = {}
+            for k in log1:
+                if k == "ids" or (k == "pixels" and not PP2):
+                    continue
+                a = log1[k]
+                if sel2 is not None:                    # phase 2 followed a subset: the checked envs are that subset, all steps
+                    rows = [r for r in sel2 if r < PP1] if k == "pixels" else sel2
+                    a = a[:, torch.as_tensor(rows, dtype=torch.int64, device=dev)]
+                host[k] = np.concatenate([a.cpu().numpy()] + ([log2[k].cpu().numpy()] if log2 is not None else []))
+            par = cpu_baseline.parity_replay(level, host, args.seed, args.action_seed, first, PP2, env_ids=[first + i for i in ids2], pool=pool)
         except Exception as exc:
             par = {"error": repr(exc), "mismatches": None}          # the CHECKER broke: reported, not a parity verdict
         bad = ranks.sum(par["mismatches"] or 0)
         broken = ranks.sum(1 if par["mismatches"] is None else 0)
         if rank == 0:
-            par["mismatches_all_ranks"] = bad
+            par["mismatches_all_ranks"] = None if broken else bad       # never readable as "0 mismatches" when nothing was checked
             par["checker_errors_all_ranks"] = broken
-            par["envs_all_ranks"] = P * world
-            par["steps_checked"] = "all %d steps of the run (warmup, probe block and the %d timed blocks)" % (S, len(blocks))
+            par["envs_all_ranks"] = len(ids2) * world
+            par["env_selection"] = "scattered over each shard: both ends, wave / block boundaries, pseudo-random spread (shard.scattered_ids)"
+            par["env_ids_rank0"] = {"min": min(ids2), "max": max(ids2), "count": len(ids2), "shard_envs": E}
+            par["steps_checked"] = "all %d steps of the run (warmup, probe block and the %d timed blocks)" % (S, want)
             out["parity"] = par
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if broken:
+            exit_code = 4
+        elif bad:
+            exit_code = 3                   # a fast kernel whose results differ from the oracle's is not done
+    ranks.barrier()
+    if rank == 0 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline.run(args.level, pixel, args.cpu_baseline_seconds, args.seed, args.action_seed, pool=pool)
+            cb = cpu_baseline.run(level, pixel, args.cpu_baseline_seconds, args.seed, args.action_seed, pool=pool, cores=pool_size)
+            cb.update(cpu_baseline.reference_over_port(level, pixel))
+            out["cpu_baseline"] = cb
         except Exception as exc:      # the baseline is a reported number, never the product path
             out["cpu_baseline"] = {"error": repr(exc)}
     if pool is not None:
         pool.terminate()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     env.close()
+    ranks.barrier()
     ranks.close()
-    if rank == 0 and out["parity"] and (out["parity"].get("mismatches_all_ranks") or 0) != 0:
-        sys.exit(3)                     # a fast kernel whose results differ from the oracle's is not done
+    sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -7,9 +7,10 @@
  * data_ptr() of torch tensors on the handle's device); launches are asynchronous on
  * the caller's hipStream_t (passed as void*; NULL = default stream).  No exceptions
  * cross the boundary: every call returns 0 or a negative bbai_status.  One handle per
- * device; a handle is not thread-safe and follows ONE caller stream at a time: a call that arrives
- * on a different stream than the previous one is ordered (by an event) behind everything the handle
- * enqueued on the previous stream (which must therefore still exist at that point).
+ * device; a handle is not thread-safe and follows ONE caller stream at a time: every call that launches on the caller's
+ * stream (reset / step / render / bot_act) ends by recording the handle's completion event there, and a call that
+ * arrives on a different stream than the previous one first makes its stream wait for that event.  The previous stream
+ * is never touched again, so it may have been destroyed in between.
  */
 #ifndef BBAI_H
 #define BBAI_H
@@ -80,6 +81,12 @@ int bbai_reset(bbai_env* env, uint8_t* image_dev, uint8_t* dir_dev, void* stream
  * actions_dev[i] is 0..6 (MiniGridEnv.Actions), or BBAI_ACTION_RESET_ENV = "env.reset() for this env now": the
  * episode is abandoned with done = 1, reward = 0 and handled like any finished env above (a ParallelEnv worker's
  * `reset` command, penv.py:12-14; scripts/make_agent_demos.py:84-88 after a bot crash).
+ * UNKNOWN ACTIONS: the reference asserts on an action outside its enum (gym_minigrid MiniGridEnv.step: `assert False,
+ * "unknown action"`, reached from levelgen.py:50).  A kernel cannot raise: bytes 8..255 are DEFINED here as the `done`
+ * action (no movement; the step is counted, the verifier sees a done action).  Callers that want the reference's
+ * behaviour check their actions first: the Python binding does (BatchedBabyAIEnv(validate_actions=True) / step(...,
+ * validate=True): one device-side max-reduce and a host sync, off by default; the list-of-dicts adapters, whose actions
+ * are host arrays anyway, always check and raise AssertionError("unknown action")).
  * reward_dev[i]   = float32 rounding of the reward (what babyai/rl/algos/base.py:162-167 makes of it);
  * reward64_dev[i] = the reference's own return value: MiniGridEnv._reward() as a Python float (levelgen.py:59-61),
  *                   bit for bit (what babyai/evaluate.py:128 accumulates).  May be NULL. */
@@ -142,6 +149,12 @@ int bbai_bot_stats(bbai_env* env, uint64_t* gave_up, uint64_t* capacity);
 int bbai_tap(int64_t count, int64_t pix_count, const uint8_t* image_dev, const uint8_t* dir_dev, const double* reward64_dev,
              const uint8_t* done_dev, const uint8_t* pixels_dev, uint8_t* image_out, uint8_t* dir_out, double* reward64_out,
              uint8_t* done_out, uint8_t* pixels_out, void* stream);
+/* The same for an arbitrary list of envs: ids_dev int64[count] on the device, env ids_dev[k] -> log row k (pixels of the
+ * first pix_count <= count listed envs).  bench.py taps ids scattered over the whole shard (both ends, block and wave
+ * boundaries, a pseudo-random spread: babyai_amd/shard.py scattered_ids). */
+int bbai_tap_ids(int64_t count, int64_t pix_count, const int64_t* ids_dev, const uint8_t* image_dev, const uint8_t* dir_dev,
+                 const double* reward64_dev, const uint8_t* done_dev, const uint8_t* pixels_dev, uint8_t* image_out, uint8_t* dir_out,
+                 double* reward64_out, uint8_t* done_out, uint8_t* pixels_out, void* stream);
 
 /* Generalised advantage estimation of a rollout on the current device (the loop of babyai/rl/algos/base.py:196-202 as
  * one reverse scan per env).  All buffers float32, env-major [num_envs][num_frames] (the order base.py:207-232 flattens
@@ -154,7 +167,8 @@ int bbai_gae(int64_t num_envs, int num_frames, const float* rewards_dev, const f
 
 /* Per-kernel timing for measurements (bench.py's roofline): while enabled, every k_step / k_consume / k_render launch is
  * bracketed by a HIP event pair ON THE STREAM IT IS LAUNCHED ON; bbai_profile_read returns the summed milliseconds and the
- * launch counts in that order.  Enabling resets the totals.  Costs two event records per launch. */
+ * launch counts in that order.  enable: 1 = start from zero, 2 = resume (totals kept), 0 = pause (totals stay readable).
+ * Costs two event records per launch. */
 int bbai_profile(bbai_env* env, int enable);
 int bbai_profile_read(bbai_env* env, double* ms_total /* [3] */, int64_t* launches /* [3] */);
 

@@ -82,8 +82,10 @@ def _worker(args):
     return steps, time.perf_counter() - t0
 
 
-def run(level="BossLevel", pixel=True, seconds=12.0, seed_base=0, action_seed=1234, pool=None):
-    cores = usable_cores()
+def run(level="BossLevel", pixel=True, seconds=12.0, seed_base=0, action_seed=1234, pool=None, cores=None):
+    """`cores` = workers to use (default: every usable core; bench.py passes the size of the pool it forked -- on a
+    multi-rank node rank 0 leaves two cores to each other rank)."""
+    cores = cores or usable_cores()
     own = pool is None
     if own:
         pool = make_pool(cores)
@@ -103,8 +105,27 @@ def run(level="BossLevel", pixel=True, seconds=12.0, seed_base=0, action_seed=12
                   "stream), one process per usable core x %.0f s, auto-reset (%d steps)"
                   % (level, " + RGBImgPartialObsWrapper" if pixel else "", cores - 1, seconds, total),
         "single_core_value": single, "parallel_efficiency": (total / wall) / (cores * single),
-        "os_cpu_count": os.cpu_count(),
+        "os_cpu_count": os.cpu_count(), "usable_cores": usable_cores(),
     }
+
+
+def reference_over_port(level, pixel):
+    """The measured speed ratio reference / port for this workload, from profiles/r03/cpu_port_vs_reference.json (taken in
+    the build container, where /root/reference can be imported: tools/cpu_port_vs_reference.py -- same seeds, same actions,
+    equal output digests).  The reference tree never reaches the GPU box, so the bench line carries the port's figure and
+    this ratio to convert it.  {} when no measurement is on file for the workload."""
+    import json
+    path = os.path.join(_ROOT, "profiles", "r03", "cpu_port_vs_reference.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+        row = table["workloads"]["%s/%s" % (level, "pixel" if pixel else "encoded")]
+    except (OSError, ValueError, KeyError):
+        return {}
+    return {"reference_over_port": row["reference_over_port"],
+            "reference_over_port_provenance": {"file": "profiles/r03/cpu_port_vs_reference.json", "digest_equal": row["digest_equal"],
+                                               "reference_steps_per_s": row["reference_steps_per_s"], "port_steps_per_s": row["port_steps_per_s"],
+                                               "steps": row["steps"], "where": table.get("where"), "commit": table.get("commit")}}
 
 
 # ---- in-run parity --------------------------------------------------------------------------------------------------

@@ -38,6 +38,19 @@ def test_action_stream_is_one_function_of_seed_step_and_global_index():
     assert counts.min() > 98500 and counts.max() < 101500 and len(counts) == 7
 
 
+def test_scattered_ids_cover_both_ends_and_the_boundaries():
+    for n in (1, 5, 64, 300, 1024, 65536, 1048576):
+        for want in (1, 16, 1024):
+            ids = shard.scattered_ids(n, want)
+            assert ids == sorted(set(ids)) and len(ids) == min(n, want) and all(0 <= i < n for i in ids)
+            assert ids == shard.scattered_ids(n, want)                      # deterministic
+    ids = shard.scattered_ids(1048576, 1024)
+    assert {0, 1, 63, 64, 255, 256, 257, 524288, 1048576 - 256, 1048576 - 64, 1048575} <= set(ids)
+    quart = np.bincount(np.asarray(ids) * 4 // 1048576, minlength=4)
+    assert quart.min() > 200                                              # a spread, not a prefix
+    assert shard.scattered_ids(131072, 128, salt=131072) != shard.scattered_ids(131072, 128, salt=0)
+
+
 LEVEL, TOTAL, W, K, BLOCKS, SEED, ASEED = "GoToObjS4", 24, 3, 8, 2, 700, 99
 
 
@@ -61,12 +74,16 @@ def _worker(rank, world, port, q):
     first, count = shard.shard_range(TOTAL, world, rank)
     assert np.array_equal(shard.shard_seeds(SEED, TOTAL, world, rank), np.arange(first, first + count, dtype=np.uint64) + np.uint64(SEED))
     env, dig, blocks = _rollout(ranks, first, count)
+    group = ranks.describe()                  # what bench.py records as `rccl`
     full_img = shard.gather_to_rank0(env.image, ranks.dist)
     full_dig = shard.gather_to_rank0(dig.h, ranks.dist, via_all_gather=True)
+    local = []
+    shard.timed_blocks(env, actions_torch(ASEED, 100, 104, first, count, "cpu"), 0, 2, 2, ranks, local_out=local,
+                       before_block=lambda i: local.append(("before", i)))
     t = ranks.max(0.5 + rank)
     n = ranks.sum(count)
     if rank == 0:
-        q.put((full_img.numpy(), full_dig.numpy(), blocks, t, n))
+        q.put((full_img.numpy(), full_dig.numpy(), blocks, t, n, group, local))
     ranks.barrier()
     ranks.close()
 
@@ -81,10 +98,13 @@ def test_two_rank_gloo_shards_equal_the_unsharded_run():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    full_img, full_dig, blocks, t, n = q.get(timeout=300)
+    full_img, full_dig, blocks, t, n, group, local = q.get(timeout=300)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    assert group["world"] == 2 and group["backend"] == "gloo" and group["allreduce_of_ones"] == 2
+    assert [r["rank"] for r in group["ranks"]] == [0, 1] and len(set(r["pid"] for r in group["ranks"])) == 2
+    assert local[0] == ("before", 0) and local[2] == ("before", 1) and local[1] > 0 and local[3] > 0      # hook order, own times
     env, dig, _ = _rollout(shard.Ranks(), 0, TOTAL)
     assert np.array_equal(full_img, env.image.numpy())          # rank-ordered concatenation == unsharded result
     assert np.array_equal(full_dig, dig.h.numpy())              # ... at every step, every output (running digests)

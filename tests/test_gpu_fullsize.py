@@ -164,11 +164,13 @@ def test_baseline_configs_1024_scattered_envs_vs_oracle(gpu, level, n, pixel, st
     from babyai_amd.engine import BatchedBabyAIEnv
     from babyai_amd.action_stream import actions_torch
     from oracle import cpu_baseline
-    rng = np.random.RandomState(n % 9973)
-    ids = sorted(set([0, 1, 63, 64, 255, 256, 257, n // 2 - 1, n // 2, n - 257, n - 256, n - 65, n - 2, n - 1]
-                     + rng.randint(0, n, size=1400).tolist()))[:1024]
-    assert len(ids) == 1024
-    PP = 32 if pixel else 0
+    from babyai_amd.shard import scattered_ids
+    ids = scattered_ids(n, 1024)                   # (the list bench.py taps in its timed region)
+    assert len(ids) == 1024 and ids[0] == 0 and ids[-1] == n - 1 and {63, 64, 255, 256, n // 2, n - 256, n - 64} <= set(ids)
+    # pixels are checked on the first PP log rows: put a spread (both ends) there
+    head = sorted(set(ids[1023 * k // 31] for k in range(32))) if pixel else []
+    ids = head + [i for i in ids if i not in set(head)]
+    PP = len(head)
     sel = torch.as_tensor(ids, device=gpu)
     env = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, pixel=pixel, seeds=5000)
     env.reset()
@@ -188,6 +190,10 @@ def test_baseline_configs_1024_scattered_envs_vs_oracle(gpu, level, n, pixel, st
         for k in range(acts.shape[0]):
             t = t0 + k
             env.step(acts[k])
+            if t % 2:           # alternately through the one-launch tap (bbai_tap_ids) and through torch indexing
+                env.tap(log["image"][t + 1], log["direction"][t + 1], log["reward64"][t], log["done"][t],
+                        log["pixels"][t + 1] if PP else None, ids=sel)
+                continue
             log["image"][t + 1] = env.image[sel]
             log["direction"][t + 1] = env.direction[sel]
             log["reward64"][t] = env.reward64[sel]

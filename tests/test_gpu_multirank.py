@@ -1,8 +1,12 @@
-"""bench.py with WORLD_SIZE > 1 on ONE GPU (the box has one): `torch.distributed.run --nproc-per-node 4 bench.py --gpus 4
---share-device --dist-backend gloo` -- the launch line, rank plumbing, sharding, action stream, barrier-bracketed blocks,
-max-reduce and JSON contract of the multi-GPU run -- and the per-env output digests of the four shards must concatenate
-to those of the unsharded 16384-env run.  A second test tries the RCCL backend with two ranks on the one visible
-device; RCCL may refuse that ("duplicate GPU"), in which case it is skipped with RCCL's message."""
+"""bench.py with more than one rank on ONE GPU (the box has one): the launch line, rank plumbing, sharding, action stream,
+barrier-bracketed blocks, max-reduce and JSON contract of the multi-GPU run -- and the per-env output digests of the four
+shards must concatenate to those of the unsharded 16384-env run.
+  * `python bench.py --gpus 4 ...` with NO launcher: bench.py starts its own four ranks (the way an unattended driver
+    would call it) and the line must say n_gpus 4 / rccl.world 4, strong scaling (the total is fixed);
+  * the same under an external `torch.distributed.run` (the driver's documented launch line);
+  * the RCCL backend with two ranks on the one visible device; RCCL may refuse that ("duplicate GPU"), in which case it
+    is skipped with RCCL's message.
+CPU part (no GPU needed): a launch whose world does not match --gpus fails, and the self-launch really spawns N ranks."""
 import json
 import os
 import socket
@@ -13,7 +17,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMON = ["--level", "GoToLocal", "--no-pixel", "--steps", "16", "--warmup", "4", "--min-seconds", "30", "--max-blocks", "3",
+COMMON = ["--level", "GoToLocal", "--no-pixel", "--steps", "16", "--warmup", "4", "--min-seconds", "30", "--max-blocks", "4",
           "--no-cpu-baseline", "--prewarm-seconds", "0", "--parity-envs", "64"]
 
 
@@ -23,8 +27,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(cmd, timeout=600):
+def _run(cmd, timeout=600, extra_env=None):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     return p, (json.loads(lines[-1]) if lines else None)
@@ -36,24 +43,52 @@ def _launch(world, backend, envs, prefix, extra=()):
                  "--envs", str(envs), "--dump-digest", prefix] + COMMON + list(extra))
 
 
+def _digests(prefix, world):
+    return np.concatenate([np.load(prefix + ".rank%d.npy" % r) for r in range(world)])
+
+
 @pytest.mark.gpu
 def test_bench_four_ranks_on_one_gpu_equal_the_unsharded_run(gpu, tmp_path):
     p1, one = _run([sys.executable, "bench.py", "--envs", "16384", "--dump-digest", str(tmp_path / "one")] + COMMON)
     assert p1.returncode == 0, p1.stderr[-2000:]
     p4, four = _launch(4, "gloo", 4096, str(tmp_path / "four"))
     assert p4.returncode == 0, p4.stderr[-2000:]
-    assert one["n_gpus"] == 1 and four["n_gpus"] == 4 and four["scaling"] == "weak"
+    assert one["n_gpus"] == 1 and four["n_gpus"] == 4 and four["scaling"] == "weak"        # explicit per-GPU count
     assert four["config"]["total_envs"] == 16384 and four["config"]["envs_per_gpu"] == 4096
     assert four["steps"] == 16 and four["warmup"] == 4 and four["value"] > 0 and four["timing"]["blocks"] >= 1
     assert one["timing"]["blocks"] == four["timing"]["blocks"]          # same number of steps in both runs
     assert one["parity"]["mismatches"] == 0 and four["parity"]["mismatches_all_ranks"] == 0
     assert four["parity"]["envs_all_ranks"] == 4 * four["parity"]["envs"]
     whole = np.load(str(tmp_path / "one") + ".rank0.npy")
-    parts = np.concatenate([np.load(str(tmp_path / "four") + ".rank%d.npy" % r) for r in range(4)])
-    assert whole.shape == (16384,) and np.array_equal(whole, parts)
+    assert whole.shape == (16384,) and np.array_equal(whole, _digests(str(tmp_path / "four"), 4))
     assert one["config"]["resets_in_timed_region"] == four["config"]["resets_in_timed_region"] > 0
     # the optional obs gather to rank 0 ran (over gloo here) and is reported outside `value`
     assert four["obs_gather"]["ms"] > 0 and four["obs_gather"]["bytes_per_peer"] == 4096 * 147 and "obs_gather" not in one
+    # the line says what the live process group was
+    assert four["rccl"]["world"] == 4 and four["rccl"]["backend"] == "gloo" and four["rccl"]["allreduce_of_ones"] == 4
+    assert len(four["rccl"]["ranks"]) == 4 and len(four["rccl"]["per_rank_ms_per_step"]) == 4
+    assert four["rccl"]["launched_by"] == "external launcher" and one["rccl"]["world"] == 1
+    # plain and profiled blocks alternate: the kernel times come with the step time of the blocks they were taken in
+    t = four["timing"]
+    assert t["profiled_blocks"] >= 1 and t["profiled_ms_per_step"] > 0
+    assert sum(one["roofline"]["kernel_avg_ms"].values()) <= one["timing"]["profiled_ms_per_step"] * 1.02
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks(gpu, tmp_path):
+    """`python bench.py --gpus 4` and nothing else: four ranks, the metric's total split over them (strong scaling), the
+    same per-env digests as the one-rank run of the same total."""
+    base = ["--total-envs", "16384"] + COMMON
+    p1, one = _run([sys.executable, "bench.py", "--gpus", "1", "--dump-digest", str(tmp_path / "one")] + base)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    p4, four = _run([sys.executable, "bench.py", "--gpus", "4", "--share-device", "--dist-backend", "gloo",
+                     "--dump-digest", str(tmp_path / "four")] + base)
+    assert p4.returncode == 0, p4.stderr[-3000:]
+    assert four["n_gpus"] == 4 and four["scaling"] == "strong" and one["scaling"] == "strong"
+    assert four["config"]["total_envs"] == 16384 == one["config"]["total_envs"] and four["config"]["envs_per_gpu"] == 4096
+    assert four["rccl"]["world"] == 4 and four["rccl"]["launched_by"] == "bench.py itself"
+    assert four["parity"]["mismatches_all_ranks"] == 0 and four["parity"]["checker_errors_all_ranks"] == 0
+    assert np.array_equal(np.load(str(tmp_path / "one") + ".rank0.npy"), _digests(str(tmp_path / "four"), 4))
 
 
 @pytest.mark.gpu
@@ -67,3 +102,47 @@ def test_bench_two_ranks_rccl_on_one_gpu(gpu, tmp_path):
             pytest.skip("RCCL refuses two ranks on one device: " + hits[0].strip()[:240])
         assert False, err[-3000:]
     assert two["n_gpus"] == 2 and two["parity"]["mismatches_all_ranks"] == 0
+
+
+# ---- no GPU needed ------------------------------------------------------------------------------------------------------
+
+def test_world_size_that_does_not_match_gpus_is_an_error():
+    """Round 2's bench ran ONE rank and printed n_gpus 1 when asked for --gpus 8 without a launcher; now a launcher that
+    started a different number of ranks is refused before anything is measured."""
+    p, line = _run([sys.executable, "bench.py", "--gpus", "8"] + COMMON, extra_env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and line is None
+    assert "--gpus 8" in p.stderr and "WORLD_SIZE=1" in p.stderr
+
+
+def test_self_launch_spawns_n_ranks():
+    """Without a GPU every rank stops at "needs a ROCm GPU" -- but there must be N of them, started by bench.py itself, and
+    the launcher's exit code must say that the run failed.  (On a GPU box the same call is test_bench_launches_its_own_ranks.)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked self-launch test")
+    p, line = _run([sys.executable, "bench.py", "--gpus", "2", "--parity-envs", "0", "--no-cpu-baseline"], timeout=300)
+    assert p.returncode != 0 and line is None
+    assert "launching 2 ranks" in p.stderr
+    assert p.stderr.count("bench.py needs a ROCm GPU") >= 2
+
+
+def test_default_workload_is_the_metric_configuration():
+    """BASELINE.json: "1M parallel envs, BossLevel, 1/2/4/8 MI355X" = 1 048 576 envs IN TOTAL, pixel obs; --weak and
+    --envs are the opt-outs."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for n in (1, 2, 4, 8):
+        a = bench.parse_args(["--gpus", str(n)])
+        assert bench.resolve_workload(a) == ("BossLevel", True, 1048576 // n, 1048576, "strong")
+        a = bench.parse_args(["--gpus", str(n), "--weak"])
+        assert bench.resolve_workload(a) == ("BossLevel", True, 1048576, 1048576 * n, "weak")
+        a = bench.parse_args(["--gpus", str(n), "--config", "C4"])
+        assert bench.resolve_workload(a) == ("GoTo", False, 1048576 // n, 1048576, "strong")
+        a = bench.parse_args(["--gpus", str(n), "--config", "C5-shard"])
+        assert bench.resolve_workload(a) == ("BossLevel", True, 131072, 131072 * n, "weak")
+    a = bench.parse_args(["--config", "C2"])
+    assert bench.resolve_workload(a) == ("GoToLocal", False, 65536, 65536, "strong")
+    a = bench.parse_args(["--gpus", "2", "--envs", "4096", "--level", "GoTo", "--no-pixel"])
+    assert bench.resolve_workload(a) == ("GoTo", False, 4096, 8192, "weak")
+    with pytest.raises(SystemExit):
+        bench.resolve_workload(bench.parse_args(["--gpus", "3"]))

@@ -405,6 +405,20 @@ def test_batch_evaluate_matches_reference_driver(gpu):
     assert list(logs["num_frames_per_episode"]) == list(num_frames)
     assert list(logs["return_per_episode"]) == list(returns)          # float64, bit for bit
     assert list(logs["seed_per_episode"]) == list(range(seed, seed + episodes))
+    # the wrapper with the reference's own signature and log shape (babyai/evaluate.py:85): same numbers, plus the
+    # observations / actions of every episode up to its end
+    from babyai_amd.evaluate import batch_evaluate
+    ref_like = batch_evaluate(_ScriptedAgent(), name, seed, episodes, return_obss_actions=True, device=str(gpu))
+    assert set(ref_like) == {"num_frames_per_episode", "return_per_episode", "observations_per_episode", "actions_per_episode", "seed_per_episode"}
+    assert list(ref_like["num_frames_per_episode"]) == list(num_frames) and list(ref_like["return_per_episode"]) == list(returns)
+    assert [len(a) for a in ref_like["actions_per_episode"]] == list(num_frames)
+    assert [len(o) for o in ref_like["observations_per_episode"]] == list(num_frames)
+    o0 = ref_like["observations_per_episode"][3][0]
+    assert set(o0) == {"image", "direction", "mission"} and o0["image"].shape == (7, 7, 3) and isinstance(o0["mission"], str)
+    # the reference rounds the episode count up to whole rounds of min(256, episodes) envs (evaluate.py:86,104)
+    big = batch_evaluate(_ScriptedAgent(), name, seed, 300, device=str(gpu))
+    assert len(big["return_per_episode"]) == 512 and big["seed_per_episode"] == list(range(seed, seed + 512))
+    assert list(big["num_frames_per_episode"][:episodes]) == list(num_frames) and big["observations_per_episode"] == []
 
 
 @pytest.mark.gpu
@@ -1094,3 +1108,53 @@ def test_render_launch_shapes_are_byte_identical(gpu, group, tpb, monkeypatch):
             o, r, d, _ = wr[k].step(int(a[i]))
             ro[k] = wr[k].reset() if d else o
     env.close()
+
+
+@pytest.mark.gpu
+def test_unknown_actions_are_defined_and_can_be_rejected(gpu):
+    """The reference asserts on an action outside MiniGridEnv.Actions (gym_minigrid step: `assert False, "unknown action"`,
+    reached from levelgen.py:50).  The kernel cannot raise: include/bbai.h DEFINES bytes 8..255 as the `done` action; the
+    binding can check first (validate_actions / step(validate=True): AssertionError like the reference), and the
+    reference-protocol adapters always do."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from babyai_amd.vec_env import BatchedParallelEnv, SingleEnv
+    n = 512
+    a = BatchedBabyAIEnv("BabyAI-GoToLocal-v0", n, device=gpu, seeds=31)
+    b = BatchedBabyAIEnv("BabyAI-GoToLocal-v0", n, device=gpu, seeds=31)
+    a.reset()
+    b.reset()
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(1)
+    for t in range(150):
+        acts = torch.randint(0, 7, (n,), dtype=torch.uint8, device=gpu, generator=gen)
+        junk = torch.randint(8, 256, (n,), dtype=torch.int64, device=gpu, generator=gen).to(torch.uint8)
+        swap = acts == 6
+        a.step(acts)
+        b.step(torch.where(swap, junk, acts))                 # every `done` replaced by an arbitrary byte 8..255
+        assert torch.equal(a.image, b.image) and torch.equal(a.reward64, b.reward64) and torch.equal(a.done, b.done)
+    assert a.reset_count() == b.reset_count() > n
+    bad = torch.zeros(n, dtype=torch.uint8, device=gpu)
+    bad[n // 2] = 9
+    with pytest.raises(AssertionError, match="unknown action"):
+        a.step(bad, validate=True)
+    ok = torch.full((n,), a.RESET_ENV, dtype=torch.uint8, device=gpu)
+    a.step(ok, validate=True)                                  # the per-env reset command is known
+    with pytest.raises(AssertionError, match="unknown action"):
+        a.step(bad.cpu().numpy())                              # host data is checked for free, always
+    c = BatchedBabyAIEnv("BabyAI-GoToLocal-v0", 64, device=gpu, seeds=1, validate_actions=True)
+    c.reset()
+    with pytest.raises(AssertionError, match="unknown action"):
+        c.step(torch.full((64,), 200, dtype=torch.uint8, device=gpu))
+    for e in (a, b, c):
+        e.close()
+    p = BatchedParallelEnv("BabyAI-GoToLocal-v0", 4, device=gpu, seeds=[1, 2, 3, 4])
+    p.reset()
+    with pytest.raises(AssertionError, match="unknown action"):
+        p.step(np.array([0, 1, 7, 2]))                        # 7 is the engine's own command, not a MiniGrid action
+    p.close()
+    s = SingleEnv("BabyAI-GoToLocal-v0", device=gpu, seed=3)
+    s.reset()
+    with pytest.raises(AssertionError, match="unknown action"):
+        s.step(7)
+    s.close()

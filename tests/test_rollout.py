@@ -64,3 +64,24 @@ def test_device_rollout_equals_reference_collect_experiences(level, scale):
             assert np.allclose(log_ref[k], log[k], rtol=0 if exact else 1e-6, atol=0 if exact else 1e-6), k
         total_done += log["episodes_done"]
     assert total_done >= 5                                 # the comparison crossed auto-resets
+
+
+def test_collect_experiences_copy_survives_the_next_collection():
+    """`exps` of collect_experiences() alias the collector's buffers (module docstring); copy=True hands out tensors of
+    the caller's own, like the reference's fresh transposed copies (base.py:207-232)."""
+    from babyai_amd.rollout import DeviceRollout
+    seeds = [900 + i for i in range(4)]
+    roll = DeviceRollout(OracleTensorEnv("GoToObjS4", seeds), ToyACModel(), 12, 0.99, 0.95, reward_scale=20.0)
+    views, _ = roll.collect_experiences()
+    own, _ = roll_b = DeviceRollout(OracleTensorEnv("GoToObjS4", seeds), ToyACModel(), 12, 0.99, 0.95, reward_scale=20.0).collect_experiences(copy=True)
+    for f in FIELDS:
+        assert torch.equal(getattr(views, f), getattr(own, f)), f
+    keep = {f: getattr(own, f).clone() for f in FIELDS}
+    keep_img = own.obs.image.clone()
+    assert views.value.data_ptr() == roll.values.data_ptr() and own.value.data_ptr() != roll.values.data_ptr()
+    before = views.action.clone()
+    roll.collect_experiences()                             # overwrites what `views` points at ...
+    assert not torch.equal(views.action, before) or not torch.equal(views.value, keep["value"])
+    for f in FIELDS:                                       # ... and leaves the copies alone
+        assert torch.equal(getattr(own, f), keep[f]), f
+    assert torch.equal(own.obs.image, keep_img)
