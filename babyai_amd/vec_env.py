@@ -11,7 +11,7 @@ surface (same method names, argument meaning, return shapes and auto-reset / fre
 behaviour) while every env lives on the GPU, so `ObssPreprocessor` (babyai/utils/format.py:100-119),
 `ModelAgent.act_batch` (babyai/utils/agent.py:51-72) and `BaseAlgo.collect_experiences`
 (babyai/rl/algos/base.py:110-251) consume the results unchanged.  See INTEGRATION.md for
-the two-line patch a maintainer would apply.
+the no-edit route (`babyai_amd.integrate.install()`).
 
 `make(env_id, num_envs, ...)` is the batched twin of `gym.make(env_id)`.
 """
@@ -75,9 +75,18 @@ class ObsList(object):
         return (self[i] for i in range(len(self)))
 
 
+class _EnvView(object):
+    """What the reference reads off `envs[0]` (scripts/train_rl.py:86-99, babyai/rl/utils/penv.py:24-25)."""
+
+    def __init__(self, vec):
+        self.observation_space, self.action_space = vec.observation_space, vec.action_space
+
+
 class _VecBase(object):
-    def __init__(self, env_id, num_envs, device="cuda:0", pixel=False, auto_reset=True, seeds=None):
-        self.engine = BatchedBabyAIEnv(env_id, num_envs, device=device, pixel=pixel, auto_reset=auto_reset)
+    def __init__(self, env_id, num_envs, device="cuda:0", pixel=False, auto_reset=True, seeds=None, engine=None):
+        """`engine`: an object with BatchedBabyAIEnv's tensor protocol to run on instead of building one (tests put the
+        CPU oracle there to drive the reference's consumers through this adapter code without a GPU)."""
+        self.engine = engine if engine is not None else BatchedBabyAIEnv(env_id, num_envs, device=device, pixel=pixel, auto_reset=auto_reset)
         self.num_envs = num_envs
         self.pixel = pixel
         self.observation_space, self.action_space = _spaces(pixel)
@@ -87,6 +96,16 @@ class _VecBase(object):
     def seed(self, seeds):
         """ManyEnvs.seed(seeds) (evaluate.py:64-65) / per-env env.seed(s) (train_rl.py:59)."""
         return self.engine.seed(seeds)
+
+    # the list operations the reference applies to its `envs` argument: len(envs) (base.py:86), envs[0].observation_space
+    # / .action_space (train_rl.py:86-99) -- so that an adapter can stand where the list of gym envs stood
+    def __len__(self):
+        return self.num_envs
+
+    def __getitem__(self, i):
+        if not -self.num_envs <= int(i) < self.num_envs:
+            raise IndexError(i)
+        return _EnvView(self)
 
     def _obs_list(self, obs):
         # everything an obs dict may be asked for later is copied out now: images, directions and the mission programs
@@ -123,16 +142,16 @@ class BatchedParallelEnv(_VecBase):
     """`ParallelEnv` protocol (penv.py:18-59): auto-reset -- when an env finishes, the returned obs is the
     first obs of its next episode while reward/done belong to the terminal step (penv.py:8-11,49-50)."""
 
-    def __init__(self, env_id, num_envs, device="cuda:0", pixel=False, seeds=None):
-        super().__init__(env_id, num_envs, device=device, pixel=pixel, auto_reset=True, seeds=seeds)
+    def __init__(self, env_id, num_envs, device="cuda:0", pixel=False, seeds=None, engine=None):
+        super().__init__(env_id, num_envs, device=device, pixel=pixel, auto_reset=True, seeds=seeds, engine=engine)
 
 
 class BatchedManyEnvs(_VecBase):
     """`ManyEnvs` protocol (evaluate.py:58-81): no auto-reset; a finished env re-emits its last
     (obs, reward, done, info) until the next reset()."""
 
-    def __init__(self, env_id, num_envs, device="cuda:0", pixel=False, seeds=None):
-        super().__init__(env_id, num_envs, device=device, pixel=pixel, auto_reset=False, seeds=seeds)
+    def __init__(self, env_id, num_envs, device="cuda:0", pixel=False, seeds=None, engine=None):
+        super().__init__(env_id, num_envs, device=device, pixel=pixel, auto_reset=False, seeds=seeds, engine=engine)
         self.done = [False] * num_envs
 
     def reset(self):

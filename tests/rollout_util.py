@@ -83,3 +83,73 @@ class OracleTensorEnv(object):
         self.reward64 = torch.as_tensor(np.array(rewards, dtype=np.float64))
         self.done = torch.as_tensor(np.array(dones, dtype=np.uint8))
         return (self._publish(obss), self.reward64.to(torch.float32), self.done, {})
+
+
+class _MissionList(object):
+    """What BatchedBabyAIEnv puts under obs['mission']: indexable, with snapshot() (engine.py Missions)."""
+
+    def __init__(self, texts):
+        self._texts = list(texts)
+
+    def snapshot(self):
+        return self
+
+    def __len__(self):
+        return len(self._texts)
+
+    def __getitem__(self, i):
+        return self._texts[i]
+
+    def __iter__(self):
+        return iter(self._texts)
+
+
+class OracleEngine(object):
+    """BatchedBabyAIEnv's tensor protocol (seed / reset / step with auto-reset or freeze, reward64, lazy missions) on CPU
+    tensors over oracle envs: lets the protocol adapters of babyai_amd/vec_env.py and the reference's consumers on top
+    of them run in a container without a GPU.  TEST DOUBLE: the product has no CPU path."""
+
+    def __init__(self, level, num_envs, auto_reset=True):
+        from oracle import levels as olevels
+        self.envs = [olevels.make_env(level) for _ in range(num_envs)]
+        self.num_envs, self.auto_reset, self.pixel = num_envs, auto_reset, False
+        self.device = torch.device("cpu")
+        self.frozen = [False] * num_envs
+        self.last = [None] * num_envs
+        self.closed = False
+
+    def seed(self, seeds):
+        for e, s in zip(self.envs, seeds):
+            e.seed(int(s))
+
+    def _obs(self, obss):
+        return {"image": torch.as_tensor(np.stack([o["image"] for o in obss])),
+                "direction": torch.as_tensor(np.array([o["direction"] for o in obss], dtype=np.uint8)),
+                "mission": _MissionList(o["mission"] for o in obss)}
+
+    def reset(self):
+        self.frozen = [False] * self.num_envs
+        self.cur = [e.reset() for e in self.envs]
+        return self._obs(self.cur)
+
+    def step(self, actions):
+        actions = np.asarray(actions.cpu() if hasattr(actions, "cpu") else actions).reshape(-1)
+        rewards, dones = [], []
+        for k, (e, a) in enumerate(zip(self.envs, actions.tolist())):
+            if self.frozen[k]:
+                o, r, d = self.last[k]
+            else:
+                o, r, d, _ = e.step(int(a))
+                if d and self.auto_reset:
+                    o = e.reset()
+                elif d:
+                    self.frozen[k] = True
+                self.last[k] = (o, r, d)
+            self.cur[k] = o
+            rewards.append(r); dones.append(d)
+        self.reward64 = torch.as_tensor(np.array(rewards, dtype=np.float64))
+        self.done = torch.as_tensor(np.array(dones, dtype=np.uint8))
+        return self._obs(self.cur), self.reward64.to(torch.float32), self.done, {}
+
+    def close(self):
+        self.closed = True

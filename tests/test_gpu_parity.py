@@ -92,11 +92,16 @@ def test_parallel_env_adapter_vs_oracle(gpu, level, pixel):
     """The ParallelEnv-protocol adapter against a list of oracle envs driven the way
     babyai/rl/utils/penv.py drives them (seeds 100*seed+i as in scripts/train_rl.py:59)."""
     from babyai_amd.vec_env import BatchedParallelEnv
+    from babyai_amd import integrate
     from oracle import levels as olevels
     from gym_minigrid.wrappers import RGBImgPartialObsWrapper
     n, T = 12, 150
     seeds = [100 * 3 + i for i in range(n)]
-    venv = BatchedParallelEnv("BabyAI-%s-v0" % level, n, device=gpu, pixel=pixel, seeds=seeds)
+    # built the way a training script would with the no-edit integration (babyai_amd/integrate.py): seeds 100*seed+i, and
+    # the object answers the list operations BaseAlgo / train_rl.py apply to `envs`
+    venv = integrate.make_envs("BabyAI-%s-v0" % level, n, 3, pixel=pixel, device=gpu)
+    assert isinstance(venv, BatchedParallelEnv) and len(venv) == n and venv[0].action_space.n == 7
+    assert [int(s) for s in venv.engine.seeds] == seeds
     refs = []
     for s in seeds:
         e = olevels.make_env(level)
