@@ -833,7 +833,7 @@ static int create_finish(bbai_env* e) {
     }
     {
         const char* cv = getenv("BBAI_CALL_EVENTS");
-        e->call_events = !(cv && atoi(cv) == 0);
+        e->call_events = cv && atoi(cv) != 0;
         const char* ev = getenv("BBAI_PREGEN_BLOCKS");
         e->pregen_cap = ev ? std::max(64, atoi(ev)) : 256 * 32;
         const char* rv = getenv("BBAI_RENDER_GROUP");
@@ -886,11 +886,14 @@ static unsigned pregen_grid(const bbai_env* e, int64_t count_hint) {
 }
 
 // A handle's launches are ordered by ONE caller stream at a time (plus the private look-ahead stream, which is tied to
-// it by events).  Every call that launches on the caller's stream ends by recording the handle's completion event
-// there (leave_call); a call that arrives on a DIFFERENT stream than the previous one first makes its stream wait for
-// that event (enter_call).  The previous stream itself is never touched again -- it may have been destroyed since --
-// and its pointer is only compared.  (BBAI_CALL_EVENTS=0: round 2's scheme, an event recorded on the previous stream
-// at the moment of the switch; kept for A/B measurements of the per-call record.)
+// it by events).  A call that arrives on a DIFFERENT stream than the previous one is ordered behind everything the
+// handle enqueued before.  Two ways to get the event that stream waits for (bbai_set_call_events):
+//   off (default)  the event is recorded on the PREVIOUS stream at the moment of the switch -- free on the step path, but
+//                  the previous stream must still exist then;
+//   on             every call ends by recording the handle's completion event on its own stream and a switch only waits
+//                  for it: the previous stream is never touched again (it may have been destroyed).  Measured cost
+//                  (profiles/r03/call_events_ab.jsonl): +3.4 us per step at 65 536 GoToLocal envs (46.9 vs 43.5 us), +7 us
+//                  per step + render at 131 072 pixel envs -- which is why it is opt-in.
 static int enter_call(bbai_env* e, hipStream_t s) {
     if (e->have_stream && e->last_stream != s) {
         if (!e->call_events) HIP_TRY(hipEventRecord(e->ev_switch, e->last_stream));
@@ -1329,6 +1332,16 @@ int bbai_gae(int64_t num_envs, int num_frames, const float* rewards, const float
     hipLaunchKernelGGL(k_gae, dim3((unsigned)((num_envs + 63) / 64)), dim3(64), 0, (hipStream_t)stream, num_envs, num_frames, rewards, values,
                        masks, last_mask, last_value, (float)discount, (float)(discount * gae_lambda), advantage, returnn);
     HIP_TRY(hipGetLastError());
+    return BBAI_OK;
+}
+
+int bbai_set_call_events(bbai_env* e, int enable) {
+    if (!e) ARG_FAIL("null handle");
+    if (enable && !e->call_events && e->have_stream) {      // switching on mid-run: the event must describe the work so far
+        ON_DEVICE(e->device);
+        HIP_TRY(hipEventRecord(e->ev_switch, e->last_stream));
+    }
+    e->call_events = enable != 0;
     return BBAI_OK;
 }
 

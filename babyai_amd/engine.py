@@ -65,6 +65,7 @@ def load_library():
     lib.bbai_tap.argtypes = [I64, I64, P, P, P, P, P, P, P, P, P, P, P]
     lib.bbai_tap_ids.argtypes = [I64, I64, P, P, P, P, P, P, P, P, P, P, P, P]
     lib.bbai_gae.argtypes = [I64, I32, P, P, P, P, P, ctypes.c_double, ctypes.c_double, P, P, P]
+    lib.bbai_set_call_events.argtypes = [P, I32]
     lib.bbai_profile.argtypes = [P, I32]
     lib.bbai_profile_read.argtypes = [P, P, P]
     lib.bbai_checkpoint_bytes.argtypes = [P]
@@ -84,7 +85,7 @@ EXPORTED_SYMBOLS = (
     "bbai_reset", "bbai_step", "bbai_set_atlas", "bbai_render", "bbai_set_token_buffer", "bbai_export_state", "bbai_import_state",
     "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures", "bbai_bot_act", "bbai_bot_stats",
     "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load", "bbai_profile", "bbai_profile_read", "bbai_gae", "bbai_tap",
-    "bbai_tap_ids",
+    "bbai_tap_ids", "bbai_set_call_events",
 )
 
 
@@ -387,6 +388,11 @@ class BatchedBabyAIEnv(object):
             if ids.dtype != self.torch.int64 or ids.device != self.device or ids.numel() != count or not ids.is_contiguous():
                 raise ValueError("ids: contiguous int64[%d] on %s" % (count, self.device))
             _check(self.lib, self.lib.bbai_tap_ids(count, pp, ids.data_ptr(), *src, *dst), "bbai_tap_ids")
+
+    def set_call_events(self, enable=True):
+        """Record the handle's completion event at the end of every call, so that a caller may destroy a stream it used
+        for this env and come back on another one (include/bbai.h bbai_set_call_events; off by default: ~3 us per call)."""
+        _check(self.lib, self.lib.bbai_set_call_events(self.handle, 1 if enable else 0), "bbai_set_call_events")
 
     def profile(self, enable=True):
         """Bracket every k_step / k_consume / k_render launch with HIP events on its launch stream (bench.py)."""

@@ -7,10 +7,10 @@
  * data_ptr() of torch tensors on the handle's device); launches are asynchronous on
  * the caller's hipStream_t (passed as void*; NULL = default stream).  No exceptions
  * cross the boundary: every call returns 0 or a negative bbai_status.  One handle per
- * device; a handle is not thread-safe and follows ONE caller stream at a time: every call that launches on the caller's
- * stream (reset / step / render / bot_act) ends by recording the handle's completion event there, and a call that
- * arrives on a different stream than the previous one first makes its stream wait for that event.  The previous stream
- * is never touched again, so it may have been destroyed in between.
+ * device; a handle is not thread-safe and follows ONE caller stream at a time: a call that arrives on a different
+ * stream than the previous one is ordered (by an event) behind everything the handle enqueued before.  By default that
+ * event is recorded on the previous stream at the moment of the switch, so the previous stream must still exist then;
+ * see bbai_set_call_events for callers that create and destroy streams.
  */
 #ifndef BBAI_H
 #define BBAI_H
@@ -171,6 +171,12 @@ int bbai_gae(int64_t num_envs, int num_frames, const float* rewards_dev, const f
  * Costs two event records per launch. */
 int bbai_profile(bbai_env* env, int enable);
 int bbai_profile_read(bbai_env* env, double* ms_total /* [3] */, int64_t* launches /* [3] */);
+
+/* Stream switching policy.  enable != 0: every reset / step / render / bot_act ends by recording the handle's completion
+ * event on its own stream, and a call on another stream only waits for that event -- the previous stream is never
+ * touched again and may have been destroyed.  Costs one event record per call (measured +3.4 us per step at 65 536 envs,
+ * profiles/r03/call_events_ab.jsonl), hence off by default (BBAI_CALL_EVENTS=1 in the environment turns it on at create). */
+int bbai_set_call_events(bbai_env* env, int enable);
 
 /* Number of level generations (resets) performed so far, all envs. */
 int bbai_reset_count(bbai_env* env, uint64_t* out);

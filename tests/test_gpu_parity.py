@@ -1018,15 +1018,19 @@ def test_reseed_in_the_middle_of_a_window(gpu, lookahead, first_leg, monkeypatch
 
 
 @pytest.mark.gpu
-def test_caller_may_change_streams_between_calls(gpu):
+@pytest.mark.parametrize("call_events", [False, True])
+def test_caller_may_change_streams_between_calls(gpu, call_events):
     """A handle follows one caller stream at a time; when the caller comes back on another stream the engine orders it
-    behind the work it enqueued on the previous one (include/bbai.h).  Alternating two streams per step, with no
-    synchronisation by the caller, must give the single-stream result."""
+    behind the work it enqueued before (include/bbai.h).  Alternating streams per step, with no synchronisation by the
+    caller, must give the single-stream result.  With bbai_set_call_events the previous stream is never touched again:
+    there the caller creates a FRESH stream for every step and drops the old one."""
     import torch
     from babyai_amd.engine import BatchedBabyAIEnv
     n = 4096
     a = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=9, pixel=True)
     b = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=9, pixel=True)
+    if call_events:
+        b.set_call_events(True)
     a.reset()
     b.reset()
     acts = torch.randint(0, 7, (96, n), dtype=torch.uint8, device=gpu)
@@ -1034,8 +1038,15 @@ def test_caller_may_change_streams_between_calls(gpu):
     streams = [torch.cuda.Stream(device=gpu), torch.cuda.Stream(device=gpu)]
     for t in range(96):
         a.step(acts[t])
-        with torch.cuda.stream(streams[t & 1]):
-            b.step(acts[t])
+        if call_events:
+            s = torch.cuda.Stream(device=gpu)        # a new stream every step; the previous one is released
+            s.wait_stream(torch.cuda.current_stream(gpu))      # (acts was produced on the default stream)
+            with torch.cuda.stream(s):
+                b.step(acts[t])
+            streams[t & 1] = s
+        else:
+            with torch.cuda.stream(streams[t & 1]):
+                b.step(acts[t])
     for s in streams:
         s.synchronize()
     torch.cuda.synchronize()
