@@ -118,7 +118,8 @@ struct bbai_env {
     bool call_events;
     int render_tpb;       // BBAI_RENDER_TPB: 256 / 512 / 1024 threads per render block; anything else = by batch size
     int render_group;     // BBAI_RENDER_GROUP: 2, 4 or 8 envs per one-shot render block; anything else = by batch size (bbai_render)
-    int pregen_cap;       // BBAI_PREGEN_BLOCKS: upper bound on resident look-ahead workgroups (experiments)
+    int pregen_cap;       // BBAI_PREGEN_BLOCKS: upper bound on look-ahead lane groups per launch (experiments)
+    int pregen_group;     // BBAI_PREGEN_GROUP: lanes per env in k_pregen: 16 (default: four envs per wave), 32 or 64
     // optional per-kernel timing (bbai_profile): HIP event pairs on the launch stream around k_step / k_consume / k_render
     bool prof_on;
     struct ProfSlot { hipEvent_t a, b; bool used; } prof[3][PROF_RING];
@@ -332,91 +333,147 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(LevelCfg c, int64_t n, uint
 // ------------------------------------------------------------------------------------------
 // k_pregen / k_consume : look-ahead level generation (one wavefront generates one env's levels)
 // ------------------------------------------------------------------------------------------
-struct WaveCtx {
-    __device__ __forceinline__ int lane() const { return (int)threadIdx.x; }
-    __device__ __forceinline__ int nlanes() const { return 64; }
-    __device__ __forceinline__ void sync() const { __syncthreads(); }
-    __device__ __forceinline__ uint32_t shfl_up1(uint32_t v) const { uint32_t t = __shfl_up(v, 1); return threadIdx.x == 0 ? 0u : t; }
-    __device__ __forceinline__ uint32_t shfl_down1(uint32_t v) const { uint32_t t = __shfl_down(v, 1); return threadIdx.x == 63 ? 0u : t; }
-    __device__ __forceinline__ bool any(bool p) const { return __ballot(p) != 0ull; }
+// One env per group of G lanes, 64 / G envs per wavefront (bbai_gen.hpp "Execution model").  sync() orders the group's LDS
+// accesses: it is reached under divergent control flow (the groups of a wave are in different places of the generator),
+// so it is a wave-local fence, never a workgroup barrier -- the workgroup is one wave.
+template <int G>
+struct GroupCtx {
+    static constexpr int kLanes = G;
+    __device__ __forceinline__ int lane() const { return (int)threadIdx.x & (G - 1); }
+    __device__ __forceinline__ int nlanes() const { return G; }
+    __device__ __forceinline__ void sync() const {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    __device__ __forceinline__ uint32_t shfl(uint32_t v, int src) const { return __shfl(v, src, G); }
+    __device__ __forceinline__ uint32_t shfl_up1(uint32_t v) const { uint32_t t = __shfl_up(v, 1, G); return lane() == 0 ? 0u : t; }
+    __device__ __forceinline__ uint32_t shfl_down1(uint32_t v) const { uint32_t t = __shfl_down(v, 1, G); return lane() == G - 1 ? 0u : t; }
+    __device__ __forceinline__ bool any(bool p) const {
+        const unsigned long long b = __ballot(p);
+        constexpr unsigned long long m = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
+        return ((b >> ((int)threadIdx.x & ~(G - 1) & 63)) & m) != 0ull;
+    }
 };
 
-template <int KIND>
-__global__ __launch_bounds__(64, KIND == K_BONUS ? 4 : 1) void k_pregen(LevelCfg c, int64_t n, uint8_t* __restrict__ next_recs,
-                                               Hot* __restrict__ next_hots, uint32_t* __restrict__ mts,
-                                               int32_t* __restrict__ mtis, const int32_t* __restrict__ win_list,
-                                               const uint32_t* __restrict__ win_count, int all, int depth,
-                                               uint8_t* __restrict__ pending, const uint8_t* __restrict__ first_slot,
-                                               unsigned long long* __restrict__ gen_failures) {
-    __shared__ GenWork w;
+// The look-ahead generator.  A workgroup is ONE wave carrying 64 / G envs; every group walks its share of the work list
+// (window list entries, or all envs) on its own: fetch an env that has levels pending, load its MT19937 state into the
+// group's LDS block, then one ATTEMPT of the generator's rejection loop per trip of the main loop (Gen::attempt) -- a
+// group whose attempt was accepted writes the level out and goes on to its next level / env while its neighbours retry,
+// so the wave only idles lanes inside an attempt, never across attempts.
+template <int KIND, int G>
+__global__ __launch_bounds__(64, 2) void k_pregen(LevelCfg c, int64_t n, uint8_t* __restrict__ next_recs,
+                                                  Hot* __restrict__ next_hots, uint32_t* __restrict__ mts,
+                                                  int32_t* __restrict__ mtis, const int32_t* __restrict__ win_list,
+                                                  const uint32_t* __restrict__ win_count, int all, int depth,
+                                                  uint8_t* __restrict__ pending, const uint8_t* __restrict__ first_slot,
+                                                  unsigned long long* __restrict__ gen_failures) {
+    constexpr int NG = 64 / G;
+    __shared__ GenWork ws[NG];
+    typedef GroupCtx<G> Ctx;
+    const Ctx ctx;
+    GenWork& w = ws[threadIdx.x / G];
+    const int lane = ctx.lane();
     int64_t count = n;
     if (!all) {                                          // window list = concatenated per-tick lists
         count = 0;
         for (int j = 0; j < MAX_PERIOD; ++j) count += (int64_t)win_count[1 + j];
     }
-    const int lane = threadIdx.x;
-    for (int64_t it = blockIdx.x; it < count; it += gridDim.x) {
-        const int64_t env = all ? it : (int64_t)win_list[it];
-        if (env < 0) continue;                           // repeat consumption of an env already listed in this window
-        const int cnt = pending[env];                    // levels to generate for this env (consecutive ring slots)
-        if (cnt == 0) continue;                          // (all-mode: env was not consumed in this window)
-        uint32_t* mt = mts + env * MT_N;
-        __syncthreads();
-        for (int k = lane; k < MT_N; k += 64) w.mt[k] = mt[k];
-        int mti = mtis[env];
-        int slot = first_slot[env];
-        const int prev = slot == 0 ? depth - 1 : slot - 1;          // holds the level generated just before
-        int last_locked = next_hots[(int64_t)prev * n + env].last_locked;   // LevelGen.locked_room survives episodes
-        last_locked = last_locked == NONE8 ? -1 : last_locked;
-        for (int j = 0; j < cnt; ++j) {
-            __syncthreads();
-            Gen<WaveCtx> g(WaveCtx(), c, w, mti, last_locked);
-            const int max_steps = g.template generate_kind<KIND>();
-            mti = g.mti;
-            last_locked = g.last_locked;
-            __syncthreads();
-            // write-out: record planes, tables, program
-            uint8_t* rec = next_recs + ((int64_t)slot * n + env) * (int64_t)c.rec_bytes;
-            {
-                const uint32_t* src = (const uint32_t*)w.E;
-                uint32_t* dst = (uint32_t*)rec;
-                const int ndw = (c.ES * c.EH) >> 2;
-                for (int k = lane; k < ndw; k += 64) dst[k] = src[k];
+    int64_t it = (int64_t)blockIdx.x * NG + threadIdx.x / G;
+    const int64_t stride = (int64_t)gridDim.x * NG;
+    // the group's current env
+    bool have = false;
+    int64_t env = 0;
+    int cnt = 0, done_levels = 0, slot = 0, mti = 0, last_locked = -1, attempts = 0;
+    for (;;) {
+        if (!have) {
+            while (it < count) {
+                const int64_t cand = all ? it : (int64_t)win_list[it];
+                it += stride;
+                if (cand < 0) continue;                   // repeat consumption of an env already listed in this window
+                const int pc = pending[cand];            // levels to generate for this env (consecutive ring slots)
+                if (pc == 0) continue;                   // (all-mode: env was not consumed in this window)
+                env = cand; cnt = pc; have = true;
+                break;
             }
-            for (int k = lane; k < c.W * c.H; k += 64) rec[c.off_I + k] = w.I[k];
-            for (int k = lane; k < c.maxo; k += 64) {
-                bool used = k < g.nobj;
-                rec[c.off_app + k] = used ? w.app[k] : 0;
-                rec[c.off_pos + 2 * k] = used ? w.px[k] : 0;
-                rec[c.off_pos + 2 * k + 1] = used ? w.py[k] : 0;
-                rec[c.off_cont + k] = used ? w.cont[k] : NONE8;
+            if (have) {
+                const uint32_t* mt = mts + env * MT_N;
+                ctx.sync();
+                for (int k = lane; k < MT_N; k += G) w.mt[k] = mt[k];
+                ctx.sync();
+                mti = mtis[env];
+                slot = first_slot[env];
+                const int prev = slot == 0 ? depth - 1 : slot - 1;          // holds the level generated just before
+                last_locked = next_hots[(int64_t)prev * n + env].last_locked;   // LevelGen.locked_room survives episodes
+                last_locked = last_locked == NONE8 ? -1 : last_locked;
+                done_levels = 0; attempts = 0;
             }
-            {
-                const uint32_t* src = (const uint32_t*)&w.prog;
-                uint32_t* dst = (uint32_t*)(rec + c.off_prog);
-                for (int k = lane; k < (int)(sizeof(Prog) / 4); k += 64) dst[k] = src[k];
-            }
-            if (lane == 0) {
-                Hot h;
-                h.ax = (uint8_t)g.ax; h.ay = (uint8_t)g.ay; h.dir = (uint8_t)g.adir; h.carry = NONE8;
-                h.step = 0; h.max_steps = (uint16_t)max_steps;
-                h.pre4 = 0xFFFFFFFFu;
-                h.vstate = 0; h.frozen = 0;
-                if (g.gave_up) {                 // never seen; keeps an impossible level from hanging the device
-                    h.frozen = 2;
-                    atomicAdd(gen_failures, 1ull);
-                }
-                h.last_locked = last_locked < 0 ? NONE8 : (uint8_t)last_locked;
-                h.slot = 0;
-                next_hots[(int64_t)slot * n + env] = h;
-            }
-            slot = slot + 1 == depth ? 0 : slot + 1;
         }
-        __syncthreads();
-        for (int k = lane; k < MT_N; k += 64) mt[k] = w.mt[k];
+        if (__ballot(have) == 0ull) break;               // every group of the wave has run out of work
+        if (!have) continue;
+        Gen<Ctx> g(ctx, c, w, mti, last_locked);
+        bool ok = g.template attempt<KIND>();
+        mti = g.mti;
+        last_locked = g.last_locked;
+        // last-resort guard (Gen::MAX_ATTEMPTS): never seen; keeps an impossible level from hanging the device
+        const bool gave_up = !ok && ++attempts >= Gen<Ctx>::MAX_ATTEMPTS;
+        if (!ok && !gave_up) continue;
+        const int max_steps = g.finish();
+        // write-out: record planes, tables, program
+        uint8_t* rec = next_recs + ((int64_t)slot * n + env) * (int64_t)c.rec_bytes;
+        {
+            const uint32_t* src = (const uint32_t*)w.E;
+            uint32_t* dst = (uint32_t*)rec;
+            const int ndw = (c.ES * c.EH) >> 2;
+            for (int k = lane; k < ndw; k += G) dst[k] = src[k];
+        }
+        {
+            const int cells = c.W * c.H, ndw = (cells + 3) >> 2;          // off_I is a dword multiple, the plane is padded to one
+            const uint32_t* src = (const uint32_t*)w.I;
+            uint32_t* dst = (uint32_t*)(rec + c.off_I);
+            for (int k = lane; k < ndw; k += G) {
+                uint32_t v = src[k];
+                if (4 * k + 4 > cells) v &= 0xFFFFFFFFu >> (8 * (4 * k + 4 - cells));      // bytes past the plane stay zero
+                dst[k] = v;
+            }
+        }
+        for (int k = lane; k < c.maxo; k += G) {
+            bool used = k < g.nobj;
+            rec[c.off_app + k] = used ? w.app[k] : 0;
+            rec[c.off_pos + 2 * k] = used ? w.px[k] : 0;
+            rec[c.off_pos + 2 * k + 1] = used ? w.py[k] : 0;
+            rec[c.off_cont + k] = used ? w.cont[k] : NONE8;
+        }
+        {
+            const uint32_t* src = (const uint32_t*)&w.prog;
+            uint32_t* dst = (uint32_t*)(rec + c.off_prog);
+            for (int k = lane; k < (int)(sizeof(Prog) / 4); k += G) dst[k] = src[k];
+        }
         if (lane == 0) {
-            mtis[env] = mti;
-            pending[env] = 0;                            // buffer entry is free for a later window
+            Hot h;
+            h.ax = (uint8_t)g.ax; h.ay = (uint8_t)g.ay; h.dir = (uint8_t)g.adir; h.carry = NONE8;
+            h.step = 0; h.max_steps = (uint16_t)max_steps;
+            h.pre4 = 0xFFFFFFFFu;
+            h.vstate = 0; h.frozen = 0;
+            if (gave_up) {
+                h.frozen = 2;
+                atomicAdd(gen_failures, 1ull);
+            }
+            h.last_locked = last_locked < 0 ? NONE8 : (uint8_t)last_locked;
+            h.slot = 0;
+            next_hots[(int64_t)slot * n + env] = h;
+        }
+        slot = slot + 1 == depth ? 0 : slot + 1;
+        attempts = 0;
+        if (++done_levels == cnt) {                      // this env's levels are done: MT state back, buffer entry free
+            uint32_t* mt = mts + env * MT_N;
+            ctx.sync();
+            for (int k = lane; k < MT_N; k += G) mt[k] = w.mt[k];
+            if (lane == 0) {
+                mtis[env] = mti;
+                pending[env] = 0;                        // buffer entry is free for a later window
+            }
+            have = false;
         }
     }
 }
@@ -835,7 +892,9 @@ static int create_finish(bbai_env* e) {
         const char* cv = getenv("BBAI_CALL_EVENTS");
         e->call_events = cv && atoi(cv) != 0;
         const char* ev = getenv("BBAI_PREGEN_BLOCKS");
-        e->pregen_cap = ev ? std::max(64, atoi(ev)) : 256 * 32;
+        e->pregen_cap = ev ? std::max(64, atoi(ev)) : 256 * 32 * 4;
+        const char* pg = getenv("BBAI_PREGEN_GROUP");
+        e->pregen_group = pg ? atoi(pg) : 16;
         const char* rv = getenv("BBAI_RENDER_GROUP");
         e->render_group = rv ? atoi(rv) : 0;
         const char* tv = getenv("BBAI_RENDER_TPB");
@@ -863,24 +922,36 @@ void bbai_destroy(bbai_env* e) {
     delete e;
 }
 
-// k_pregen is instantiated per level family so that a launch carries only that family's mission code
-static void launch_pregen(const bbai_env* e, unsigned grid, const int32_t* win_list, const uint32_t* win_count, int all,
-                          uint8_t* pending, const uint8_t* first_slot) {
+}  // extern "C"
+
+// k_pregen is instantiated per level family so that a launch carries only that family's mission code, and per group
+// width G (envs per wave = 64 / G; BBAI_PREGEN_GROUP, default 16)
+template <int G>
+static void launch_pregen_g(const bbai_env* e, unsigned groups, const int32_t* win_list, const uint32_t* win_count, int all,
+                            uint8_t* pending, const uint8_t* first_slot) {
     unsigned long long* fails = (unsigned long long*)(e->total_resets + 1);
-    const dim3 g(grid), b(64);
+    const dim3 g((groups + 64 / G - 1) / (64 / G)), b(64);
     if (e->cfg.kind == K_LEVELGEN)
-        hipLaunchKernelGGL(k_pregen<K_LEVELGEN>, g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
+        hipLaunchKernelGGL((k_pregen<K_LEVELGEN, G>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
                            win_count, all, e->depth, pending, first_slot, fails);
     else if (e->cfg.kind == K_BONUS)
-        hipLaunchKernelGGL(k_pregen<K_BONUS>, g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
+        hipLaunchKernelGGL((k_pregen<K_BONUS, G>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
                            win_count, all, e->depth, pending, first_slot, fails);
     else
-        hipLaunchKernelGGL(k_pregen<K_GOTO>, g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
+        hipLaunchKernelGGL((k_pregen<K_GOTO, G>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
                            win_count, all, e->depth, pending, first_slot, fails);
 }
+static void launch_pregen(const bbai_env* e, unsigned groups, const int32_t* win_list, const uint32_t* win_count, int all,
+                          uint8_t* pending, const uint8_t* first_slot) {
+    if (e->pregen_group == 64) launch_pregen_g<64>(e, groups, win_list, win_count, all, pending, first_slot);
+    else if (e->pregen_group == 32) launch_pregen_g<32>(e, groups, win_list, win_count, all, pending, first_slot);
+    else launch_pregen_g<16>(e, groups, win_list, win_count, all, pending, first_slot);
+}
+
+extern "C" {
 
 static unsigned pregen_grid(const bbai_env* e, int64_t count_hint) {
-    // one single-wave workgroup per env, capped at 256 CUs x 32 wave slots
+    // one lane group per env, capped at pregen_cap groups in flight (the rest is reached by the groups' strides)
     int64_t g = std::min<int64_t>(count_hint, e->pregen_cap);
     return (unsigned)std::max<int64_t>(g, 1);
 }

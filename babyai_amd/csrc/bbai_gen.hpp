@@ -12,11 +12,15 @@
 //   RoomGrid / MiniGridEnv placement helpers      gym_minigrid (absent dependency), restated
 //                                                 per SURVEY.md Appendix B3-B7
 //
-// Execution model: ONE WAVEFRONT = ONE ENV.  Control flow is wave-uniform (every lane
-// runs the same scalar program on the same RNG draws); the working set (MT state, both
-// grid planes, room / object tables) sits in LDS; lanes split the data-parallel parts
-// (MT twist, grid fill, reachability rows, record write-out).  The same code compiles
-// for the host with nlanes == 1 (unit tests only, never a product path).
+// Execution model: ONE LANE GROUP = ONE ENV, Ctx::kLanes lanes wide (device: 16 -> four envs per wavefront, k_pregen in
+// bbai_engine.hip; host: 1).  Inside a group control flow is uniform (every lane runs the same scalar program on the
+// same RNG draws); the working set (MT state, both grid planes, room / object tables) sits in LDS, one GenWork per
+// group; the group's lanes split the data-parallel parts (MT twist, grid fill, reachability rows, record write-out).
+// Groups of one wave diverge from each other like any SIMT lanes do (different draws, different rejection counts): what
+// was a wave-uniform SCALAR program when a whole wave served one env (round 2: 16 k of 22 k instructions per level on the
+// CU's one scalar unit) is VECTOR work shared by the wave's groups now.  Ctx::sync() therefore orders LDS accesses
+// within the wave (it is reached under divergent control flow: never a workgroup barrier); shuffles and ballots are
+// group-relative.  The same code compiles for the host with kLanes == 1 (unit tests only, never a product path).
 #pragma once
 #include "bbai_types.hpp"
 
@@ -38,9 +42,9 @@ struct GenWork {                                 // lives in LDS on the device
     Prog prog;
 };
 
-// Ctx contract: lane(), nlanes(), sync(), shfl_up1/shfl_down1(v) (neighbour lane's value, 0 at the
-// ends), any(pred).  Host: 0,1,no-ops.  Device: lane id in the wave, 64, workgroup barrier (one wave
-// per workgroup), wave shuffles / ballot.
+// Ctx contract: static constexpr int kLanes; lane() in [0, kLanes), nlanes() == kLanes, sync() (LDS accesses of the group
+// before / after it are ordered), shfl_up1 / shfl_down1(v) (neighbour lane's value inside the group, 0 at the ends),
+// shfl(v, src) (lane src of the group), any(pred) over the group.  Host: one lane, no-ops.
 // Optional phase profiling (tools/genprof.hip): a Ctx that defines `static constexpr bool kProfile = true` and
 // `now()` gets per-phase cycle totals in prof[]; the product contexts leave it off and the hooks vanish.
 template <class C, class = void> struct ctx_profiles { static constexpr bool value = false; };
@@ -59,10 +63,11 @@ template <class Ctx>
 BB_HD void mt_twist_chunk(Ctx ctx, uint32_t* mt, int lo, int hi) {
     // new[k] = src[k+397 mod] ^ mix(old[k], old[k+1]) for k in [lo,hi); reads complete
     // before any write of the chunk (sync), so lanes never see half-updated inputs.
-    // (chunks are <= 227 long: 4 strided elements per lane cover them with 64 lanes)
-    uint32_t tmp[4];
+    // (chunks are <= 227 long: Q strided elements per lane cover them)
+    constexpr int Q = (227 + Ctx::kLanes - 1) / Ctx::kLanes;
+    uint32_t tmp[Q];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < Q; ++q) {
         int k = lo + ctx.lane() + q * ctx.nlanes();
         if (k < hi) {
             int m = k + 397; if (m >= MT_N) m -= MT_N;
@@ -71,7 +76,7 @@ BB_HD void mt_twist_chunk(Ctx ctx, uint32_t* mt, int lo, int hi) {
     }
     ctx.sync();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < Q; ++q) {
         int k = lo + ctx.lane() + q * ctx.nlanes();
         if (k < hi) mt[k] = tmp[q];
     }
@@ -374,27 +379,48 @@ struct Gen {
         uint32_t* fl = w.rowbuf[1];
         ctx.sync();
         if (ctx.nlanes() > 1) {
-            // device: lane y owns grid row y; rows exchange their flood masks with wave shuffles
-            const int y = ctx.lane();
-            uint32_t p = 0;
-            if (y < H)
-                for (int x = 0; x < W; ++x) {
-                    int e = w.E[eidx(x, y)];
-                    if (e == E_EMPTY || e_type(e) == T_DOOR) p |= 1u << x;
-                }
-            uint32_t f = (y == ay) ? (1u << ax) : 0u;
+            // device: lane l owns grid rows l, l + kLanes, ... (K rows per lane); rows exchange their flood masks with
+            // group shuffles, the row above the first row of pass k being the last lane's row of pass k - 1
+            constexpr int NL = Ctx::kLanes;
+            constexpr int K = (MAX_W + NL - 1) / NL;
+            const int l = ctx.lane();
+            uint32_t p[K], f[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int y = k * NL + l;
+                p[k] = 0;
+                if (y < H)
+                    for (int x = 0; x < W; ++x) {
+                        int e = w.E[eidx(x, y)];
+                        if (e == E_EMPTY || e_type(e) == T_DOOR) p[k] |= 1u << x;
+                    }
+                f[k] = (y == ay) ? (1u << ax) : 0u;
+            }
             for (;;) {
-                uint32_t g = (f | ctx.shfl_up1(f) | ctx.shfl_down1(f)) & p;
-                for (;;) {                      // horizontal closure inside the row
-                    uint32_t g2 = (g | (g << 1) | (g >> 1)) & p;
-                    if (g2 == g) break;
-                    g = g2;
+                bool changed = false;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    uint32_t up = ctx.shfl_up1(f[k]), down = ctx.shfl_down1(f[k]);
+                    if (K > 1) {
+                        const uint32_t wrap_up = k > 0 ? ctx.shfl(f[k > 0 ? k - 1 : 0], NL - 1) : 0u;      // row k*NL - 1
+                        const uint32_t wrap_dn = k + 1 < K ? ctx.shfl(f[k + 1 < K ? k + 1 : k], 0) : 0u;   // row (k+1)*NL
+                        if (l == 0) up = wrap_up;
+                        if (l == NL - 1) down = wrap_dn;
+                    }
+                    uint32_t g = (f[k] | up | down) & p[k];
+                    for (;;) {                      // horizontal closure inside the row
+                        uint32_t g2 = (g | (g << 1) | (g >> 1)) & p[k];
+                        if (g2 == g) break;
+                        g = g2;
+                    }
+                    changed |= g != f[k];
+                    f[k] = g;
                 }
-                bool changed = g != f;
-                f = g;
                 if (!ctx.any(changed)) break;
             }
-            if (y < H) fl[y] = f;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (k * NL + l < H) fl[k * NL + l] = f[k];
             ctx.sync();
         } else {
             for (int y = 0; y < H; ++y) {
@@ -1158,18 +1184,30 @@ struct Gen {
             // Last-resort guard against a generation that can never succeed (every known unbounded loop of the
             // reference is bounded above; this only keeps an unknown one from hanging the GPU): the caller freezes
             // the env and counts the failure (bbai_generator_failures) instead of spinning for ever.
-            if (attempts >= 200000) { gave_up = true; break; }
-            count(PH_ATTEMPTS);
-            build_rooms();
-            bool ok;
-            if constexpr (KIND == K_LEVELGEN) ok = mission_levelgen();
-            else if constexpr (KIND == K_BONUS) ok = mission_bonus();
-            else ok = mission_goto();
-            tick(PH_INSTR);
-            bool v = ok && validate();
-            tick(PH_VALIDATE);
-            if (v) break;
+            if (attempts >= MAX_ATTEMPTS) { gave_up = true; break; }
+            if (attempt<KIND>()) break;
         }
+        return finish();
+    }
+    static constexpr int MAX_ATTEMPTS = 200000;
+    // ONE pass of the rejection loop of RoomGridLevel._gen_grid (levelgen.py:80-102): layout, mission, validation.
+    // k_pregen drives this directly, so that the groups of a wave stay together at attempt granularity: a group whose
+    // attempt succeeded moves on to its next level while its neighbours retry.
+    template <int KIND>
+    BB_HD bool attempt() {
+        count(PH_ATTEMPTS);
+        build_rooms();
+        bool ok;
+        if constexpr (KIND == K_LEVELGEN) ok = mission_levelgen();
+        else if constexpr (KIND == K_BONUS) ok = mission_bonus();
+        else ok = mission_goto();
+        tick(PH_INSTR);
+        bool v = ok && validate();
+        tick(PH_VALIDATE);
+        return v;
+    }
+    // max_steps of the accepted level (levelgen.py:42-45)
+    BB_HD int finish() {
         ctx.sync();
         int navs = 0;
         for (int leaf = 0; leaf < 4; ++leaf)

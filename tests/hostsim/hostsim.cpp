@@ -12,11 +12,13 @@
 using namespace bbai;
 
 struct HostCtx {
+    static constexpr int kLanes = 1;
     int lane() const { return 0; }
     int nlanes() const { return 1; }
     void sync() const {}
     uint32_t shfl_up1(uint32_t) const { return 0; }
     uint32_t shfl_down1(uint32_t) const { return 0; }
+    uint32_t shfl(uint32_t v, int) const { return v; }
     bool any(bool p) const { return p; }
 };
 

@@ -11,6 +11,8 @@
 using namespace bbai;
 struct ProfCtx {
     static constexpr bool kProfile = true;
+    static constexpr int kLanes = 64;
+    __device__ uint32_t shfl(uint32_t v, int src) const { return __shfl(v, src); }
     __device__ int lane() const { return (int)threadIdx.x; }
     __device__ int nlanes() const { return 64; }
     __device__ void sync() const { __syncthreads(); }

@@ -16,7 +16,15 @@
 //              from LDS.  Lanes that hit the same 64/128-B piece of a record are one request instead of 2-4.
 //   coopU      coopR on the PRE-action window widened by one row / column in the facing direction (8 passes): it holds the
 //              front cell AND the window after a forward move, so the per-lane front-cell load disappears as well
-// each on two record layouts: pitch 32 (today: 22 cells + 2 x 5 margin) and pitch 24 (no side margin).
+//   envtile    (VERDICT r2 task 2 i) appearance plane ENV-TILED: E[tile of 64 envs][cell][64] -- a wave's 64 lanes read byte
+//              `lane` of 49 (+1 front) cell rows of 64 B; coalesced only when the lanes want the SAME cells, and the agents of
+//              64 random envs never stand on the same cell: 50 half-lines per env
+//   ztile      (task 2 ii) appearance plane in 16x8-cell tiles of 128 B (one line each): the window overlaps 1-4 tiles
+//   vline      a REDUNDANT window plane: one 128-byte line (8 rows x 16 cells) for every window origin class
+//              (x origin / 8, y origin / 2): 52 lines = 6.5 KB per env instead of 1 KB, the window of any pose lies in ONE
+//              line; the front cell of the transition comes from a 2-byte SoA cache written by the previous step (the
+//              window it was taken from is the one fetched then), so no other record line is touched on a plain step
+// chain / flat / coop* run on two record layouts: pitch 32 (today: 22 cells + 2 x 5 margin) and pitch 24 (no side margin).
 // Output: one JSON line per (variant, layout): ms per launch over 1 048 576 envs, GB/s against k_step's 235 algorithmic
 // bytes per env-step.
 //   hipcc --offload-arch=gfx950 -O3 -o tools/ubench_gather tools/ubench_gather.hip && tools/ubench_gather
@@ -169,6 +177,84 @@ __global__ __launch_bounds__(BLOCK) void k_shape(Args a) {
     copy_out<BLOCK>(s_obs, a.image, env0, a.n);
 }
 
+
+// ---- round 3 layouts ------------------------------------------------------------------------------------------------
+// LAYOUT 0 envtile, 1 ztile, 2 vline.  `plane` is the layout's own buffer; everything else as in k_shape.
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void k_layout(Args a, const uint8_t* __restrict__ plane, uint16_t* __restrict__ fcache) {
+    constexpr int BLOCK = 256;
+    __shared__ __attribute__((aligned(16))) uint8_t s_obs[BLOCK * PAD];
+    const int64_t env0 = (int64_t)blockIdx.x * BLOCK, env = env0 + threadIdx.x;
+    const bool active = env < a.n;
+    Hot h; uint64_t st = 0; uint32_t vh = 0; uint64_t vs = 0; int action = 0;
+    const int64_t ee = active ? env : a.n - 1;
+    h = a.hot[ee];
+    if (active) { st = a.stale[env]; vh = a.vhead[env]; vs = a.vset[env]; action = a.act[env]; }
+    uint32_t w[24];
+    int nw = 4;
+    w[0] = h.pre4; w[1] = vh; w[2] = (uint32_t)vs; w[3] = (uint32_t)st;
+    uint32_t extra = 0;
+    const int fx = h.ax + fdx(h.dir), fy = h.ay + fdy(h.dir);
+    if (active) {
+        int fe;
+        if (LAYOUT == 0) {
+            const uint8_t* tile = plane + (ee >> 6) * (int64_t)(1024 * 64) + (ee & 63);
+            fe = tile[((fy + 5) * 32 + fx + 5) * 64];
+            if (action == 2 && (fe & 1)) { h.ax = fx; h.ay = fy; }
+            const int tx = h.ax + 5 + (h.dir == 0 ? 0 : h.dir == 2 ? -6 : -3), ty = h.ay + 5 + (h.dir == 1 ? 0 : h.dir == 3 ? -6 : -3);
+            uint32_t acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 7; ++r)
+#pragma unroll
+                for (int q = 0; q < 7; ++q) {
+                    const int idx = r * 7 + q;
+                    acc[idx >> 2] |= (uint32_t)tile[((ty + r) * 32 + tx + q) * 64] << (8 * (idx & 3));
+                }
+#pragma unroll
+            for (int k = 0; k < 13; ++k) w[k] = acc[k];
+            nw = 13;
+        } else if (LAYOUT == 1) {
+            const uint8_t* rec = plane + ee * (int64_t)1024;
+            auto zaddr = [](int x, int y) { return ((y >> 3) * 2 + (x >> 4)) * 128 + (y & 7) * 16 + (x & 15); };
+            fe = rec[zaddr(fx + 5, fy + 5)];
+            if (action == 2 && (fe & 1)) { h.ax = fx; h.ay = fy; }
+            const int tx = h.ax + 5 + (h.dir == 0 ? 0 : h.dir == 2 ? -6 : -3), ty = h.ay + 5 + (h.dir == 1 ? 0 : h.dir == 3 ? -6 : -3);
+            const int x4 = tx & ~3;
+#pragma unroll
+            for (int r = 0; r < 7; ++r)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) w[3 * r + d] = *(const uint32_t*)(rec + zaddr(x4 + 4 * d, ty + r));
+            nw = 21;
+        } else {
+            const uint32_t fc = fcache[env];                                      // coalesced: last step's front cell + carried appearance
+            fe = fc & 0xFF;
+            if (action == 2 && (fe & 1)) { h.ax = fx; h.ay = fy; }
+            const int tx = h.ax + 5 + (h.dir == 0 ? 0 : h.dir == 2 ? -6 : -3), ty = h.ay + 5 + (h.dir == 1 ? 0 : h.dir == 3 ? -6 : -3);
+            const int xo = tx >> 3, yo = ty >> 1;
+            const uint8_t* line = plane + ee * (int64_t)(52 * 128) + (yo * 4 + xo) * 128;
+            const int c4 = (tx - 8 * xo) & ~3, r0 = ty - 2 * yo;
+#pragma unroll
+            for (int r = 0; r < 7; ++r) {
+                const uint32_t* q = (const uint32_t*)(line + (r0 + r) * 16 + c4);
+                w[3 * r] = q[0]; w[3 * r + 1] = q[1]; w[3 * r + 2] = (c4 + 8 < 16) ? q[2] : 0u;
+            }
+            nw = 21;
+            extra = fc >> 8;
+            fcache[env] = (uint16_t)((w[10] & 0xFF) | (fc & 0xFF00));            // next step's front cell out of this window
+        }
+        if (LAYOUT != 2) extra = (fe & 2) ? 1u : 0u;
+        h.step++;
+        a.hot[env] = h;
+        a.stale[env] = st + 1;
+        a.rew[env] = (float)extra;
+        a.done[env] = (uint8_t)(extra & 1);
+        a.dirs[env] = h.dir;
+        fake_obs((uint32_t*)(s_obs + threadIdx.x * PAD), w, nw, extra);
+    }
+    __syncthreads();
+    copy_out<BLOCK>(s_obs, a.image, env0, a.n);
+}
+
 constexpr int BLOCK = 256;
 // two envs per lane: the block of 256 lanes owns 512 envs; every lane issues both envs' loads before using either
 __global__ __launch_bounds__(BLOCK) void k_flat2(Args a) {
@@ -273,6 +359,40 @@ int main(int argc, char** argv) {
         }
         (void)hipFree(rec_base); (void)hipFree(a.hot); (void)hipFree(a.stale); (void)hipFree((void*)a.vhead); (void)hipFree((void*)a.vset);
         (void)hipFree((void*)a.act); (void)hipFree(a.image); (void)hipFree(a.dirs); (void)hipFree(a.rew); (void)hipFree(a.done); (void)hipFree(a.sink);
+    }
+    {   // round 3 layouts: their own planes (cells 0/1 like the records above), the same SoA arrays
+        Args a; a.n = n; a.L = LAY32;
+        (void)hipMalloc(&a.hot, n * 16); (void)hipMalloc(&a.stale, n * 8);
+        (void)hipMalloc((void**)&a.vhead, n * 4); (void)hipMalloc((void**)&a.vset, n * 8); (void)hipMalloc((void**)&a.act, n);
+        (void)hipMalloc(&a.image, n * OBS + 64); (void)hipMalloc(&a.dirs, n); (void)hipMalloc(&a.rew, n * 4); (void)hipMalloc(&a.done, n);
+        (void)hipMalloc(&a.sink, n * 4);
+        uint8_t* scratch_rec; (void)hipMalloc(&scratch_rec, (size_t)n * 64);
+        hipLaunchKernelGGL(k_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, a.hot, a.stale, (uint32_t*)a.vhead, (uint64_t*)a.vset,
+                           (uint8_t*)a.act, scratch_rec, 64);
+        const size_t plane_bytes[3] = {(size_t)((n + 63) / 64) * 1024 * 64, (size_t)n * 1024, (size_t)n * 52 * 128};
+        const char* names[3] = {"envtile: E[tile][cell][64]", "ztile: 16x8-cell tiles (128 B)", "vline: one line per window origin class (x/8, y/2) + cached front cell"};
+        uint16_t* fcache; (void)hipMalloc(&fcache, n * 2); (void)hipMemset(fcache, 1, n * 2);
+        const unsigned grid = (unsigned)((n + 255) / 256);
+        for (int v = 0; v < 3; ++v) {
+            uint8_t* plane; (void)hipMalloc(&plane, plane_bytes[v] + 4096); (void)hipMemset(plane, 1, plane_bytes[v] + 4096);
+            (void)hipDeviceSynchronize();
+            float best = 1e9f, sum = 0; const int reps = 24, skip = 4;
+            for (int r = 0; r < reps; ++r) {
+                (void)hipEventRecord(e0, 0);
+                if (v == 0) hipLaunchKernelGGL((k_layout<0>), dim3(grid), dim3(256), 0, 0, a, plane, fcache);
+                else if (v == 1) hipLaunchKernelGGL((k_layout<1>), dim3(grid), dim3(256), 0, 0, a, plane, fcache);
+                else hipLaunchKernelGGL((k_layout<2>), dim3(grid), dim3(256), 0, 0, a, plane, fcache);
+                (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+                float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+                if (r >= skip) { sum += ms; if (ms < best) best = ms; }
+            }
+            const float avg = sum / (reps - skip);
+            printf("{\"variant\": \"%s\", \"envs\": %lld, \"plane_bytes_per_env\": %.0f, \"avg_ms\": %.4f, \"min_ms\": %.4f, "
+                   "\"alg_bytes_per_env\": 235, \"alg_GBs_at_avg\": %.0f, \"frac_of_8TBs\": %.3f}\n", names[v], (long long)n, (double)plane_bytes[v] / n, avg, best,
+                   n * 235.0 / avg / 1e6, n * 235.0 / avg / 1e6 / 8000.0);
+            fflush(stdout);
+            (void)hipFree(plane);
+        }
     }
     return 0;
 }
