@@ -119,7 +119,8 @@ struct bbai_env {
     int render_tpb;       // BBAI_RENDER_TPB: 256 / 512 / 1024 threads per render block; anything else = by batch size
     int render_group;     // BBAI_RENDER_GROUP: 2, 4 or 8 envs per one-shot render block; anything else = by batch size (bbai_render)
     int pregen_cap;       // BBAI_PREGEN_BLOCKS: upper bound on look-ahead lane groups per launch (experiments)
-    int pregen_group;     // BBAI_PREGEN_GROUP: lanes per env in k_pregen: 16 (default: four envs per wave), 32 or 64
+    int pregen_group;     // BBAI_PREGEN_GROUP: lanes per env in k_pregen: 32 (default: two envs per wave), 16 or 64
+    int step_prio;        // BBAI_STEP_PRIO: s_setprio level of the step-path kernels' waves (they share CUs with k_pregen)
     // optional per-kernel timing (bbai_profile): HIP event pairs on the launch stream around k_step / k_consume / k_render
     bool prof_on;
     struct ProfSlot { hipEvent_t a, b; bool used; } prof[3][PROF_RING];
@@ -127,6 +128,8 @@ struct bbai_env {
     double prof_ms[3];
     int64_t prof_n[3];
     int64_t tick;         // number of consume_and_refill calls so far
+    uint8_t* tiles;       // [n][TILE_PITCH] fused tile plane of the CURRENT observations (allocated by bbai_set_atlas: pixel mode)
+    bool tiles_valid;     // written by the last reset / step of every env
     uint8_t* atlas;       // [n_tiles][192]
     uint8_t* lut;         // [2][256]
     int n_tiles;
@@ -154,8 +157,12 @@ constexpr int OBS_PAD = 148;           // LDS row per env (bytes), dword multipl
 // orientation as 7 rows x 3 aligned dwords, byte-aligned with v_alignbyte, parked in the tail of the lane's own
 // LDS obs row, and read back in VIEW orientation (rotation = per-direction address arithmetic on ds_read_u8).
 // All of a lane's reads precede its writes and lanes only touch their own row, so no barrier is needed here.
+// `mb` (optional, EMIT): the same view as ONE byte per cell -- the appearance byte where the cell is visible, 0 where it is
+// not -- 49 bytes in view order [vi][vj] + 3 zero bytes: the pixel render's input (TILE_PITCH bytes per env).
+constexpr int TILE_PITCH = 52;
+template <bool EMIT>
 __device__ __forceinline__ void observe_lane_lds(const LevelCfg& c, const uint8_t* __restrict__ rec, const Hot& h,
-                                                 uint8_t* __restrict__ row /* this lane's OBS_PAD-byte LDS row */) {
+                                                 uint8_t* __restrict__ row /* this lane's OBS_PAD-byte LDS row */, uint32_t* mb) {
     const int dir = h.dir;
     // Grid.slice extents (get_view_exts): top-left world cell of the axis-aligned 7x7 window
     const int tx = h.ax + (dir == 0 ? 0 : dir == 2 ? -6 : -3);
@@ -196,6 +203,19 @@ __device__ __forceinline__ void observe_lane_lds(const LevelCfg& c, const uint8_
     uint32_t od[37];
 #pragma unroll
     for (int k = 0; k < 37; ++k) od[k] = 0;
+    if (EMIT) {
+        // the plane row = cp with the invisible cells zeroed: one byte-select mask per dword (v_perm-free: 4 bits -> 4 bytes)
+#pragma unroll
+        for (int k = 0; k < 13; ++k) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int idx = 4 * k + b;
+                if (idx < VIEW * VIEW) m |= (vis[idx % VIEW] >> (idx / VIEW) & 1u) ? 0xFFu << (8 * b) : 0u;
+            }
+            mb[k] = cp[k] & m;
+        }
+    }
 #pragma unroll
     for (int vi = 0; vi < VIEW; ++vi)
 #pragma unroll
@@ -219,7 +239,7 @@ __device__ __forceinline__ void observe_lane_lds(const LevelCfg& c, const uint8_
 // (vi, vj) = (l % 7, l / 7); the opacity mask of the whole view is one ballot; every lane runs the 7-row
 // visibility sweep on it and writes its own three bytes.
 __device__ __forceinline__ void observe_wave(const LevelCfg& c, const uint8_t* __restrict__ rec, const Hot& h,
-                                             uint8_t* __restrict__ dst, int lane) {
+                                             uint8_t* __restrict__ dst, int lane, uint8_t* __restrict__ tile_row /* or NULL */) {
     const int vi = lane % VIEW, vj = lane / VIEW;
     int e = E_EMPTY;
     if (lane < VIEW * VIEW) {
@@ -240,17 +260,22 @@ __device__ __forceinline__ void observe_wave(const LevelCfg& c, const uint8_t* _
         const bool v = row >> vi & 1;
         uint8_t* o = dst + (vi * VIEW + vj) * 3;
         o[0] = v ? e_type(e) : 0; o[1] = v ? e_color(e) : 0; o[2] = v ? e_state(e) : 0;
+        if (tile_row) tile_row[vi * VIEW + vj] = v ? (uint8_t)e : (uint8_t)0;
     }
 }
 
-__global__ __launch_bounds__(STEP_BLOCK) void k_step(LevelCfg c, int64_t n, uint8_t* __restrict__ recs,
+template <bool EMIT>
+__global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, int64_t n, uint8_t* __restrict__ recs,
                                                      Hot* __restrict__ hots, uint64_t* __restrict__ stales,
                                                      const uint32_t* __restrict__ vheads, const uint64_t* __restrict__ vsets,
                                                      const uint8_t* __restrict__ actions, uint8_t* __restrict__ image,
                                                      uint8_t* __restrict__ dirs, float* __restrict__ rewards,
                                                      double* __restrict__ rewards64, uint8_t* __restrict__ dones, int auto_reset,
-                                                     int32_t* __restrict__ reset_list, uint32_t* __restrict__ counters) {
+                                                     int32_t* __restrict__ reset_list, uint32_t* __restrict__ counters,
+                                                     uint8_t* __restrict__ tiles /* EMIT: [n][TILE_PITCH] render input */, int prio) {
     __shared__ __attribute__((aligned(16))) uint8_t s_obs[STEP_BLOCK * OBS_PAD];
+    if (prio) __builtin_amdgcn_s_setprio(3);            // the look-ahead generator's waves share the CUs: issue ours first
+    uint32_t mb[13];
     const int64_t env0 = (int64_t)blockIdx.x * STEP_BLOCK;
     const int64_t env = env0 + threadIdx.x;
     const bool active = env < n;
@@ -271,7 +296,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(LevelCfg c, int64_t n, uint
             if (rewards64) rewards64[env] = reward;        // the reference's Python float, bit for bit (levelgen.py:59-61)
             dones[env] = done ? 1 : 0;
             dirs[env] = h.dir;
-            observe_lane_lds(c, rec, h, s_obs + threadIdx.x * OBS_PAD);
+            observe_lane_lds<EMIT>(c, rec, h, s_obs + threadIdx.x * OBS_PAD, mb);
         }
         // frozen envs keep re-emitting their last outputs: copy them through LDS unchanged
         else {
@@ -283,6 +308,15 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(LevelCfg c, int64_t n, uint
             }
             const uint8_t* src = image + env * OBS_BYTES;
             for (int b = 0; b < OBS_BYTES; ++b) s_obs[threadIdx.x * OBS_PAD + b] = src[b];
+            if (EMIT) {      // the plane row of a frozen env is re-derived from its (caller-kept) encoding: type | colour << 3 | state << 6
+#pragma unroll
+                for (int k = 0; k < 13; ++k) mb[k] = 0;
+                for (int idx = 0; idx < VIEW * VIEW; ++idx) {
+                    const uint32_t key = src[3 * idx] | (src[3 * idx + 1] << 3) | (src[3 * idx + 2] << 6);
+#pragma unroll
+                    for (int k = 0; k < 13; ++k) mb[k] |= (idx >> 2) == k ? key << (8 * (idx & 3)) : 0u;
+                }
+            }
         }
     }
     // compact finished envs into the reset list: one atomic per wave
@@ -327,6 +361,20 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(LevelCfg c, int64_t n, uint
     for (int b = (ndw << 2) + threadIdx.x; b < total; b += STEP_BLOCK) {
         int e = b / OBS_BYTES, off = b - e * OBS_BYTES;
         out[b] = s_obs[e * OBS_PAD + off];
+    }
+    if (EMIT) {
+        // second pass through the same LDS: the block's tile-plane rows (52 B per env, LDS pitch == output pitch) leave as
+        // one contiguous dword span, written LAST so that the render finds them in the memory-side cache
+        __syncthreads();
+        uint32_t* s32 = (uint32_t*)s_obs;
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 13; ++k) s32[threadIdx.x * 13 + k] = mb[k];
+        }
+        __syncthreads();
+        uint32_t* tout = (uint32_t*)(tiles + env0 * TILE_PITCH);
+        const int tdw = (int)nb * 13;
+        for (int d = threadIdx.x; d < tdw; d += STEP_BLOCK) tout[d] = s32[d];
     }
 }
 
@@ -488,7 +536,8 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
                                                  uint8_t* __restrict__ pending, uint8_t* __restrict__ first_slot,
                                                  int32_t* __restrict__ win_list, uint32_t* __restrict__ win_count, int pos,
                                                  uint8_t* __restrict__ image, uint8_t* __restrict__ dirs,
-                                                 uint32_t* __restrict__ other_counter) {
+                                                 uint32_t* __restrict__ other_counter, uint8_t* __restrict__ tiles /* or NULL */, int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(3);
     const int64_t count = all ? n : (int64_t)counter[0];
     // this tick's entries go behind those of the window's earlier ticks (their counts were written by earlier
     // launches); no atomics: an env appears at most once per tick, repeats within the window are marked -1
@@ -511,7 +560,7 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
         Hot h = next_hots[(int64_t)slot * n + env];
         h.slot = (uint8_t)(slot + 1 == depth ? 0 : slot + 1);
         // first observation of the new episode, straight from the slot (identical bytes to the live copy)
-        observe_wave(c, nrec, h, image + env * OBS_BYTES, lane);
+        observe_wave(c, nrec, h, image + env * OBS_BYTES, lane, tiles ? tiles + env * TILE_PITCH : nullptr);
         if (lane == 0) {
             uint64_t stale0 = 0;
             // PutNext*Carrying: the first observation above still shows the object on the grid (the reference builds
@@ -617,7 +666,9 @@ __device__ __forceinline__ uint64_t render_chunk(const uint8_t* s_atlas, const u
     return *(const uint64_t*)(s_atlas + tile * TILE_BYTES + ty * 24 + part * 8);
 }
 
-template <int RENDER_GROUP, int RENDER_BLOCK>     // envs rendered per block iteration (between two barriers); threads per block
+// FROM_PLANE: `image` is the fused tile plane ([n][TILE_PITCH], one masked appearance byte per cell, written by k_step /
+// k_consume) instead of the 147-byte encoding: a third of the input bytes, and the last thing the step wrote.
+template <int RENDER_GROUP, int RENDER_BLOCK, bool FROM_PLANE>     // envs per block iteration (between two barriers); threads per block
 __global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_t* __restrict__ image,
                                                          uint8_t* __restrict__ pixels, const uint8_t* __restrict__ atlas,
                                                          const uint8_t* __restrict__ lut, int n_tiles) {
@@ -635,8 +686,13 @@ __global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_
         // encoded cell -> atlas tile, once per cell (49 per env)
         for (int c = threadIdx.x; c < ne * VIEW * VIEW; c += RENDER_BLOCK) {
             const int e = c / (VIEW * VIEW), cell = c - e * (VIEW * VIEW);
-            const uint8_t* o = image + (env0 + e) * OBS_BYTES + cell * 3;
-            const int key = o[0] | (o[1] << 3) | (o[2] << 6);
+            int key;
+            if (FROM_PLANE) {
+                key = image[(env0 + e) * TILE_PITCH + cell];
+            } else {
+                const uint8_t* o = image + (env0 + e) * OBS_BYTES + cell * 3;
+                key = o[0] | (o[1] << 3) | (o[2] << 6);
+            }
             s_tile[c] = s_lut[(cell == 3 * VIEW + 6 ? 256 : 0) + key];
         }
         __syncthreads();
@@ -894,7 +950,9 @@ static int create_finish(bbai_env* e) {
         const char* ev = getenv("BBAI_PREGEN_BLOCKS");
         e->pregen_cap = ev ? std::max(64, atoi(ev)) : 256 * 32 * 4;
         const char* pg = getenv("BBAI_PREGEN_GROUP");
-        e->pregen_group = pg ? atoi(pg) : 16;
+        e->pregen_group = pg ? atoi(pg) : 32;
+        const char* sp = getenv("BBAI_STEP_PRIO");
+        e->step_prio = sp ? atoi(sp) : 0;
         const char* rv = getenv("BBAI_RENDER_GROUP");
         e->render_group = rv ? atoi(rv) : 0;
         const char* tv = getenv("BBAI_RENDER_TPB");
@@ -917,7 +975,7 @@ void bbai_destroy(bbai_env* e) {
     void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
     void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_list, e->win_count, e->reset_list, e->counters,
-                    e->total_resets, e->atlas, e->lut};
+                    e->total_resets, e->atlas, e->lut, e->tiles};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete e;
 }
@@ -943,9 +1001,14 @@ static void launch_pregen_g(const bbai_env* e, unsigned groups, const int32_t* w
 }
 static void launch_pregen(const bbai_env* e, unsigned groups, const int32_t* win_list, const uint32_t* win_count, int all,
                           uint8_t* pending, const uint8_t* first_slot) {
+    // Measured (profiles/r03/gen_rate_by_group_width.jsonl, pregen_group_width_in_bench.jsonl): levels per second of a bulk
+    // fill 64 -> 32 -> 16 lanes per env: BossLevel 1 : 1.16 : 1.18, GoTo 1 : 1.13 : 1.17, PickupLoc 1 : 1.20 : 1.27,
+    // GoToLocal 1 : 1.25 : 1.36; inside the step loop 32 is never behind 64 (GoToLocal 65 536 envs -3 %, PickupLoc 262 144
+    // -6 %, GoTo 131 072 +-0) while 16 costs the step kernels of GoTo 131 072 9 % (fewer, fatter generator waves next to
+    // them: 200 VGPRs and 20 KB of LDS each).
     if (e->pregen_group == 64) launch_pregen_g<64>(e, groups, win_list, win_count, all, pending, first_slot);
-    else if (e->pregen_group == 32) launch_pregen_g<32>(e, groups, win_list, win_count, all, pending, first_slot);
-    else launch_pregen_g<16>(e, groups, win_list, win_count, all, pending, first_slot);
+    else if (e->pregen_group == 16) launch_pregen_g<16>(e, groups, win_list, win_count, all, pending, first_slot);
+    else launch_pregen_g<32>(e, groups, win_list, win_count, all, pending, first_slot);
 }
 
 extern "C" {
@@ -1027,7 +1090,7 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
                        e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, e->reset_list, e->counters + 16 * e->step_parity, all,
                        e->total_resets, D, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n,
                        e->win_list + (size_t)wb * e->period * e->n, e->win_count + WIN_STRIDE * wb, pos, image, dirs,
-                       e->counters + 16 * (e->step_parity ^ 1));
+                       e->counters + 16 * (e->step_parity ^ 1), e->tiles, e->step_prio);
     }
     if (e->tokens)
         hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n, e->rec,
@@ -1090,6 +1153,7 @@ int bbai_reset(bbai_env* e, uint8_t* image, uint8_t* dirs, void* stream) {
     rc = consume_and_refill(e, s, image, dirs, 1);
     if (rc != BBAI_OK) return rc;
     e->live = true;
+    e->tiles_valid = e->tiles != nullptr;
     return leave_call(e, s);
 }
 
@@ -1110,8 +1174,14 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
     e->next_counter_clean = false;
     {
         ProfScope prof_(e, 0, s);
-        hipLaunchKernelGGL(k_step, dim3((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), dim3(STEP_BLOCK), 0, s, e->cfg, e->n,
-                           e->rec, e->hot, e->stale, e->vhead, e->vset, actions, image, dirs, rewards, rewards64, dones, auto_reset, list, counter);
+        const dim3 grid((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), block(STEP_BLOCK);
+        if (e->tiles)
+            hipLaunchKernelGGL(k_step<true>, grid, block, 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, image, dirs,
+                               rewards, rewards64, dones, auto_reset, list, counter, e->tiles, e->step_prio);
+        else
+            hipLaunchKernelGGL(k_step<false>, grid, block, 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, image, dirs,
+                               rewards, rewards64, dones, auto_reset, list, counter, (uint8_t*)nullptr, e->step_prio);
+        e->tiles_valid = e->tiles != nullptr;
     }
     HIP_TRY(hipGetLastError());
     // the number of finished envs is only known on the device: fixed grids, device-side count
@@ -1125,13 +1195,20 @@ int bbai_set_atlas(bbai_env* e, const uint8_t* tiles, int n_tiles, const uint8_t
     HIP_TRY(hipMemcpy(e->atlas, tiles, (size_t)n_tiles * TILE_BYTES, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->lut, lut, 512, hipMemcpyHostToDevice));
     e->n_tiles = n_tiles;
+    // pixel mode: from now on reset / step also keep the fused tile plane of the current observations (bbai_render_current)
+    const char* fv = getenv("BBAI_RENDER_FUSED");
+    if (!e->tiles && !(fv && atoi(fv) == 0)) {
+        HIP_TRY(hipMalloc((void**)&e->tiles, (size_t)e->n * TILE_PITCH));
+        HIP_TRY(hipMemset(e->tiles, 0, (size_t)e->n * TILE_PITCH));
+        e->tiles_valid = false;
+    }
     return BBAI_OK;
 }
 
-int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream) {
-    if (!e || !image || !pixels) ARG_FAIL("null handle or buffer");
-    if (e->n_tiles <= 0) { snprintf(g_err, sizeof(g_err), "render before set_atlas"); return BBAI_ERR_STATE; }
-    ON_DEVICE(e->device);
+}  // extern "C"
+
+template <bool FROM_PLANE>
+static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, void* stream) {
     // Launch shape: ONE G-env group (G x 9.4 KB of pixels) per one-shot block of T threads.  Chosen by wall-clock step time
     // inside the real bench, shapes alternated within one lease, on fast and slow boxes (profiles/r02/render_shape_*.jsonl,
     // render_tpb_*.jsonl): (T, G) = (1024, 8) from 786 432 envs up, (512, 2) below.  Against round 1's looped shape (256
@@ -1146,12 +1223,32 @@ int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream
     if (G != 2 && G != 4 && G != 8) G = big ? 8 : 2;
     if (T != 256 && T != 512 && T != 1024) T = big ? 1024 : 512;
     const dim3 grid((unsigned)((e->n + G - 1) / G));
-#define RENDER_LAUNCH(GG, TT) hipLaunchKernelGGL((k_render<GG, TT>), grid, dim3(TT), 0, (hipStream_t)stream, e->n, image, pixels, e->atlas, e->lut, e->n_tiles)
+#define RENDER_LAUNCH(GG, TT) hipLaunchKernelGGL((k_render<GG, TT, FROM_PLANE>), grid, dim3(TT), 0, (hipStream_t)stream, e->n, input, pixels, e->atlas, e->lut, e->n_tiles)
 #define RENDER_G(GG) do { if (T == 1024) RENDER_LAUNCH(GG, 1024); else if (T == 512) RENDER_LAUNCH(GG, 512); else RENDER_LAUNCH(GG, 256); } while (0)
     if (G == 2) RENDER_G(2); else if (G == 4) RENDER_G(4); else RENDER_G(8);
+#undef RENDER_G
+#undef RENDER_LAUNCH
     }
     HIP_TRY(hipGetLastError());
     return leave_call(e, (hipStream_t)stream);
+}
+
+extern "C" {
+
+int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream) {
+    if (!e || !image || !pixels) ARG_FAIL("null handle or buffer");
+    if (e->n_tiles <= 0) { snprintf(g_err, sizeof(g_err), "render before set_atlas"); return BBAI_ERR_STATE; }
+    ON_DEVICE(e->device);
+    return render_launch<false>(e, image, pixels, stream);
+}
+
+// The pixels of the CURRENT observation of every env, from the tile plane the last reset / step left behind.
+int bbai_render_current(bbai_env* e, uint8_t* pixels, void* stream) {
+    if (!e || !pixels) ARG_FAIL("null handle or buffer");
+    if (e->n_tiles <= 0) { snprintf(g_err, sizeof(g_err), "render before set_atlas"); return BBAI_ERR_STATE; }
+    if (!e->tiles || !e->tiles_valid) { snprintf(g_err, sizeof(g_err), "render_current: no reset / step since set_atlas (or BBAI_RENDER_FUSED=0)"); return BBAI_ERR_STATE; }
+    ON_DEVICE(e->device);
+    return render_launch<true>(e, e->tiles, pixels, stream);
 }
 
 // Register (or clear with NULL) a caller-owned uint8[n][72] device buffer that the engine keeps filled with the
@@ -1187,6 +1284,7 @@ int bbai_import_state(bbai_env* e, int64_t first, int64_t count, const uint8_t* 
     if (rec) HIP_TRY(hipMemcpy(e->rec + first * e->cfg.rec_bytes, rec, (size_t)count * e->cfg.rec_bytes, hipMemcpyHostToDevice));
     if (hot) HIP_TRY(hipMemcpy(e->hot + first, hot, (size_t)count * sizeof(Hot), hipMemcpyHostToDevice));
     if (stale) HIP_TRY(hipMemcpy(e->stale + first, stale, (size_t)count * 8, hipMemcpyHostToDevice));
+    e->tiles_valid = false;             // (the plane describes observations; the next reset / step rewrites it)
     if (rec && count > 0) {
         hipLaunchKernelGGL(k_sync_prog, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, e->cfg, e->n, first, count, e->rec,
                            e->vhead, e->vset);
@@ -1277,6 +1375,7 @@ int bbai_checkpoint_load(bbai_env* e, const void* host_buf, int64_t bytes) {
     const uint8_t* src = (const uint8_t*)host_buf + sizeof(CkptHeader);
     for (int i = 0; i < k; ++i) { HIP_TRY(hipMemcpy(seg[i].p, src, seg[i].bytes, hipMemcpyHostToDevice)); src += seg[i].bytes; }
     e->step_parity = h.step_parity; e->next_counter_clean = h.next_counter_clean != 0; e->seeded = h.seeded != 0; e->live = h.live != 0;
+    e->tiles_valid = false;
     for (int i = 0; i < 3; ++i) e->win_all[i] = h.win_all[i];
     e->tick = h.tick;
     // the refill events of the saved run completed before the save: re-record them on the (idle) look-ahead stream

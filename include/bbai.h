@@ -98,6 +98,12 @@ int bbai_step(bbai_env* env, const uint8_t* actions_dev, uint8_t* image_dev, uin
  * scripts/train_rl.py:57-58): encoded obs uint8[N][147] -> pixels uint8[N][56][56][3].
  * The tile atlas must have been installed with bbai_set_atlas. */
 int bbai_set_atlas(bbai_env* env, const uint8_t* tiles_host, int n_tiles, const uint8_t* lut_host /* [2][256] */);
+/* The same wrapper applied to the CURRENT observation of every env (what a training / evaluation loop renders after
+ * each reset / step): once an atlas is installed, bbai_reset / bbai_step also leave a 52-byte tile plane per env behind
+ * (one masked appearance byte per view cell, written last), and this entry renders from it -- a third of the input bytes
+ * of bbai_render(image), still in the memory-side cache.  Byte-identical to bbai_render of the image the same call wrote.
+ * BBAI_ERR_STATE when no reset / step has happened since the atlas was installed (or after import / checkpoint_load). */
+int bbai_render_current(bbai_env* env, uint8_t* pixels_dev, void* stream);
 int bbai_render(bbai_env* env, const uint8_t* image_dev, uint8_t* pixels_dev, void* stream);
 
 /* Mission text as token ids, device-resident (replaces the per-step regex tokenisation of every mission in

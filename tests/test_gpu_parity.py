@@ -1174,3 +1174,46 @@ def test_unknown_actions_are_defined_and_can_be_rejected(gpu):
     with pytest.raises(AssertionError, match="unknown action"):
         s.step(7)
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("auto_reset", [True, False])
+def test_render_current_equals_render_of_the_encoding(gpu, auto_reset):
+    """bbai_render_current (pixels from the tile plane that reset / step leave behind: one masked appearance byte per view
+    cell) against bbai_render (pixels from the 147-byte encoding the same call wrote), every step, through auto-resets and
+    -- ManyEnvs mode -- frozen envs, whose plane rows are re-derived from their encoding."""
+    import ctypes
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv, _check
+    n = 5000                                          # not a multiple of the step block: ragged last block
+    env = BatchedBabyAIEnv("BabyAI-GoToObjS6-v0" if auto_reset else "BabyAI-PickupLoc-v0", n, device=gpu, pixel=True, seeds=77,
+                           auto_reset=auto_reset)
+    assert env.render_fused
+    other = torch.zeros_like(env.pixels)
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(3)
+
+    def check(tag):
+        _check(env.lib, env.lib.bbai_render(env.handle, env.image.data_ptr(), other.data_ptr(), env._stream()), "bbai_render")
+        assert torch.equal(env.pixels, other), tag
+
+    env.reset()
+    check("reset")
+    for t in range(140):
+        env.step(torch.randint(0, 7, (n,), dtype=torch.uint8, device=gpu, generator=gen))
+        check(t)
+    if auto_reset:
+        assert env.reset_count() > 2 * n
+    else:
+        assert int(env.done.sum()) > n // 2               # most envs sat frozen for a while
+        env.reset()
+        check("second reset")
+    # the plane is not part of a checkpoint: after a load the binding renders from the encoding until the next step
+    blob = env.save_checkpoint()
+    env.load_checkpoint(blob)
+    assert not env._tiles_ok
+    rc = env.lib.bbai_render_current(env.handle, other.data_ptr(), env._stream())
+    assert rc == -3                                        # BBAI_ERR_STATE, not stale pixels
+    env.step(torch.randint(0, 7, (n,), dtype=torch.uint8, device=gpu, generator=gen))
+    check("after load")
+    env.close()

@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void k_layout(Args a, const uint8_t* __restric
     Hot h; uint64_t st = 0; uint32_t vh = 0; uint64_t vs = 0; int action = 0;
     const int64_t ee = active ? env : a.n - 1;
     h = a.hot[ee];
+    const uint8_t ax0 = h.ax, ay0 = h.ay;          // (the pose is NOT advanced across launches: these planes have no slack rows)
     if (active) { st = a.stale[env]; vh = a.vhead[env]; vs = a.vset[env]; action = a.act[env]; }
     uint32_t w[24];
     int nw = 4;
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(256) void k_layout(Args a, const uint8_t* __restric
         }
         if (LAYOUT != 2) extra = (fe & 2) ? 1u : 0u;
         h.step++;
+        h.ax = ax0; h.ay = ay0;
         a.hot[env] = h;
         a.stale[env] = st + 1;
         a.rew[env] = (float)extra;
