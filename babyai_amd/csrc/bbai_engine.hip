@@ -128,6 +128,8 @@ struct bbai_env {
     double prof_ms[3];
     int64_t prof_n[3];
     int64_t tick;         // number of consume_and_refill calls so far
+    uint8_t* vplane;      // [n][v_bytes] window plane (bbai_types.hpp): one 128-byte line per window-origin class; BBAI_VPLANE=0: none
+    uint16_t* fcache;     // [n] appearance of the front cell (low byte) and of the carried object (high byte) after the last step
     uint8_t* tiles;       // [n][TILE_PITCH] fused tile plane of the CURRENT observations (allocated by bbai_set_atlas: pixel mode)
     bool tiles_valid;     // written by the last reset / step of every env
     uint8_t* atlas;       // [n_tiles][192]
@@ -159,22 +161,21 @@ constexpr int OBS_PAD = 148;           // LDS row per env (bytes), dword multipl
 // All of a lane's reads precede its writes and lanes only touch their own row, so no barrier is needed here.
 // `mb` (optional, EMIT): the same view as ONE byte per cell -- the appearance byte where the cell is visible, 0 where it is
 // not -- 49 bytes in view order [vi][vj] + 3 zero bytes: the pixel render's input (TILE_PITCH bytes per env).
+// The window's rows come from `q` (first aligned dword of row 0), `rstride` dwords apart, `off` = byte offset of the
+// window's first column inside that dword: the record's appearance plane (rstride = ES / 4) or the env's V-plane line
+// (rstride = 4).  `ce` = appearance of what the agent carries (E_EMPTY: nothing).  `fe2` receives the appearance of the
+// cell in front of the agent (view cell (3, 5)) for the verifier and the next step's transition.
 constexpr int TILE_PITCH = 52;
-template <bool EMIT>
-__device__ __forceinline__ void observe_lane_lds(const LevelCfg& c, const uint8_t* __restrict__ rec, const Hot& h,
-                                                 uint8_t* __restrict__ row /* this lane's OBS_PAD-byte LDS row */, uint32_t* mb) {
-    const int dir = h.dir;
-    // Grid.slice extents (get_view_exts): top-left world cell of the axis-aligned 7x7 window
-    const int tx = h.ax + (dir == 0 ? 0 : dir == 2 ? -6 : -3);
-    const int ty = h.ay + (dir == 1 ? 0 : dir == 3 ? -6 : -3);
-    const int a0 = (ty + MARGIN) * c.ES + (tx + MARGIN);
-    const int off = a0 & 3;                                  // same for every row: ES is a multiple of 4
-    const uint32_t* q = (const uint32_t*)(rec + (a0 - off));
-    const int es4 = c.ES >> 2;
+constexpr int64_t FUSED_MIN_ENVS = 786432;      // batches from this size up keep the fused tile plane (bbai_set_atlas)
+// Two halves, so that the verifier (which only needs fe2) can run between them while nothing of the 37-dword encoding is
+// live yet: view_cells fetches and rotates the window (cp = the 49 cells, vis = visibility rows), encode_view writes the
+// encoding (and the plane row) from them.
+__device__ __forceinline__ void view_cells(const uint32_t* __restrict__ q, int rstride, int off, int dir, uint32_t ce,
+                                           uint8_t* __restrict__ row /* this lane's OBS_PAD-byte LDS row */, uint32_t* cp, uint32_t* vis, int& fe2) {
     uint32_t* win = (uint32_t*)(row + 88);                   // 7 rows x 8 bytes, dword aligned (row = tid * 148)
 #pragma unroll
     for (int r = 0; r < VIEW; ++r) {
-        const uint32_t d0 = q[r * es4], d1 = q[r * es4 + 1], d2 = q[r * es4 + 2];
+        const uint32_t d0 = q[r * rstride], d1 = q[r * rstride + 1], d2 = q[r * rstride + 2];
         win[2 * r] = __builtin_amdgcn_alignbyte(d1, d0, off);
         win[2 * r + 1] = __builtin_amdgcn_alignbyte(d2, d1, off);
     }
@@ -183,8 +184,9 @@ __device__ __forceinline__ void observe_lane_lds(const LevelCfg& c, const uint8_
     const int kvi = dir == 0 ? 8 : dir == 1 ? -1 : dir == 2 ? -8 : 1;
     const int kvj = dir == 0 ? -1 : dir == 1 ? -8 : dir == 2 ? 1 : 8;
     const uint8_t* wb = row + 88 + k0;
-    uint32_t cp[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // the 49 cells, 4 per dword, view order [vi][vj]
-    uint32_t opq[VIEW] = {0, 0, 0, 0, 0, 0, 0}, vis[VIEW];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) cp[k] = 0;                      // the 49 cells, 4 per dword, view order [vi][vj]
+    uint32_t opq[VIEW] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int vi = 0; vi < VIEW; ++vi)
 #pragma unroll
@@ -195,11 +197,14 @@ __device__ __forceinline__ void observe_lane_lds(const LevelCfg& c, const uint8_
             opq[vj] |= (e_opaque((int)e) ? 1u : 0u) << vi;
         }
     process_vis_rows(opq, vis);
+    fe2 = (int)((cp[(3 * VIEW + 5) >> 2] >> (8 * ((3 * VIEW + 5) & 3))) & 0xFFu);
     {   // the agent's own cell (3,6) shows what it carries
-        const uint32_t ce = h.carry != NONE8 ? rec[c.off_app + h.carry] : (uint32_t)E_EMPTY;
         constexpr int idx = 3 * VIEW + 6;
         cp[idx >> 2] = (cp[idx >> 2] & ~(0xFFu << (8 * (idx & 3)))) | (ce << (8 * (idx & 3)));
     }
+}
+template <bool EMIT>
+__device__ __forceinline__ void encode_view(const uint32_t* cp, const uint32_t* vis, uint8_t* __restrict__ row, uint32_t* mb) {
     uint32_t od[37];
 #pragma unroll
     for (int k = 0; k < 37; ++k) od[k] = 0;
@@ -264,7 +269,42 @@ __device__ __forceinline__ void observe_wave(const LevelCfg& c, const uint8_t* _
     }
 }
 
-template <bool EMIT>
+// V-plane helpers (bbai_types.hpp "window plane").  Patch one cell into every line that holds it.
+__device__ __forceinline__ void v_patch(const LevelCfg& c, uint8_t* __restrict__ vrow, int x, int y, int val) {
+    const int xm = x + MARGIN, ym = y + MARGIN, nxo = v_nxo(c), nyo = v_nyo(c);
+    const int yo_lo = ym >= 6 ? (ym - 6) >> 1 : 0, yo_hi = (ym >> 1) < nyo - 1 ? (ym >> 1) : nyo - 1;
+    for (int xo = (xm >> 3) - 1; xo <= (xm >> 3); ++xo) {
+        if (xo < 0 || xo >= nxo) continue;
+        for (int yo = yo_lo; yo <= yo_hi; ++yo) vrow[(yo * nxo + xo) * VLINE + (ym - 2 * yo) * 16 + (xm - 8 * xo)] = (uint8_t)val;
+    }
+}
+// One 16-byte row segment of a V-plane line out of an appearance plane (`E`, row pitch ES); `sc` = plane index of a cell
+// to show as empty (the start-carry object, which leaves the grid right after the first observation), or -1.
+__device__ __forceinline__ u32x4 v_segment(const LevelCfg& c, const uint8_t* __restrict__ E, int line, int r, int sc) {
+    const int nxo = v_nxo(c);
+    const int yo = line / nxo, xo = line - yo * nxo;
+    const int prow = 2 * yo + r, pcol = 8 * xo;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (prow < c.EH) {
+        const int base = prow * c.ES + pcol;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            if (pcol + 4 * d < c.ES) {
+                uint32_t v = *(const uint32_t*)(E + base + 4 * d);
+                const int k = sc - (base + 4 * d);
+                if (k >= 0 && k < 4) v = (v & ~(0xFFu << (8 * k))) | ((uint32_t)E_EMPTY << (8 * k));
+                w[d] = v;
+            }
+    }
+    u32x4 out = {w[0], w[1], w[2], w[3]};
+    return out;
+}
+
+// VP: the window comes from the env's V-plane line (ONE 128-byte line per step) and the transition's inputs -- the
+// appearance of the front cell and of the carried object -- from the 2-byte cache the previous step left (`fcache`), so a
+// plain move / turn touches no other record line; without VP both come out of the record (round 2's path: 2-3 lines for
+// the window + the lines of the front cell's id and the carried object's appearance).
+template <bool EMIT, bool VP>
 __global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, int64_t n, uint8_t* __restrict__ recs,
                                                      Hot* __restrict__ hots, uint64_t* __restrict__ stales,
                                                      const uint32_t* __restrict__ vheads, const uint64_t* __restrict__ vsets,
@@ -272,7 +312,8 @@ __global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, i
                                                      uint8_t* __restrict__ dirs, float* __restrict__ rewards,
                                                      double* __restrict__ rewards64, uint8_t* __restrict__ dones, int auto_reset,
                                                      int32_t* __restrict__ reset_list, uint32_t* __restrict__ counters,
-                                                     uint8_t* __restrict__ tiles /* EMIT: [n][TILE_PITCH] render input */, int prio) {
+                                                     uint8_t* __restrict__ tiles /* EMIT: [n][TILE_PITCH] render input */, int prio,
+                                                     uint8_t* __restrict__ vplane, uint16_t* __restrict__ fcache) {
     __shared__ __attribute__((aligned(16))) uint8_t s_obs[STEP_BLOCK * OBS_PAD];
     if (prio) __builtin_amdgcn_s_setprio(3);            // the look-ahead generator's waves share the CUs: issue ours first
     uint32_t mb[13];
@@ -285,18 +326,49 @@ __global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, i
         uint8_t* rec = recs + env * (int64_t)c.rec_bytes;
         if (!h.frozen) {
             uint64_t stale = stales[env];
-            double reward;
+            double reward = 0.0;
             VProg vp; vp.head = vheads[env]; vp.sets = vsets + env; vp.stride = n;
-            bool done = step_env_cmd(c, rec, vp, h, stale, actions[env], reward);
+            const EnvRef r = env_ref(c, rec, vp);
+            const int action = actions[env];
+            uint8_t* vrow = VP ? vplane + env * (int64_t)v_bytes(c) : nullptr;
+            int fe, ce;
+            if (VP) {
+                const uint32_t fc = fcache[env];
+                fe = (int)(fc & 0xFFu); ce = (int)(fc >> 8);
+            } else {
+                fe = r.E[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];
+                ce = h.carry != NONE8 ? r.app[h.carry] : (int)E_EMPTY;
+            }
+            if (action != A_RESET_ENV) {
+                const int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
+                const int nfe = apply_action(c, r, h, stale, action, fe, ce);
+                if (VP && nfe >= 0) v_patch(c, vrow, fx, fy, nfe);
+            }
+            // the 7x7 window of the pose after the action.  Grid.slice extents (get_view_exts): its top-left world cell
+            const int dir = h.dir;
+            const int txm = h.ax + MARGIN + (dir == 0 ? 0 : dir == 2 ? -6 : -3);
+            const int tym = h.ay + MARGIN + (dir == 1 ? 0 : dir == 3 ? -6 : -3);
+            int fe2;
+            uint32_t cp[13], vis[VIEW];
+            if (VP) {
+                const uint8_t* line = vrow + ((tym >> 1) * v_nxo(c) + (txm >> 3)) * VLINE + (tym & 1) * 16 + (txm & 4);
+                view_cells((const uint32_t*)line, 4, txm & 3, dir, (uint32_t)ce, s_obs + threadIdx.x * OBS_PAD, cp, vis, fe2);
+            } else {
+                const int a0 = tym * c.ES + txm;                         // same for every row: ES is a multiple of 4
+                view_cells((const uint32_t*)(rec + (a0 & ~3)), c.ES >> 2, a0 & 3, dir, (uint32_t)ce, s_obs + threadIdx.x * OBS_PAD, cp, vis, fe2);
+            }
+            // "env.reset() for THIS env, now" (A_RESET_ENV, bbai_step.hpp): the episode ends with done = 1, reward = 0
+            const bool done = action == A_RESET_ENV ? true : finish_step(c, r, h, stale, action, fe2, reward);
             if (done && !auto_reset) h.frozen = 1;
             want_reset = done && auto_reset;
             hots[env] = h;
             stales[env] = stale;
+            if (VP) fcache[env] = (uint16_t)((uint32_t)fe2 | ((uint32_t)ce << 8));
             rewards[env] = (float)reward;
             if (rewards64) rewards64[env] = reward;        // the reference's Python float, bit for bit (levelgen.py:59-61)
             dones[env] = done ? 1 : 0;
             dirs[env] = h.dir;
-            observe_lane_lds<EMIT>(c, rec, h, s_obs + threadIdx.x * OBS_PAD, mb);
+            encode_view<EMIT>(cp, vis, s_obs + threadIdx.x * OBS_PAD, mb);
         }
         // frozen envs keep re-emitting their last outputs: copy them through LDS unchanged
         else {
@@ -536,7 +608,8 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
                                                  uint8_t* __restrict__ pending, uint8_t* __restrict__ first_slot,
                                                  int32_t* __restrict__ win_list, uint32_t* __restrict__ win_count, int pos,
                                                  uint8_t* __restrict__ image, uint8_t* __restrict__ dirs,
-                                                 uint32_t* __restrict__ other_counter, uint8_t* __restrict__ tiles /* or NULL */, int prio) {
+                                                 uint32_t* __restrict__ other_counter, uint8_t* __restrict__ tiles /* or NULL */, int prio,
+                                                 uint8_t* __restrict__ vplane /* or NULL */, uint16_t* __restrict__ fcache) {
     if (prio) __builtin_amdgcn_s_setprio(3);
     const int64_t count = all ? n : (int64_t)counter[0];
     // this tick's entries go behind those of the window's earlier ticks (their counts were written by earlier
@@ -561,6 +634,21 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
         h.slot = (uint8_t)(slot + 1 == depth ? 0 : slot + 1);
         // first observation of the new episode, straight from the slot (identical bytes to the live copy)
         observe_wave(c, nrec, h, image + env * OBS_BYTES, lane, tiles ? tiles + env * TILE_PITCH : nullptr);
+        if (vplane) {
+            // the new episode's window plane, straight from the slot; a start-carry object (it leaves the grid right after
+            // this first observation, below) is already shown as an empty cell
+            int sc = -1;
+            if (p->start_carry != NONE8) sc = e_index(c, nrec[c.off_pos + 2 * p->start_carry], nrec[c.off_pos + 2 * p->start_carry + 1]);
+            uint8_t* vrow = vplane + env * (int64_t)v_bytes(c);
+            const int nseg = v_nxo(c) * v_nyo(c) * 8;
+            for (int sg = lane; sg < nseg; sg += 64) *(u32x4*)(vrow + (sg >> 3) * VLINE + (sg & 7) * 16) = v_segment(c, nrec, sg >> 3, sg & 7, sc);
+            if (lane == 0) {
+                const int fi = e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir));
+                const uint32_t fe0 = fi == sc ? (uint32_t)E_EMPTY : nrec[fi];
+                const uint32_t ce0 = p->start_carry != NONE8 ? nrec[c.off_app + p->start_carry] : (uint32_t)E_EMPTY;
+                fcache[env] = (uint16_t)(fe0 | (ce0 << 8));
+            }
+        }
         if (lane == 0) {
             uint64_t stale0 = 0;
             // PutNext*Carrying: the first observation above still shows the object on the grid (the reference builds
@@ -592,6 +680,27 @@ __global__ void k_sync_prog(LevelCfg c, int64_t n, int64_t first, int64_t count,
     const Prog* p = (const Prog*)(recs + env * (int64_t)c.rec_bytes + c.off_prog);
     for (int k = 0; k < 8; ++k) vsets[(int64_t)k * n + env] = p->set[k >> 1][k & 1];
     vheads[env] = vhead_pack(*p);
+}
+
+// rebuild the window plane and the front-cell cache from the live records (after bbai_import_state / checkpoint_load):
+// one wave per env
+__global__ __launch_bounds__(256) void k_sync_view(LevelCfg c, int64_t first, int64_t count, const uint8_t* __restrict__ recs,
+                                                   const Hot* __restrict__ hots, uint8_t* __restrict__ vplane, uint16_t* __restrict__ fcache) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const int nseg = v_nxo(c) * v_nyo(c) * 8;
+    for (int64_t it = wave; it < count; it += nwaves) {
+        const int64_t env = first + it;
+        const uint8_t* rec = recs + env * (int64_t)c.rec_bytes;
+        uint8_t* vrow = vplane + env * (int64_t)v_bytes(c);
+        for (int sg = lane; sg < nseg; sg += 64) *(u32x4*)(vrow + (sg >> 3) * VLINE + (sg & 7) * 16) = v_segment(c, rec, sg >> 3, sg & 7, -1);
+        if (lane == 0) {
+            const Hot h = hots[env];
+            const uint32_t fe = rec[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];
+            const uint32_t ce = h.carry != NONE8 ? rec[c.off_app + h.carry] : (uint32_t)E_EMPTY;
+            fcache[env] = (uint16_t)(fe | (ce << 8));
+        }
+    }
 }
 
 // The reference's expert for every env (babyai/bot.py Bot.replan): lane = env, grid-stride over the batch with one BFS
@@ -872,6 +981,13 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->first_slot, 3 * (size_t)n_envs);
     alloc((void**)&e->win_count, 3 * WIN_STRIDE * 4);
     {
+        const char* vv = getenv("BBAI_VPLANE");              // 0: round 2's record-only step path (A/B runs)
+        if (!(vv && atoi(vv) == 0)) {
+            alloc((void**)&e->vplane, (size_t)n_envs * v_bytes(c));
+            alloc((void**)&e->fcache, (size_t)n_envs * 2);
+        }
+    }
+    {
         // Refill period B (ticks per look-ahead refill, BBAI_LOOKAHEAD); ring depth D = 2B.  One k_pregen launch per
         // window lasts as long as its slowest level (hundreds of microseconds to milliseconds: rejection sampling has a
         // heavy tail) and has to land within one window, so B ticks of the step path must outlast it or the step stream
@@ -935,6 +1051,10 @@ static int create_finish(bbai_env* e) {
     HIP_TRY(hipMemset(e->vset, 0, (size_t)n_envs * 64));
     HIP_TRY(hipMemset(e->counters, 0, 128));
     HIP_TRY(hipMemset(e->total_resets, 0, 16));
+    if (e->vplane) {
+        HIP_TRY(hipMemset(e->vplane, 0, (size_t)n_envs * v_bytes(c)));
+        HIP_TRY(hipMemset(e->fcache, 0, (size_t)n_envs * 2));
+    }
     {
         int lo = 0, hi = 0;     // look-ahead generation should get wave slots as soon as any free up
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -952,7 +1072,7 @@ static int create_finish(bbai_env* e) {
         const char* pg = getenv("BBAI_PREGEN_GROUP");
         e->pregen_group = pg ? atoi(pg) : 32;
         const char* sp = getenv("BBAI_STEP_PRIO");
-        e->step_prio = sp ? atoi(sp) : 0;
+        e->step_prio = sp ? atoi(sp) : 1;        // (never slower, GoTo 131 072 envs -2 %: profiles/r03/step_prio_ab.jsonl)
         const char* rv = getenv("BBAI_RENDER_GROUP");
         e->render_group = rv ? atoi(rv) : 0;
         const char* tv = getenv("BBAI_RENDER_TPB");
@@ -975,7 +1095,7 @@ void bbai_destroy(bbai_env* e) {
     void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
     void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_list, e->win_count, e->reset_list, e->counters,
-                    e->total_resets, e->atlas, e->lut, e->tiles};
+                    e->total_resets, e->atlas, e->lut, e->tiles, e->vplane, e->fcache};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete e;
 }
@@ -1090,7 +1210,7 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
                        e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, e->reset_list, e->counters + 16 * e->step_parity, all,
                        e->total_resets, D, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n,
                        e->win_list + (size_t)wb * e->period * e->n, e->win_count + WIN_STRIDE * wb, pos, image, dirs,
-                       e->counters + 16 * (e->step_parity ^ 1), e->tiles, e->step_prio);
+                       e->counters + 16 * (e->step_parity ^ 1), e->tiles, e->step_prio, e->vplane, e->fcache);
     }
     if (e->tokens)
         hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n, e->rec,
@@ -1175,12 +1295,11 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
     {
         ProfScope prof_(e, 0, s);
         const dim3 grid((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), block(STEP_BLOCK);
-        if (e->tiles)
-            hipLaunchKernelGGL(k_step<true>, grid, block, 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, image, dirs,
-                               rewards, rewards64, dones, auto_reset, list, counter, e->tiles, e->step_prio);
-        else
-            hipLaunchKernelGGL(k_step<false>, grid, block, 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, image, dirs,
-                               rewards, rewards64, dones, auto_reset, list, counter, (uint8_t*)nullptr, e->step_prio);
+#define STEP_LAUNCH(EM, VV) hipLaunchKernelGGL((k_step<EM, VV>), grid, block, 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, \
+                                               image, dirs, rewards, rewards64, dones, auto_reset, list, counter, e->tiles, e->step_prio, e->vplane, e->fcache)
+        if (e->tiles) { if (e->vplane) STEP_LAUNCH(true, true); else STEP_LAUNCH(true, false); }
+        else { if (e->vplane) STEP_LAUNCH(false, true); else STEP_LAUNCH(false, false); }
+#undef STEP_LAUNCH
         e->tiles_valid = e->tiles != nullptr;
     }
     HIP_TRY(hipGetLastError());
@@ -1196,8 +1315,14 @@ int bbai_set_atlas(bbai_env* e, const uint8_t* tiles, int n_tiles, const uint8_t
     HIP_TRY(hipMemcpy(e->lut, lut, 512, hipMemcpyHostToDevice));
     e->n_tiles = n_tiles;
     // pixel mode: from now on reset / step also keep the fused tile plane of the current observations (bbai_render_current)
+    // -- for LARGE batches only.  Measured inside the step loop (profiles/r03/render_fused_ab_*.jsonl): at 1 048 576 envs
+    // the render from the plane with (512, 4) blocks takes 1.59 ms against 1.68 ms from the encoding with round 2's
+    // (1024, 8) and the step 1.78 against 1.85 ms (k_step pays 0.013 ms for the extra 52 B per env); at 131 072 envs the
+    // whole encoding is still in the memory-side cache when the render starts and the plane only costs (0.243 vs 0.231 ms).
+    // BBAI_RENDER_FUSED=1 / 0 forces it on / off.
     const char* fv = getenv("BBAI_RENDER_FUSED");
-    if (!e->tiles && !(fv && atoi(fv) == 0)) {
+    const bool want = fv ? atoi(fv) != 0 : e->n >= FUSED_MIN_ENVS;
+    if (!e->tiles && want) {
         HIP_TRY(hipMalloc((void**)&e->tiles, (size_t)e->n * TILE_PITCH));
         HIP_TRY(hipMemset(e->tiles, 0, (size_t)e->n * TILE_PITCH));
         e->tiles_valid = false;
@@ -1218,10 +1343,12 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
     { int rc = enter_call(e, (hipStream_t)stream); if (rc != BBAI_OK) return rc; }
     {
     ProfScope prof_(e, 2, (hipStream_t)stream);
+    // (round 3, from the tile plane: (512, 4) from 786 432 envs up -- 1.59 ms at 1 048 576 envs against 1.62-1.66 for
+    // (1024, 8) and 1.81-1.85 for (512, 2), profiles/r03/render_fused_ab_1M.jsonl)
     const bool big = e->n >= 786432;
     int G = e->render_group, T = e->render_tpb;
-    if (G != 2 && G != 4 && G != 8) G = big ? 8 : 2;
-    if (T != 256 && T != 512 && T != 1024) T = big ? 1024 : 512;
+    if (G != 2 && G != 4 && G != 8) G = big ? (FROM_PLANE ? 4 : 8) : 2;
+    if (T != 256 && T != 512 && T != 1024) T = big ? (FROM_PLANE ? 512 : 1024) : 512;
     const dim3 grid((unsigned)((e->n + G - 1) / G));
 #define RENDER_LAUNCH(GG, TT) hipLaunchKernelGGL((k_render<GG, TT, FROM_PLANE>), grid, dim3(TT), 0, (hipStream_t)stream, e->n, input, pixels, e->atlas, e->lut, e->n_tiles)
 #define RENDER_G(GG) do { if (T == 1024) RENDER_LAUNCH(GG, 1024); else if (T == 512) RENDER_LAUNCH(GG, 512); else RENDER_LAUNCH(GG, 256); } while (0)
@@ -1277,6 +1404,16 @@ int bbai_export_state(bbai_env* e, int64_t first, int64_t count, uint8_t* rec, u
     return BBAI_OK;
 }
 
+// window plane + front-cell cache follow the records (they are derived state: not part of exports or checkpoints)
+static int sync_view(bbai_env* e, int64_t first, int64_t count) {
+    if (!e->vplane) return BBAI_OK;
+    hipLaunchKernelGGL(k_sync_view, dim3((unsigned)std::min<int64_t>((count + 3) / 4, 16384)), dim3(256), 0, 0, e->cfg, first, count, e->rec, e->hot,
+                       e->vplane, e->fcache);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return BBAI_OK;
+}
+
 int bbai_import_state(bbai_env* e, int64_t first, int64_t count, const uint8_t* rec, const uint8_t* hot, const uint64_t* stale) {
     if (!e || first < 0 || count < 0 || first + count > e->n) ARG_FAIL("null handle or env range out of bounds");
     ON_DEVICE(e->device);
@@ -1291,6 +1428,7 @@ int bbai_import_state(bbai_env* e, int64_t first, int64_t count, const uint8_t* 
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
     }
+    if (count > 0) { int rc = sync_view(e, first, count); if (rc != BBAI_OK) return rc; }
     e->live = true;
     return BBAI_OK;
 }
@@ -1381,7 +1519,7 @@ int bbai_checkpoint_load(bbai_env* e, const void* host_buf, int64_t bytes) {
     // the refill events of the saved run completed before the save: re-record them on the (idle) look-ahead stream
     for (int i = 0; i < 3; ++i) HIP_TRY(hipEventRecord(e->ev_refill[i], e->side));
     HIP_TRY(hipDeviceSynchronize());
-    return BBAI_OK;
+    return sync_view(e, 0, e->n);
 }
 
 int bbai_get_programs(bbai_env* e, int64_t first, int64_t count, uint8_t* prog) {
@@ -1514,6 +1652,8 @@ int bbai_set_call_events(bbai_env* e, int enable) {
     e->call_events = enable != 0;
     return BBAI_OK;
 }
+
+int bbai_has_tile_plane(bbai_env* e) { return e && e->tiles ? 1 : 0; }
 
 int bbai_profile(bbai_env* e, int enable) {
     if (!e) ARG_FAIL("null handle");

@@ -34,7 +34,9 @@ BB_HD int dir_dy(int d) { return (d == 1) - (d == 3); }
 
 // One ActionInstr.verify_action.  `visited` semantics: preCarrying is only updated when the
 // leaf is actually evaluated (verifier.py:331-334,394-396).
-BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int leaf, int action) {
+// `fe2` = appearance byte of the cell in front of the agent AFTER the action (callers that have the 7x7 window at hand pass
+// its cell (3,5); step_env reads it from the appearance plane).
+BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int leaf, int action, int fe2) {
     const int kind = r.prog.kind(leaf);
     const uint64_t set0 = r.prog.set(leaf, 0);
     if (kind == L_GOTO) {
@@ -43,7 +45,7 @@ BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale
         // the last refresh.  The id plane is only consulted when the appearance plane (whose
         // lines the observation needs anyway) shows an object there.
         int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
-        if (e_type(r.E[e_index(c, fx, fy)]) >= T_DOOR) {
+        if (e_type(fe2) >= T_DOOR) {
             int id = r.I[i_index(c, fx, fy)];
             if (id >= 2 && (set0 >> (id - 2) & 1)) return V_SUCCESS;
         }
@@ -58,7 +60,7 @@ BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale
     if (kind == L_OPEN) {
         if (action != A_TOGGLE) return V_CONTINUE;
         int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
-        int fe = r.E[e_index(c, fx, fy)];
+        int fe = fe2;
         if (e_type(fe) != T_DOOR) return V_CONTINUE;
         if (e_state(fe) == S_OPEN) {
             int id = r.I[i_index(c, fx, fy)];
@@ -95,35 +97,35 @@ BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale
 
 // One side of a Seq (an ActionInstr, or an AndInstr of two).  bit_a/bit_b: And progress bits.
 // An AndInstr never reports failure (verifier.py:536-550); a lone ActionInstr passes it through.
-BB_HD int verify_side(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int base, int n, int bit_a, int action) {
-    if (n == 1) return verify_leaf(c, r, h, stale, base, action);
+BB_HD int verify_side(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int base, int n, int bit_a, int action, int fe2) {
+    if (n == 1) return verify_leaf(c, r, h, stale, base, action, fe2);
     if (!(h.vstate >> bit_a & 1))
-        if (verify_leaf(c, r, h, stale, base, action) == V_SUCCESS) h.vstate |= 1 << bit_a;
+        if (verify_leaf(c, r, h, stale, base, action, fe2) == V_SUCCESS) h.vstate |= 1 << bit_a;
     if (!(h.vstate >> (bit_a + 1) & 1))
-        if (verify_leaf(c, r, h, stale, base + 1, action) == V_SUCCESS) h.vstate |= 1 << (bit_a + 1);
+        if (verify_leaf(c, r, h, stale, base + 1, action, fe2) == V_SUCCESS) h.vstate |= 1 << (bit_a + 1);
     return (h.vstate >> bit_a & 3) == 3 ? V_SUCCESS : V_CONTINUE;
 }
 
-BB_HD int verify_root(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action) {
+BB_HD int verify_root(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2) {
     const VProg* p = &r.prog;
-    if (p->root() == R_ACTION || p->root() == R_AND) return verify_side(c, r, h, stale, 0, p->n_a(), 1, action);
+    if (p->root() == R_ACTION || p->root() == R_AND) return verify_side(c, r, h, stale, 0, p->n_a(), 1, action, fe2);
     // Before: a then b; After: b then a.  The second part is verified with the SAME action in
     // the step the first part completes (verifier.py:463-464,504-505); a failure of either part fails.
     const bool before = p->root() == R_BEFORE;
     const int b1 = before ? 0 : 2, n1 = before ? p->n_a() : p->n_b(), s1 = before ? 1 : 3;
     const int b2 = before ? 2 : 0, n2 = before ? p->n_b() : p->n_a(), s2 = before ? 3 : 1;
     if (!(h.vstate & 1)) {
-        int st = verify_side(c, r, h, stale, b1, n1, s1, action);
+        int st = verify_side(c, r, h, stale, b1, n1, s1, action, fe2);
         if (st == V_FAILURE) return st;
         if (st != V_SUCCESS) {
             // strict Seq: completing the second part first fails (verifier.py:466-469,507-510); the probe IS a verify()
             // of the second part, with its side effects (preCarrying, And progress bits)
-            if (p->strict_seq() && verify_side(c, r, h, stale, b2, n2, s2, action) == V_SUCCESS) return V_FAILURE;
+            if (p->strict_seq() && verify_side(c, r, h, stale, b2, n2, s2, action, fe2) == V_SUCCESS) return V_FAILURE;
             return st;
         }
         h.vstate |= 1;
     }
-    return verify_side(c, r, h, stale, b2, n2, s2, action);
+    return verify_side(c, r, h, stale, b2, n2, s2, action, fe2);
 }
 
 // reward = 1 - 0.9 * (step_count / max_steps) in float64 (MiniGridEnv._reward, returned as a Python float at
@@ -139,13 +141,16 @@ BB_HD double success_reward(int step, int max_steps) {
 #endif
 }
 
-// MiniGridEnv.step + RoomGridLevel.step for one env.  Returns done; reward by reference.
-BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, double& reward) {
-    EnvRef r = env_ref(c, rec, vp);
+// MiniGridEnv.step's effect on the world, first half of a step.  `fe` = appearance byte of the cell in front of the agent
+// BEFORE the action; `ce` = appearance byte of what the agent carries (E_EMPTY: nothing) -- both are passed in so that
+// callers which cache them (k_step: 2 bytes per env) never touch the record on a plain move / turn; `ce` is kept current.
+// Returns the NEW appearance byte of that front cell when the action changed it, else -1 (callers that keep derived copies
+// of the appearance plane patch them with it).  All other record updates (id plane, positions) happen here.
+BB_HD int apply_action(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t& stale, int action, int fe, int& ce) {
     h.step = (uint16_t)(h.step + 1);
     const int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
     const int ei = e_index(c, fx, fy), ii = i_index(c, fx, fy);
-    const int fe = r.E[ei];
+    int nfe = -1;
     switch (action) {
     case A_LEFT: h.dir = (h.dir + 3) & 3; break;
     case A_RIGHT: h.dir = (h.dir + 1) & 3; break;
@@ -156,50 +161,67 @@ BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, ui
         if (e_type(fe) >= T_KEY && h.carry == NONE8) {
             int o = r.I[ii] - 2;
             h.carry = (uint8_t)o;
-            r.E[ei] = E_EMPTY; r.I[ii] = 0;
+            ce = fe;                                 // a key / ball / box looks the same on the floor and in the hand
+            nfe = E_EMPTY; r.I[ii] = 0;
             stale |= 1ull << o;                      // its recorded position is now stale
         }
         break;
     case A_DROP:
         if (fe == E_EMPTY && h.carry != NONE8) {
             int o = h.carry;
-            r.E[ei] = r.app[o]; r.I[ii] = (uint8_t)(o + 2);
+            nfe = ce; r.I[ii] = (uint8_t)(o + 2);
             r.pos[2 * o] = (uint8_t)fx; r.pos[2 * o + 1] = (uint8_t)fy;
             h.carry = NONE8;
+            ce = E_EMPTY;
         }
         break;
     case A_TOGGLE:
         if (e_type(fe) == T_DOOR) {
             if (e_state(fe) == S_LOCKED) {
-                if (h.carry != NONE8) {
-                    int ce = r.app[h.carry];
-                    if (e_type(ce) == T_KEY && e_color(ce) == e_color(fe)) r.E[ei] = (uint8_t)e_make(T_DOOR, e_color(fe), S_OPEN);
-                }
+                if (h.carry != NONE8 && e_type(ce) == T_KEY && e_color(ce) == e_color(fe)) nfe = e_make(T_DOOR, e_color(fe), S_OPEN);
             } else {
-                r.E[ei] = (uint8_t)e_make(T_DOOR, e_color(fe), e_state(fe) == S_OPEN ? S_CLOSED : S_OPEN);
+                nfe = e_make(T_DOOR, e_color(fe), e_state(fe) == S_OPEN ? S_CLOSED : S_OPEN);
             }
         } else if (e_type(fe) == T_BOX) {            // box is replaced by its contents (nothing, or a hidden object)
             int o = r.I[ii] - 2;
             int inner = r.cont[o];
             if (inner == NONE8) {
-                r.E[ei] = E_EMPTY; r.I[ii] = 0;
+                nfe = E_EMPTY; r.I[ii] = 0;
             } else {
-                r.E[ei] = r.app[inner]; r.I[ii] = (uint8_t)(inner + 2);
+                nfe = r.app[inner]; r.I[ii] = (uint8_t)(inner + 2);
                 r.pos[2 * inner] = (uint8_t)fx; r.pos[2 * inner + 1] = (uint8_t)fy;
             }
             stale |= 1ull << o;
         }
         break;
-    default: break;                                   // done
+    default: break;                                   // done (and, by definition, every byte above 7: include/bbai.h)
     }
+    if (nfe >= 0) r.E[ei] = (uint8_t)nfe;
     // every drop ACTION refreshes the tracked positions (levelgen.py:53-54)
     if (action == A_DROP) stale = 0;
-    const int status = verify_root(c, r, h, stale, action);
+    return nfe;
+}
+
+// Second half: the instruction verifier and the episode end (RoomGridLevel.step, levelgen.py:56-66).  `fe2` = appearance
+// byte of the front cell of the pose AFTER the action.  Returns done; reward by reference.
+BB_HD bool finish_step(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2, double& reward) {
+    const int status = verify_root(c, r, h, stale, action, fe2);
     bool done = h.step >= h.max_steps;
     reward = 0.0;
     if (status == V_SUCCESS) { done = true; reward = success_reward(h.step, h.max_steps); }
     else if (status == V_FAILURE) done = true;      // levelgen.py:62-64
     return done;
+}
+
+// MiniGridEnv.step + RoomGridLevel.step for one env, everything read from the record (host build, reference form of the
+// two halves above).  Returns done; reward by reference.
+BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, double& reward) {
+    EnvRef r = env_ref(c, rec, vp);
+    const int fe = r.E[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];
+    int ce = h.carry != NONE8 ? r.app[h.carry] : (int)E_EMPTY;
+    apply_action(c, r, h, stale, action, fe, ce);
+    const int fe2 = r.E[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];
+    return finish_step(c, r, h, stale, action, fe2, reward);
 }
 
 // Not a MiniGrid action: "env.reset() for THIS env, now" -- what a ParallelEnv worker does on a `reset` command

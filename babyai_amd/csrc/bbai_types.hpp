@@ -194,6 +194,19 @@ inline int fill_layout(LevelCfg& c) {
     return 0;
 }
 
+// ---- window plane ("V plane"): a redundant, window-shaped copy of the appearance plane for k_step ----------------------
+// HBM moves 128-byte lines.  A 7x7 window cut out of the row-major appearance plane (7 rows x 12 B at a 32-byte pitch)
+// touches 2-3 lines for 49 useful bytes (profiles/r03/fetchcal*: the gather costs whole lines).  The V plane stores, for
+// every window-origin class (xo, yo) = (tx >> 3, ty >> 1) -- tx, ty = top-left cell of the window in plane coordinates --
+// ONE line of 8 rows x 16 cells starting at plane cell (8 xo, 2 yo): the window of any agent pose lies inside exactly one
+// line (columns tx - 8 xo + 0..6 <= 13, rows ty - 2 yo + 0..6 <= 7).  Each cell is stored in up to 8 lines; only k_step's
+// own rare grid writes (pickup / drop / toggle) and the per-episode rebuild pay for that.  BossLevel: 4 x 13 lines =
+// 6.5 KB per env next to the 1 KB plane -- what 288 GB of HBM is for.
+constexpr int VLINE = 128;
+BB_HD int v_nxo(const LevelCfg& c) { return ((c.ES - VIEW) >> 3) + 1; }
+BB_HD int v_nyo(const LevelCfg& c) { return ((c.EH - VIEW) >> 1) + 1; }
+BB_HD int v_bytes(const LevelCfg& c) { return v_nxo(c) * v_nyo(c) * VLINE; }
+
 BB_HD int e_index(const LevelCfg& c, int x, int y) { return (y + MARGIN) * c.ES + (x + MARGIN); }
 BB_HD int i_index(const LevelCfg& c, int x, int y) { return y * c.W + x; }
 

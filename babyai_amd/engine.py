@@ -59,6 +59,7 @@ def load_library():
     lib.bbai_set_atlas.argtypes = [P, P, I32, P]
     lib.bbai_render.argtypes = [P, P, P, P]
     lib.bbai_render_current.argtypes = [P, P, P]
+    lib.bbai_has_tile_plane.argtypes = [P]
     lib.bbai_set_token_buffer.argtypes = [P, P]
     lib.bbai_export_state.argtypes = [P, I64, I64, P, P, P]
     lib.bbai_import_state.argtypes = [P, I64, I64, P, P, P]
@@ -86,7 +87,7 @@ EXPORTED_SYMBOLS = (
     "bbai_reset", "bbai_step", "bbai_set_atlas", "bbai_render", "bbai_set_token_buffer", "bbai_export_state", "bbai_import_state",
     "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures", "bbai_bot_act", "bbai_bot_stats",
     "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load", "bbai_profile", "bbai_profile_read", "bbai_gae", "bbai_tap",
-    "bbai_tap_ids", "bbai_set_call_events", "bbai_render_current",
+    "bbai_tap_ids", "bbai_set_call_events", "bbai_render_current", "bbai_has_tile_plane",
 )
 
 
@@ -189,7 +190,7 @@ class BatchedBabyAIEnv(object):
             self.reward64 = torch.zeros((n,), dtype=torch.float64, device=self.device)
             self.done = torch.zeros((n,), dtype=torch.uint8, device=self.device)
             self.pixels = None
-            self.render_fused = os.environ.get("BBAI_RENDER_FUSED", "1") != "0"       # (0: render from the 147-byte encoding, A/B runs)
+            self.render_fused = False
             if self.pixel:
                 self.pixels = torch.zeros((n, PIX, PIX, 3), dtype=torch.uint8, device=self.device)
                 atlas = np.load(ATLAS_PATH)
@@ -197,6 +198,8 @@ class BatchedBabyAIEnv(object):
                 lut = np.ascontiguousarray(atlas["lut"], dtype=np.uint8)
                 _check(self.lib, self.lib.bbai_set_atlas(self.handle, tiles.ctypes.data, tiles.shape[0],
                                                           lut.ctypes.data), "bbai_set_atlas")
+                # large batches keep a fused tile plane and render from it (include/bbai.h bbai_render_current)
+                self.render_fused = bool(self.lib.bbai_has_tile_plane(self.handle))
         self._missions = None
         self._tiles_ok = False         # the engine's tile plane describes the observation about to be rendered (set by reset / step)
         self._obs_version = 0
@@ -251,6 +254,15 @@ class BatchedBabyAIEnv(object):
         self._obs_version += 1
         self._missions = Missions(self)
         return {"image": img, "direction": self.direction, "mission": self._missions}
+
+    def render_encoding(self, image=None, out=None):
+        """RGBImgPartialObsWrapper.observation for ANY encoded batch uint8[N,7,7,3] on the device (default: the current
+        one) -> uint8[N,56,56,3] (include/bbai.h bbai_render).  step() / reset() already return pixels in pixel mode; this
+        is for stored or hand-made encodings."""
+        image = self.image if image is None else image
+        out = self.pixels if out is None else out
+        _check(self.lib, self.lib.bbai_render(self.handle, image.data_ptr(), out.data_ptr(), self._stream()), "bbai_render")
+        return out
 
     def reset(self):
         _check(self.lib, self.lib.bbai_reset(self.handle, self.image.data_ptr(), self.direction.data_ptr(),

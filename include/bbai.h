@@ -104,6 +104,9 @@ int bbai_set_atlas(bbai_env* env, const uint8_t* tiles_host, int n_tiles, const 
  * of bbai_render(image), still in the memory-side cache.  Byte-identical to bbai_render of the image the same call wrote.
  * BBAI_ERR_STATE when no reset / step has happened since the atlas was installed (or after import / checkpoint_load). */
 int bbai_render_current(bbai_env* env, uint8_t* pixels_dev, void* stream);
+/* 1 when the handle keeps the tile plane (batches of 786 432 envs and more, where it pays: profiles/r03/render_fused_ab_*;
+ * BBAI_RENDER_FUSED=1 / 0 in the environment at bbai_set_atlas forces it on / off), else 0: use bbai_render. */
+int bbai_has_tile_plane(bbai_env* env);
 int bbai_render(bbai_env* env, const uint8_t* image_dev, uint8_t* pixels_dev, void* stream);
 
 /* Mission text as token ids, device-resident (replaces the per-step regex tokenisation of every mission in

@@ -347,9 +347,7 @@ def test_render_every_tile_vs_oracle(gpu):
     env.reset()
     torch.cuda.synchronize()
     env.image.copy_(torch.as_tensor(img, device=gpu))
-    obs = env._obs()
-    torch.cuda.synchronize()
-    pix = obs["image"].cpu().numpy()
+    pix = env.render_encoding().cpu().numpy()          # a hand-made encoding: the general entry, not the current-obs fast path
     ref_env = olevels.make_env("GoToLocal")
     seen = set()
     for e in range(n):
@@ -1178,7 +1176,7 @@ def test_unknown_actions_are_defined_and_can_be_rejected(gpu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("auto_reset", [True, False])
-def test_render_current_equals_render_of_the_encoding(gpu, auto_reset):
+def test_render_current_equals_render_of_the_encoding(gpu, auto_reset, monkeypatch):
     """bbai_render_current (pixels from the tile plane that reset / step leave behind: one masked appearance byte per view
     cell) against bbai_render (pixels from the 147-byte encoding the same call wrote), every step, through auto-resets and
     -- ManyEnvs mode -- frozen envs, whose plane rows are re-derived from their encoding."""
@@ -1186,6 +1184,7 @@ def test_render_current_equals_render_of_the_encoding(gpu, auto_reset):
     import torch
     from babyai_amd.engine import BatchedBabyAIEnv, _check
     n = 5000                                          # not a multiple of the step block: ragged last block
+    monkeypatch.setenv("BBAI_RENDER_FUSED", "1")      # (small batches do not keep the plane by default)
     env = BatchedBabyAIEnv("BabyAI-GoToObjS6-v0" if auto_reset else "BabyAI-PickupLoc-v0", n, device=gpu, pixel=True, seeds=77,
                            auto_reset=auto_reset)
     assert env.render_fused
