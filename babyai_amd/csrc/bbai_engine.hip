@@ -611,6 +611,9 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
                                                  uint32_t* __restrict__ other_counter, uint8_t* __restrict__ tiles /* or NULL */, int prio,
                                                  uint8_t* __restrict__ vplane /* or NULL */, uint16_t* __restrict__ fcache) {
     if (prio) __builtin_amdgcn_s_setprio(3);
+    // the appearance plane of the wave's current env, parked while the record is copied: the window plane is cut out of it
+    __shared__ __attribute__((aligned(16))) uint8_t s_plane[4][GEN_ES * GEN_EH + 20];
+    uint8_t* plane = s_plane[threadIdx.x >> 6];
     const int64_t count = all ? n : (int64_t)counter[0];
     // this tick's entries go behind those of the window's earlier ticks (their counts were written by earlier
     // launches); no atomics: an env appears at most once per tick, repeats within the window are marked -1
@@ -625,7 +628,12 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
         const uint8_t* nrec = next_recs + ((int64_t)slot * n + env) * (int64_t)c.rec_bytes;
         const u32x4* src = (const u32x4*)nrec;
         u32x4* dst = (u32x4*)(recs + env * (int64_t)c.rec_bytes);
-        for (int k = lane; k < nvec; k += 64) dst[k] = src[k];
+        const int plane_vec = vplane ? (c.ES * c.EH + 15) >> 4 : 0;     // (the E plane is the head of the record)
+        for (int k = lane; k < nvec; k += 64) {
+            const u32x4 v = src[k];
+            dst[k] = v;
+            if (k < plane_vec) *(u32x4*)(plane + 16 * k) = v;
+        }
         // the verifier's SoA view of the new program
         const Prog* p = (const Prog*)(nrec + c.off_prog);
         if (lane < 8) vsets[(int64_t)lane * n + env] = p->set[lane >> 1][lane & 1];
@@ -641,7 +649,11 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
             if (p->start_carry != NONE8) sc = e_index(c, nrec[c.off_pos + 2 * p->start_carry], nrec[c.off_pos + 2 * p->start_carry + 1]);
             uint8_t* vrow = vplane + env * (int64_t)v_bytes(c);
             const int nseg = v_nxo(c) * v_nyo(c) * 8;
-            for (int sg = lane; sg < nseg; sg += 64) *(u32x4*)(vrow + (sg >> 3) * VLINE + (sg & 7) * 16) = v_segment(c, nrec, sg >> 3, sg & 7, sc);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the wave's parked plane is complete (one wave: no barrier)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (int sg = lane; sg < nseg; sg += 64) *(u32x4*)(vrow + (sg >> 3) * VLINE + (sg & 7) * 16) = v_segment(c, plane, sg >> 3, sg & 7, sc);
+            __builtin_amdgcn_wave_barrier();                             // (before the next env's copy overwrites the plane)
             if (lane == 0) {
                 const int fi = e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir));
                 const uint32_t fe0 = fi == sc ? (uint32_t)E_EMPTY : nrec[fi];
