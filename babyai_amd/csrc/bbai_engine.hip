@@ -119,6 +119,7 @@ struct bbai_env {
     int render_tpb;       // BBAI_RENDER_TPB: 256 / 512 / 1024 threads per render block; anything else = by batch size
     int render_group;     // BBAI_RENDER_GROUP: 2, 4 or 8 envs per one-shot render block; anything else = by batch size (bbai_render)
     int pregen_cap;       // BBAI_PREGEN_BLOCKS: upper bound on look-ahead lane groups per launch (experiments)
+    int pregen_cus;       // CUs the look-ahead stream may use (BBAI_PREGEN_CUS; all of them when no mask is set)
     int pregen_group;     // BBAI_PREGEN_GROUP: lanes per env in k_pregen: 32 (default: two envs per wave), 16 or 64
     int step_prio;        // BBAI_STEP_PRIO: s_setprio level of the step-path kernels' waves (they share CUs with k_pregen)
     // optional per-kernel timing (bbai_profile): HIP event pairs on the launch stream around k_step / k_consume / k_render
@@ -149,6 +150,7 @@ struct bbai_env {
 // k_step
 // ------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int PREGEN_CUS_DEFAULT = 0;   // 0 = no CU mask on the look-ahead stream (BBAI_PREGEN_CUS overrides)
 constexpr int MAX_PERIOD = 32;          // refill period B (ticks per look-ahead refill); ring depth D = 2B
 constexpr int WIN_STRIDE = 64;          // uint32 per window-count block (1 + MAX_PERIOD used)
 constexpr int STEP_BLOCK = 256;
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, i
                                                      int32_t* __restrict__ reset_list, uint32_t* __restrict__ counters,
                                                      uint8_t* __restrict__ tiles /* EMIT: [n][TILE_PITCH] render input */, int prio,
                                                      uint8_t* __restrict__ vplane, uint16_t* __restrict__ fcache) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_obs[STEP_BLOCK * OBS_PAD];
+    __shared__ __attribute__((aligned(16))) uint8_t s_obs[STEP_BLOCK * OBS_PAD + 16];      // (+16: the copy-out reads one dword ahead)
     if (prio) __builtin_amdgcn_s_setprio(3);            // the look-ahead generator's waves share the CUs: issue ours first
     uint32_t mb[13];
     const int64_t env0 = (int64_t)blockIdx.x * STEP_BLOCK;
@@ -404,31 +406,30 @@ __global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, i
         }
     }
     __syncthreads();
-    // cooperative, dword-coalesced write of the block's contiguous obs span.  LDS rows are 148 B apart, the output
-    // is 147-B packed: output dword d starts at byte off = 4d % 147 of row e = 4d / 147; when it lies inside the row
-    // it is two aligned LDS dwords funnel-shifted by off & 3 (148 is a dword multiple), else (3 of 147) bytewise.
+    // cooperative, dword-coalesced write of the block's contiguous obs span.  LDS rows are 148 B apart, the output is
+    // 147-B packed: output dword d starts at byte off = 4d % 147 of row e = 4d / 147, i.e. at LDS byte A = 148 e + off, and
+    // its byte k sits at A + k, one further once the row's pad byte is crossed (off + k >= 147).  Branch-free: the four
+    // bytes at A and the four at A + 1 (funnel shifts of three aligned LDS dwords) blended by the crossing point; e / off
+    // advance incrementally (a thread's next dword is 1024 bytes = 6 rows + 142 bytes on): no division in the loop.
     const int64_t nb = n - env0 < STEP_BLOCK ? n - env0 : STEP_BLOCK;      // envs in this block
     const int total = (int)nb * OBS_BYTES;
     uint8_t* out = image + env0 * OBS_BYTES;                              // 256*147 is a dword multiple
     const int ndw = total >> 2;
     const uint32_t* s_obs32 = (const uint32_t*)s_obs;
-    for (int d = threadIdx.x; d < ndw; d += STEP_BLOCK) {
-        const int b = 4 * d;
-        const int e = b / OBS_BYTES, off = b - e * OBS_BYTES;
-        uint32_t v;
-        if (off <= OBS_BYTES - 4) {
-            const int q = e * (OBS_PAD / 4) + (off >> 2);
-            v = __builtin_amdgcn_alignbyte(s_obs32[q + 1], s_obs32[q], off & 3);
-        } else {
-            v = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int bb = b + k;
-                const int ee = bb / OBS_BYTES, oo = bb - ee * OBS_BYTES;
-                v |= (uint32_t)s_obs[ee * OBS_PAD + oo] << (8 * k);
-            }
+    {
+        int e37 = (4 * (int)threadIdx.x / OBS_BYTES), off = 4 * (int)threadIdx.x - e37 * OBS_BYTES;
+        e37 *= OBS_PAD / 4;                                               // first LDS dword of the row
+        for (int d = threadIdx.x; d < ndw; d += STEP_BLOCK) {
+            const int q = e37 + (off >> 2), sh = off & 3;
+            const uint32_t d0 = s_obs32[q], d1 = s_obs32[q + 1], d2 = s_obs32[q + 2];
+            const uint32_t va = __builtin_amdgcn_alignbyte(d1, d0, sh);                                   // bytes A .. A+3
+            const uint32_t vb = __builtin_amdgcn_alignbyte(sh == 3 ? d2 : d1, sh == 3 ? d1 : d0, (sh + 1) & 3);   // bytes A+1 .. A+4
+            const int nlow = OBS_BYTES - off;                             // bytes of this dword before the pad byte (>= 1)
+            const uint32_t lowmask = nlow >= 4 ? 0xFFFFFFFFu : (1u << (8 * nlow)) - 1u;
+            ((uint32_t*)out)[d] = (va & lowmask) | (vb & ~lowmask);
+            off += STEP_BLOCK * 4 - 6 * OBS_BYTES; e37 += 6 * (OBS_PAD / 4);
+            if (off >= OBS_BYTES) { off -= OBS_BYTES; e37 += OBS_PAD / 4; }
         }
-        ((uint32_t*)out)[d] = v;
     }
     for (int b = (ndw << 2) + threadIdx.x; b < total; b += STEP_BLOCK) {
         int e = b / OBS_BYTES, off = b - e * OBS_BYTES;
@@ -611,9 +612,6 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
                                                  uint32_t* __restrict__ other_counter, uint8_t* __restrict__ tiles /* or NULL */, int prio,
                                                  uint8_t* __restrict__ vplane /* or NULL */, uint16_t* __restrict__ fcache) {
     if (prio) __builtin_amdgcn_s_setprio(3);
-    // the appearance plane of the wave's current env, parked while the record is copied: the window plane is cut out of it
-    __shared__ __attribute__((aligned(16))) uint8_t s_plane[4][GEN_ES * GEN_EH + 20];
-    uint8_t* plane = s_plane[threadIdx.x >> 6];
     const int64_t count = all ? n : (int64_t)counter[0];
     // this tick's entries go behind those of the window's earlier ticks (their counts were written by earlier
     // launches); no atomics: an env appears at most once per tick, repeats within the window are marked -1
@@ -628,12 +626,7 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
         const uint8_t* nrec = next_recs + ((int64_t)slot * n + env) * (int64_t)c.rec_bytes;
         const u32x4* src = (const u32x4*)nrec;
         u32x4* dst = (u32x4*)(recs + env * (int64_t)c.rec_bytes);
-        const int plane_vec = vplane ? (c.ES * c.EH + 15) >> 4 : 0;     // (the E plane is the head of the record)
-        for (int k = lane; k < nvec; k += 64) {
-            const u32x4 v = src[k];
-            dst[k] = v;
-            if (k < plane_vec) *(u32x4*)(plane + 16 * k) = v;
-        }
+        for (int k = lane; k < nvec; k += 64) dst[k] = src[k];
         // the verifier's SoA view of the new program
         const Prog* p = (const Prog*)(nrec + c.off_prog);
         if (lane < 8) vsets[(int64_t)lane * n + env] = p->set[lane >> 1][lane & 1];
@@ -649,11 +642,10 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
             if (p->start_carry != NONE8) sc = e_index(c, nrec[c.off_pos + 2 * p->start_carry], nrec[c.off_pos + 2 * p->start_carry + 1]);
             uint8_t* vrow = vplane + env * (int64_t)v_bytes(c);
             const int nseg = v_nxo(c) * v_nyo(c) * 8;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the wave's parked plane is complete (one wave: no barrier)
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            for (int sg = lane; sg < nseg; sg += 64) *(u32x4*)(vrow + (sg >> 3) * VLINE + (sg & 7) * 16) = v_segment(c, plane, sg >> 3, sg & 7, sc);
-            __builtin_amdgcn_wave_barrier();                             // (before the next env's copy overwrites the plane)
+            // (read back from the slot -- L2 hits right after the copy above.  Parking the plane in LDS instead was measured
+            // and dropped: any LDS at all makes k_consume's blocks queue behind the generator's waves for it -- GoToLocal
+            // 65 536 envs: k_consume 14 -> 38 us, profiles/r03/NOTES.md)
+            for (int sg = lane; sg < nseg; sg += 64) *(u32x4*)(vrow + (sg >> 3) * VLINE + (sg & 7) * 16) = v_segment(c, nrec, sg >> 3, sg & 7, sc);
             if (lane == 0) {
                 const int fi = e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir));
                 const uint32_t fe0 = fi == sc ? (uint32_t)E_EMPTY : nrec[fi];
@@ -1068,10 +1060,24 @@ static int create_finish(bbai_env* e) {
         HIP_TRY(hipMemset(e->fcache, 0, (size_t)n_envs * 2));
     }
     {
+        // The look-ahead stream.  BBAI_PREGEN_CUS = k (0 < k < all CUs): its kernels may only run on k CUs, spread evenly over
+        // the chip (a CU mask).  Generator waves are long-lived and hold LDS (5 KB per env in flight): wherever they sit,
+        // the step kernels' workgroups (38 KB of LDS each) queue for room.  Confining them keeps the other CUs clear.
         int lo = 0, hi = 0;     // look-ahead generation should get wave slots as soon as any free up
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         const char* pv = getenv("BBAI_PREGEN_PRIORITY");     // 1 (default): highest priority, 0: default priority
-        HIP_TRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, (pv && atoi(pv) == 0) ? lo : hi));
+        const char* cv = getenv("BBAI_PREGEN_CUS");
+        int cus = 0, want = cv ? atoi(cv) : PREGEN_CUS_DEFAULT;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+        if (want > 0 && want < cus) {
+            uint32_t mask[16] = {0};
+            for (int k = 0; k < want; ++k) { const int cu = (int)((int64_t)k * cus / want); mask[cu >> 5] |= 1u << (cu & 31); }
+            HIP_TRY(hipExtStreamCreateWithCUMask(&e->side, (uint32_t)((cus + 31) / 32), mask));
+            e->pregen_cus = want;
+        } else {
+            HIP_TRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, (pv && atoi(pv) == 0) ? lo : hi));
+            e->pregen_cus = cus;
+        }
         HIP_TRY(hipEventCreateWithFlags(&e->ev_consumed, hipEventDisableTiming));
         for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreateWithFlags(&e->ev_refill[k], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_switch, hipEventDisableTiming));

@@ -134,6 +134,7 @@ def parse_args(argv=None):
     ap.add_argument("--prewarm-seconds", type=float, default=1.0, help="untimed GPU activity before the warmup steps")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (test rigs: ranks may share a GPU)")
     ap.add_argument("--share-device", action="store_true", help="test rigs only: every rank uses cuda:0")
+    ap.add_argument("--own-stream", action="store_true", help="run the rollout on a stream of its own instead of torch's default (NULL) stream")
     ap.add_argument("--dump-digest", default=None, help="write per-env output digests of this rank to <prefix>.rank<r>.npy")
     args = ap.parse_args(argv)
     if args.gpus < 1:
@@ -227,6 +228,8 @@ def main():
 
     first, count = shard.shard_range(total_envs, world, rank)
     assert count == E
+    if args.own_stream:
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
     env = BatchedBabyAIEnv("BabyAI-%s-v0" % level, E, device=dev, pixel=pixel)
     env.seed(shard.shard_seeds(args.seed, total_envs, world, rank))
     K, W = args.steps, args.warmup
