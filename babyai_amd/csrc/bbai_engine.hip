@@ -119,7 +119,6 @@ struct bbai_env {
     int render_tpb;       // BBAI_RENDER_TPB: 256 / 512 / 1024 threads per render block; anything else = by batch size
     int render_group;     // BBAI_RENDER_GROUP: 2, 4 or 8 envs per one-shot render block; anything else = by batch size (bbai_render)
     int pregen_cap;       // BBAI_PREGEN_BLOCKS: upper bound on look-ahead lane groups per launch (experiments)
-    int pregen_cus;       // CUs the look-ahead stream may use (BBAI_PREGEN_CUS; all of them when no mask is set)
     int pregen_group;     // BBAI_PREGEN_GROUP: lanes per env in k_pregen: 32 (default: two envs per wave), 16 or 64
     int step_prio;        // BBAI_STEP_PRIO: s_setprio level of the step-path kernels' waves (they share CUs with k_pregen)
     // optional per-kernel timing (bbai_profile): HIP event pairs on the launch stream around k_step / k_consume / k_render
@@ -150,7 +149,6 @@ struct bbai_env {
 // k_step
 // ------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr int PREGEN_CUS_DEFAULT = 0;   // 0 = no CU mask on the look-ahead stream (BBAI_PREGEN_CUS overrides)
 constexpr int MAX_PERIOD = 32;          // refill period B (ticks per look-ahead refill); ring depth D = 2B
 constexpr int WIN_STRIDE = 64;          // uint32 per window-count block (1 + MAX_PERIOD used)
 constexpr int STEP_BLOCK = 256;
@@ -205,41 +203,33 @@ __device__ __forceinline__ void view_cells(const uint32_t* __restrict__ q, int r
         cp[idx >> 2] = (cp[idx >> 2] & ~(0xFFu << (8 * (idx & 3)))) | (ce << (8 * (idx & 3)));
     }
 }
+// Four cells at a time: a dword of (visibility-masked) appearance bytes e0..e3 becomes the 12 encoding bytes
+// t0 c0 s0 t1 | c1 s1 t2 c2 | s2 t3 c3 s3 (type = e & 7, colour = (e >> 3) & 7, state = e >> 6) with three field extractions on
+// the whole dword and six byte permutes (v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first,
+// 0x0C is zero) -- 11 instructions per four cells instead of ~55 shifting every channel byte into place on its own.
 template <bool EMIT>
 __device__ __forceinline__ void encode_view(const uint32_t* cp, const uint32_t* vis, uint8_t* __restrict__ row, uint32_t* mb) {
-    uint32_t od[37];
-#pragma unroll
-    for (int k = 0; k < 37; ++k) od[k] = 0;
-    if (EMIT) {
-        // the plane row = cp with the invisible cells zeroed: one byte-select mask per dword (v_perm-free: 4 bits -> 4 bytes)
-#pragma unroll
-        for (int k = 0; k < 13; ++k) {
-            uint32_t m = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int idx = 4 * k + b;
-                if (idx < VIEW * VIEW) m |= (vis[idx % VIEW] >> (idx / VIEW) & 1u) ? 0xFFu << (8 * b) : 0u;
-            }
-            mb[k] = cp[k] & m;
-        }
-    }
-#pragma unroll
-    for (int vi = 0; vi < VIEW; ++vi)
-#pragma unroll
-        for (int vj = 0; vj < VIEW; ++vj) {
-            const int idx = vi * VIEW + vj;
-            const uint32_t e = (cp[idx >> 2] >> (8 * (idx & 3))) & 0xFFu;
-            const uint32_t m = (vis[vj] >> vi & 1u) ? 0xFFu : 0u;
-            const uint32_t ch[3] = {(e & 7u) & m, ((e >> 3) & 7u) & m, (e >> 6) & m};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int b = 3 * idx + k;
-                od[b >> 2] |= ch[k] << (8 * (b & 3));
-            }
-        }
     uint32_t* o = (uint32_t*)row;
 #pragma unroll
-    for (int k = 0; k < 37; ++k) o[k] = od[k];
+    for (int k = 0; k < 13; ++k) {
+        // the cells of this dword that are visible: byte b <- bit (idx / 7) of vis[idx % 7], idx = 4k + b
+        uint32_t m = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int idx = 4 * k + b;
+            if (idx < VIEW * VIEW) m |= (uint32_t)__builtin_amdgcn_sbfe((int)vis[idx % VIEW], idx / VIEW, 1) & (0xFFu << (8 * b));   // v_bfe_i32: 0 / ~0
+        }
+        const uint32_t x = cp[k] & m;
+        if (EMIT) mb[k] = x;               // the plane row = the view with the invisible cells zeroed
+        const uint32_t t = x & 0x07070707u, c = (x >> 3) & 0x07070707u, st = (x >> 6) & 0x03030303u;
+        if (k < 12) {
+            o[3 * k] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(t, c, 0x050C0004u), st, 0x07000504u);
+            o[3 * k + 1] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(c, st, 0x060C0105u), t, 0x07020504u);
+            o[3 * k + 2] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(st, t, 0x070C0306u), c, 0x07030504u);
+        } else {
+            o[36] = (t & 0xFFu) | ((c & 0xFFu) << 8) | ((st & 0xFFu) << 16);      // cell 48: three bytes, the row's last dword
+        }
+    }
 }
 
 // Wave-cooperative observation of ONE env (used where a wave owns an env: k_consume): lane l < 49 owns view cell
@@ -1060,24 +1050,14 @@ static int create_finish(bbai_env* e) {
         HIP_TRY(hipMemset(e->fcache, 0, (size_t)n_envs * 2));
     }
     {
-        // The look-ahead stream.  BBAI_PREGEN_CUS = k (0 < k < all CUs): its kernels may only run on k CUs, spread evenly over
-        // the chip (a CU mask).  Generator waves are long-lived and hold LDS (5 KB per env in flight): wherever they sit,
-        // the step kernels' workgroups (38 KB of LDS each) queue for room.  Confining them keeps the other CUs clear.
+        // The look-ahead stream.  (Confining it to a subset of the CUs with a CU mask was measured in round 3 --
+        // profiles/r03/pregen_cus_ab.jsonl: 32 / 64 / 96 / 128 CUs change no step time by more than 1 %, and a masked stream is a
+        // BLOCKING stream: with a caller on the NULL stream it serialises generation and stepping, 46 -> 72 us per step at
+        // 65 536 GoToLocal envs.  Not kept.)
         int lo = 0, hi = 0;     // look-ahead generation should get wave slots as soon as any free up
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         const char* pv = getenv("BBAI_PREGEN_PRIORITY");     // 1 (default): highest priority, 0: default priority
-        const char* cv = getenv("BBAI_PREGEN_CUS");
-        int cus = 0, want = cv ? atoi(cv) : PREGEN_CUS_DEFAULT;
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
-        if (want > 0 && want < cus) {
-            uint32_t mask[16] = {0};
-            for (int k = 0; k < want; ++k) { const int cu = (int)((int64_t)k * cus / want); mask[cu >> 5] |= 1u << (cu & 31); }
-            HIP_TRY(hipExtStreamCreateWithCUMask(&e->side, (uint32_t)((cus + 31) / 32), mask));
-            e->pregen_cus = want;
-        } else {
-            HIP_TRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, (pv && atoi(pv) == 0) ? lo : hi));
-            e->pregen_cus = cus;
-        }
+        HIP_TRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, (pv && atoi(pv) == 0) ? lo : hi));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_consumed, hipEventDisableTiming));
         for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreateWithFlags(&e->ev_refill[k], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_switch, hipEventDisableTiming));

@@ -1,32 +1,49 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun), ONE lease: the judged bench line, the rocprofv3 kernel trace of the same command, the
-# HBM counter passes, the BASELINE configs at their per-GPU sizes, and the microbenchmarks the design notes quote.
+# Run on the GPU box (via gpurun), ONE lease: the GPU suite, the judged bench line, the rocprofv3 kernel trace of the same
+# command, the HBM counter passes, the BASELINE configs at their per-GPU sizes, the self-launched multi-rank line, generator
+# and expert rates, a short soak.
 # usage: tools/gpu_profile.sh <round-tag>      then, in the build container:  python tools/summarize_profile.py <round-tag>
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+cd $REPO
+timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests_final.log 2>&1; echo "tests rc=$?" >> $OUT/gpu_tests_final.log
+tail -3 $OUT/gpu_tests_final.log
 cd /tmp && export TMPDIR=/tmp
 B="python $REPO/bench.py --steps 20 --warmup 5"
 timeout 900 $B > $OUT/bench_boss_pixel_1M.json 2> $OUT/bench_boss_pixel_1M.err
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o boss -- $B --no-cpu-baseline --parity-envs 0 > $OUT/bench_boss_pixel_1M_under_rocprof.json 2> $OUT/rocprof_stats.log
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o boss -- $B --no-cpu-baseline --parity-envs 0 --min-seconds 0 > $OUT/rocprof_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o boss -- $B --no-cpu-baseline --parity-envs 0 --min-seconds 0 > $OUT/rocprof_write.log 2>&1
-timeout 600 python $REPO/bench.py --steps 64 --warmup 8 --no-pixel --no-cpu-baseline > $OUT/bench_boss_encoded_1M.json 2>> $OUT/bench.err
-timeout 600 python $REPO/bench.py --config C2 --steps 256 --warmup 16 --no-cpu-baseline > $OUT/bench_gotolocal_65536.json 2>> $OUT/bench.err
-timeout 600 python $REPO/bench.py --config C3 --steps 128 --warmup 16 --no-cpu-baseline > $OUT/bench_pickuploc_262144.json 2>> $OUT/bench.err
-timeout 600 python $REPO/bench.py --config C4 --steps 128 --warmup 16 --no-cpu-baseline > $OUT/bench_goto_131072.json 2>> $OUT/bench.err
-timeout 600 python $REPO/bench.py --config C5 --steps 64 --warmup 8 --no-cpu-baseline > $OUT/bench_boss_pixel_131072.json 2>> $OUT/bench.err
+timeout 600 python $REPO/bench.py --steps 64 --warmup 8 --no-pixel --cpu-baseline-seconds 4 > $OUT/bench_boss_encoded_1M.json 2>> $OUT/bench.err
+timeout 600 python $REPO/bench.py --config C2 --steps 256 --warmup 16 --cpu-baseline-seconds 4 > $OUT/bench_gotolocal_65536.json 2>> $OUT/bench.err
+timeout 600 python $REPO/bench.py --config C3 --steps 128 --warmup 16 --cpu-baseline-seconds 4 > $OUT/bench_pickuploc_262144.json 2>> $OUT/bench.err
+timeout 600 python $REPO/bench.py --config C4-shard --steps 128 --warmup 16 --cpu-baseline-seconds 4 > $OUT/bench_goto_131072.json 2>> $OUT/bench.err
+timeout 600 python $REPO/bench.py --config C5-shard --steps 64 --warmup 8 --no-cpu-baseline > $OUT/bench_boss_pixel_131072.json 2>> $OUT/bench.err
 cd $REPO
+timeout 600 python bench.py --gpus 4 --share-device --dist-backend gloo --total-envs 262144 --steps 32 --warmup 8 --min-seconds 0.3 --cpu-baseline-seconds 3 --parity-envs 256 > $OUT/bench_selflaunch_4ranks_one_gpu.json 2> $OUT/bench_selflaunch.err
 timeout 120 python tools/membw.py > $OUT/membw.json 2> $OUT/membw.err
-timeout 200 tools/ubench_gather > $OUT/ubench_gather.jsonl 2> $OUT/ubench_gather.err
-timeout 300 tools/ubench_render > $OUT/ubench_render.jsonl 2> $OUT/ubench_render.err
-timeout 200 tools/ubench_store > $OUT/ubench_store.txt 2> $OUT/ubench_store.err
+timeout 300 python tools/gen_rate.py > $OUT/gen_rate.jsonl 2> $OUT/gen_rate.err
+for job in "BossLevel 1048576 60" "BossLevel 262144 120" "GoTo 131072 150" "PickupLoc 262144 150" "GoToLocal 65536 200"; do
+  timeout 300 python tools/bot_bench.py $job >> $OUT/bot_bench.jsonl 2>> $OUT/bot_bench.err
+done
+timeout 600 python - > $OUT/soak_random.txt 2>&1 <<PY
+import sys
+sys.path.insert(0, "$REPO/tools"); sys.path.insert(0, "$REPO")
+import gpu_soak
+bad = 0
+for level, n, T in (("BossLevel", 1048576, 200), ("GoToLocal", 65536, 400), ("PickupLoc", 262144, 300), ("GoTo", 131072, 300), ("PutNextS5N2Carrying", 65536, 300), ("KeyInBox", 65536, 300), ("SynthSeq", 131072, 200)):
+    bad += gpu_soak.soak(level, n, T, 48, 12345)
+print("soak mismatches:", bad)
+PY
+tail -9 $OUT/soak_random.txt
 # keep the merged payload small: traces can be large
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
-ls -la $OUT $OUT/stats 2>/dev/null | head -40
 for f in $OUT/bench_*.json; do echo "== $f"; python -c "
 import json,sys
 d=json.loads(open('$f').read().strip().splitlines()[-1])
-print(round(d['value']/1e6,1),'M steps/s', round(d['ms_per_step'],4),'ms/step', 'frac', round(d['roofline']['frac'],3), 'of achievable', d['roofline']['frac_of_achievable'], 'parity', (d['parity'] or {}).get('mismatches'), 'kernels', d['roofline']['kernel_avg_ms'])
+print(round(d['value']/1e6,1),'M steps/s', round(d['ms_per_step'],4),'ms/step', 'frac', round(d['roofline']['frac'],3), 'of achievable', d['roofline']['frac_of_achievable'], 'parity', (d['parity'] or {}).get('mismatches_all_ranks'), 'kernels', d['roofline']['kernel_avg_ms'], 'cpu', (d.get('cpu_baseline') or {}).get('value'))
 "; done
+cat $OUT/gen_rate.jsonl $OUT/bot_bench.jsonl
