@@ -22,6 +22,11 @@ timeout 600 python $REPO/bench.py --config C2 --steps 256 --warmup 16 --cpu-base
 timeout 600 python $REPO/bench.py --config C3 --steps 128 --warmup 16 --cpu-baseline-seconds 4 > $OUT/bench_pickuploc_262144.json 2>> $OUT/bench.err
 timeout 600 python $REPO/bench.py --config C4-shard --steps 128 --warmup 16 --cpu-baseline-seconds 4 > $OUT/bench_goto_131072.json 2>> $OUT/bench.err
 timeout 600 python $REPO/bench.py --config C5-shard --steps 64 --warmup 8 --no-cpu-baseline > $OUT/bench_boss_pixel_131072.json 2>> $OUT/bench.err
+for rep in 1 2; do for vp in 1 0; do
+  BBAI_VPLANE=$vp timeout 300 python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --parity-envs 128 --min-seconds 1.0 2>>$OUT/bench.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps({'vplane': $vp, 'config': 'boss_pixel_1M', 'ms_per_step': d['ms_per_step'], 'value': d['value'], 'parity': d['parity']['mismatches_all_ranks'], 'kernels': d['roofline']['kernel_avg_ms']}))" >> $OUT/vplane_ab_final.jsonl
+done; done
 cd $REPO
 timeout 600 python bench.py --gpus 4 --share-device --dist-backend gloo --total-envs 262144 --steps 32 --warmup 8 --min-seconds 0.3 --cpu-baseline-seconds 3 --parity-envs 256 > $OUT/bench_selflaunch_4ranks_one_gpu.json 2> $OUT/bench_selflaunch.err
 timeout 120 python tools/membw.py > $OUT/membw.json 2> $OUT/membw.err
