@@ -416,7 +416,7 @@ __global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, i
             const uint32_t vb = __builtin_amdgcn_alignbyte(sh == 3 ? d2 : d1, sh == 3 ? d1 : d0, (sh + 1) & 3);   // bytes A+1 .. A+4
             const int nlow = OBS_BYTES - off;                             // bytes of this dword before the pad byte (>= 1)
             const uint32_t lowmask = nlow >= 4 ? 0xFFFFFFFFu : (1u << (8 * nlow)) - 1u;
-            ((uint32_t*)out)[d] = (va & lowmask) | (vb & ~lowmask);
+            ((uint32_t*)out)[d] = (va & lowmask) | (vb & ~lowmask);      // (non-temporal here: measured, no effect -- profiles/r03/NOTES.md)
             off += STEP_BLOCK * 4 - 6 * OBS_BYTES; e37 += 6 * (OBS_PAD / 4);
             if (off >= OBS_BYTES) { off -= OBS_BYTES; e37 += OBS_PAD / 4; }
         }
