@@ -152,13 +152,13 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int MAX_PERIOD = 32;          // refill period B (ticks per look-ahead refill); ring depth D = 2B
 constexpr int WIN_STRIDE = 64;          // uint32 per window-count block (1 + MAX_PERIOD used)
 constexpr int STEP_BLOCK = 256;
-constexpr int OBS_PAD = 148;           // LDS row per env (bytes), dword multiple
 
 // Observation with the 7x7 window staged in LDS (the k_step path).  49 scattered byte loads per lane keep the
 // texture-address unit busy for most of k_step (tools/step_ab.py ablation), so the window is fetched in WORLD
-// orientation as 7 rows x 3 aligned dwords, byte-aligned with v_alignbyte, parked in the tail of the lane's own
-// LDS obs row, and read back in VIEW orientation (rotation = per-direction address arithmetic on ds_read_u8).
-// All of a lane's reads precede its writes and lanes only touch their own row, so no barrier is needed here.
+// orientation as 7 rows x 3 aligned dwords, byte-aligned with v_alignbyte, parked in 56 dword-aligned bytes inside the
+// lane's own LDS obs row (`scr`, bbai_step.hpp row_scratch), and read back in VIEW orientation (rotation = per-direction
+// address arithmetic on ds_read_u8).  All of a lane's reads precede its writes and lanes only touch bytes of their own
+// row, so no barrier is needed here.
 // `mb` (optional, EMIT): the same view as ONE byte per cell -- the appearance byte where the cell is visible, 0 where it is
 // not -- 49 bytes in view order [vi][vj] + 3 zero bytes: the pixel render's input (TILE_PITCH bytes per env).
 // The window's rows come from `q` (first aligned dword of row 0), `rstride` dwords apart, `off` = byte offset of the
@@ -171,8 +171,8 @@ constexpr int64_t FUSED_MIN_ENVS = 786432;      // batches from this size up kee
 // live yet: view_cells fetches and rotates the window (cp = the 49 cells, vis = visibility rows), encode_view writes the
 // encoding (and the plane row) from them.
 __device__ __forceinline__ void view_cells(const uint32_t* __restrict__ q, int rstride, int off, int dir, uint32_t ce,
-                                           uint8_t* __restrict__ row /* this lane's OBS_PAD-byte LDS row */, uint32_t* cp, uint32_t* vis, int& fe2) {
-    uint32_t* win = (uint32_t*)(row + 88);                   // 7 rows x 8 bytes, dword aligned (row = tid * 148)
+                                           uint8_t* __restrict__ scr /* this lane's 56 bytes of LDS scratch */, uint32_t* cp, uint32_t* vis, int& fe2) {
+    uint32_t* win = (uint32_t*)scr;                          // 7 rows x 8 bytes, dword aligned
 #pragma unroll
     for (int r = 0; r < VIEW; ++r) {
         const uint32_t d0 = q[r * rstride], d1 = q[r * rstride + 1], d2 = q[r * rstride + 2];
@@ -183,7 +183,7 @@ __device__ __forceinline__ void view_cells(const uint32_t* __restrict__ q, int r
     const int k0 = dir == 0 ? 6 : dir == 1 ? 54 : dir == 2 ? 48 : 0;
     const int kvi = dir == 0 ? 8 : dir == 1 ? -1 : dir == 2 ? -8 : 1;
     const int kvj = dir == 0 ? -1 : dir == 1 ? -8 : dir == 2 ? 1 : 8;
-    const uint8_t* wb = row + 88 + k0;
+    const uint8_t* wb = scr + k0;
 #pragma unroll
     for (int k = 0; k < 13; ++k) cp[k] = 0;                      // the 49 cells, 4 per dword, view order [vi][vj]
     uint32_t opq[VIEW] = {0, 0, 0, 0, 0, 0, 0};
@@ -208,8 +208,7 @@ __device__ __forceinline__ void view_cells(const uint32_t* __restrict__ q, int r
 // the whole dword and six byte permutes (v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first,
 // 0x0C is zero) -- 11 instructions per four cells instead of ~55 shifting every channel byte into place on its own.
 template <bool EMIT>
-__device__ __forceinline__ void encode_view(const uint32_t* cp, const uint32_t* vis, uint8_t* __restrict__ row, uint32_t* mb) {
-    uint32_t* o = (uint32_t*)row;
+__device__ __forceinline__ void encode_view(const uint32_t* cp, const uint32_t* vis, RowPacker o, uint32_t* mb) {
 #pragma unroll
     for (int k = 0; k < 13; ++k) {
         // the cells of this dword that are visible: byte b <- bit (idx / 7) of vis[idx % 7], idx = 4k + b
@@ -223,13 +222,14 @@ __device__ __forceinline__ void encode_view(const uint32_t* cp, const uint32_t* 
         if (EMIT) mb[k] = x;               // the plane row = the view with the invisible cells zeroed
         const uint32_t t = x & 0x07070707u, c = (x >> 3) & 0x07070707u, st = (x >> 6) & 0x03030303u;
         if (k < 12) {
-            o[3 * k] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(t, c, 0x050C0004u), st, 0x07000504u);
-            o[3 * k + 1] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(c, st, 0x060C0105u), t, 0x07020504u);
-            o[3 * k + 2] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(st, t, 0x070C0306u), c, 0x07030504u);
+            o.put(3 * k, __builtin_amdgcn_perm(__builtin_amdgcn_perm(t, c, 0x050C0004u), st, 0x07000504u));
+            o.put(3 * k + 1, __builtin_amdgcn_perm(__builtin_amdgcn_perm(c, st, 0x060C0105u), t, 0x07020504u));
+            o.put(3 * k + 2, __builtin_amdgcn_perm(__builtin_amdgcn_perm(st, t, 0x070C0306u), c, 0x07030504u));
         } else {
-            o[36] = (t & 0xFFu) | ((c & 0xFFu) << 8) | ((st & 0xFFu) << 16);      // cell 48: three bytes, the row's last dword
+            o.put(36, (t & 0xFFu) | ((c & 0xFFu) << 8) | ((st & 0xFFu) << 16));   // cell 48: three bytes, the row's last dword
         }
     }
+    o.finish();
 }
 
 // Wave-cooperative observation of ONE env (used where a wave owns an env: k_consume): lane l < 49 owns view cell
@@ -306,7 +306,9 @@ __global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, i
                                                      int32_t* __restrict__ reset_list, uint32_t* __restrict__ counters,
                                                      uint8_t* __restrict__ tiles /* EMIT: [n][TILE_PITCH] render input */, int prio,
                                                      uint8_t* __restrict__ vplane, uint16_t* __restrict__ fcache) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_obs[STEP_BLOCK * OBS_PAD + 16];      // (+16: the copy-out reads one dword ahead)
+    // the block's 256 observation rows at the OUTPUT pitch of 147 bytes (bbai_step.hpp RowPacker), 16 bytes of front padding
+    __shared__ __attribute__((aligned(16))) uint8_t s_obs[ROWS_FRONT + STEP_BLOCK * OBS_BYTES + 16];
+    uint8_t* const s_rows = s_obs + ROWS_FRONT;
     if (prio) __builtin_amdgcn_s_setprio(3);            // the look-ahead generator's waves share the CUs: issue ours first
     uint32_t mb[13];
     const int64_t env0 = (int64_t)blockIdx.x * STEP_BLOCK;
@@ -344,10 +346,10 @@ __global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, i
             uint32_t cp[13], vis[VIEW];
             if (VP) {
                 const uint8_t* line = vrow + ((tym >> 1) * v_nxo(c) + (txm >> 3)) * VLINE + (tym & 1) * 16 + (txm & 4);
-                view_cells((const uint32_t*)line, 4, txm & 3, dir, (uint32_t)ce, s_obs + threadIdx.x * OBS_PAD, cp, vis, fe2);
+                view_cells((const uint32_t*)line, 4, txm & 3, dir, (uint32_t)ce, s_rows + row_scratch(threadIdx.x), cp, vis, fe2);
             } else {
                 const int a0 = tym * c.ES + txm;                         // same for every row: ES is a multiple of 4
-                view_cells((const uint32_t*)(rec + (a0 & ~3)), c.ES >> 2, a0 & 3, dir, (uint32_t)ce, s_obs + threadIdx.x * OBS_PAD, cp, vis, fe2);
+                view_cells((const uint32_t*)(rec + (a0 & ~3)), c.ES >> 2, a0 & 3, dir, (uint32_t)ce, s_rows + row_scratch(threadIdx.x), cp, vis, fe2);
             }
             // "env.reset() for THIS env, now" (A_RESET_ENV, bbai_step.hpp): the episode ends with done = 1, reward = 0
             const bool done = action == A_RESET_ENV ? true : finish_step(c, r, h, stale, action, fe2, reward);
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, i
             if (rewards64) rewards64[env] = reward;        // the reference's Python float, bit for bit (levelgen.py:59-61)
             dones[env] = done ? 1 : 0;
             dirs[env] = h.dir;
-            encode_view<EMIT>(cp, vis, s_obs + threadIdx.x * OBS_PAD, mb);
+            encode_view<EMIT>(cp, vis, RowPacker(s_rows, threadIdx.x), mb);
         }
         // frozen envs keep re-emitting their last outputs: copy them through LDS unchanged
         else {
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, i
                 want_reset = true;
             }
             const uint8_t* src = image + env * OBS_BYTES;
-            for (int b = 0; b < OBS_BYTES; ++b) s_obs[threadIdx.x * OBS_PAD + b] = src[b];
+            for (int b = 0; b < OBS_BYTES; ++b) s_rows[threadIdx.x * OBS_BYTES + b] = src[b];
             if (EMIT) {      // the plane row of a frozen env is re-derived from its (caller-kept) encoding: type | colour << 3 | state << 6
 #pragma unroll
                 for (int k = 0; k < 13; ++k) mb[k] = 0;
@@ -396,34 +398,27 @@ __global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, i
         }
     }
     __syncthreads();
-    // cooperative, dword-coalesced write of the block's contiguous obs span.  LDS rows are 148 B apart, the output is
-    // 147-B packed: output dword d starts at byte off = 4d % 147 of row e = 4d / 147, i.e. at LDS byte A = 148 e + off, and
-    // its byte k sits at A + k, one further once the row's pad byte is crossed (off + k >= 147).  Branch-free: the four
-    // bytes at A and the four at A + 1 (funnel shifts of three aligned LDS dwords) blended by the crossing point; e / off
-    // advance incrementally (a thread's next dword is 1024 bytes = 6 rows + 142 bytes on): no division in the loop.
+    // the block's contiguous obs span leaves as it lies in LDS: 16 bytes per lane per store (256 x 147 B = 2352 x 16 B; the
+    // span of every full block starts 16-byte aligned in the output).  The last, partial block ends with a byte tail.
     const int64_t nb = n - env0 < STEP_BLOCK ? n - env0 : STEP_BLOCK;      // envs in this block
     const int total = (int)nb * OBS_BYTES;
-    uint8_t* out = image + env0 * OBS_BYTES;                              // 256*147 is a dword multiple
-    const int ndw = total >> 2;
-    const uint32_t* s_obs32 = (const uint32_t*)s_obs;
+    uint8_t* out = image + env0 * OBS_BYTES;
     {
-        int e37 = (4 * (int)threadIdx.x / OBS_BYTES), off = 4 * (int)threadIdx.x - e37 * OBS_BYTES;
-        e37 *= OBS_PAD / 4;                                               // first LDS dword of the row
-        for (int d = threadIdx.x; d < ndw; d += STEP_BLOCK) {
-            const int q = e37 + (off >> 2), sh = off & 3;
-            const uint32_t d0 = s_obs32[q], d1 = s_obs32[q + 1], d2 = s_obs32[q + 2];
-            const uint32_t va = __builtin_amdgcn_alignbyte(d1, d0, sh);                                   // bytes A .. A+3
-            const uint32_t vb = __builtin_amdgcn_alignbyte(sh == 3 ? d2 : d1, sh == 3 ? d1 : d0, (sh + 1) & 3);   // bytes A+1 .. A+4
-            const int nlow = OBS_BYTES - off;                             // bytes of this dword before the pad byte (>= 1)
-            const uint32_t lowmask = nlow >= 4 ? 0xFFFFFFFFu : (1u << (8 * nlow)) - 1u;
-            ((uint32_t*)out)[d] = (va & lowmask) | (vb & ~lowmask);      // (non-temporal here: measured, no effect -- profiles/r03/NOTES.md)
-            off += STEP_BLOCK * 4 - 6 * OBS_BYTES; e37 += 6 * (OBS_PAD / 4);
-            if (off >= OBS_BYTES) { off -= OBS_BYTES; e37 += OBS_PAD / 4; }
+        // (a caller's buffer that is not 16-byte aligned -- a row of a [T][n][147] history with odd n -- gets dwords or bytes)
+        const int al = (int)((uintptr_t)out & 15);
+        int done_bytes = 0;
+        if (al == 0) {
+            const int nvec = total >> 4;
+            const u32x4* s128 = (const u32x4*)s_rows;
+            for (int v = threadIdx.x; v < nvec; v += STEP_BLOCK) ((u32x4*)out)[v] = s128[v];     // (non-temporal here: measured, no effect -- profiles/r03/NOTES.md)
+            done_bytes = nvec << 4;
+        } else if ((al & 3) == 0) {
+            const int ndw = total >> 2;
+            const uint32_t* s32 = (const uint32_t*)s_rows;
+            for (int d = threadIdx.x; d < ndw; d += STEP_BLOCK) ((uint32_t*)out)[d] = s32[d];
+            done_bytes = ndw << 2;
         }
-    }
-    for (int b = (ndw << 2) + threadIdx.x; b < total; b += STEP_BLOCK) {
-        int e = b / OBS_BYTES, off = b - e * OBS_BYTES;
-        out[b] = s_obs[e * OBS_PAD + off];
+        for (int b = done_bytes + threadIdx.x; b < total; b += STEP_BLOCK) out[b] = s_rows[b];
     }
     if (EMIT) {
         // second pass through the same LDS: the block's tile-plane rows (52 B per env, LDS pitch == output pitch) leave as
@@ -703,7 +698,9 @@ template <int WAVES_PER_SIMD>
 __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_bot(LevelCfg c, int64_t n, const uint8_t* __restrict__ recs, const Hot* __restrict__ hots,
                                             const uint64_t* __restrict__ stales, uint8_t* __restrict__ states, int stack_cap,
                                             uint16_t* __restrict__ works, uint32_t* __restrict__ slow_rows, int eager, const uint8_t* __restrict__ prev_actions,
-                                            uint8_t* __restrict__ out, unsigned long long* __restrict__ stats) {
+                                            uint8_t* __restrict__ out, unsigned long long* __restrict__ stats,
+                                            int dead_action /* what a bot that gave up emits: BOT_DEAD, or A_RESET_ENV in a rollout */,
+                                            uint8_t* __restrict__ gave_up /* or NULL: [n] 1 where the bot gave up at this decision */) {
     // the searches' hot row masks (expandable / queued / seen), [row][lane] in LDS: every lane on its own bank
     extern __shared__ uint32_t s_rows[];              // [R_FAST][H][64] row masks, then the queue ring uint16 [BOT_RING][64]
     uint16_t* s_ring = (uint16_t*)(s_rows + R_FAST * c.H * 64);
@@ -721,13 +718,14 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_bot(LevelCfg c, int64_t 
     w.stride = 1;
     for (int64_t i = tid; i < n; i += nthreads) {
         const Hot h = hots[i];
-        if (h.frozen) { out[i] = A_DONE; continue; }
+        if (h.frozen) { out[i] = A_DONE; if (gave_up) gave_up[i] = 0; continue; }
         BotState& st = *(BotState*)(states + i * (int64_t)bot_state_bytes(stack_cap));
         const bool first = h.step == 0 || st.next_step != h.step;       // (bot_decide applies the same rule)
         const int taken = (prev_actions && !first) ? prev_actions[i] : -1;
         const bool was_dead = !first && st.dead;
         const int a = bot_decide(c, recs + i * (int64_t)c.rec_bytes, h, stales[i], st, stack_cap, w, first, taken);
-        out[i] = (uint8_t)a;
+        out[i] = (uint8_t)(a == BOT_DEAD ? dead_action : a);
+        if (gave_up) gave_up[i] = a == BOT_DEAD ? 1 : 0;
         if (a == BOT_DEAD && !was_dead) atomicAdd(&stats[st.dead == DEAD_CAPACITY ? 1 : 0], 1ull);
     }
 }
@@ -1275,17 +1273,9 @@ int bbai_reset(bbai_env* e, uint8_t* image, uint8_t* dirs, void* stream) {
     return leave_call(e, s);
 }
 
-int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64,
-              uint8_t* dones, int auto_reset, void* stream) {
-    if (!e || !actions || !image || !dirs || !rewards || !dones) ARG_FAIL("null handle or buffer");
-    if (!e->live) { snprintf(g_err, sizeof(g_err), "step before reset"); return BBAI_ERR_STATE; }
-    if (auto_reset && !e->seeded) {     // live through import_state only: there is no level stream to reset from
-        snprintf(g_err, sizeof(g_err), "auto-reset step before seed");
-        return BBAI_ERR_STATE;
-    }
-    ON_DEVICE(e->device);
-    hipStream_t s = (hipStream_t)stream;
-    { int rc = enter_call(e, s); if (rc != BBAI_OK) return rc; }
+// k_step (+ the consume / refill of the envs it finished) on stream s; the caller has entered the call
+static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64,
+                       uint8_t* dones, int auto_reset, hipStream_t s) {
     int32_t* list = e->reset_list;
     uint32_t* counter = e->counters + 16 * e->step_parity;
     if (!e->next_counter_clean) HIP_TRY(hipMemsetAsync(counter, 0, 4, s));   // (k_consume of the previous step zeroes it)
@@ -1303,6 +1293,21 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
     HIP_TRY(hipGetLastError());
     // the number of finished envs is only known on the device: fixed grids, device-side count
     if (auto_reset) { int rc = consume_and_refill(e, s, image, dirs, 0); if (rc != BBAI_OK) return rc; }
+    return BBAI_OK;
+}
+
+int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64,
+              uint8_t* dones, int auto_reset, void* stream) {
+    if (!e || !actions || !image || !dirs || !rewards || !dones) ARG_FAIL("null handle or buffer");
+    if (!e->live) { snprintf(g_err, sizeof(g_err), "step before reset"); return BBAI_ERR_STATE; }
+    if (auto_reset && !e->seeded) {     // live through import_state only: there is no level stream to reset from
+        snprintf(g_err, sizeof(g_err), "auto-reset step before seed");
+        return BBAI_ERR_STATE;
+    }
+    ON_DEVICE(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    { int rc = enter_call(e, s); if (rc != BBAI_OK) return rc; }
+    { int rc = step_launch(e, actions, image, dirs, rewards, rewards64, dones, auto_reset, s); if (rc != BBAI_OK) return rc; }
     return leave_call(e, s);
 }
 
@@ -1551,10 +1556,8 @@ static int bot_alloc(bbai_env* e, int cap) {             // the expert's state: 
     return BBAI_OK;
 }
 
-int bbai_bot_act(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions, void* stream) {
-    if (!e || !actions) ARG_FAIL("null handle or output buffer");
-    if (!e->live) { snprintf(g_err, sizeof(g_err), "bot_act before reset"); return BBAI_ERR_STATE; }
-    ON_DEVICE(e->device);
+// k_bot on stream s (allocates the expert's state on first use); the caller has entered the call
+static int bot_launch(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions, int dead_action, uint8_t* gave_up, hipStream_t s) {
     if (!e->bot_state) {                                   // first use
         // Subgoal stack depth per env.  The reference's list is unbounded; 48 covers every plan that makes progress (the
         // rare bot that loops without progress grows its stack until max_steps and fails the episode -- here it gives up
@@ -1563,25 +1566,55 @@ int bbai_bot_act(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions, voi
         int rc = bot_alloc(e, ev ? std::max(8, std::min(atoi(ev), 4096)) : BOT_STACK);
         if (rc != BBAI_OK) return rc;
     }
-    {
-        // Occupancy target, measured (profiles/r01/bot_bench.jsonl): the fully inlined expert wants ~400
-        // registers; capping it at 256 (2 waves/SIMD, spills to scratch) is +35 % on maze levels (BossLevel 1M envs 22.8 ->
-        // 17.0 ms) and -10 % on single rooms, 128 registers (4 waves/SIMD) loses everywhere, real calls instead of inlining too.
-        const bool maze = e->cfg.num_rows * e->cfg.num_cols > 1;
-        const dim3 grid((unsigned)(e->bot_threads / 64)), block(64);
-        hipStream_t s = (hipStream_t)stream;
-        { int rc = enter_call(e, s); if (rc != BBAI_OK) return rc; }
-        unsigned long long* stats = (unsigned long long*)e->bot_stats;
-        const size_t lds = (size_t)R_FAST * e->cfg.H * 64 * 4 + (size_t)BOT_RING * 64 * 2;     // BossLevel: 11.3 + 8 KB -> 8 waves per CU
-        if (maze)
-            hipLaunchKernelGGL(k_bot<2>, grid, block, lds, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
-                               e->bot_rows, e->bot_eager, prev_actions, actions, stats);
-        else
-            hipLaunchKernelGGL(k_bot<1>, grid, block, lds, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
-                               e->bot_rows, e->bot_eager, prev_actions, actions, stats);
-    }
+    // Occupancy target, measured (profiles/r01/bot_bench.jsonl): the fully inlined expert wants ~400
+    // registers; capping it at 256 (2 waves/SIMD, spills to scratch) is +35 % on maze levels (BossLevel 1M envs 22.8 ->
+    // 17.0 ms) and -10 % on single rooms, 128 registers (4 waves/SIMD) loses everywhere, real calls instead of inlining too.
+    const bool maze = e->cfg.num_rows * e->cfg.num_cols > 1;
+    const dim3 grid((unsigned)(e->bot_threads / 64)), block(64);
+    unsigned long long* stats = (unsigned long long*)e->bot_stats;
+    const size_t lds = (size_t)R_FAST * e->cfg.H * 64 * 4 + (size_t)BOT_RING * 64 * 2;     // BossLevel: 11.3 + 8 KB -> 8 waves per CU
+    if (maze)
+        hipLaunchKernelGGL(k_bot<2>, grid, block, lds, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
+                           e->bot_rows, e->bot_eager, prev_actions, actions, stats, dead_action, gave_up);
+    else
+        hipLaunchKernelGGL(k_bot<1>, grid, block, lds, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
+                           e->bot_rows, e->bot_eager, prev_actions, actions, stats, dead_action, gave_up);
     HIP_TRY(hipGetLastError());
-    return leave_call(e, (hipStream_t)stream);
+    return BBAI_OK;
+}
+
+int bbai_bot_act(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions, void* stream) {
+    if (!e || !actions) ARG_FAIL("null handle or output buffer");
+    if (!e->live) { snprintf(g_err, sizeof(g_err), "bot_act before reset"); return BBAI_ERR_STATE; }
+    ON_DEVICE(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    { int rc = enter_call(e, s); if (rc != BBAI_OK) return rc; }
+    { int rc = bot_launch(e, prev_actions, actions, BOT_DEAD, nullptr, s); if (rc != BBAI_OK) return rc; }
+    return leave_call(e, s);
+}
+
+// T expert decisions + steps with no host round trip in between (the inner loop of generate_demos).
+int bbai_bot_rollout(bbai_env* e, int T, uint8_t* image, uint8_t* dirs, uint8_t* images_out, uint8_t* dirs_out, uint8_t* tokens_out,
+                     uint8_t* actions_out, float* rewards_out, uint8_t* dones_out, uint8_t* gave_up_out, void* stream) {
+    if (!e || T < 1 || !image || !dirs || !images_out || !dirs_out || !actions_out || !rewards_out || !dones_out || !gave_up_out)
+        ARG_FAIL("null handle or buffer, or T < 1");
+    if (!e->live || !e->seeded) { snprintf(g_err, sizeof(g_err), "bot_rollout before seed + reset"); return BBAI_ERR_STATE; }
+    if (tokens_out && !e->tokens) { snprintf(g_err, sizeof(g_err), "bot_rollout: tokens_out needs a registered token buffer (bbai_set_token_buffer)"); return BBAI_ERR_STATE; }
+    ON_DEVICE(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    { int rc = enter_call(e, s); if (rc != BBAI_OK) return rc; }
+    const size_t n = (size_t)e->n;
+    for (int t = 0; t < T; ++t) {
+        // what the expert decides on: the observation (and mission) BEFORE the step
+        HIP_TRY(hipMemcpyAsync(images_out + (size_t)t * n * OBS_BYTES, image, n * OBS_BYTES, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dirs_out + (size_t)t * n, dirs, n, hipMemcpyDeviceToDevice, s));
+        if (tokens_out) HIP_TRY(hipMemcpyAsync(tokens_out + (size_t)t * n * TOK_MAX, e->tokens, n * TOK_MAX, hipMemcpyDeviceToDevice, s));
+        int rc = bot_launch(e, nullptr, actions_out + (size_t)t * n, A_RESET_ENV, gave_up_out + (size_t)t * n, s);
+        if (rc != BBAI_OK) return rc;
+        rc = step_launch(e, actions_out + (size_t)t * n, image, dirs, rewards_out + (size_t)t * n, nullptr, dones_out + (size_t)t * n, 1, s);
+        if (rc != BBAI_OK) return rc;
+    }
+    return leave_call(e, s);
 }
 
 #if defined(BBAI_BOT_PROF)

@@ -263,6 +263,57 @@ BB_HD void process_vis_rows(const uint32_t opq[VIEW], uint32_t vis[VIEW]) {
     }
 }
 
+// ---- k_step's observation rows in LDS, packed at the OUTPUT pitch ----------------------------------------------------------
+// A block's 256 observations leave as one contiguous span of 256 x 147 bytes.  With the rows parked in LDS at that same
+// 147-byte pitch the copy-out is a plain 16-byte-per-lane stream (ds_read_b128 -> global_store_dwordx4); parked at a
+// dword-aligned 148-byte pitch instead (round 2 / early round 3) every output dword had to be re-assembled from three LDS
+// dwords -- 26 VALU instructions per dword, a third of k_step's vector work.  The price is paid once per lane here: the
+// lane's 37 encoding dwords are shifted by its row's byte phase (one v_alignbyte_b32 each) and written as ALIGNED dwords;
+// the first and last bytes of a row share a dword with the neighbouring rows and go out as byte writes, so lanes never
+// touch each other's bytes and no barrier is needed before the block-wide one.
+BB_HD uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t s) {     // ({hi, lo} >> 8 s) & 0xFFFFFFFF, s = 0..3
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, s);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (s & 3)));
+#endif
+}
+constexpr int ROWS_FRONT = 16;       // bytes in front of row 0 (row 0's "previous dword" exists; keeps the span 16-byte aligned)
+struct RowPacker {
+    uint8_t* p;          // dword j of the lane's shifted stream lives at p + 4 j
+    uint32_t prev, s;
+    int shp;             // 1..4: bytes of the row's first LDS dword that belong to the previous row
+    // `rows` = LDS byte ROWS_FRONT of the block's row area (16-byte aligned), row r = bytes [147 r, 147 r + 147)
+    BB_HD RowPacker(uint8_t* rows, int r) {
+        const int base = r * OBS_BYTES;
+        shp = (base & 3) ? (base & 3) : 4;
+        p = rows + (base - shp);
+        s = (uint32_t)(4 - shp);
+        prev = 0;
+    }
+    // dword j of the row (j = 0..36, in order; dword 36 = the last three bytes + one zero byte)
+    BB_HD void put(int j, uint32_t d) {
+        const uint32_t w = align_bytes(d, prev, s);
+        if (j == 0) {        // stream bytes 0 .. 3 - shp, at byte positions shp .. 3
+            if (shp <= 1) p[1] = (uint8_t)(w >> 8);
+            if (shp <= 2) p[2] = (uint8_t)(w >> 16);
+            if (shp <= 3) p[3] = (uint8_t)(w >> 24);
+        } else {
+            *(uint32_t*)(p + 4 * j) = w;
+        }
+        prev = d;
+    }
+    BB_HD void finish() {    // stream bytes 148 - shp .. 146: the shp - 1 low bytes of dword 37
+        const uint32_t w = align_bytes(0u, prev, s);
+        uint8_t* q = p + 4 * 37;
+        if (shp >= 2) q[0] = (uint8_t)w;
+        if (shp >= 3) q[1] = (uint8_t)(w >> 8);
+        if (shp >= 4) q[2] = (uint8_t)(w >> 16);
+    }
+};
+// the lane's 56 bytes of dword-aligned scratch (the 7x7 window in world orientation) inside its own row
+BB_HD int row_scratch(int r) { return (r * OBS_BYTES + 88 + 3) & ~3; }
+
 // World cell shown at view cell (vi, vj): pos + f*(6-vj) + r*(vi-3), r = (-f.y, f.x).
 BB_HD void view_to_world(int ax, int ay, int dir, int vi, int vj, int& x, int& y) {
     int fx = dir_dx(dir), fy = dir_dy(dir);

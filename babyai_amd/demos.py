@@ -6,10 +6,12 @@ Same result as the reference's sequential loop: demo k is the first episode of s
 (`env.seed(seed + len(demos))`, and after a failure or a bot crash `env.reset()` on the SAME stream,
 make_agent_demos.py:84-88,112-123), as the tuple `(mission, images, directions, actions)` of
 make_agent_demos.py:111-112 -- `images` is uint8[T,7,7,3] (the reference stores `blosc.pack_array` of it; pass
-`pack=blosc.pack_array` to get the identical container format).
+`pack=blosc.pack_array` to get the identical container format).  The mission text is rebuilt from the token ids the engine
+keeps per episode (`missions.detokenize`: the baby language has 32 words and one punctuation mark).
 """
 import numpy as np
 
+from . import missions
 from .engine import BatchedBabyAIEnv
 
 
@@ -22,47 +24,43 @@ def generate_demos(env_name, n_episodes, seed, device="cuda:0", batch=4096, filt
 
 
 def _generate_batch(env_name, seed, n, device, filter_steps, pack, max_steps, demos, offset):
-    import torch
+    """One batch of streams.  The per-step loop runs on the device (`bbai_bot_rollout`: decide, step, auto-reset, history
+    rows written by the engine, `chunk` steps per call); the host only looks at whole chunks."""
     env = BatchedBabyAIEnv(env_name, n, device=device, seeds=[seed + k for k in range(n)], auto_reset=True)
-    obs = env.reset()
-    missions = list(obs["mission"])
-    # whole-batch history, one row per step; an episode is the slice [ep_start[i], t] of column i
-    hist_img, hist_dir, hist_act = [], [], []
-    ep_start = np.zeros(n, dtype=np.int64)
+    env.enable_instr_tokens()
+    env.reset()
+    budget = max_steps if max_steps is not None else 64 * env.max_steps_bound
+    chunk = max(1, min(128, max(16, env.max_steps_bound // 4), budget))
+    hist = {"image": [], "direction": [], "action": [], "tokens": []}     # host copies of the chunks, [chunk, n, ...] each
+    last_done = np.full(n, -1, dtype=np.int64)     # global index of the stream's latest episode end
     span = np.full((n, 2), -1, dtype=np.int64)     # [first, last] step of the stream's first solved episode
     open_ = np.ones(n, dtype=bool)                 # streams still looking for it
-    budget = max_steps if max_steps is not None else 64 * env.max_steps_bound
-    reset_cmd = torch.full((n,), env.RESET_ENV, dtype=torch.uint8, device=env.device)
-    for t in range(budget):
-        if not open_.any():
-            break
-        hist_img.append(obs["image"].cpu().numpy())
-        hist_dir.append(obs["direction"].cpu().numpy())
-        act = env.bot_actions(None)
-        crashed = act == env.BOT_GAVE_UP
-        act = torch.where(crashed, reset_cmd, act)          # bot crash: env.reset() on the same stream
-        obs, reward, done, _ = env.step(act)
-        hist_act.append(act.cpu().numpy())
-        crashed_h = crashed.cpu().numpy()
-        reward_h, done_h = reward.cpu().numpy(), done.cpu().numpy().astype(bool)
-        length = t - ep_start + 1
-        solved = open_ & done_h & ~crashed_h & (reward_h > 0)
+    g0 = 0
+    while open_.any() and g0 < budget:
+        r = env.bot_rollout(chunk, tokens=True)
+        for k in hist:
+            hist[k].append(r[k].cpu().numpy())
+        done = r["done"].cpu().numpy().astype(bool)
+        # "mission failed" / bot crash (RESET_ENV): the stream goes on with its next level (make_agent_demos.py:84-88,112-123)
+        ok = done & (r["gave_up"].cpu().numpy() == 0) & (r["reward"].cpu().numpy() > 0)
+        idx = np.arange(g0, g0 + chunk, dtype=np.int64)[:, None]
+        ends = np.maximum.accumulate(np.where(done, idx, -1), axis=0)           # latest episode end at or before each step
+        start = np.maximum(np.vstack([last_done[None, :], ends[:-1]]), last_done[None, :]) + 1    # first step of each step's episode
         if filter_steps:
-            solved &= length <= filter_steps
-        span[solved, 0], span[solved, 1] = ep_start[solved], t
-        open_ &= ~solved
-        again = open_ & done_h                               # "mission failed" / crash: next level of the same stream
-        if again.any():
-            fresh = obs["mission"]
-            for i in np.nonzero(again)[0]:
-                missions[i] = fresh[i]
-        ep_start[done_h] = t + 1
+            ok &= (idx - start + 1) <= filter_steps
+        found = ok.any(axis=0) & open_
+        first = ok.argmax(axis=0)
+        cols = np.nonzero(found)[0]
+        span[cols, 0], span[cols, 1] = start[first[cols], cols], g0 + first[cols]
+        open_ &= ~found
+        last_done = np.maximum(last_done, ends[-1])
+        g0 += chunk
     env.close()
     if open_.any():
         raise RuntimeError("no solvable episode found for %d stream(s) within the step budget" % int(open_.sum()))
-    img, dirs, acts = np.stack(hist_img), np.stack(hist_dir), np.stack(hist_act)
+    img, dirs, acts, toks = (np.concatenate(hist[k]) for k in ("image", "direction", "action", "tokens"))
     for i in range(n):
         lo, hi = span[i, 0], span[i, 1] + 1
         stack = np.ascontiguousarray(img[lo:hi, i])
-        demos[offset + i] = (missions[i], pack(stack) if pack else stack,
-                             [int(v) for v in dirs[lo:hi, i]], [int(v) for v in acts[lo:hi, i]])
+        demos[offset + i] = (missions.detokenize(toks[lo, i]), pack(stack) if pack else stack,
+                             dirs[lo:hi, i].tolist(), acts[lo:hi, i].tolist())

@@ -78,6 +78,7 @@ def load_library():
     lib.bbai_generator_failures.argtypes = [P, P]
     lib.bbai_bot_act.argtypes = [P, P, P, P]
     lib.bbai_bot_stats.argtypes = [P, P, P]
+    lib.bbai_bot_rollout.argtypes = [P, I32, P, P, P, P, P, P, P, P, P, P]
     _lib = lib
     return lib
 
@@ -87,7 +88,7 @@ EXPORTED_SYMBOLS = (
     "bbai_reset", "bbai_step", "bbai_set_atlas", "bbai_render", "bbai_set_token_buffer", "bbai_export_state", "bbai_import_state",
     "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures", "bbai_bot_act", "bbai_bot_stats",
     "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load", "bbai_profile", "bbai_profile_read", "bbai_gae", "bbai_tap",
-    "bbai_tap_ids", "bbai_set_call_events", "bbai_render_current", "bbai_has_tile_plane",
+    "bbai_tap_ids", "bbai_set_call_events", "bbai_render_current", "bbai_has_tile_plane", "bbai_bot_rollout",
 )
 
 
@@ -384,6 +385,34 @@ class BatchedBabyAIEnv(object):
             self._bot_prev = prev_actions        # keep alive until the launch is consumed
             prev_ptr = prev_actions.data_ptr()
         _check(self.lib, self.lib.bbai_bot_act(self.handle, prev_ptr, out.data_ptr(), self._stream()), "bbai_bot_act")
+        return out
+
+    def bot_rollout(self, steps, tokens=False):
+        """`steps` expert decisions + auto-reset steps for every env with no host round trip in between (include/bbai.h
+        bbai_bot_rollout: the inner loop of scripts/make_agent_demos.py:71-137).  Returns device tensors [steps, N, ...]:
+        image / direction (and tokens, uint8[steps, N, 72] mission token ids, if asked) = what the expert decided on at
+        each step, action = its decision (RESET_ENV where it gave up: gave_up = 1), reward, done = the step's results.
+        Afterwards self.image / self.direction hold the current observation as after step()."""
+        torch = self.torch
+        T, n = int(steps), self.num_envs
+        if not self.auto_reset:
+            raise EngineError("bot_rollout steps with ParallelEnv semantics: construct the env with auto_reset=True")
+        with torch.cuda.device(self.dev_index):
+            u8 = dict(dtype=torch.uint8, device=self.device)
+            out = {"image": torch.empty((T, n, 7, 7, 3), **u8), "direction": torch.empty((T, n), **u8),
+                   "action": torch.empty((T, n), **u8), "reward": torch.empty((T, n), dtype=torch.float32, device=self.device),
+                   "done": torch.empty((T, n), **u8), "gave_up": torch.empty((T, n), **u8)}
+            tok_ptr = None
+            if tokens:
+                self.enable_instr_tokens()
+                out["tokens"] = torch.empty((T, n, TOK_MAX), **u8)
+                tok_ptr = out["tokens"].data_ptr()
+        _check(self.lib, self.lib.bbai_bot_rollout(self.handle, T, self.image.data_ptr(), self.direction.data_ptr(),
+                                                    out["image"].data_ptr(), out["direction"].data_ptr(), tok_ptr,
+                                                    out["action"].data_ptr(), out["reward"].data_ptr(), out["done"].data_ptr(),
+                                                    out["gave_up"].data_ptr(), self._stream()), "bbai_bot_rollout")
+        self._tiles_ok = True
+        self._obs_version += 1
         return out
 
     def bot_stats(self):

@@ -72,6 +72,13 @@ def tokenize(mission):
     return [WORD_TO_ID[w] for w in re.findall("([a-z]+)", mission.lower())]
 
 
+def detokenize(ids):
+    """Mission string of a row of fixed-vocabulary token ids (0 = padding): the inverse of `tokenize` on the baby language,
+    whose only punctuation is the comma of BeforeInstr's ', then ' (babyai/levels/verifier.py:439-440)."""
+    words = [VOCAB[int(t) - 1] for t in ids if int(t)]
+    return " ".join(words).replace(" then ", ", then ")
+
+
 def max_mission_tokens(cfg):
     """Upper bound on the token count of any mission of a level (so that a model can be fed a fixed instruction width,
     no host synchronisation per frame): per descriptor article + colour + type (+ up to 4 location words); per leaf the

@@ -143,6 +143,19 @@ int bbai_checkpoint_load(bbai_env* env, const void* host_buf, int64_t bytes);
  * The expert's plan lives in the handle (allocated on first use, ~1.7 KB per env) and is not part of
  * bbai_export_state / bbai_import_state: import states at episode boundaries when the expert is in use. */
 int bbai_bot_act(bbai_env* env, const uint8_t* prev_actions_dev, uint8_t* actions_dev, void* stream);
+/* The inner loop of expert-driven demonstration generation (scripts/make_agent_demos.py:71-137 generate_demos with
+ * BotAgent, babyai/utils/agent.py:139-155) for every env, T steps per call with NO host round trip between the steps:
+ *   for t in 0..T-1:  images_out[t], dirs_out[t] (, tokens_out[t]) = the observation (and mission tokens) the expert decides on;
+ *                     actions_out[t] = Bot.replan(None) -- a bot that gave up emits BBAI_ACTION_RESET_ENV ("env.reset() on the
+ *                     same stream", make_agent_demos.py:84-88) and gave_up_out[t] = 1 there;
+ *                     step with ParallelEnv semantics (auto-reset); rewards_out[t], dones_out[t].
+ * image_dev / dir_dev hold the CURRENT observation on entry (what the last reset / step / rollout wrote) and on return.
+ * History buffers are [T][n_envs] rows of the per-step layouts (147 / 1 / 72 / 1 / 4 / 1 / 1 bytes per env).  tokens_out may
+ * be NULL; otherwise a token buffer must be registered (bbai_set_token_buffer).  The expert and the step are the kernels of
+ * bbai_bot_act / bbai_step: same decisions, same bytes (tests/test_gpu_parity.py::test_bot_rollout_*). */
+int bbai_bot_rollout(bbai_env* env, int T, uint8_t* image_dev, uint8_t* dir_dev, uint8_t* images_out, uint8_t* dirs_out,
+                     uint8_t* tokens_out, uint8_t* actions_out, float* rewards_out, uint8_t* dones_out, uint8_t* gave_up_out,
+                     void* stream);
 /* Bots that gave up so far: by the reference's own rules / because a fixed-size structure of this port overflowed
  * (subgoal stack, 48 entries unless the environment variable BBAI_BOT_STACK says otherwise when the expert is first
  * used; same-colour keys 12).  The reference's stack is an unbounded list: a bot that replans for ever inside one

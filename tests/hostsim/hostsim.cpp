@@ -86,6 +86,22 @@ void hs_observe(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, uint8_t
     observe_env(*cfg, rec, *hot, out);
 }
 
+// ---- k_step's LDS row packing (bbai_step.hpp RowPacker), one lane at a time in the caller's lane order ---------------------
+// rows_in: [n][37] dwords (147 bytes + one pad byte each); lds: ROWS_FRONT + n * 147 + 16 bytes, pre-filled by the caller;
+// scratch_fill != 0 also scribbles over every lane's window scratch first (it must stay inside the lane's own row).
+void hs_pack_rows(const uint32_t* rows_in, const int32_t* order, int n, uint8_t* lds, int scratch_fill) {
+    uint8_t* rows = lds + ROWS_FRONT;
+    if (scratch_fill)
+        for (int i = 0; i < n; ++i) memset(rows + row_scratch(i), 0xEE, 56);
+    for (int k = 0; k < n; ++k) {
+        const int r = order[k];
+        RowPacker o(rows, r);
+        for (int j = 0; j < 37; ++j) o.put(j, rows_in[r * 37 + j]);
+        o.finish();
+    }
+}
+int hs_row_scratch(int r) { return row_scratch(r); }
+
 // ---- the expert (bbai_bot.hpp) -------------------------------------------------------------------------------
 int hs_bot_state_bytes(int stack_cap) { return (int)bot_state_bytes(stack_cap); }
 int hs_bot_dead_reason(const uint8_t* state) { return ((const BotState*)state)->dead; }

@@ -1216,3 +1216,83 @@ def test_render_current_equals_render_of_the_encoding(gpu, auto_reset, monkeypat
     env.step(torch.randint(0, 7, (n,), dtype=torch.uint8, device=gpu, generator=gen))
     check("after load")
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level,n,steps", [("GoToLocal", 300, 96), ("BossLevel", 129, 160), ("UnlockToUnlock", 64, 200)])
+def test_bot_rollout_equals_the_stepwise_loop(gpu, level, n, steps):
+    """bbai_bot_rollout (T expert decisions + auto-reset steps per call, history written by the engine) against the same
+    loop driven from the host with bbai_bot_act + bbai_step: every history row, the final observation and the mission
+    tokens, across chunk boundaries and bot crashes (UnlockToUnlock: the stack-capacity give-ups)."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from babyai_amd.missions import detokenize
+    a = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=4400)
+    b = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=4400)
+    oa = a.reset()
+    b.reset()
+    reset_cmd = torch.full((n,), a.RESET_ENV, dtype=torch.uint8, device=a.device)
+    ref = {k: [] for k in ("image", "direction", "action", "reward", "done", "gave_up", "mission")}
+    for t in range(steps):
+        ref["image"].append(a.image.cpu().numpy().copy())
+        ref["direction"].append(a.direction.cpu().numpy().copy())
+        ref["mission"].append(list(oa["mission"]))
+        act = a.bot_actions(None)
+        crashed = act == a.BOT_GAVE_UP
+        act = torch.where(crashed, reset_cmd, act)
+        oa, r, d, _ = a.step(act)
+        ref["action"].append(act.cpu().numpy().copy())
+        ref["gave_up"].append(crashed.cpu().numpy().astype(np.uint8))
+        ref["reward"].append(r.cpu().numpy().copy())
+        ref["done"].append(d.cpu().numpy().copy())
+    got = {k: [] for k in ("image", "direction", "action", "reward", "done", "gave_up", "tokens")}
+    t = 0
+    for chunk in (1, 7, 32, steps):          # uneven chunks: the state carried between calls is the engine's own
+        chunk = min(chunk, steps - t)
+        if chunk <= 0:
+            break
+        r = b.bot_rollout(chunk, tokens=True)
+        for k in got:
+            got[k].append(r[k].cpu().numpy())
+        t += chunk
+    assert t == steps
+    for k in ("image", "direction", "action", "reward", "done", "gave_up"):
+        assert np.array_equal(np.concatenate(got[k]), np.stack(ref[k])), k
+    toks = np.concatenate(got["tokens"])
+    for t in range(0, steps, 13):
+        for i in range(0, n, 17):
+            assert detokenize(toks[t, i]) == ref["mission"][t][i], (t, i)
+    assert np.array_equal(a.image.cpu().numpy(), b.image.cpu().numpy())
+    assert np.array_equal(a.direction.cpu().numpy(), b.direction.cpu().numpy())
+    assert np.stack(ref["done"]).any()
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("offset", [0, 4, 8, 1, 3])
+def test_step_writes_observations_into_unaligned_caller_buffers(gpu, offset):
+    """k_step's copy-out streams 16 bytes per lane when the caller's image buffer allows it and falls back to dwords /
+    bytes when it does not (a row of a [T][n][147] history with odd n): same bytes either way, nothing outside the rows."""
+    import ctypes
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv, _check
+    n = 777                                         # three full blocks + a partial one
+    a = BatchedBabyAIEnv("BabyAI-GoTo-v0", n, device=gpu, seeds=90)
+    b = BatchedBabyAIEnv("BabyAI-GoTo-v0", n, device=gpu, seeds=90)
+    a.reset()
+    b.reset()
+    big = torch.full((n * 147 + 64,), 0xA5, dtype=torch.uint8, device=a.device)
+    rng = np.random.RandomState(3)
+    for t in range(12):
+        act = torch.as_tensor(rng.randint(0, 7, n).astype(np.uint8), device=a.device)
+        a.step(act)
+        big.fill_(0xA5)
+        _check(b.lib, b.lib.bbai_step(b.handle, act.data_ptr(), big.data_ptr() + 16 + offset, b.direction.data_ptr(), b.reward.data_ptr(),
+                                      b.reward64.data_ptr(), b.done.data_ptr(), 1, b._stream()), "bbai_step")
+        torch.cuda.synchronize()
+        h = big.cpu().numpy()
+        assert np.array_equal(h[16 + offset:16 + offset + n * 147], a.image.cpu().numpy().reshape(-1)), t
+        assert (h[:16 + offset] == 0xA5).all() and (h[16 + offset + n * 147:] == 0xA5).all(), t
+    a.close()
+    b.close()

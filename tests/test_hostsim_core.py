@@ -110,3 +110,28 @@ def test_max_mission_tokens_bounds_every_level():
                 h.reset()
                 longest = max(longest, len(tokenize(h.mission)))
         assert longest <= bound <= 72, (name, longest, bound)
+
+
+def test_row_packer_lays_rows_out_at_the_output_pitch():
+    """k_step parks its 256 observation rows in LDS at the 147-byte OUTPUT pitch (bbai_step.hpp RowPacker): every lane
+    shifts its 37 dwords by the row's byte phase and writes aligned dwords + byte-sized head / tail pieces.  Lanes run in
+    any order without a barrier, so no lane may write a byte outside its own row -- including its window scratch."""
+    import ctypes
+    import numpy as np
+    from hostsim_util import lib
+    L = lib()
+    L.hs_pack_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    L.hs_row_scratch.argtypes = [ctypes.c_int]
+    rng = np.random.RandomState(7)
+    n = 256
+    for trial in range(8):
+        rows = rng.randint(0, 256, size=(n, 148)).astype(np.uint8)
+        rows[:, 147] = 0                                   # dword 36 = three bytes + a zero byte
+        order = rng.permutation(n).astype(np.int32)
+        lds = np.full(16 + n * 147 + 16, 0xA5, np.uint8)
+        L.hs_pack_rows(np.ascontiguousarray(rows).view(np.uint32).ctypes.data, order.ctypes.data, n, lds.ctypes.data, trial & 1)
+        assert np.array_equal(lds[16:16 + n * 147].reshape(n, 147), rows[:, :147])
+        assert (lds[:16] == 0xA5).all() and (lds[16 + n * 147:] == 0xA5).all()     # nothing before row 0 / after row 255
+    for r in range(n):
+        s = L.hs_row_scratch(r)
+        assert s % 4 == 0 and r * 147 <= s and s + 56 <= (r + 1) * 147
