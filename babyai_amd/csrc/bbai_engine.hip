@@ -170,20 +170,28 @@ constexpr int64_t FUSED_MIN_ENVS = 786432;      // batches from this size up kee
 // Two halves, so that the verifier (which only needs fe2) can run between them while nothing of the 37-dword encoding is
 // live yet: view_cells fetches and rotates the window (cp = the 49 cells, vis = visibility rows), encode_view writes the
 // encoding (and the plane row) from them.
-__device__ __forceinline__ void view_cells(const uint32_t* __restrict__ q, int rstride, int off, int dir, uint32_t ce,
+// window_fetch issues the loads (7 rows x 3 dwords: one dwordx3 each); view_cells consumes them.  k_step puts the rare
+// object actions (pickup / drop / toggle: dependent record loads and stores) BETWEEN the two, so their memory round trips
+// overlap the window's instead of preceding it.  Such an action changes exactly one cell of the window that was fetched
+// before it ran -- the one in front of the agent, view cell (3, 5): `nfe` >= 0 is its new appearance, patched in LDS.
+__device__ __forceinline__ void window_fetch(const uint32_t* __restrict__ q, int rstride, uint32_t* wd) {
+#pragma unroll
+    for (int r = 0; r < VIEW; ++r) { wd[3 * r] = q[r * rstride]; wd[3 * r + 1] = q[r * rstride + 1]; wd[3 * r + 2] = q[r * rstride + 2]; }
+}
+__device__ __forceinline__ void view_cells(const uint32_t* wd, int off, int dir, uint32_t ce, int nfe,
                                            uint8_t* __restrict__ scr /* this lane's 56 bytes of LDS scratch */, uint32_t* cp, uint32_t* vis, int& fe2) {
     uint32_t* win = (uint32_t*)scr;                          // 7 rows x 8 bytes, dword aligned
 #pragma unroll
     for (int r = 0; r < VIEW; ++r) {
-        const uint32_t d0 = q[r * rstride], d1 = q[r * rstride + 1], d2 = q[r * rstride + 2];
-        win[2 * r] = __builtin_amdgcn_alignbyte(d1, d0, off);
-        win[2 * r + 1] = __builtin_amdgcn_alignbyte(d2, d1, off);
+        win[2 * r] = __builtin_amdgcn_alignbyte(wd[3 * r + 1], wd[3 * r], off);
+        win[2 * r + 1] = __builtin_amdgcn_alignbyte(wd[3 * r + 2], wd[3 * r + 1], off);
     }
     // view (vi, vj) -> window byte: dir3 (vj, vi), dir0 (vi, 6-vj), dir1 (6-vj, 6-vi), dir2 (6-vi, vj); row pitch 8
     const int k0 = dir == 0 ? 6 : dir == 1 ? 54 : dir == 2 ? 48 : 0;
     const int kvi = dir == 0 ? 8 : dir == 1 ? -1 : dir == 2 ? -8 : 1;
     const int kvj = dir == 0 ? -1 : dir == 1 ? -8 : dir == 2 ? 1 : 8;
-    const uint8_t* wb = scr + k0;
+    uint8_t* wb = scr + k0;
+    if (nfe >= 0) wb[kvi * 3 + kvj * 5] = (uint8_t)nfe;      // (same lane: LDS operations of a lane stay in order)
 #pragma unroll
     for (int k = 0; k < 13; ++k) cp[k] = 0;                      // the 49 cells, 4 per dword, view order [vi][vj]
     uint32_t opq[VIEW] = {0, 0, 0, 0, 0, 0, 0};
@@ -316,41 +324,50 @@ __global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, i
     const bool active = env < n;
     bool want_reset = false;
     if (active) {
-        Hot h = hots[env];
+        // everything the step needs from the SoA arrays in ONE memory round trip, before the frozen test (the loads the
+        // branch would otherwise delay are a second round trip on every step's critical path)
+        u32x4 hv = *(const u32x4*)(hots + env);
+        uint64_t stale = stales[env];
+        VProg vp; vp.bind(vheads[env], vsets + env, n);
+        int action = actions[env];
+        uint32_t fc = VP ? (uint32_t)fcache[env] : 0u;
+        // (the empty asm pins the loaded values here: the compiler would otherwise sink the loads into the branch)
+        asm volatile("" : "+v"(hv), "+v"(stale), "+v"(vp.head), "+v"(vp.set00), "+v"(action), "+v"(fc));
+        Hot h;
+        __builtin_memcpy(&h, &hv, sizeof(h));
         uint8_t* rec = recs + env * (int64_t)c.rec_bytes;
         if (!h.frozen) {
-            uint64_t stale = stales[env];
             double reward = 0.0;
-            VProg vp; vp.head = vheads[env]; vp.sets = vsets + env; vp.stride = n;
             const EnvRef r = env_ref(c, rec, vp);
-            const int action = actions[env];
             uint8_t* vrow = VP ? vplane + env * (int64_t)v_bytes(c) : nullptr;
             int fe, ce;
             if (VP) {
-                const uint32_t fc = fcache[env];
                 fe = (int)(fc & 0xFFu); ce = (int)(fc >> 8);
             } else {
                 fe = r.E[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];
                 ce = h.carry != NONE8 ? r.app[h.carry] : (int)E_EMPTY;
             }
-            if (action != A_RESET_ENV) {
-                const int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
-                const int nfe = apply_action(c, r, h, stale, action, fe, ce);
-                if (VP && nfe >= 0) v_patch(c, vrow, fx, fy, nfe);
-            }
+            if (action != A_RESET_ENV) apply_pose(h, action, fe);
             // the 7x7 window of the pose after the action.  Grid.slice extents (get_view_exts): its top-left world cell
             const int dir = h.dir;
             const int txm = h.ax + MARGIN + (dir == 0 ? 0 : dir == 2 ? -6 : -3);
             const int tym = h.ay + MARGIN + (dir == 1 ? 0 : dir == 3 ? -6 : -3);
-            int fe2;
-            uint32_t cp[13], vis[VIEW];
+            uint32_t wd[3 * VIEW];
             if (VP) {
                 const uint8_t* line = vrow + ((tym >> 1) * v_nxo(c) + (txm >> 3)) * VLINE + (tym & 1) * 16 + (txm & 4);
-                view_cells((const uint32_t*)line, 4, txm & 3, dir, (uint32_t)ce, s_rows + row_scratch(threadIdx.x), cp, vis, fe2);
+                window_fetch((const uint32_t*)line, 4, wd);
             } else {
-                const int a0 = tym * c.ES + txm;                         // same for every row: ES is a multiple of 4
-                view_cells((const uint32_t*)(rec + (a0 & ~3)), c.ES >> 2, a0 & 3, dir, (uint32_t)ce, s_rows + row_scratch(threadIdx.x), cp, vis, fe2);
+                window_fetch((const uint32_t*)(rec + ((tym * c.ES + txm) & ~3)), c.ES >> 2, wd);     // (ES is a multiple of 4)
             }
+            // pickup / drop / toggle, while the window is on its way
+            int nfe = -1;
+            if (action != A_RESET_ENV) {
+                nfe = apply_objects(c, r, h, stale, action, fe, ce);
+                if (VP && nfe >= 0) v_patch(c, vrow, h.ax + dir_dx(dir), h.ay + dir_dy(dir), nfe);
+            }
+            int fe2;
+            uint32_t cp[13], vis[VIEW];
+            view_cells(wd, txm & 3, dir, (uint32_t)ce, nfe, s_rows + row_scratch(threadIdx.x), cp, vis, fe2);
             // "env.reset() for THIS env, now" (A_RESET_ENV, bbai_step.hpp): the episode ends with done = 1, reward = 0
             const bool done = action == A_RESET_ENV ? true : finish_step(c, r, h, stale, action, fe2, reward);
             if (done && !auto_reset) h.frozen = 1;

@@ -141,48 +141,51 @@ BB_HD double success_reward(int step, int max_steps) {
 #endif
 }
 
-// MiniGridEnv.step's effect on the world, first half of a step.  `fe` = appearance byte of the cell in front of the agent
-// BEFORE the action; `ce` = appearance byte of what the agent carries (E_EMPTY: nothing) -- both are passed in so that
-// callers which cache them (k_step: 2 bytes per env) never touch the record on a plain move / turn; `ce` is kept current.
-// Returns the NEW appearance byte of that front cell when the action changed it, else -1 (callers that keep derived copies
-// of the appearance plane patch them with it).  All other record updates (id plane, positions) happen here.
-BB_HD int apply_action(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t& stale, int action, int fe, int& ce) {
+// MiniGridEnv.step's effect on the world, first half of a step, in two pieces so that k_step can put the window fetch of the
+// NEW pose between them (the pose only needs the action and the front cell; the object actions never move the agent):
+//   apply_pose     step counter + turn / move;
+//   apply_objects  pickup / drop / toggle: the record updates (appearance + id plane, positions, stale set).
+// `fe` = appearance byte of the cell in front of the agent BEFORE the action; `ce` = appearance byte of what the agent carries
+// (E_EMPTY: nothing) -- both are passed in so that callers which cache them (k_step: 2 bytes per env) never touch the record
+// on a plain move / turn; `ce` is kept current.  apply_objects returns the NEW appearance byte of the front cell when the
+// action changed it, else -1 (callers that keep derived copies of the appearance plane patch them with it; the changed cell
+// is view cell (3, 5) of the observation that follows).
+BB_HD void apply_pose(Hot& h, int action, int fe) {
     h.step = (uint16_t)(h.step + 1);
-    const int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
-    const int ei = e_index(c, fx, fy), ii = i_index(c, fx, fy);
+    if (action == A_LEFT) h.dir = (h.dir + 3) & 3;
+    else if (action == A_RIGHT) h.dir = (h.dir + 1) & 3;
+    else if (action == A_FORWARD && (fe == E_EMPTY || (e_type(fe) == T_DOOR && e_state(fe) == S_OPEN))) {
+        h.ax = (uint8_t)(h.ax + dir_dx(h.dir)); h.ay = (uint8_t)(h.ay + dir_dy(h.dir));
+    }
+}
+BB_HD int apply_objects(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t& stale, int action, int fe, int& ce) {
     int nfe = -1;
-    switch (action) {
-    case A_LEFT: h.dir = (h.dir + 3) & 3; break;
-    case A_RIGHT: h.dir = (h.dir + 1) & 3; break;
-    case A_FORWARD:
-        if (fe == E_EMPTY || (e_type(fe) == T_DOOR && e_state(fe) == S_OPEN)) { h.ax = fx; h.ay = fy; }
-        break;
-    case A_PICKUP:
-        if (e_type(fe) >= T_KEY && h.carry == NONE8) {
-            int o = r.I[ii] - 2;
-            h.carry = (uint8_t)o;
-            ce = fe;                                 // a key / ball / box looks the same on the floor and in the hand
-            nfe = E_EMPTY; r.I[ii] = 0;
-            stale |= 1ull << o;                      // its recorded position is now stale
-        }
-        break;
-    case A_DROP:
-        if (fe == E_EMPTY && h.carry != NONE8) {
-            int o = h.carry;
-            nfe = ce; r.I[ii] = (uint8_t)(o + 2);
-            r.pos[2 * o] = (uint8_t)fx; r.pos[2 * o + 1] = (uint8_t)fy;
-            h.carry = NONE8;
-            ce = E_EMPTY;
-        }
-        break;
-    case A_TOGGLE:
-        if (e_type(fe) == T_DOOR) {
+    if (action == A_PICKUP || action == A_DROP || action == A_TOGGLE) {
+        const int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
+        const int ei = e_index(c, fx, fy), ii = i_index(c, fx, fy);
+        if (action == A_PICKUP) {
+            if (e_type(fe) >= T_KEY && h.carry == NONE8) {
+                int o = r.I[ii] - 2;
+                h.carry = (uint8_t)o;
+                ce = fe;                                 // a key / ball / box looks the same on the floor and in the hand
+                nfe = E_EMPTY; r.I[ii] = 0;
+                stale |= 1ull << o;                      // its recorded position is now stale
+            }
+        } else if (action == A_DROP) {
+            if (fe == E_EMPTY && h.carry != NONE8) {
+                int o = h.carry;
+                nfe = ce; r.I[ii] = (uint8_t)(o + 2);
+                r.pos[2 * o] = (uint8_t)fx; r.pos[2 * o + 1] = (uint8_t)fy;
+                h.carry = NONE8;
+                ce = E_EMPTY;
+            }
+        } else if (e_type(fe) == T_DOOR) {
             if (e_state(fe) == S_LOCKED) {
                 if (h.carry != NONE8 && e_type(ce) == T_KEY && e_color(ce) == e_color(fe)) nfe = e_make(T_DOOR, e_color(fe), S_OPEN);
             } else {
                 nfe = e_make(T_DOOR, e_color(fe), e_state(fe) == S_OPEN ? S_CLOSED : S_OPEN);
             }
-        } else if (e_type(fe) == T_BOX) {            // box is replaced by its contents (nothing, or a hidden object)
+        } else if (e_type(fe) == T_BOX) {                // box is replaced by its contents (nothing, or a hidden object)
             int o = r.I[ii] - 2;
             int inner = r.cont[o];
             if (inner == NONE8) {
@@ -193,13 +196,15 @@ BB_HD int apply_action(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t& sta
             }
             stale |= 1ull << o;
         }
-        break;
-    default: break;                                   // done (and, by definition, every byte above 7: include/bbai.h)
+        if (nfe >= 0) r.E[ei] = (uint8_t)nfe;
+        // every drop ACTION refreshes the tracked positions (levelgen.py:53-54)
+        if (action == A_DROP) stale = 0;
     }
-    if (nfe >= 0) r.E[ei] = (uint8_t)nfe;
-    // every drop ACTION refreshes the tracked positions (levelgen.py:53-54)
-    if (action == A_DROP) stale = 0;
-    return nfe;
+    return nfe;                                           // (done, and by definition every byte above 7: nothing -- include/bbai.h)
+}
+BB_HD int apply_action(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t& stale, int action, int fe, int& ce) {
+    apply_pose(h, action, fe);
+    return apply_objects(c, r, h, stale, action, fe, ce);
 }
 
 // Second half: the instruction verifier and the episode end (RoomGridLevel.step, levelgen.py:56-66).  `fe2` = appearance

@@ -108,13 +108,16 @@ struct VProg {
     uint32_t head;
     const uint64_t* sets;       // set(leaf, slot) = sets[(2*leaf + slot) * stride]
     int64_t stride;
+    uint64_t set00;             // set(0, 0), fetched with the rest of the env's hot state (every mission's first leaf needs it:
+                                // one memory round trip less on the verifier's path)
+    BB_HD void bind(uint32_t head_, const uint64_t* sets_, int64_t stride_) { head = head_; sets = sets_; stride = stride_; set00 = sets_[0]; }
     BB_HD int root() const { return head & 3; }
     BB_HD int n_a() const { return (head >> 2) & 3; }
     BB_HD int n_b() const { return (head >> 4) & 3; }
     BB_HD int kind(int leaf) const { return (head >> (8 + 3 * leaf)) & 7; }
     BB_HD bool strict(int leaf) const { return (head >> (20 + leaf)) & 1; }
     BB_HD bool strict_seq() const { return (head >> 24) & 1; }
-    BB_HD uint64_t set(int leaf, int slot) const { return sets[(int64_t)(2 * leaf + slot) * stride]; }
+    BB_HD uint64_t set(int leaf, int slot) const { return (leaf | slot) == 0 ? set00 : sets[(int64_t)(2 * leaf + slot) * stride]; }
 };
 
 struct Hot {                // 16 bytes, one per env, SoA array => one dwordx4 per lane

@@ -72,7 +72,7 @@ int hs_step64(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int 
     const Prog* p = (const Prog*)(rec + cfg->off_prog);
     uint64_t sets[8];
     for (int k = 0; k < 8; ++k) sets[k] = p->set[k >> 1][k & 1];
-    VProg vp; vp.head = vhead_pack(*p); vp.sets = sets; vp.stride = 1;
+    VProg vp; vp.bind(vhead_pack(*p), sets, 1);
     return step_env_cmd(*cfg, rec, vp, *hot, *stale, action, *reward) ? 1 : 0;
 }
 int hs_step(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int action, float* reward) {
