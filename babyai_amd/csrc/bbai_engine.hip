@@ -130,6 +130,8 @@ struct bbai_env {
     int64_t tick;         // number of consume_and_refill calls so far
     uint8_t* vplane;      // [n][v_bytes] window plane (bbai_types.hpp): one 128-byte line per window-origin class; BBAI_VPLANE=0: none
     uint16_t* fcache;     // [n] appearance of the front cell (low byte) and of the carried object (high byte) after the last step
+    uint8_t* lsm;         // [n] done-action verifier mode only (BABYAI_DONE_ACTIONS / bbai_set_done_actions): bit k = leaf k's
+                          //     lastStepMatch (babyai/levels/verifier.py:213-230); NULL = the normal mode
     uint8_t* tiles;       // [n][TILE_PITCH] fused tile plane of the CURRENT observations (allocated by bbai_set_atlas: pixel mode)
     bool tiles_valid;     // written by the last reset / step of every env
     uint8_t* atlas;       // [n_tiles][192]
@@ -313,7 +315,8 @@ __global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, i
                                                      double* __restrict__ rewards64, uint8_t* __restrict__ dones, int auto_reset,
                                                      int32_t* __restrict__ reset_list, uint32_t* __restrict__ counters,
                                                      uint8_t* __restrict__ tiles /* EMIT: [n][TILE_PITCH] render input */, int prio,
-                                                     uint8_t* __restrict__ vplane, uint16_t* __restrict__ fcache) {
+                                                     uint8_t* __restrict__ vplane, uint16_t* __restrict__ fcache,
+                                                     uint8_t* __restrict__ lsm_arr /* NULL, or the done-action mode's per-env bits */) {
     // the block's 256 observation rows at the OUTPUT pitch of 147 bytes (bbai_step.hpp RowPacker), 16 bytes of front padding
     __shared__ __attribute__((aligned(16))) uint8_t s_obs[ROWS_FRONT + STEP_BLOCK * OBS_BYTES + 16];
     uint8_t* const s_rows = s_obs + ROWS_FRONT;
@@ -331,6 +334,7 @@ __global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, i
         VProg vp; vp.bind(vheads[env], vsets + env, n);
         int action = actions[env];
         uint32_t fc = VP ? (uint32_t)fcache[env] : 0u;
+        uint32_t lsm = lsm_arr ? (uint32_t)lsm_arr[env] : 0u;
         // (the empty asm pins the loaded values here: the compiler would otherwise sink the loads into the branch)
         asm volatile("" : "+v"(hv), "+v"(stale), "+v"(vp.head), "+v"(vp.set00), "+v"(action), "+v"(fc));
         Hot h;
@@ -369,7 +373,8 @@ __global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, i
             uint32_t cp[13], vis[VIEW];
             view_cells(wd, txm & 3, dir, (uint32_t)ce, nfe, s_rows + row_scratch(threadIdx.x), cp, vis, fe2);
             // "env.reset() for THIS env, now" (A_RESET_ENV, bbai_step.hpp): the episode ends with done = 1, reward = 0
-            const bool done = action == A_RESET_ENV ? true : finish_step(c, r, h, stale, action, fe2, reward);
+            const bool done = action == A_RESET_ENV ? true : finish_step(c, r, h, stale, action, fe2, reward, lsm_arr ? &lsm : nullptr);
+            if (lsm_arr) lsm_arr[env] = (uint8_t)lsm;
             if (done && !auto_reset) h.frozen = 1;
             want_reset = done && auto_reset;
             hots[env] = h;
@@ -612,7 +617,8 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
                                                  int32_t* __restrict__ win_list, uint32_t* __restrict__ win_count, int pos,
                                                  uint8_t* __restrict__ image, uint8_t* __restrict__ dirs,
                                                  uint32_t* __restrict__ other_counter, uint8_t* __restrict__ tiles /* or NULL */, int prio,
-                                                 uint8_t* __restrict__ vplane /* or NULL */, uint16_t* __restrict__ fcache) {
+                                                 uint8_t* __restrict__ vplane /* or NULL */, uint16_t* __restrict__ fcache,
+                                                 uint8_t* __restrict__ lsm_arr /* or NULL */) {
     if (prio) __builtin_amdgcn_s_setprio(3);
     const int64_t count = all ? n : (int64_t)counter[0];
     // this tick's entries go behind those of the window's earlier ticks (their counts were written by earlier
@@ -662,6 +668,7 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
             if (p->start_carry != NONE8) apply_start_carry(c, recs + env * (int64_t)c.rec_bytes, h, stale0, p->start_carry);
             hots[env] = h;
             stales[env] = stale0;
+            if (lsm_arr) lsm_arr[env] = 0;                  // fresh instruction objects: lastStepMatch = False (verifier.py:213-214)
             dirs[env] = h.dir;
             // window bookkeeping for the batched refill: first consumption in this window registers the env
             const int pend = pending[env];
@@ -1029,6 +1036,11 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
             if (b == 1 || ev) err = r3;                    // an explicit BBAI_LOOKAHEAD is a request, not a hint
         }
     }
+    {
+        // babyai/levels/verifier.py:17 `use_done_actions = os.environ.get('BABYAI_DONE_ACTIONS', False)`: any non-empty value
+        const char* dv = getenv("BABYAI_DONE_ACTIONS");
+        if (dv && dv[0]) alloc((void**)&e->lsm, (size_t)n_envs);
+    }
     alloc((void**)&e->reset_list, (size_t)n_envs * 4);
     alloc((void**)&e->counters, 128);
     alloc((void**)&e->total_resets, 16);
@@ -1060,6 +1072,7 @@ static int create_finish(bbai_env* e) {
     HIP_TRY(hipMemset(e->vset, 0, (size_t)n_envs * 64));
     HIP_TRY(hipMemset(e->counters, 0, 128));
     HIP_TRY(hipMemset(e->total_resets, 0, 16));
+    if (e->lsm) HIP_TRY(hipMemset(e->lsm, 0, (size_t)n_envs));
     if (e->vplane) {
         HIP_TRY(hipMemset(e->vplane, 0, (size_t)n_envs * v_bytes(c)));
         HIP_TRY(hipMemset(e->fcache, 0, (size_t)n_envs * 2));
@@ -1108,7 +1121,7 @@ void bbai_destroy(bbai_env* e) {
     void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
     void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_list, e->win_count, e->reset_list, e->counters,
-                    e->total_resets, e->atlas, e->lut, e->tiles, e->vplane, e->fcache};
+                    e->total_resets, e->atlas, e->lut, e->tiles, e->vplane, e->fcache, e->lsm};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete e;
 }
@@ -1223,7 +1236,7 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
                        e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, e->reset_list, e->counters + 16 * e->step_parity, all,
                        e->total_resets, D, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n,
                        e->win_list + (size_t)wb * e->period * e->n, e->win_count + WIN_STRIDE * wb, pos, image, dirs,
-                       e->counters + 16 * (e->step_parity ^ 1), e->tiles, e->step_prio, e->vplane, e->fcache);
+                       e->counters + 16 * (e->step_parity ^ 1), e->tiles, e->step_prio, e->vplane, e->fcache, e->lsm);
     }
     if (e->tokens)
         hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n, e->rec,
@@ -1301,7 +1314,7 @@ static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint
         ProfScope prof_(e, 0, s);
         const dim3 grid((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), block(STEP_BLOCK);
 #define STEP_LAUNCH(EM, VV) hipLaunchKernelGGL((k_step<EM, VV>), grid, block, 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, \
-                                               image, dirs, rewards, rewards64, dones, auto_reset, list, counter, e->tiles, e->step_prio, e->vplane, e->fcache)
+                                               image, dirs, rewards, rewards64, dones, auto_reset, list, counter, e->tiles, e->step_prio, e->vplane, e->fcache, e->lsm)
         if (e->tiles) { if (e->vplane) STEP_LAUNCH(true, true); else STEP_LAUNCH(true, false); }
         else { if (e->vplane) STEP_LAUNCH(false, true); else STEP_LAUNCH(false, false); }
 #undef STEP_LAUNCH
@@ -1442,6 +1455,7 @@ int bbai_import_state(bbai_env* e, int64_t first, int64_t count, const uint8_t* 
     if (hot) HIP_TRY(hipMemcpy(e->hot + first, hot, (size_t)count * sizeof(Hot), hipMemcpyHostToDevice));
     if (stale) HIP_TRY(hipMemcpy(e->stale + first, stale, (size_t)count * 8, hipMemcpyHostToDevice));
     e->tiles_valid = false;             // (the plane describes observations; the next reset / step rewrites it)
+    if (e->lsm && count > 0) HIP_TRY(hipMemset(e->lsm + first, 0, (size_t)count));     // (not part of the exported state: lastStepMatch = False)
     if (rec && count > 0) {
         hipLaunchKernelGGL(k_sync_prog, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, e->cfg, e->n, first, count, e->rec,
                            e->vhead, e->vset);
@@ -1471,6 +1485,7 @@ static int ckpt_segments(const bbai_env* e, Seg* out) {
     out[k++] = {e->win_count, 3 * WIN_STRIDE * 4}; out[k++] = {e->reset_list, n * 4}; out[k++] = {e->counters, 128};
     out[k++] = {e->total_resets, 16};
     if (e->bot_state) { out[k++] = {e->bot_state, n * bot_state_bytes(e->bot_stack)}; out[k++] = {e->bot_stats, 16}; }
+    if (e->lsm) out[k++] = {e->lsm, n};
     return k;
 }
 
@@ -1529,7 +1544,7 @@ int bbai_checkpoint_load(bbai_env* e, const void* host_buf, int64_t bytes) {
     e->bot_state = keep_state;
     size_t total = sizeof(CkptHeader);
     for (int i = 0; i < k; ++i) total += seg[i].bytes;
-    if ((int64_t)total != bytes) ARG_FAIL("checkpoint size does not match this handle");
+    if ((int64_t)total != bytes) ARG_FAIL("checkpoint size does not match this handle (different done-action mode, bbai_set_done_actions?)");
     const uint8_t* src = (const uint8_t*)host_buf + sizeof(CkptHeader);
     for (int i = 0; i < k; ++i) { HIP_TRY(hipMemcpy(seg[i].p, src, seg[i].bytes, hipMemcpyHostToDevice)); src += seg[i].bytes; }
     e->step_parity = h.step_parity; e->next_counter_clean = h.next_counter_clean != 0; e->seeded = h.seeded != 0; e->live = h.live != 0;
@@ -1702,6 +1717,19 @@ int bbai_set_call_events(bbai_env* e, int enable) {
 }
 
 int bbai_has_tile_plane(bbai_env* e) { return e && e->tiles ? 1 : 0; }
+
+// The reference's BABYAI_DONE_ACTIONS verifier mode for this handle (on by default iff that variable was non-empty at
+// bbai_create, as the reference reads it at import).  Switching it resets every env's lastStepMatch bits.
+int bbai_set_done_actions(bbai_env* e, int enable) {
+    if (!e) ARG_FAIL("null handle");
+    ON_DEVICE(e->device);
+    HIP_TRY(hipDeviceSynchronize());
+    if (enable && !e->lsm) HIP_TRY(hipMalloc((void**)&e->lsm, (size_t)e->n));
+    if (!enable && e->lsm) { HIP_TRY(hipFree(e->lsm)); e->lsm = nullptr; }
+    if (e->lsm) HIP_TRY(hipMemset(e->lsm, 0, (size_t)e->n));
+    return BBAI_OK;
+}
+int bbai_get_done_actions(bbai_env* e) { return e && e->lsm ? 1 : 0; }
 
 int bbai_profile(bbai_env* e, int enable) {
     if (!e) ARG_FAIL("null handle");

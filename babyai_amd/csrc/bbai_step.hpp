@@ -21,7 +21,7 @@ namespace bbai {
 struct EnvRef {             // views into one env's record + its verifier program (SoA)
     uint8_t* E; uint8_t* I; uint8_t* app; uint8_t* pos; uint8_t* cont; VProg prog;
 };
-enum : int { V_CONTINUE = 0, V_SUCCESS = 1, V_FAILURE = 2 };
+enum : int { V_CONTINUE = 0, V_SUCCESS = 1, V_FAILURE = 2, V_NONE = 3 /* done-action mode: ActionInstr.verify returned None */ };
 BB_HD EnvRef env_ref(const LevelCfg& c, uint8_t* rec, const VProg& vp) {
     EnvRef r;
     r.E = rec; r.I = rec + c.off_I; r.app = rec + c.off_app; r.pos = rec + c.off_pos; r.cont = rec + c.off_cont;
@@ -36,7 +36,7 @@ BB_HD int dir_dy(int d) { return (d == 1) - (d == 3); }
 // leaf is actually evaluated (verifier.py:331-334,394-396).
 // `fe2` = appearance byte of the cell in front of the agent AFTER the action (callers that have the 7x7 window at hand pass
 // its cell (3,5); step_env reads it from the appearance plane).
-BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int leaf, int action, int fe2) {
+BB_HD int verify_leaf_action(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int leaf, int action, int fe2) {
     const int kind = r.prog.kind(leaf);
     const uint64_t set0 = r.prog.set(leaf, 0);
     if (kind == L_GOTO) {
@@ -95,37 +95,53 @@ BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale
     return V_CONTINUE;
 }
 
+// ActionInstr.verify (verifier.py:216-230).  `lsm` = NULL: the normal mode, verify_action's result.  Otherwise the
+// BABYAI_DONE_ACTIONS mode (verifier.py:17): bit `leaf` of *lsm is the instruction's lastStepMatch; a `done` action (and,
+// by include/bbai.h's definition, every byte above 7) succeeds iff the previous evaluated action completed the instruction
+// and FAILS otherwise; any other action only records whether it did and returns None (V_NONE: neither success nor
+// failure for the callers, exactly as the reference's missing `return` behaves).
+BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int leaf, int action, int fe2, uint32_t* lsm) {
+    if (!lsm) return verify_leaf_action(c, r, h, stale, leaf, action, fe2);
+    if (action >= A_DONE) return (*lsm >> leaf & 1u) ? V_SUCCESS : V_FAILURE;
+    const int res = verify_leaf_action(c, r, h, stale, leaf, action, fe2);
+    *lsm = (*lsm & ~(1u << leaf)) | ((res == V_SUCCESS ? 1u : 0u) << leaf);
+    return V_NONE;
+}
+
 // One side of a Seq (an ActionInstr, or an AndInstr of two).  bit_a/bit_b: And progress bits.
-// An AndInstr never reports failure (verifier.py:536-550); a lone ActionInstr passes it through.
-BB_HD int verify_side(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int base, int n, int bit_a, int action, int fe2) {
-    if (n == 1) return verify_leaf(c, r, h, stale, base, action, fe2);
+// An AndInstr never reports failure (verifier.py:536-550); a lone ActionInstr passes it through.  (In done-action mode the
+// reference's AndInstr has a failure rule behind `action is self.env.actions.done`, verifier.py:543-545: an identity test
+// against the enum member that no int / numpy action ever passes -- every vectorised caller steps with ints,
+// babyai/rl/utils/penv.py:8 -- so a byte-action engine has nothing to restate there; oracle/levels.py keeps the test.)
+BB_HD int verify_side(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int base, int n, int bit_a, int action, int fe2, uint32_t* lsm) {
+    if (n == 1) return verify_leaf(c, r, h, stale, base, action, fe2, lsm);
     if (!(h.vstate >> bit_a & 1))
-        if (verify_leaf(c, r, h, stale, base, action, fe2) == V_SUCCESS) h.vstate |= 1 << bit_a;
+        if (verify_leaf(c, r, h, stale, base, action, fe2, lsm) == V_SUCCESS) h.vstate |= 1 << bit_a;
     if (!(h.vstate >> (bit_a + 1) & 1))
-        if (verify_leaf(c, r, h, stale, base + 1, action, fe2) == V_SUCCESS) h.vstate |= 1 << (bit_a + 1);
+        if (verify_leaf(c, r, h, stale, base + 1, action, fe2, lsm) == V_SUCCESS) h.vstate |= 1 << (bit_a + 1);
     return (h.vstate >> bit_a & 3) == 3 ? V_SUCCESS : V_CONTINUE;
 }
 
-BB_HD int verify_root(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2) {
+BB_HD int verify_root(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2, uint32_t* lsm) {
     const VProg* p = &r.prog;
-    if (p->root() == R_ACTION || p->root() == R_AND) return verify_side(c, r, h, stale, 0, p->n_a(), 1, action, fe2);
+    if (p->root() == R_ACTION || p->root() == R_AND) return verify_side(c, r, h, stale, 0, p->n_a(), 1, action, fe2, lsm);
     // Before: a then b; After: b then a.  The second part is verified with the SAME action in
     // the step the first part completes (verifier.py:463-464,504-505); a failure of either part fails.
     const bool before = p->root() == R_BEFORE;
     const int b1 = before ? 0 : 2, n1 = before ? p->n_a() : p->n_b(), s1 = before ? 1 : 3;
     const int b2 = before ? 2 : 0, n2 = before ? p->n_b() : p->n_a(), s2 = before ? 3 : 1;
     if (!(h.vstate & 1)) {
-        int st = verify_side(c, r, h, stale, b1, n1, s1, action, fe2);
+        int st = verify_side(c, r, h, stale, b1, n1, s1, action, fe2, lsm);
         if (st == V_FAILURE) return st;
         if (st != V_SUCCESS) {
             // strict Seq: completing the second part first fails (verifier.py:466-469,507-510); the probe IS a verify()
-            // of the second part, with its side effects (preCarrying, And progress bits)
-            if (p->strict_seq() && verify_side(c, r, h, stale, b2, n2, s2, action, fe2) == V_SUCCESS) return V_FAILURE;
+            // of the second part, with its side effects (preCarrying, And progress bits, lastStepMatch)
+            if (p->strict_seq() && verify_side(c, r, h, stale, b2, n2, s2, action, fe2, lsm) == V_SUCCESS) return V_FAILURE;
             return st;
         }
         h.vstate |= 1;
     }
-    return verify_side(c, r, h, stale, b2, n2, s2, action, fe2);
+    return verify_side(c, r, h, stale, b2, n2, s2, action, fe2, lsm);
 }
 
 // reward = 1 - 0.9 * (step_count / max_steps) in float64 (MiniGridEnv._reward, returned as a Python float at
@@ -209,8 +225,8 @@ BB_HD int apply_action(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t& sta
 
 // Second half: the instruction verifier and the episode end (RoomGridLevel.step, levelgen.py:56-66).  `fe2` = appearance
 // byte of the front cell of the pose AFTER the action.  Returns done; reward by reference.
-BB_HD bool finish_step(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2, double& reward) {
-    const int status = verify_root(c, r, h, stale, action, fe2);
+BB_HD bool finish_step(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2, double& reward, uint32_t* lsm = nullptr) {
+    const int status = verify_root(c, r, h, stale, action, fe2, lsm);
     bool done = h.step >= h.max_steps;
     reward = 0.0;
     if (status == V_SUCCESS) { done = true; reward = success_reward(h.step, h.max_steps); }
@@ -220,22 +236,22 @@ BB_HD bool finish_step(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stal
 
 // MiniGridEnv.step + RoomGridLevel.step for one env, everything read from the record (host build, reference form of the
 // two halves above).  Returns done; reward by reference.
-BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, double& reward) {
+BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, double& reward, uint32_t* lsm = nullptr) {
     EnvRef r = env_ref(c, rec, vp);
     const int fe = r.E[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];
     int ce = h.carry != NONE8 ? r.app[h.carry] : (int)E_EMPTY;
     apply_action(c, r, h, stale, action, fe, ce);
     const int fe2 = r.E[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];
-    return finish_step(c, r, h, stale, action, fe2, reward);
+    return finish_step(c, r, h, stale, action, fe2, reward, lsm);
 }
 
 // Not a MiniGrid action: "env.reset() for THIS env, now" -- what a ParallelEnv worker does on a `reset` command
 // (babyai/rl/utils/penv.py:12-14) and what make_agent_demos.py:84-88 does after a bot crash.  The episode ends with
 // done = 1, reward = 0 and (auto-reset) the next observation is the first one of the env's next level.
 constexpr int A_RESET_ENV = 7;
-BB_HD bool step_env_cmd(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, double& reward) {
+BB_HD bool step_env_cmd(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, double& reward, uint32_t* lsm = nullptr) {
     if (action == A_RESET_ENV) { reward = 0.0; return true; }
-    return step_env(c, rec, vp, h, stale, action, reward);
+    return step_env(c, rec, vp, h, stale, action, reward, lsm);
 }
 
 // bonus_levels.py:821-829: right after reset (and after the first observation was produced) the object is taken

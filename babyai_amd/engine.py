@@ -79,6 +79,8 @@ def load_library():
     lib.bbai_bot_act.argtypes = [P, P, P, P]
     lib.bbai_bot_stats.argtypes = [P, P, P]
     lib.bbai_bot_rollout.argtypes = [P, I32, P, P, P, P, P, P, P, P, P, P]
+    lib.bbai_set_done_actions.argtypes = [P, I32]
+    lib.bbai_get_done_actions.argtypes = [P]
     _lib = lib
     return lib
 
@@ -88,7 +90,7 @@ EXPORTED_SYMBOLS = (
     "bbai_reset", "bbai_step", "bbai_set_atlas", "bbai_render", "bbai_set_token_buffer", "bbai_export_state", "bbai_import_state",
     "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures", "bbai_bot_act", "bbai_bot_stats",
     "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load", "bbai_profile", "bbai_profile_read", "bbai_gae", "bbai_tap",
-    "bbai_tap_ids", "bbai_set_call_events", "bbai_render_current", "bbai_has_tile_plane", "bbai_bot_rollout",
+    "bbai_tap_ids", "bbai_set_call_events", "bbai_render_current", "bbai_has_tile_plane", "bbai_bot_rollout", "bbai_set_done_actions", "bbai_get_done_actions",
 )
 
 
@@ -154,18 +156,19 @@ class BatchedBabyAIEnv(object):
     pixel : apply RGBImgPartialObsWrapper semantics (obs image uint8[N,56,56,3])
     auto_reset : True = ParallelEnv protocol (penv.py:8-11); False = ManyEnvs protocol
                  (evaluate.py:73-81: finished envs freeze until reset())
+    done_actions : the reference's BABYAI_DONE_ACTIONS verifier mode (babyai/levels/verifier.py:17,216-230: an instruction
+                 succeeds only on a `done` action right after the step that completed it; include/bbai.h
+                 bbai_set_done_actions).  None (default) = as the reference decides it: on iff that environment variable is
+                 non-empty; True / False force it for this batch
     validate_actions : check every step()'s actions on the device first and raise AssertionError("unknown action") like
                  the reference (gym_minigrid MiniGridEnv.step) instead of treating bytes 8..255 as `done` (include/bbai.h);
                  costs one reduction and a host synchronisation per step, so it is off by default
     """
 
-    def __init__(self, env_id, num_envs, device="cuda:0", seeds=None, pixel=False, auto_reset=True, validate_actions=False):
+    def __init__(self, env_id, num_envs, device="cuda:0", seeds=None, pixel=False, auto_reset=True, validate_actions=False,
+                 done_actions=None):
         import torch
         self.torch = torch
-        if os.environ.get("BABYAI_DONE_ACTIONS"):
-            # babyai/levels/verifier.py:17,221-230,543-545: any non-empty value switches the verifier to
-            # "done"-action semantics, which the engine does not implement -- refuse rather than diverge.
-            raise EngineError("BABYAI_DONE_ACTIONS is set: the done-action verifier mode is not supported")
         if not torch.cuda.is_available():
             raise EngineError("no ROCm GPU visible: the batched engine has no CPU path")
         self.lib = load_library()
@@ -182,6 +185,9 @@ class BatchedBabyAIEnv(object):
         self.handle = ctypes.c_void_p()
         _check(self.lib, self.lib.bbai_create(ctypes.byref(self.cfg), self.num_envs, self.dev_index,
                                                ctypes.byref(self.handle)), "bbai_create")
+        if done_actions is not None:
+            _check(self.lib, self.lib.bbai_set_done_actions(self.handle, 1 if done_actions else 0), "bbai_set_done_actions")
+        self.done_actions = bool(self.lib.bbai_get_done_actions(self.handle))
         n = self.num_envs
         with torch.cuda.device(self.dev_index):
             self.image = torch.zeros((n, 7, 7, 3), dtype=torch.uint8, device=self.device)

@@ -200,6 +200,17 @@ int bbai_profile_read(bbai_env* env, double* ms_total /* [3] */, int64_t* launch
  * profiles/r03/call_events_ab.jsonl), hence off by default (BBAI_CALL_EVENTS=1 in the environment turns it on at create). */
 int bbai_set_call_events(bbai_env* env, int enable);
 
+/* The reference's done-action verifier mode (babyai/levels/verifier.py:17 `use_done_actions = os.environ.get(
+ * 'BABYAI_DONE_ACTIONS', False)`, :216-230 ActionInstr.verify): an action instruction succeeds only on a `done` action taken
+ * right after the step that completed it, and a `done` action at any other time FAILS it (episode over, reward 0).  A handle
+ * starts in that mode iff the variable is non-empty in the environment at bbai_create -- the reference reads it at import --
+ * and this call switches it explicitly (every env's lastStepMatch is cleared; call it between episodes).  AndInstr's extra
+ * failure rule (verifier.py:543-545) sits behind `action is self.env.actions.done`, an identity test no int action passes
+ * (every vectorised caller of the reference steps with ints, babyai/rl/utils/penv.py:8): nothing to restate for byte
+ * actions.  The per-env bits travel in checkpoints; bbai_import_state clears them.  tests/test_done_actions.py. */
+int bbai_set_done_actions(bbai_env* env, int enable);
+int bbai_get_done_actions(bbai_env* env);
+
 /* Number of level generations (resets) performed so far, all envs. */
 int bbai_reset_count(bbai_env* env, uint64_t* out);
 

@@ -24,8 +24,10 @@ What follows which reference code (all under /root/reference/babyai/levels/):
   GoToOracle.gen_mission           iclr19_levels.py:40-63, 75-124, 224-257
   BonusOracle.gen_*                bonus_levels.py (line ranges in each method's docstring)
   FixedLayoutOracle.lay_*          test_levels.py (line ranges in each method's docstring)
-BABYAI_DONE_ACTIONS (verifier.py:17) is not restated; PutNext / Before / After `strict` (no registered level sets them)
-are, and are checked against the reference's verifier classes in tests/test_strict_modes.py.
+PutNext / Before / After `strict` (no registered level sets them) are restated and checked against the reference's verifier
+classes in tests/test_strict_modes.py.  BABYAI_DONE_ACTIONS (verifier.py:17,216-230,543-545: an action instruction only
+succeeds on a `done` action taken right after the step that completed it) is restated behind `DONE_ACTIONS` below and pinned
+by tests/golden/done_actions/ (tools/gen_golden_done.py: the reference imported with the variable set).
 """
 import os
 import sys
@@ -36,6 +38,9 @@ if _SHIM not in sys.path:
 
 from gym_minigrid.minigrid import COLOR_NAMES, DIR_TO_VEC, Ball, Box, Key  # noqa: E402
 from gym_minigrid.roomgrid import RoomGrid  # noqa: E402
+
+# verifier.py:17 `use_done_actions = os.environ.get('BABYAI_DONE_ACTIONS', False)`: any non-empty value, read at import
+DONE_ACTIONS = bool(os.environ.get('BABYAI_DONE_ACTIONS', False))
 
 TYPES_ALL = ['box', 'ball', 'key', 'door']
 TYPES_MOVABLE = ['box', 'ball', 'key']
@@ -129,6 +134,7 @@ class Clause(object):
     def start(self, env):
         self.env = env
         self.held_before = None
+        self.last_match = False       # ActionInstr.lastStepMatch (verifier.py:213-214)
         for d in self.descs():
             d.match(env)
 
@@ -140,6 +146,17 @@ class Clause(object):
         return any(_manhattan1(a.cur_pos, p) for a in self.d1.objs for p in self.d2.poss)
 
     def verify(self, action):
+        """ActionInstr.verify (verifier.py:216-230).  With done actions: a `done` succeeds iff the PREVIOUS evaluated action
+        completed the instruction and fails otherwise; any other action only records whether it did (and returns None, as
+        the reference does -- callers treat that like 'continue')."""
+        if not DONE_ACTIONS:
+            return self.verify_action(action)
+        if action == self.env.actions.done:
+            return 'success' if self.last_match else 'failure'
+        self.last_match = self.verify_action(action) == 'success'
+        return None
+
+    def verify_action(self, action):
         env = self.env
         A = env.actions
         if self.kind == 'goto':
@@ -208,6 +225,11 @@ class Combo(object):
                 self.sa = self.a.verify(action)
             if self.sb != 'success':
                 self.sb = self.b.verify(action)
+            # verifier.py:543-545 -- an IDENTITY test against the enum member: true only for callers that pass
+            # `env.actions.done` itself, never for the ints / numpy ints every vectorised caller passes (penv.py:8)
+            if DONE_ACTIONS and action is self.a.env.actions.done:
+                if self.sa == 'failure' and self.sb == 'failure':
+                    return 'failure'
             return 'success' if self.sa == 'success' and self.sb == 'success' else 'continue'
         first, second = (self.a, self.b) if self.how == 'before' else (self.b, self.a)
         if not getattr(self, '_first_done', False):

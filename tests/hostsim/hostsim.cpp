@@ -75,6 +75,14 @@ int hs_step64(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int 
     VProg vp; vp.bind(vhead_pack(*p), sets, 1);
     return step_env_cmd(*cfg, rec, vp, *hot, *stale, action, *reward) ? 1 : 0;
 }
+// the same step in the reference's BABYAI_DONE_ACTIONS mode; *lsm = the env's lastStepMatch bits (0 at episode start)
+int hs_step64_done(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int action, double* reward, uint32_t* lsm) {
+    const Prog* p = (const Prog*)(rec + cfg->off_prog);
+    uint64_t sets[8];
+    for (int k = 0; k < 8; ++k) sets[k] = p->set[k >> 1][k & 1];
+    VProg vp; vp.bind(vhead_pack(*p), sets, 1);
+    return step_env_cmd(*cfg, rec, vp, *hot, *stale, action, *reward, lsm) ? 1 : 0;
+}
 int hs_step(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int action, float* reward) {
     double r = 0.0;
     const int d = hs_step64(cfg, rec, hot, stale, action, &r);

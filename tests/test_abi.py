@@ -56,14 +56,6 @@ def test_no_cpu_fallback():
         BatchedBabyAIEnv("BabyAI-GoToLocal-v0", 4)
 
 
-def test_done_actions_mode_is_refused(monkeypatch):
-    """verifier.py:17: any non-empty BABYAI_DONE_ACTIONS changes verifier semantics; the engine must refuse it."""
-    from babyai_amd.engine import BatchedBabyAIEnv, EngineError
-    monkeypatch.setenv("BABYAI_DONE_ACTIONS", "0")
-    with pytest.raises(EngineError, match="DONE_ACTIONS"):
-        BatchedBabyAIEnv("BabyAI-GoToLocal-v0", 4)
-
-
 def test_header_is_plain_c():
     """include/bbai.h must be consumable from C (the drop-in boundary is a C ABI, not a C++ one)."""
     import subprocess
