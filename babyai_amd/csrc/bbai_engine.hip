@@ -153,7 +153,14 @@ struct bbai_env {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int MAX_PERIOD = 32;          // refill period B (ticks per look-ahead refill); ring depth D = 2B
 constexpr int WIN_STRIDE = 64;          // uint32 per window-count block (1 + MAX_PERIOD used)
-constexpr int STEP_BLOCK = 256;
+#ifndef BBAI_STEP_BLOCK
+#define BBAI_STEP_BLOCK 256            // envs (= threads) per k_step block: 64 / 128 / 256 (experiment builds: tools/gpu_r03_k.sh)
+#endif
+constexpr int STEP_BLOCK = BBAI_STEP_BLOCK;
+#ifndef BBAI_PREFETCH_ID
+#define BBAI_PREFETCH_ID 0
+#endif
+static_assert(STEP_BLOCK % 64 == 0 && STEP_BLOCK >= 64 && STEP_BLOCK <= 1024, "whole waves; 64 rows of 147 B keep every block's span 16-byte aligned");
 
 // Observation with the 7x7 window staged in LDS (the k_step path).  49 scattered byte loads per lane keep the
 // texture-address unit busy for most of k_step (tools/step_ab.py ablation), so the window is fetched in WORLD
@@ -363,17 +370,26 @@ __global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, i
             } else {
                 window_fetch((const uint32_t*)(rec + ((tym * c.ES + txm) & ~3)), c.ES >> 2, wd);     // (ES is a multiple of 4)
             }
+            // the id-plane entry of the front cell, fetched WITH the window: the verifier's common question ("is the object
+            // in front of me one of the described ones") and the object actions then need no further memory round trip
+            // (BBAI_PREFETCH_ID=0: read lazily, as rounds 1-2 did -- one more line per env-step, one round trip less)
+            int idf = -1;
+#if BBAI_PREFETCH_ID
+            idf = r.I[i_index(c, h.ax + dir_dx(dir), h.ay + dir_dy(dir))];
+#endif
             // pickup / drop / toggle, while the window is on its way
             int nfe = -1;
             if (action != A_RESET_ENV) {
-                nfe = apply_objects(c, r, h, stale, action, fe, ce);
+                int nid = -1;
+                nfe = apply_objects(c, r, h, stale, action, fe, ce, idf, &nid);
                 if (VP && nfe >= 0) v_patch(c, vrow, h.ax + dir_dx(dir), h.ay + dir_dy(dir), nfe);
+                if (idf >= 0 && nid >= 0) idf = nid;
             }
             int fe2;
             uint32_t cp[13], vis[VIEW];
             view_cells(wd, txm & 3, dir, (uint32_t)ce, nfe, s_rows + row_scratch(threadIdx.x), cp, vis, fe2);
             // "env.reset() for THIS env, now" (A_RESET_ENV, bbai_step.hpp): the episode ends with done = 1, reward = 0
-            const bool done = action == A_RESET_ENV ? true : finish_step(c, r, h, stale, action, fe2, reward, lsm_arr ? &lsm : nullptr);
+            const bool done = action == A_RESET_ENV ? true : finish_step(c, r, h, stale, action, fe2, reward, lsm_arr ? &lsm : nullptr, idf);
             if (lsm_arr) lsm_arr[env] = (uint8_t)lsm;
             if (done && !auto_reset) h.frozen = 1;
             want_reset = done && auto_reset;

@@ -36,7 +36,9 @@ BB_HD int dir_dy(int d) { return (d == 1) - (d == 3); }
 // leaf is actually evaluated (verifier.py:331-334,394-396).
 // `fe2` = appearance byte of the cell in front of the agent AFTER the action (callers that have the 7x7 window at hand pass
 // its cell (3,5); step_env reads it from the appearance plane).
-BB_HD int verify_leaf_action(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int leaf, int action, int fe2) {
+// `idf` = the id-plane entry of that front cell when the caller already has it (k_step fetches it together with the window,
+// so that the common verifications need no further memory round trip), or -1 = read it here when needed.
+BB_HD int verify_leaf_action(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int leaf, int action, int fe2, int idf) {
     const int kind = r.prog.kind(leaf);
     const uint64_t set0 = r.prog.set(leaf, 0);
     if (kind == L_GOTO) {
@@ -46,7 +48,7 @@ BB_HD int verify_leaf_action(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_
         // lines the observation needs anyway) shows an object there.
         int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
         if (e_type(fe2) >= T_DOOR) {
-            int id = r.I[i_index(c, fx, fy)];
+            int id = idf >= 0 ? idf : (int)r.I[i_index(c, fx, fy)];
             if (id >= 2 && (set0 >> (id - 2) & 1)) return V_SUCCESS;
         }
         uint64_t m = set0 & stale;
@@ -63,7 +65,7 @@ BB_HD int verify_leaf_action(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_
         int fe = fe2;
         if (e_type(fe) != T_DOOR) return V_CONTINUE;
         if (e_state(fe) == S_OPEN) {
-            int id = r.I[i_index(c, fx, fy)];
+            int id = idf >= 0 ? idf : (int)r.I[i_index(c, fx, fy)];
             if (id >= 2 && (set0 >> (id - 2) & 1)) return V_SUCCESS;
         }
         // strict: toggling any door without completing the instruction fails (verifier.py:270-272)
@@ -100,10 +102,10 @@ BB_HD int verify_leaf_action(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_
 // by include/bbai.h's definition, every byte above 7) succeeds iff the previous evaluated action completed the instruction
 // and FAILS otherwise; any other action only records whether it did and returns None (V_NONE: neither success nor
 // failure for the callers, exactly as the reference's missing `return` behaves).
-BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int leaf, int action, int fe2, uint32_t* lsm) {
-    if (!lsm) return verify_leaf_action(c, r, h, stale, leaf, action, fe2);
+BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int leaf, int action, int fe2, uint32_t* lsm, int idf) {
+    if (!lsm) return verify_leaf_action(c, r, h, stale, leaf, action, fe2, idf);
     if (action >= A_DONE) return (*lsm >> leaf & 1u) ? V_SUCCESS : V_FAILURE;
-    const int res = verify_leaf_action(c, r, h, stale, leaf, action, fe2);
+    const int res = verify_leaf_action(c, r, h, stale, leaf, action, fe2, idf);
     *lsm = (*lsm & ~(1u << leaf)) | ((res == V_SUCCESS ? 1u : 0u) << leaf);
     return V_NONE;
 }
@@ -113,35 +115,35 @@ BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale
 // reference's AndInstr has a failure rule behind `action is self.env.actions.done`, verifier.py:543-545: an identity test
 // against the enum member that no int / numpy action ever passes -- every vectorised caller steps with ints,
 // babyai/rl/utils/penv.py:8 -- so a byte-action engine has nothing to restate there; oracle/levels.py keeps the test.)
-BB_HD int verify_side(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int base, int n, int bit_a, int action, int fe2, uint32_t* lsm) {
-    if (n == 1) return verify_leaf(c, r, h, stale, base, action, fe2, lsm);
+BB_HD int verify_side(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int base, int n, int bit_a, int action, int fe2, uint32_t* lsm, int idf) {
+    if (n == 1) return verify_leaf(c, r, h, stale, base, action, fe2, lsm, idf);
     if (!(h.vstate >> bit_a & 1))
-        if (verify_leaf(c, r, h, stale, base, action, fe2, lsm) == V_SUCCESS) h.vstate |= 1 << bit_a;
+        if (verify_leaf(c, r, h, stale, base, action, fe2, lsm, idf) == V_SUCCESS) h.vstate |= 1 << bit_a;
     if (!(h.vstate >> (bit_a + 1) & 1))
-        if (verify_leaf(c, r, h, stale, base + 1, action, fe2, lsm) == V_SUCCESS) h.vstate |= 1 << (bit_a + 1);
+        if (verify_leaf(c, r, h, stale, base + 1, action, fe2, lsm, idf) == V_SUCCESS) h.vstate |= 1 << (bit_a + 1);
     return (h.vstate >> bit_a & 3) == 3 ? V_SUCCESS : V_CONTINUE;
 }
 
-BB_HD int verify_root(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2, uint32_t* lsm) {
+BB_HD int verify_root(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2, uint32_t* lsm, int idf) {
     const VProg* p = &r.prog;
-    if (p->root() == R_ACTION || p->root() == R_AND) return verify_side(c, r, h, stale, 0, p->n_a(), 1, action, fe2, lsm);
+    if (p->root() == R_ACTION || p->root() == R_AND) return verify_side(c, r, h, stale, 0, p->n_a(), 1, action, fe2, lsm, idf);
     // Before: a then b; After: b then a.  The second part is verified with the SAME action in
     // the step the first part completes (verifier.py:463-464,504-505); a failure of either part fails.
     const bool before = p->root() == R_BEFORE;
     const int b1 = before ? 0 : 2, n1 = before ? p->n_a() : p->n_b(), s1 = before ? 1 : 3;
     const int b2 = before ? 2 : 0, n2 = before ? p->n_b() : p->n_a(), s2 = before ? 3 : 1;
     if (!(h.vstate & 1)) {
-        int st = verify_side(c, r, h, stale, b1, n1, s1, action, fe2, lsm);
+        int st = verify_side(c, r, h, stale, b1, n1, s1, action, fe2, lsm, idf);
         if (st == V_FAILURE) return st;
         if (st != V_SUCCESS) {
             // strict Seq: completing the second part first fails (verifier.py:466-469,507-510); the probe IS a verify()
             // of the second part, with its side effects (preCarrying, And progress bits, lastStepMatch)
-            if (p->strict_seq() && verify_side(c, r, h, stale, b2, n2, s2, action, fe2, lsm) == V_SUCCESS) return V_FAILURE;
+            if (p->strict_seq() && verify_side(c, r, h, stale, b2, n2, s2, action, fe2, lsm, idf) == V_SUCCESS) return V_FAILURE;
             return st;
         }
         h.vstate |= 1;
     }
-    return verify_side(c, r, h, stale, b2, n2, s2, action, fe2, lsm);
+    return verify_side(c, r, h, stale, b2, n2, s2, action, fe2, lsm, idf);
 }
 
 // reward = 1 - 0.9 * (step_count / max_steps) in float64 (MiniGridEnv._reward, returned as a Python float at
@@ -165,7 +167,8 @@ BB_HD double success_reward(int step, int max_steps) {
 // (E_EMPTY: nothing) -- both are passed in so that callers which cache them (k_step: 2 bytes per env) never touch the record
 // on a plain move / turn; `ce` is kept current.  apply_objects returns the NEW appearance byte of the front cell when the
 // action changed it, else -1 (callers that keep derived copies of the appearance plane patch them with it; the changed cell
-// is view cell (3, 5) of the observation that follows).
+// is view cell (3, 5) of the observation that follows).  `idf` = the id-plane entry of the front cell if the caller fetched it
+// already (-1: read here); `nid` receives the entry this call wrote there (-1: none).
 BB_HD void apply_pose(Hot& h, int action, int fe) {
     h.step = (uint16_t)(h.step + 1);
     if (action == A_LEFT) h.dir = (h.dir + 3) & 3;
@@ -174,23 +177,23 @@ BB_HD void apply_pose(Hot& h, int action, int fe) {
         h.ax = (uint8_t)(h.ax + dir_dx(h.dir)); h.ay = (uint8_t)(h.ay + dir_dy(h.dir));
     }
 }
-BB_HD int apply_objects(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t& stale, int action, int fe, int& ce) {
-    int nfe = -1;
+BB_HD int apply_objects(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t& stale, int action, int fe, int& ce, int idf = -1, int* nid = nullptr) {
+    int nfe = -1, wid = -1;          // new appearance / new id-plane entry of the front cell (-1: unchanged)
     if (action == A_PICKUP || action == A_DROP || action == A_TOGGLE) {
         const int fx = h.ax + dir_dx(h.dir), fy = h.ay + dir_dy(h.dir);
         const int ei = e_index(c, fx, fy), ii = i_index(c, fx, fy);
         if (action == A_PICKUP) {
             if (e_type(fe) >= T_KEY && h.carry == NONE8) {
-                int o = r.I[ii] - 2;
+                int o = (idf >= 0 ? idf : (int)r.I[ii]) - 2;
                 h.carry = (uint8_t)o;
                 ce = fe;                                 // a key / ball / box looks the same on the floor and in the hand
-                nfe = E_EMPTY; r.I[ii] = 0;
+                nfe = E_EMPTY; r.I[ii] = 0; wid = 0;
                 stale |= 1ull << o;                      // its recorded position is now stale
             }
         } else if (action == A_DROP) {
             if (fe == E_EMPTY && h.carry != NONE8) {
                 int o = h.carry;
-                nfe = ce; r.I[ii] = (uint8_t)(o + 2);
+                nfe = ce; r.I[ii] = (uint8_t)(o + 2); wid = o + 2;
                 r.pos[2 * o] = (uint8_t)fx; r.pos[2 * o + 1] = (uint8_t)fy;
                 h.carry = NONE8;
                 ce = E_EMPTY;
@@ -202,12 +205,12 @@ BB_HD int apply_objects(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t& st
                 nfe = e_make(T_DOOR, e_color(fe), e_state(fe) == S_OPEN ? S_CLOSED : S_OPEN);
             }
         } else if (e_type(fe) == T_BOX) {                // box is replaced by its contents (nothing, or a hidden object)
-            int o = r.I[ii] - 2;
+            int o = (idf >= 0 ? idf : (int)r.I[ii]) - 2;
             int inner = r.cont[o];
             if (inner == NONE8) {
-                nfe = E_EMPTY; r.I[ii] = 0;
+                nfe = E_EMPTY; r.I[ii] = 0; wid = 0;
             } else {
-                nfe = r.app[inner]; r.I[ii] = (uint8_t)(inner + 2);
+                nfe = r.app[inner]; r.I[ii] = (uint8_t)(inner + 2); wid = inner + 2;
                 r.pos[2 * inner] = (uint8_t)fx; r.pos[2 * inner + 1] = (uint8_t)fy;
             }
             stale |= 1ull << o;
@@ -216,6 +219,7 @@ BB_HD int apply_objects(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t& st
         // every drop ACTION refreshes the tracked positions (levelgen.py:53-54)
         if (action == A_DROP) stale = 0;
     }
+    if (nid) *nid = wid;                                  // (callers that fetched the front cell's id before this ran)
     return nfe;                                           // (done, and by definition every byte above 7: nothing -- include/bbai.h)
 }
 BB_HD int apply_action(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t& stale, int action, int fe, int& ce) {
@@ -225,8 +229,8 @@ BB_HD int apply_action(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t& sta
 
 // Second half: the instruction verifier and the episode end (RoomGridLevel.step, levelgen.py:56-66).  `fe2` = appearance
 // byte of the front cell of the pose AFTER the action.  Returns done; reward by reference.
-BB_HD bool finish_step(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2, double& reward, uint32_t* lsm = nullptr) {
-    const int status = verify_root(c, r, h, stale, action, fe2, lsm);
+BB_HD bool finish_step(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2, double& reward, uint32_t* lsm = nullptr, int idf = -1) {
+    const int status = verify_root(c, r, h, stale, action, fe2, lsm, idf);
     bool done = h.step >= h.max_steps;
     reward = 0.0;
     if (status == V_SUCCESS) { done = true; reward = success_reward(h.step, h.max_steps); }
@@ -243,6 +247,24 @@ BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, ui
     apply_action(c, r, h, stale, action, fe, ce);
     const int fe2 = r.E[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];
     return finish_step(c, r, h, stale, action, fe2, reward, lsm);
+}
+
+// The same step in k_step's order of operations: pose, then the front cell's id fetched BEFORE the object actions (with the
+// window, in the kernel) and corrected by what they wrote, then the verifier on that id.  The host build runs the golden
+// traces through this form too (tests/test_hostsim_golden.py), so the bookkeeping is checked without a GPU.
+BB_HD bool step_env_prefetch(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, double& reward, uint32_t* lsm = nullptr) {
+    EnvRef r = env_ref(c, rec, vp);
+    const int fe = r.E[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];
+    int ce = h.carry != NONE8 ? r.app[h.carry] : (int)E_EMPTY;
+    apply_pose(h, action, fe);
+    const int fi = e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir));
+    int fe2 = r.E[fi];                                                          // (k_step: view cell (3, 5) of the fetched window)
+    int idf = r.I[i_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];
+    int nid = -1;
+    const int nfe = apply_objects(c, r, h, stale, action, fe, ce, idf, &nid);
+    if (nfe >= 0) fe2 = nfe;
+    if (nid >= 0) idf = nid;
+    return finish_step(c, r, h, stale, action, fe2, reward, lsm, idf);
 }
 
 // Not a MiniGrid action: "env.reset() for THIS env, now" -- what a ParallelEnv worker does on a `reset` command

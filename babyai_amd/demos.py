@@ -15,7 +15,9 @@ from . import missions
 from .engine import BatchedBabyAIEnv
 
 
-def generate_demos(env_name, n_episodes, seed, device="cuda:0", batch=4096, filter_steps=0, pack=None, max_steps=None):
+def generate_demos(env_name, n_episodes, seed, device="cuda:0", batch=32768, filter_steps=0, pack=None, max_steps=None):
+    """`batch` streams run side by side on the device; a batch lasts as long as its slowest stream (the expert's decision
+    kernel has a latency of about a millisecond whatever the batch size), so large batches are what makes this fast."""
     demos = [None] * n_episodes
     for start in range(0, n_episodes, batch):
         count = min(batch, n_episodes - start)
@@ -25,21 +27,23 @@ def generate_demos(env_name, n_episodes, seed, device="cuda:0", batch=4096, filt
 
 def _generate_batch(env_name, seed, n, device, filter_steps, pack, max_steps, demos, offset):
     """One batch of streams.  The per-step loop runs on the device (`bbai_bot_rollout`: decide, step, auto-reset, history
-    rows written by the engine, `chunk` steps per call); the host only looks at whole chunks."""
+    rows written by the engine, `chunk` steps per call) and the history STAYS there: per chunk the host reads 6 bytes per
+    env-step (done, gave-up flag, reward) to find every stream's first solved episode, and at the end the spans of those
+    episodes are gathered on the device and cross PCIe once."""
+    import torch
     env = BatchedBabyAIEnv(env_name, n, device=device, seeds=[seed + k for k in range(n)], auto_reset=True)
     env.enable_instr_tokens()
     env.reset()
     budget = max_steps if max_steps is not None else 64 * env.max_steps_bound
     chunk = max(1, min(128, max(16, env.max_steps_bound // 4), budget))
-    hist = {"image": [], "direction": [], "action": [], "tokens": []}     # host copies of the chunks, [chunk, n, ...] each
+    hist = []                                      # the chunks' device tensors, [chunk, n, ...] each
     last_done = np.full(n, -1, dtype=np.int64)     # global index of the stream's latest episode end
     span = np.full((n, 2), -1, dtype=np.int64)     # [first, last] step of the stream's first solved episode
     open_ = np.ones(n, dtype=bool)                 # streams still looking for it
     g0 = 0
     while open_.any() and g0 < budget:
         r = env.bot_rollout(chunk, tokens=True)
-        for k in hist:
-            hist[k].append(r[k].cpu().numpy())
+        hist.append(r)
         done = r["done"].cpu().numpy().astype(bool)
         # "mission failed" / bot crash (RESET_ENV): the stream goes on with its next level (make_agent_demos.py:84-88,112-123)
         ok = done & (r["gave_up"].cpu().numpy() == 0) & (r["reward"].cpu().numpy() > 0)
@@ -55,12 +59,35 @@ def _generate_batch(env_name, seed, n, device, filter_steps, pack, max_steps, de
         open_ &= ~found
         last_done = np.maximum(last_done, ends[-1])
         g0 += chunk
-    env.close()
     if open_.any():
+        env.close()
         raise RuntimeError("no solvable episode found for %d stream(s) within the step budget" % int(open_.sum()))
-    img, dirs, acts, toks = (np.concatenate(hist[k]) for k in ("image", "direction", "action", "tokens"))
+    # gather the spans on the device: entry k of the flat result = step t_idx[k] of stream i_idx[k]
+    lens = span[:, 1] - span[:, 0] + 1
+    ends_flat = np.cumsum(lens)
+    total = int(ends_flat[-1])
+    i_idx = np.repeat(np.arange(n, dtype=np.int64), lens)
+    t_idx = np.arange(total, dtype=np.int64) - np.repeat(ends_flat - lens, lens) + np.repeat(span[:, 0], lens)
+    dev = env.device
+    img = torch.empty((total, 7, 7, 3), dtype=torch.uint8, device=dev)
+    dirs = torch.empty((total,), dtype=torch.uint8, device=dev)
+    acts = torch.empty((total,), dtype=torch.uint8, device=dev)
+    toks = torch.empty((n, hist[0]["tokens"].shape[2]), dtype=torch.uint8, device=dev)
+    for c, r in enumerate(hist):
+        lo = c * chunk
+        sel = np.nonzero((t_idx >= lo) & (t_idx < lo + chunk))[0]
+        if sel.size:
+            at = torch.as_tensor(sel, device=dev)
+            src = torch.as_tensor((t_idx[sel] - lo) * n + i_idx[sel], device=dev)
+            img[at] = r["image"].view(chunk * n, 7, 7, 3)[src]
+            dirs[at] = r["direction"].view(-1)[src]
+            acts[at] = r["action"].view(-1)[src]
+        sel = np.nonzero((span[:, 0] >= lo) & (span[:, 0] < lo + chunk))[0]      # the mission is the one of the episode's first step
+        if sel.size:
+            toks[torch.as_tensor(sel, device=dev)] = r["tokens"].view(chunk * n, -1)[torch.as_tensor((span[sel, 0] - lo) * n + sel, device=dev)]
+    img, dirs, acts, toks = img.cpu().numpy(), dirs.cpu().numpy(), acts.cpu().numpy(), toks.cpu().numpy()
+    env.close()
     for i in range(n):
-        lo, hi = span[i, 0], span[i, 1] + 1
-        stack = np.ascontiguousarray(img[lo:hi, i])
-        demos[offset + i] = (missions.detokenize(toks[lo, i]), pack(stack) if pack else stack,
-                             dirs[lo:hi, i].tolist(), acts[lo:hi, i].tolist())
+        lo, hi = int(ends_flat[i] - lens[i]), int(ends_flat[i])
+        stack = img[lo:hi]
+        demos[offset + i] = (missions.detokenize(toks[i]), pack(stack) if pack else stack, dirs[lo:hi].tolist(), acts[lo:hi].tolist())

@@ -75,6 +75,15 @@ int hs_step64(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int 
     VProg vp; vp.bind(vhead_pack(*p), sets, 1);
     return step_env_cmd(*cfg, rec, vp, *hot, *stale, action, *reward) ? 1 : 0;
 }
+// the step in k_step's order of operations (bbai_step.hpp step_env_prefetch); lsm may be NULL (normal mode)
+int hs_step64_prefetch(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int action, double* reward, uint32_t* lsm) {
+    const Prog* p = (const Prog*)(rec + cfg->off_prog);
+    uint64_t sets[8];
+    for (int k = 0; k < 8; ++k) sets[k] = p->set[k >> 1][k & 1];
+    VProg vp; vp.bind(vhead_pack(*p), sets, 1);
+    if (action == A_RESET_ENV) { *reward = 0.0; return 1; }
+    return step_env_prefetch(*cfg, rec, vp, *hot, *stale, action, *reward, lsm) ? 1 : 0;
+}
 // the same step in the reference's BABYAI_DONE_ACTIONS mode; *lsm = the env's lastStepMatch bits (0 at episode start)
 int hs_step64_done(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int action, double* reward, uint32_t* lsm) {
     const Prog* p = (const Prog*)(rec + cfg->off_prog);

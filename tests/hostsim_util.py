@@ -24,6 +24,7 @@ def lib():
         L.hs_generate.argtypes = [P, P, P, P, P]
         L.hs_step.argtypes = [P, P, P, P, ctypes.c_int, P]
         L.hs_step64.argtypes = [P, P, P, P, ctypes.c_int, P]
+        L.hs_step64_prefetch.argtypes = [P, P, P, P, ctypes.c_int, P, P]
         L.hs_observe.argtypes = [P, P, P, P]
         L.hs_fill_layout.argtypes = [P]
         L.hs_start_carry.argtypes = [P, P, P, P]
@@ -63,10 +64,16 @@ class HostEnv(object):
         self.L.hs_observe(ctypes.byref(self.cfg), self.rec.ctypes.data, self.hot.ctypes.data, self.out.ctypes.data)
         return self.out.reshape(7, 7, 3).copy()
 
+    prefetch_order = False      # True: step in k_step's order of operations (bbai_step.hpp step_env_prefetch)
+
     def step(self, action):
         rew = ctypes.c_double(0)
-        d = self.L.hs_step64(ctypes.byref(self.cfg), self.rec.ctypes.data, self.hot.ctypes.data,
-                             ctypes.byref(self.stale), int(action), ctypes.byref(rew))
+        if self.prefetch_order:
+            d = self.L.hs_step64_prefetch(ctypes.byref(self.cfg), self.rec.ctypes.data, self.hot.ctypes.data,
+                                          ctypes.byref(self.stale), int(action), ctypes.byref(rew), None)
+        else:
+            d = self.L.hs_step64(ctypes.byref(self.cfg), self.rec.ctypes.data, self.hot.ctypes.data,
+                                 ctypes.byref(self.stale), int(action), ctypes.byref(rew))
         self.last_reward64 = rew.value            # the f64 the kernel core computes; the f32 output is its rounding
         return self.observe(), np.float32(rew.value), bool(d)
 

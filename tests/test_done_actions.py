@@ -74,13 +74,16 @@ def test_oracle_normal_mode_differs_on_these_traces(monkeypatch):
     assert not same
 
 
+@pytest.mark.parametrize("order", ["reference", "k_step"])
 @pytest.mark.parametrize("path", GOLDEN, ids=IDS)
-def test_host_build_matches_reference_in_done_action_mode(path):
-    """bbai_step.hpp's verifier with the lastStepMatch bits (`lsm`), compiled for the host, against the same traces."""
+def test_host_build_matches_reference_in_done_action_mode(path, order):
+    """bbai_step.hpp's verifier with the lastStepMatch bits (`lsm`), compiled for the host, against the same traces -- in the
+    reference's order of operations and in k_step's (step_env_prefetch)."""
     from babyai_amd.levels import make_cfg
     from hostsim_util import HostEnv, lib
     L = lib()
     L.hs_step64_done.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    step = L.hs_step64_done if order == "reference" else L.hs_step64_prefetch
     g = load(path)
     name = str(g["level"])
     T = g["actions"].shape[0]
@@ -94,8 +97,8 @@ def test_host_build_matches_reference_in_done_action_mode(path):
             if t == T:
                 break
             rew = ctypes.c_double(0)
-            d = L.hs_step64_done(ctypes.byref(h.cfg), h.rec.ctypes.data, h.hot.ctypes.data, ctypes.byref(h.stale),
-                                 int(g["actions"][t, i]), ctypes.byref(rew), ctypes.byref(lsm))
+            d = step(ctypes.byref(h.cfg), h.rec.ctypes.data, h.hot.ctypes.data, ctypes.byref(h.stale),
+                     int(g["actions"][t, i]), ctypes.byref(rew), ctypes.byref(lsm))
             assert np.float64(rew.value).view(np.uint64) == g["reward64"][t, i].view(np.uint64), (name, i, t)
             assert bool(d) == bool(g["done"][t, i]), (name, i, t)
             if d:

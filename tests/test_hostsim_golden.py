@@ -13,8 +13,11 @@ from hostsim_util import HostEnv
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
 
 
+@pytest.mark.parametrize("order", ["reference", "k_step"])
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
-def test_core_replays_reference_trace(path):
+def test_core_replays_reference_trace(path, order):
+    """order = "k_step": the step in the kernel's order of operations (pose, front-cell id fetched before the object
+    actions and corrected by what they wrote, verifier on that id: bbai_step.hpp step_env_prefetch)."""
     with np.load(path, allow_pickle=False) as f:
         g = {k: f[k] for k in f.files}      # decompress once (NpzFile re-reads on every access)
     name = str(g["level"])
@@ -22,6 +25,7 @@ def test_core_replays_reference_trace(path):
     T = g["actions"].shape[0]
     for i, s in enumerate(g["seeds"]):
         sim = HostEnv(cfg, int(s))
+        sim.prefetch_order = order == "k_step"
         for r in range(g["pre_image"].shape[0]):
             assert np.array_equal(sim.reset(), g["pre_image"][r, i])
             assert sim.mission == str(g["pre_mission"][r, i])
