@@ -153,14 +153,27 @@ struct bbai_env {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int MAX_PERIOD = 32;          // refill period B (ticks per look-ahead refill); ring depth D = 2B
 constexpr int WIN_STRIDE = 64;          // uint32 per window-count block (1 + MAX_PERIOD used)
+// envs (= threads) per k_step block.  The kernel is bound by its chain of dependent memory round trips, not by bytes or
+// instructions, and the block is what waits at its two barriers for its slowest wave: ONE wave per block (64) measured
+// against 128 / 256 (profiles/r03/step_variants_ab.jsonl: BossLevel encoded 1 048 576 envs k_step 0.130 -> 0.124 -> 0.111 ms,
+// PickupLoc 262 144 0.071 -> 0.061 -> 0.051, GoTo 131 072 0.0212 -> 0.0192 -> 0.0184, GoToLocal 65 536 0.0244 -> 0.0216 -> 0.0214).
+// With the fused tile-plane pass (pixel batches from 786 432 envs) the size makes no difference -- step_block_pixel_ab.jsonl:
+// 1.853-1.861 / 1.857-1.871 / 1.865-1.879 ms per step for 256 / 128 / 64 -- and that path stays at 256.
 #ifndef BBAI_STEP_BLOCK
-#define BBAI_STEP_BLOCK 256            // envs (= threads) per k_step block: 64 / 128 / 256 (experiment builds: tools/gpu_r03_k.sh)
+#define BBAI_STEP_BLOCK 64
 #endif
-constexpr int STEP_BLOCK = BBAI_STEP_BLOCK;
+#ifndef BBAI_STEP_BLOCK_FUSED
+#define BBAI_STEP_BLOCK_FUSED 256
+#endif
+template <bool EMIT> struct StepBlock { static constexpr int N = EMIT ? BBAI_STEP_BLOCK_FUSED : BBAI_STEP_BLOCK; };
+static_assert(StepBlock<false>::N % 64 == 0 && StepBlock<true>::N % 64 == 0 && StepBlock<false>::N <= 1024 && StepBlock<true>::N <= 1024,
+              "whole waves; 64 rows of 147 B keep every block's span 16-byte aligned");
+// BBAI_PREFETCH_ID=1 (experiment): the id-plane entry of the front cell fetched WITH the window.  Measured slower everywhere
+// (step_variants_ab.jsonl: BossLevel encoded 1M k_step 0.130 -> 0.148 ms, GoTo 131 072 0.021 -> 0.028): one more line per
+// env-step costs more than the verifier's occasional extra round trip.  Off.
 #ifndef BBAI_PREFETCH_ID
 #define BBAI_PREFETCH_ID 0
 #endif
-static_assert(STEP_BLOCK % 64 == 0 && STEP_BLOCK >= 64 && STEP_BLOCK <= 1024, "whole waves; 64 rows of 147 B keep every block's span 16-byte aligned");
 
 // Observation with the 7x7 window staged in LDS (the k_step path).  49 scattered byte loads per lane keep the
 // texture-address unit busy for most of k_step (tools/step_ab.py ablation), so the window is fetched in WORLD
@@ -314,7 +327,7 @@ __device__ __forceinline__ u32x4 v_segment(const LevelCfg& c, const uint8_t* __r
 // plain move / turn touches no other record line; without VP both come out of the record (round 2's path: 2-3 lines for
 // the window + the lines of the front cell's id and the carried object's appearance).
 template <bool EMIT, bool VP>
-__global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, int64_t n, uint8_t* __restrict__ recs,
+__global__ __launch_bounds__(StepBlock<EMIT>::N, EMIT ? 4 : 1) void k_step(LevelCfg c, int64_t n, uint8_t* __restrict__ recs,
                                                      Hot* __restrict__ hots, uint64_t* __restrict__ stales,
                                                      const uint32_t* __restrict__ vheads, const uint64_t* __restrict__ vsets,
                                                      const uint8_t* __restrict__ actions, uint8_t* __restrict__ image,
@@ -324,7 +337,8 @@ __global__ __launch_bounds__(STEP_BLOCK, EMIT ? 4 : 1) void k_step(LevelCfg c, i
                                                      uint8_t* __restrict__ tiles /* EMIT: [n][TILE_PITCH] render input */, int prio,
                                                      uint8_t* __restrict__ vplane, uint16_t* __restrict__ fcache,
                                                      uint8_t* __restrict__ lsm_arr /* NULL, or the done-action mode's per-env bits */) {
-    // the block's 256 observation rows at the OUTPUT pitch of 147 bytes (bbai_step.hpp RowPacker), 16 bytes of front padding
+    constexpr int STEP_BLOCK = StepBlock<EMIT>::N;
+    // the block's observation rows at the OUTPUT pitch of 147 bytes (bbai_step.hpp RowPacker), 16 bytes of front padding
     __shared__ __attribute__((aligned(16))) uint8_t s_obs[ROWS_FRONT + STEP_BLOCK * OBS_BYTES + 16];
     uint8_t* const s_rows = s_obs + ROWS_FRONT;
     if (prio) __builtin_amdgcn_s_setprio(3);            // the look-ahead generator's waves share the CUs: issue ours first
@@ -1328,8 +1342,7 @@ static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint
     e->next_counter_clean = false;
     {
         ProfScope prof_(e, 0, s);
-        const dim3 grid((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), block(STEP_BLOCK);
-#define STEP_LAUNCH(EM, VV) hipLaunchKernelGGL((k_step<EM, VV>), grid, block, 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, \
+#define STEP_LAUNCH(EM, VV) hipLaunchKernelGGL((k_step<EM, VV>), dim3((unsigned)((e->n + StepBlock<EM>::N - 1) / StepBlock<EM>::N)), dim3(StepBlock<EM>::N), 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, \
                                                image, dirs, rewards, rewards64, dones, auto_reset, list, counter, e->tiles, e->step_prio, e->vplane, e->fcache, e->lsm)
         if (e->tiles) { if (e->vplane) STEP_LAUNCH(true, true); else STEP_LAUNCH(true, false); }
         else { if (e->vplane) STEP_LAUNCH(false, true); else STEP_LAUNCH(false, false); }

@@ -87,7 +87,12 @@ def _generate_batch(env_name, seed, n, device, filter_steps, pack, max_steps, de
             toks[torch.as_tensor(sel, device=dev)] = r["tokens"].view(chunk * n, -1)[torch.as_tensor((span[sel, 0] - lo) * n + sel, device=dev)]
     img, dirs, acts, toks = img.cpu().numpy(), dirs.cpu().numpy(), acts.cpu().numpy(), toks.cpu().numpy()
     env.close()
+    uniq, inv = np.unique(toks, axis=0, return_inverse=True)         # a batch holds far fewer distinct missions than streams
+    text = [missions.detokenize(u) for u in uniq]
+    inv = inv.reshape(-1)
+    lo = 0
     for i in range(n):
-        lo, hi = int(ends_flat[i] - lens[i]), int(ends_flat[i])
+        hi = int(ends_flat[i])
         stack = img[lo:hi]
-        demos[offset + i] = (missions.detokenize(toks[i]), pack(stack) if pack else stack, dirs[lo:hi].tolist(), acts[lo:hi].tolist())
+        demos[offset + i] = (text[inv[i]], pack(stack) if pack else stack, dirs[lo:hi].tolist(), acts[lo:hi].tolist())
+        lo = hi
