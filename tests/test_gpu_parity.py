@@ -1296,3 +1296,34 @@ def test_step_writes_observations_into_unaligned_caller_buffers(gpu, offset):
         assert (h[:16 + offset] == 0xA5).all() and (h[16 + offset + n * 147:] == 0xA5).all(), t
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", ["0", "1"])
+@pytest.mark.parametrize("level", ["BossLevel", "PutNextS6N3Carrying", "KeyInBox"])
+def test_record_path_equals_window_plane_path(gpu, level, fused, monkeypatch):
+    """BBAI_VPLANE=0 (the step's window and front cell come out of the record's appearance plane: round 2's path, kept for
+    A/B measurements) against the default window-plane path, with and without the fused tile-plane pass -- all four
+    k_step instantiations: same observations, rewards, dones and pixels at every step, object actions included."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    n, steps = 1500, 120
+    monkeypatch.setenv("BBAI_RENDER_FUSED", fused)
+    a = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=31, pixel=True)
+    monkeypatch.setenv("BBAI_VPLANE", "0")
+    b = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=31, pixel=True)
+    monkeypatch.delenv("BBAI_VPLANE")
+    assert a.render_fused == (fused == "1") and b.render_fused == (fused == "1")
+    oa, ob = a.reset(), b.reset()
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(8)
+    weights = torch.tensor([1.0, 1.0, 2.0, 2.0, 2.0, 2.0, 0.2], device=gpu)      # plenty of pickup / drop / toggle
+    for t in range(steps):
+        assert torch.equal(a.image, b.image) and torch.equal(oa["image"], ob["image"]) and torch.equal(a.direction, b.direction), t
+        act = torch.multinomial(weights, n, replacement=True, generator=gen).to(torch.uint8)
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(a.reward64, b.reward64) and torch.equal(da, db), t
+    assert a.reset_count() == b.reset_count() and a.reset_count() > n
+    a.close()
+    b.close()
