@@ -37,27 +37,31 @@ def _generate_batch(env_name, seed, n, device, filter_steps, pack, max_steps, de
     budget = max_steps if max_steps is not None else 64 * env.max_steps_bound
     chunk = max(1, min(128, max(16, env.max_steps_bound // 4), budget))
     hist = []                                      # the chunks' device tensors, [chunk, n, ...] each
-    last_done = np.full(n, -1, dtype=np.int64)     # global index of the stream's latest episode end
+    last_done = np.full(n, -1, dtype=np.int32)     # global index of the stream's latest episode end
     span = np.full((n, 2), -1, dtype=np.int64)     # [first, last] step of the stream's first solved episode
     open_ = np.ones(n, dtype=bool)                 # streams still looking for it
     g0 = 0
     while open_.any() and g0 < budget:
         r = env.bot_rollout(chunk, tokens=True)
         hist.append(r)
-        done = r["done"].cpu().numpy().astype(bool)
+        # the scans below run along time: [n, chunk] layout, contiguous per stream
+        done = np.ascontiguousarray(r["done"].cpu().numpy().T).astype(bool)
         # "mission failed" / bot crash (RESET_ENV): the stream goes on with its next level (make_agent_demos.py:84-88,112-123)
-        ok = done & (r["gave_up"].cpu().numpy() == 0) & (r["reward"].cpu().numpy() > 0)
-        idx = np.arange(g0, g0 + chunk, dtype=np.int64)[:, None]
-        ends = np.maximum.accumulate(np.where(done, idx, -1), axis=0)           # latest episode end at or before each step
-        start = np.maximum(np.vstack([last_done[None, :], ends[:-1]]), last_done[None, :]) + 1    # first step of each step's episode
+        ok = done & (r["gave_up"].cpu().numpy().T == 0) & (r["reward"].cpu().numpy().T > 0)
+        idx = np.arange(g0, g0 + chunk, dtype=np.int32)[None, :]
+        ends = np.maximum.accumulate(np.where(done, idx, np.int32(-1)), axis=1)         # latest episode end at or before each step
+        start = np.empty_like(ends)                                                      # first step of each step's episode
+        start[:, 0] = last_done + 1
+        np.maximum(ends[:, :-1], last_done[:, None], out=start[:, 1:])
+        start[:, 1:] += 1
         if filter_steps:
             ok &= (idx - start + 1) <= filter_steps
-        found = ok.any(axis=0) & open_
-        first = ok.argmax(axis=0)
+        found = ok.any(axis=1) & open_
+        first = ok.argmax(axis=1)
         cols = np.nonzero(found)[0]
-        span[cols, 0], span[cols, 1] = start[first[cols], cols], g0 + first[cols]
+        span[cols, 0], span[cols, 1] = start[cols, first[cols]], g0 + first[cols]
         open_ &= ~found
-        last_done = np.maximum(last_done, ends[-1])
+        last_done = np.maximum(last_done, ends[:, -1])
         g0 += chunk
     if open_.any():
         env.close()
@@ -87,12 +91,14 @@ def _generate_batch(env_name, seed, n, device, filter_steps, pack, max_steps, de
             toks[torch.as_tensor(sel, device=dev)] = r["tokens"].view(chunk * n, -1)[torch.as_tensor((span[sel, 0] - lo) * n + sel, device=dev)]
     img, dirs, acts, toks = img.cpu().numpy(), dirs.cpu().numpy(), acts.cpu().numpy(), toks.cpu().numpy()
     env.close()
-    uniq, inv = np.unique(toks, axis=0, return_inverse=True)         # a batch holds far fewer distinct missions than streams
-    text = [missions.detokenize(u) for u in uniq]
-    inv = inv.reshape(-1)
+    text = {}                                      # a batch holds far fewer distinct missions than streams
     lo = 0
     for i in range(n):
         hi = int(ends_flat[i])
+        key = toks[i].tobytes()
+        mission = text.get(key)
+        if mission is None:
+            mission = text[key] = missions.detokenize(toks[i])
         stack = img[lo:hi]
-        demos[offset + i] = (text[inv[i]], pack(stack) if pack else stack, dirs[lo:hi].tolist(), acts[lo:hi].tolist())
+        demos[offset + i] = (mission, pack(stack) if pack else stack, dirs[lo:hi].tolist(), acts[lo:hi].tolist())
         lo = hi
