@@ -45,9 +45,10 @@ def _generate_batch(env_name, seed, n, device, filter_steps, pack, max_steps, de
         r = env.bot_rollout(chunk, tokens=True)
         hist.append(r)
         # the scans below run along time: [n, chunk] layout, contiguous per stream
-        done = np.ascontiguousarray(r["done"].cpu().numpy().T).astype(bool)
+        done_t = r["done"].cpu().numpy().astype(bool)
         # "mission failed" / bot crash (RESET_ENV): the stream goes on with its next level (make_agent_demos.py:84-88,112-123)
-        ok = done & (r["gave_up"].cpu().numpy().T == 0) & (r["reward"].cpu().numpy().T > 0)
+        ok = np.ascontiguousarray((done_t & (r["gave_up"].cpu().numpy() == 0) & (r["reward"].cpu().numpy() > 0)).T)
+        done = np.ascontiguousarray(done_t.T)
         idx = np.arange(g0, g0 + chunk, dtype=np.int32)[None, :]
         ends = np.maximum.accumulate(np.where(done, idx, np.int32(-1)), axis=1)         # latest episode end at or before each step
         start = np.empty_like(ends)                                                      # first step of each step's episode
@@ -91,14 +92,17 @@ def _generate_batch(env_name, seed, n, device, filter_steps, pack, max_steps, de
             toks[torch.as_tensor(sel, device=dev)] = r["tokens"].view(chunk * n, -1)[torch.as_tensor((span[sel, 0] - lo) * n + sel, device=dev)]
     img, dirs, acts, toks = img.cpu().numpy(), dirs.cpu().numpy(), acts.cpu().numpy(), toks.cpu().numpy()
     env.close()
+    # per-demo assembly on plain Python objects (a numpy slice costs more than the few elements it holds)
     text = {}                                      # a batch holds far fewer distinct missions than streams
+    width = toks.shape[1]
+    tok_bytes, dirs_l, acts_l, ends_l = toks.tobytes(), dirs.tolist(), acts.tolist(), ends_flat.tolist()
     lo = 0
     for i in range(n):
-        hi = int(ends_flat[i])
-        key = toks[i].tobytes()
+        hi = ends_l[i]
+        key = tok_bytes[i * width:(i + 1) * width]
         mission = text.get(key)
         if mission is None:
-            mission = text[key] = missions.detokenize(toks[i])
+            mission = text[key] = missions.detokenize(key)
         stack = img[lo:hi]
-        demos[offset + i] = (mission, pack(stack) if pack else stack, dirs[lo:hi].tolist(), acts[lo:hi].tolist())
+        demos[offset + i] = (mission, pack(stack) if pack else stack, dirs_l[lo:hi], acts_l[lo:hi])
         lo = hi

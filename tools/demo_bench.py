@@ -64,23 +64,28 @@ def digest(demos):
     return h.hexdigest()[:16]
 
 
-level = sys.argv[1] if len(sys.argv) > 1 else "BossLevel"
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-batch = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
-name = "BabyAI-%s-v0" % level
-generate_demos(name, 256, 1, batch=256)                      # warm-up: library, allocator, first launches
-res = {"level": level, "demos": n, "batch": batch}
-t0 = time.perf_counter()
-new = generate_demos(name, n, 1000, batch=batch)
-res["rollout_s"] = time.perf_counter() - t0
-t0 = time.perf_counter()
-old = []
-for start in range(0, n, batch):
-    old += stepwise_batch(name, 1000 + start, min(batch, n - start), "cuda:0")
-res["stepwise_s"] = time.perf_counter() - t0
-res["rollout_demos_per_s"] = n / res["rollout_s"]
-res["stepwise_demos_per_s"] = n / res["stepwise_s"]
-res["speedup"] = res["stepwise_s"] / res["rollout_s"]
-res["mean_length"] = float(np.mean([len(d[3]) for d in new]))
-res["same_demos"] = digest(new) == digest(old)
-print(json.dumps(res))
+def main():
+    level = sys.argv[1] if len(sys.argv) > 1 else "BossLevel"
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+    name = "BabyAI-%s-v0" % level
+    generate_demos(name, 256, 1, batch=256)                      # warm-up: library, allocator, first launches
+    res = {"level": level, "demos": n, "batch": batch}
+    t0 = time.perf_counter()
+    new = generate_demos(name, n, 1000, batch=batch)
+    res["rollout_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    old = []
+    for start in range(0, n, batch):
+        old += stepwise_batch(name, 1000 + start, min(batch, n - start), "cuda:0")
+    res["stepwise_s"] = time.perf_counter() - t0
+    res["rollout_demos_per_s"] = n / res["rollout_s"]
+    res["stepwise_demos_per_s"] = n / res["stepwise_s"]
+    res["speedup"] = res["stepwise_s"] / res["rollout_s"]
+    res["mean_length"] = float(np.mean([len(d[3]) for d in new]))
+    res["same_demos"] = digest(new) == digest(old)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

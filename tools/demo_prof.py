@@ -19,4 +19,13 @@ pr = cProfile.Profile()
 pr.enable()
 generate_demos(name, n, 1000, batch=batch)
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(24)
+# the stepwise host loop it is measured against (tools/demo_bench.py), same process, same box
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import demo_bench  # noqa: E402
+pr = cProfile.Profile()
+pr.enable()
+for start in range(0, n, batch):
+    demo_bench.stepwise_batch(name, 1000 + start, min(batch, n - start), "cuda:0")
+pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(16)
