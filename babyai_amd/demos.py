@@ -15,14 +15,72 @@ from . import missions
 from .engine import BatchedBabyAIEnv
 
 
-def generate_demos(env_name, n_episodes, seed, device="cuda:0", batch=32768, filter_steps=0, pack=None, max_steps=None):
+def generate_demos(env_name, n_episodes, seed, device="cuda:0", batch=32768, filter_steps=0, pack=None, max_steps=None,
+                   rollout=None):
     """`batch` streams run side by side on the device; a batch lasts as long as its slowest stream (the expert's decision
-    kernel has a latency of about a millisecond whatever the batch size), so large batches are what makes this fast."""
+    kernel has a latency of about a millisecond whatever the batch size), so large batches are what makes this fast.
+
+    rollout: True = the per-step loop runs on the device (`bbai_bot_rollout`, history kept there, spans gathered there);
+    False = one host round trip per step (rounds 1-2).  Same demonstrations either way.  None picks by what was measured
+    (profiles/r03/demo_bench_final2.jsonl, one MI355X, demos/s rollout vs stepwise): BossLevel 131 072 streams 27.9 k vs
+    17.6 k, 32 768 streams 13.7 k vs 13.5 k; GoToLocal (5-step episodes) 65 536 streams 73-75 k vs 101-126 k -- episodes
+    shorter than a rollout chunk are cheaper to follow step by step."""
+    from .levels import make_cfg
+    if rollout is None:
+        cfg = make_cfg(env_name)
+        rollout = cfg.num_rows * cfg.num_cols > 1
+    run = _generate_batch if rollout else _generate_batch_stepwise
     demos = [None] * n_episodes
     for start in range(0, n_episodes, batch):
         count = min(batch, n_episodes - start)
-        _generate_batch(env_name, seed + start, count, device, filter_steps, pack, max_steps, demos, start)
+        run(env_name, seed + start, count, device, filter_steps, pack, max_steps, demos, start)
     return demos
+
+
+def _generate_batch_stepwise(env_name, seed, n, device, filter_steps, pack, max_steps, demos, offset):
+    """One batch of streams, one host round trip per step (bbai_bot_act + bbai_step driven from here)."""
+    import torch
+    env = BatchedBabyAIEnv(env_name, n, device=device, seeds=[seed + k for k in range(n)], auto_reset=True)
+    obs = env.reset()
+    mission = list(obs["mission"])
+    # whole-batch history, one row per step; an episode is the slice [ep_start[i], t] of column i
+    hist_img, hist_dir, hist_act = [], [], []
+    ep_start = np.zeros(n, dtype=np.int64)
+    span = np.full((n, 2), -1, dtype=np.int64)     # [first, last] step of the stream's first solved episode
+    open_ = np.ones(n, dtype=bool)                 # streams still looking for it
+    budget = max_steps if max_steps is not None else 64 * env.max_steps_bound
+    reset_cmd = torch.full((n,), env.RESET_ENV, dtype=torch.uint8, device=env.device)
+    for t in range(budget):
+        if not open_.any():
+            break
+        hist_img.append(obs["image"].cpu().numpy())
+        hist_dir.append(obs["direction"].cpu().numpy())
+        act = env.bot_actions(None)
+        crashed = act == env.BOT_GAVE_UP
+        act = torch.where(crashed, reset_cmd, act)          # bot crash: env.reset() on the same stream
+        obs, reward, done, _ = env.step(act)
+        hist_act.append(act.cpu().numpy())
+        crashed_h = crashed.cpu().numpy()
+        reward_h, done_h = reward.cpu().numpy(), done.cpu().numpy().astype(bool)
+        solved = open_ & done_h & ~crashed_h & (reward_h > 0)
+        if filter_steps:
+            solved &= (t - ep_start + 1) <= filter_steps
+        span[solved, 0], span[solved, 1] = ep_start[solved], t
+        open_ &= ~solved
+        again = open_ & done_h                               # "mission failed" / crash: next level of the same stream
+        if again.any():
+            fresh = obs["mission"]
+            for i in np.nonzero(again)[0]:
+                mission[i] = fresh[i]
+        ep_start[done_h] = t + 1
+    env.close()
+    if open_.any():
+        raise RuntimeError("no solvable episode found for %d stream(s) within the step budget" % int(open_.sum()))
+    img, dirs, acts = np.stack(hist_img), np.stack(hist_dir), np.stack(hist_act)
+    for i in range(n):
+        lo, hi = span[i, 0], span[i, 1] + 1
+        stack = np.ascontiguousarray(img[lo:hi, i])
+        demos[offset + i] = (mission[i], pack(stack) if pack else stack, dirs[lo:hi, i].tolist(), acts[lo:hi, i].tolist())
 
 
 def _generate_batch(env_name, seed, n, device, filter_steps, pack, max_steps, demos, offset):

@@ -868,8 +868,9 @@ def test_per_env_reset_command(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rollout", [True, False, None])
 @pytest.mark.parametrize("level", ["GoToLocal", "PutNextLocal", "PickupDist", "BossLevel", "UnlockToUnlock"])
-def test_generate_demos_matches_reference_script(gpu, level):
+def test_generate_demos_matches_reference_script(gpu, level, rollout):
     """babyai_amd.demos.generate_demos vs demonstrations made by the reference's own loop (scripts/make_agent_demos.py:
     71-137 with BotAgent; tools/gen_golden_bot.py demos): same missions, actions, directions and images, including the
     streams where the reference bot crashed or failed first and the script moved on to the stream's next level."""
@@ -878,7 +879,7 @@ def test_generate_demos_matches_reference_script(gpu, level):
     with np.load(os.path.join(os.path.dirname(__file__), "golden", "demos", "bot_demos.npz")) as f:
         g = {k[len(level) + 1:]: f[k] for k in f.files if k.startswith(level + "_")}
     n = len(g["length"])
-    demos = generate_demos("BabyAI-%s-v0" % level, n, int(g["seed"]), device=gpu, batch=32)
+    demos = generate_demos("BabyAI-%s-v0" % level, n, int(g["seed"]), device=gpu, batch=32, rollout=rollout)
     ends = np.cumsum(g["length"])
     for k, (mission, images, directions, actions) in enumerate(demos):
         lo, hi = ends[k] - g["length"][k], ends[k]

@@ -13,47 +13,13 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from babyai_amd.demos import generate_demos  # noqa: E402
+from babyai_amd.demos import _generate_batch_stepwise, generate_demos  # noqa: E402
 from babyai_amd.engine import BatchedBabyAIEnv  # noqa: E402
 
 
 def stepwise_batch(env_name, seed, n, device):
-    """Round 2's _generate_batch (one host round trip per step), kept as the baseline of this measurement."""
-    env = BatchedBabyAIEnv(env_name, n, device=device, seeds=[seed + k for k in range(n)], auto_reset=True)
-    obs = env.reset()
-    missions = list(obs["mission"])
-    hist_img, hist_dir, hist_act = [], [], []
-    ep_start = np.zeros(n, dtype=np.int64)
-    span = np.full((n, 2), -1, dtype=np.int64)
-    open_ = np.ones(n, dtype=bool)
-    reset_cmd = torch.full((n,), env.RESET_ENV, dtype=torch.uint8, device=env.device)
-    for t in range(64 * env.max_steps_bound):
-        if not open_.any():
-            break
-        hist_img.append(obs["image"].cpu().numpy())
-        hist_dir.append(obs["direction"].cpu().numpy())
-        act = env.bot_actions(None)
-        crashed = act == env.BOT_GAVE_UP
-        act = torch.where(crashed, reset_cmd, act)
-        obs, reward, done, _ = env.step(act)
-        hist_act.append(act.cpu().numpy())
-        crashed_h = crashed.cpu().numpy()
-        reward_h, done_h = reward.cpu().numpy(), done.cpu().numpy().astype(bool)
-        solved = open_ & done_h & ~crashed_h & (reward_h > 0)
-        span[solved, 0], span[solved, 1] = ep_start[solved], t
-        open_ &= ~solved
-        again = open_ & done_h
-        if again.any():
-            fresh = obs["mission"]
-            for i in np.nonzero(again)[0]:
-                missions[i] = fresh[i]
-        ep_start[done_h] = t + 1
-    env.close()
-    img, dirs, acts = np.stack(hist_img), np.stack(hist_dir), np.stack(hist_act)
-    out = []
-    for i in range(n):
-        lo, hi = span[i, 0], span[i, 1] + 1
-        out.append((missions[i], np.ascontiguousarray(img[lo:hi, i]), [int(v) for v in dirs[lo:hi, i]], [int(v) for v in acts[lo:hi, i]]))
+    out = [None] * n
+    _generate_batch_stepwise(env_name, seed, n, device, 0, None, None, out, 0)
     return out
 
 
@@ -69,10 +35,10 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
     name = "BabyAI-%s-v0" % level
-    generate_demos(name, 256, 1, batch=256)                      # warm-up: library, allocator, first launches
+    generate_demos(name, 256, 1, batch=256, rollout=True)        # warm-up: library, allocator, first launches
     res = {"level": level, "demos": n, "batch": batch}
     t0 = time.perf_counter()
-    new = generate_demos(name, n, 1000, batch=batch)
+    new = generate_demos(name, n, 1000, batch=batch, rollout=True)
     res["rollout_s"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     old = []

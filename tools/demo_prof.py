@@ -14,10 +14,10 @@ level = sys.argv[1] if len(sys.argv) > 1 else "GoToLocal"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 name = "BabyAI-%s-v0" % level
-generate_demos(name, 256, 1, batch=256)
+generate_demos(name, 256, 1, batch=256, rollout=True)
 pr = cProfile.Profile()
 pr.enable()
-generate_demos(name, n, 1000, batch=batch)
+generate_demos(name, n, 1000, batch=batch, rollout=True)
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(24)
 # the stepwise host loop it is measured against (tools/demo_bench.py), same process, same box
