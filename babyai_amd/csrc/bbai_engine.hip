@@ -188,7 +188,6 @@ static_assert(StepBlock<false>::N % 64 == 0 && StepBlock<true>::N % 64 == 0 && S
 // (rstride = 4).  `ce` = appearance of what the agent carries (E_EMPTY: nothing).  `fe2` receives the appearance of the
 // cell in front of the agent (view cell (3, 5)) for the verifier and the next step's transition.
 constexpr int TILE_PITCH = 52;
-constexpr int64_t FUSED_MIN_ENVS = 786432;      // batches from this size up keep the fused tile plane (bbai_set_atlas)
 // Two halves, so that the verifier (which only needs fe2) can run between them while nothing of the 37-dword encoding is
 // live yet: view_cells fetches and rotates the window (cp = the 49 cells, vis = visibility rows), encode_view writes the
 // encoding (and the plane row) from them.
@@ -1376,14 +1375,19 @@ int bbai_set_atlas(bbai_env* e, const uint8_t* tiles, int n_tiles, const uint8_t
     HIP_TRY(hipMemcpy(e->atlas, tiles, (size_t)n_tiles * TILE_BYTES, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->lut, lut, 512, hipMemcpyHostToDevice));
     e->n_tiles = n_tiles;
-    // pixel mode: from now on reset / step also keep the fused tile plane of the current observations (bbai_render_current)
-    // -- for LARGE batches only.  Measured inside the step loop (profiles/r03/render_fused_ab_*.jsonl): at 1 048 576 envs
-    // the render from the plane with (512, 4) blocks takes 1.59 ms against 1.68 ms from the encoding with round 2's
-    // (1024, 8) and the step 1.78 against 1.85 ms (k_step pays 0.013 ms for the extra 52 B per env); at 131 072 envs the
-    // whole encoding is still in the memory-side cache when the render starts and the plane only costs (0.243 vs 0.231 ms).
-    // BBAI_RENDER_FUSED=1 / 0 forces it on / off.
+    // Pixel mode with BBAI_RENDER_FUSED=1: from now on reset / step also keep the fused tile plane of the current observations
+    // (bbai_render_current).  OFF by default since the end of round 3.  What was measured, always inside the step loop at
+    // 1 048 576 envs, modes alternated within one lease:
+    //   * mid round 3 (profiles/r03/render_fused_ab_*.jsonl): render from the plane with (512, 4) blocks 1.59 ms against 1.68 ms
+    //     from the encoding with (1024, 8), step 1.78 against 1.85 ms; at 131 072 envs the plane only costs (0.243 vs 0.231 ms);
+    //   * end of round 3, two other boxes, with the one-wave-per-block k_step of the encoded path (the fused pass keeps 256-thread
+    //     blocks and costs k_step 0.02 ms): profiles/r03/render_fused_ab_final.jsonl 1.868 / 1.869 / 1.868 ms per step from the
+    //     plane against 1.821 / 1.828 / 1.819 from the encoding (k_render 1.73 ms either way);
+    //     render_fused_by_step_build.jsonl: from the encoding ahead in three of four pairs, with this and the previous k_step.
+    // The plane pays on boxes where the render's input residency matters (k_render 1.59) and costs on those where the store
+    // stream alone decides (k_render 1.73): six boxes of the second kind in a row decided the default.
     const char* fv = getenv("BBAI_RENDER_FUSED");
-    const bool want = fv ? atoi(fv) != 0 : e->n >= FUSED_MIN_ENVS;
+    const bool want = fv && atoi(fv) != 0;
     if (!e->tiles && want) {
         HIP_TRY(hipMalloc((void**)&e->tiles, (size_t)e->n * TILE_PITCH));
         HIP_TRY(hipMemset(e->tiles, 0, (size_t)e->n * TILE_PITCH));

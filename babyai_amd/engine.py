@@ -205,7 +205,7 @@ class BatchedBabyAIEnv(object):
                 lut = np.ascontiguousarray(atlas["lut"], dtype=np.uint8)
                 _check(self.lib, self.lib.bbai_set_atlas(self.handle, tiles.ctypes.data, tiles.shape[0],
                                                           lut.ctypes.data), "bbai_set_atlas")
-                # large batches keep a fused tile plane and render from it (include/bbai.h bbai_render_current)
+                # BBAI_RENDER_FUSED=1: the engine keeps a fused tile plane and renders from it (include/bbai.h bbai_render_current)
                 self.render_fused = bool(self.lib.bbai_has_tile_plane(self.handle))
         self._missions = None
         self._tiles_ok = False         # the engine's tile plane describes the observation about to be rendered (set by reset / step)

@@ -99,13 +99,14 @@ int bbai_step(bbai_env* env, const uint8_t* actions_dev, uint8_t* image_dev, uin
  * The tile atlas must have been installed with bbai_set_atlas. */
 int bbai_set_atlas(bbai_env* env, const uint8_t* tiles_host, int n_tiles, const uint8_t* lut_host /* [2][256] */);
 /* The same wrapper applied to the CURRENT observation of every env (what a training / evaluation loop renders after
- * each reset / step): once an atlas is installed, bbai_reset / bbai_step also leave a 52-byte tile plane per env behind
- * (one masked appearance byte per view cell, written last), and this entry renders from it -- a third of the input bytes
- * of bbai_render(image), still in the memory-side cache.  Byte-identical to bbai_render of the image the same call wrote.
- * BBAI_ERR_STATE when no reset / step has happened since the atlas was installed (or after import / checkpoint_load). */
+ * each reset / step), from a fused tile plane: with BBAI_RENDER_FUSED=1 in the environment at bbai_set_atlas, bbai_reset /
+ * bbai_step also leave a 52-byte tile plane per env behind (one masked appearance byte per view cell, written last), and
+ * this entry renders from it -- a third of the input bytes of bbai_render(image), still in the memory-side cache.
+ * Byte-identical to bbai_render of the image the same call wrote.  Off by default: it pays on some boxes of the pool and
+ * costs on others (profiles/r03/NOTES.md sections 5 and 12).  BBAI_ERR_STATE when the handle keeps no plane, or no reset /
+ * step has happened since the atlas was installed (or after import / checkpoint_load). */
 int bbai_render_current(bbai_env* env, uint8_t* pixels_dev, void* stream);
-/* 1 when the handle keeps the tile plane (batches of 786 432 envs and more, where it pays: profiles/r03/render_fused_ab_*;
- * BBAI_RENDER_FUSED=1 / 0 in the environment at bbai_set_atlas forces it on / off), else 0: use bbai_render. */
+/* 1 when the handle keeps the tile plane (BBAI_RENDER_FUSED=1 at bbai_set_atlas), else 0: use bbai_render. */
 int bbai_has_tile_plane(bbai_env* env);
 int bbai_render(bbai_env* env, const uint8_t* image_dev, uint8_t* pixels_dev, void* stream);
 
