@@ -37,6 +37,33 @@ def generate_demos(env_name, n_episodes, seed, device="cuda:0", batch=32768, fil
     return demos
 
 
+def scan_chunk(done_t, gave_up_t, reward_t, g0, filter_steps, last_done, open_, span):
+    """One rollout chunk's results ([chunk, n] arrays as the engine writes them; global step index of row 0 = g0): for every
+    stream still open, find the first episode that ENDS in this chunk solved -- done, not a bot crash, reward > 0, at most
+    `filter_steps` long if that is set -- and record its [first, last] step in `span`; failed episodes and crashes
+    ("mission failed" / RESET_ENV, make_agent_demos.py:84-88,112-123) just move the stream on to its next level.
+    Updates last_done (global index of every stream's latest episode end), open_ and span in place."""
+    chunk = done_t.shape[0]
+    # the scans run along time: [n, chunk] layout, contiguous per stream
+    done_t = done_t.astype(bool)
+    ok = np.ascontiguousarray((done_t & (gave_up_t == 0) & (reward_t > 0)).T)
+    done = np.ascontiguousarray(done_t.T)
+    idx = np.arange(g0, g0 + chunk, dtype=np.int32)[None, :]
+    ends = np.maximum.accumulate(np.where(done, idx, np.int32(-1)), axis=1)         # latest episode end at or before each step
+    start = np.empty_like(ends)                                                      # first step of each step's episode
+    start[:, 0] = last_done + 1
+    np.maximum(ends[:, :-1], last_done[:, None], out=start[:, 1:])
+    start[:, 1:] += 1
+    if filter_steps:
+        ok &= (idx - start + 1) <= filter_steps
+    found = ok.any(axis=1) & open_
+    first = ok.argmax(axis=1)
+    cols = np.nonzero(found)[0]
+    span[cols, 0], span[cols, 1] = start[cols, first[cols]], g0 + first[cols]
+    open_ &= ~found
+    np.maximum(last_done, ends[:, -1], out=last_done)
+
+
 def _generate_batch_stepwise(env_name, seed, n, device, filter_steps, pack, max_steps, demos, offset):
     """One batch of streams, one host round trip per step (bbai_bot_act + bbai_step driven from here)."""
     import torch
@@ -102,25 +129,7 @@ def _generate_batch(env_name, seed, n, device, filter_steps, pack, max_steps, de
     while open_.any() and g0 < budget:
         r = env.bot_rollout(chunk, tokens=True)
         hist.append(r)
-        # the scans below run along time: [n, chunk] layout, contiguous per stream
-        done_t = r["done"].cpu().numpy().astype(bool)
-        # "mission failed" / bot crash (RESET_ENV): the stream goes on with its next level (make_agent_demos.py:84-88,112-123)
-        ok = np.ascontiguousarray((done_t & (r["gave_up"].cpu().numpy() == 0) & (r["reward"].cpu().numpy() > 0)).T)
-        done = np.ascontiguousarray(done_t.T)
-        idx = np.arange(g0, g0 + chunk, dtype=np.int32)[None, :]
-        ends = np.maximum.accumulate(np.where(done, idx, np.int32(-1)), axis=1)         # latest episode end at or before each step
-        start = np.empty_like(ends)                                                      # first step of each step's episode
-        start[:, 0] = last_done + 1
-        np.maximum(ends[:, :-1], last_done[:, None], out=start[:, 1:])
-        start[:, 1:] += 1
-        if filter_steps:
-            ok &= (idx - start + 1) <= filter_steps
-        found = ok.any(axis=1) & open_
-        first = ok.argmax(axis=1)
-        cols = np.nonzero(found)[0]
-        span[cols, 0], span[cols, 1] = start[cols, first[cols]], g0 + first[cols]
-        open_ &= ~found
-        last_done = np.maximum(last_done, ends[:, -1])
+        scan_chunk(r["done"].cpu().numpy(), r["gave_up"].cpu().numpy(), r["reward"].cpu().numpy(), g0, filter_steps, last_done, open_, span)
         g0 += chunk
     if open_.any():
         env.close()

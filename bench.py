@@ -405,6 +405,7 @@ def main():
             level, "56x56x3 pixel (RGBImgPartialObsWrapper)" if pixel else "7x7x3 encoded", total_envs, E, world),
             "envs_per_gpu": E, "total_envs": total_envs, "resets_in_timed_region": resets,
             "parallelism": "env-shards x%d, no collective" % world,
+            "render_input": (("fused tile plane (BBAI_RENDER_FUSED=1)" if getattr(env, "render_fused", False) else "the step's 147-byte encoding") if pixel else None),
             "actions": "counter-based (action_seed %d, step, global env index), uniform over 7" % args.action_seed},
         "rccl": dict(group, per_rank_ms_per_step=per_rank_ms,
                      per_rank_ms_per_step_min=min(per_rank_ms) if all(v is not None for v in per_rank_ms) else None,
