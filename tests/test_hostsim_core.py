@@ -135,3 +135,30 @@ def test_row_packer_lays_rows_out_at_the_output_pitch():
     for r in range(n):
         s = L.hs_row_scratch(r)
         assert s % 4 == 0 and r * 147 <= s and s + 56 <= (r + 1) * 147
+
+
+@pytest.mark.parametrize("name", sorted(LEVELS))
+def test_k_step_order_of_operations_equals_the_reference_order(name):
+    """Every level, object-action-heavy random play: the step in k_step's order (pose -> front-cell id and appearance taken
+    BEFORE the object actions and corrected by what they wrote -> verifier on those; bbai_step.hpp step_env_prefetch) must
+    leave the same record, hot state, stale set, reward and done as the reference order (step_env), step after step."""
+    import ctypes
+    from babyai_amd.levels import make_cfg
+    from hostsim_util import HostEnv
+    rng = np.random.RandomState(sum(map(ord, name)))
+    cfg = make_cfg(name)
+    for seed in (3, 4):
+        a, b = HostEnv(cfg, 9000 + seed), HostEnv(cfg, 9000 + seed)
+        b.prefetch_order = True
+        a.reset()
+        b.reset()
+        for t in range(260):
+            act = int(rng.choice(7, p=[0.12, 0.12, 0.28, 0.16, 0.12, 0.16, 0.04]))
+            ia, ra, da = a.step(act)
+            ib, rb, db = b.step(act)
+            assert da == db and a.last_reward64 == b.last_reward64, (name, seed, t)
+            assert np.array_equal(a.rec, b.rec) and np.array_equal(a.hot, b.hot) and a.stale.value == b.stale.value, (name, seed, t)
+            assert np.array_equal(ia, ib)
+            if da:
+                a.reset()
+                b.reset()
