@@ -10,6 +10,7 @@
 //              x 16 B per env written as ten 1-KiB wave stores
 //   tilein     either shape fed with 49 tile ids per env (what k_step could emit) instead of the 147-byte encoding + LUT
 // and the same for non-temporal vs plain stores, plus a plain fill of the same buffer as the in-process ceiling.
+//   queue / wqueue   persistent blocks that take their groups (envs) from an atomic ticket counter: `tools/ubench_render <n> queue`
 //   hipcc --offload-arch=gfx950 -O3 -o tools/ubench_render tools/ubench_render.hip && tools/ubench_render
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -145,6 +146,80 @@ __global__ __launch_bounds__(T) void k_shot(int64_t n, const uint8_t* __restrict
     }
 }
 
+// queue<G, T>: PERSISTENT blocks (the 11 KB atlas is loaded into LDS once per block, as in block<G>) that take their G-env
+// groups from a global atomic counter instead of a fixed stride: blocks then advance through the output in (nearly) global
+// order, like one-shot blocks being dispatched one after the other -- the order in which the pure store stream is fastest
+// (profiles/r02/ubench_store.txt: 4-KiB one-shot blocks 6.97 TB/s, 75-KB blocks 5.8, grid-stride loops 5.5) -- without paying
+// the atlas reload per group that keeps one-shot render blocks from being small.
+// NC > 1: NC ticket counters, 256 bytes apart (one address serves ~88 M atomics/s -- 11.4 ns each, measured: queue<1,..> takes
+// 11.9 ms for 1 048 576 tickets); counter c hands out the c-th NC-th of the groups to the blocks with blockIdx % NC == c.
+template <int GROUP, int T, bool NT, int NC = 1>
+__global__ __launch_bounds__(T) void k_queue(int64_t n, const uint8_t* __restrict__ image, uint8_t* __restrict__ pixels,
+                                             const uint8_t* __restrict__ atlas, const uint8_t* __restrict__ lut, unsigned int* __restrict__ counter) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_atlas[N_TILES * TILE_BYTES];
+    __shared__ uint8_t s_lut[512];
+    __shared__ uint8_t s_tile[2][GROUP * 49 + 8];
+    __shared__ unsigned int s_grp[2];
+    for (int k = threadIdx.x; k < N_TILES * TILE_BYTES / 8; k += T) ((uint64_t*)s_atlas)[k] = ((const uint64_t*)atlas)[k];
+    for (int k = threadIdx.x; k < 512; k += T) s_lut[k] = lut[k];
+    const unsigned int all_groups = (unsigned int)((n + GROUP - 1) / GROUP);
+    const unsigned int part = (all_groups + NC - 1) / NC, first = (blockIdx.x % NC) * part;
+    const unsigned int ngroups = first + part < all_groups ? first + part : all_groups;      // this counter's groups: [first, ngroups)
+    counter += 64 * (blockIdx.x % NC);
+    int buf = 0;
+    if (threadIdx.x == 0) s_grp[0] = first + atomicAdd(counter, 1u);
+    __syncthreads();
+    for (;;) {
+        const unsigned int grp = s_grp[buf];
+        if (grp >= ngroups) break;
+        const int64_t env0 = (int64_t)grp * GROUP;
+        const int ne = (int)(n - env0 < GROUP ? n - env0 : GROUP);
+        for (int c = threadIdx.x; c < ne * 49; c += T) {
+            const int e = c / 49, cell = c - e * 49;
+            const uint8_t* o = image + (env0 + e) * OBS_BYTES + cell * 3;
+            s_tile[buf][c] = s_lut[(cell == 27 ? 256 : 0) + (o[0] | (o[1] << 3) | (o[2] << 6))];
+        }
+        if (threadIdx.x == 0) s_grp[buf ^ 1] = first + atomicAdd(counter, 1u);      // the next group's ticket rides under this group's stores
+        __syncthreads();                                                    // ONE barrier per group (tile rows and tickets are double-buffered)
+        u32x4* out = (u32x4*)(pixels + env0 * PIX_BYTES);
+        for (int q = threadIdx.x; q < ne * VEC_PER_ENV; q += T) {
+            const int e = q / VEC_PER_ENV, k = q - e * VEC_PER_ENV;
+            const uint8_t* t49 = s_tile[buf] + e * 49;
+            put<NT>(out + q, render_chunk(s_atlas, t49, 2 * k), render_chunk(s_atlas, t49, 2 * k + 1));
+        }
+        buf ^= 1;
+    }
+}
+
+// wqueue<W>: the same ticket queue per WAVE (the block only shares the atlas): a wave takes one env, 49 lanes stage its tile ids
+// in a wave-private LDS row, and the wave writes the env's 9408 bytes as ten 1-KiB stores -- no block barrier after the atlas load.
+template <int WAVES, bool NT>
+__global__ __launch_bounds__(64 * WAVES) void k_wqueue(int64_t n, const uint8_t* __restrict__ image, uint8_t* __restrict__ pixels,
+                                                       const uint8_t* __restrict__ atlas, const uint8_t* __restrict__ lut, unsigned int* __restrict__ counter) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_atlas[N_TILES * TILE_BYTES];
+    __shared__ uint8_t s_lut[512];
+    __shared__ uint8_t s_tile[WAVES][56];
+    for (int k = threadIdx.x; k < N_TILES * TILE_BYTES / 8; k += 64 * WAVES) ((uint64_t*)s_atlas)[k] = ((const uint64_t*)atlas)[k];
+    for (int k = threadIdx.x; k < 512; k += 64 * WAVES) s_lut[k] = lut[k];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (;;) {
+        unsigned int env = 0;
+        if (lane == 0) env = atomicAdd(counter, 1u);
+        env = __shfl(env, 0);
+        if ((int64_t)env >= n) break;
+        if (lane < 49) {
+            const uint8_t* o = image + (int64_t)env * OBS_BYTES + lane * 3;
+            s_tile[w][lane] = s_lut[(lane == 27 ? 256 : 0) + (o[0] | (o[1] << 3) | (o[2] << 6))];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        u32x4* out = (u32x4*)(pixels + (int64_t)env * PIX_BYTES);
+        for (int k = lane; k < VEC_PER_ENV; k += 64)
+            put<NT>(out + k, render_chunk(s_atlas, s_tile[w], 2 * k), render_chunk(s_atlas, s_tile[w], 2 * k + 1));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
 // gather<T>: the plain-fill shape with the render's data: one-shot blocks of T threads, one 16-byte store per thread, NO LDS and
 // no barrier -- every lane looks its two tile ids up in a precomputed 49-byte tile plane (what k_step could emit) and reads
 // its two 8-byte tile-row pieces from the global atlas (L1).  Blocks are not aligned to envs.
@@ -227,6 +302,36 @@ int main(int argc, char** argv) {
     }
 #define SHOT_CASE(G, T, D) run("one-shot<" #G "," #T "> " #D, (int)((n + G - 1) / G), [&] { \
     hipLaunchKernelGGL((k_shot<G, T, D>), dim3((unsigned)((n + G - 1) / G)), dim3(T), 0, 0, n, image, pix, atlas, lut); })
+    if (argc > 2 && argv[2][0] == 'q') {   // tools/ubench_render <n> queue : persistent blocks fed by an atomic ticket counter
+        unsigned int* counter = nullptr;
+        (void)hipMalloc(&counter, 64 * 256);
+        const int cus = 256;
+#define QUEUEN_CASE(G, T, NC, BPC) run("queue<" #G "," #T "> nt counters=" #NC " blocks/CU=" #BPC, cus * BPC, [&] { \
+    (void)hipMemsetAsync(counter, 0, 64 * 256, 0); \
+    hipLaunchKernelGGL((k_queue<G, T, true, NC>), dim3(cus * BPC), dim3(T), 0, 0, n, image, pix, atlas, lut, counter); })
+        if (argv[2][1] == '2') {          // tools/ubench_render <n> q2 : several ticket counters
+            for (int rep = 0; rep < 2; ++rep) {
+                SHOT_CASE(8, 1024, false); SHOT_CASE(2, 512, false);
+                QUEUEN_CASE(8, 1024, 1, 2); QUEUEN_CASE(8, 1024, 8, 2); QUEUEN_CASE(4, 512, 8, 4); QUEUEN_CASE(2, 512, 8, 4); QUEUEN_CASE(2, 512, 32, 4);
+                QUEUEN_CASE(1, 256, 32, 8); QUEUEN_CASE(2, 256, 32, 8); QUEUEN_CASE(4, 1024, 16, 2); QUEUEN_CASE(2, 512, 64, 4); QUEUEN_CASE(4, 512, 32, 4);
+                QUEUEN_CASE(16, 1024, 1, 2); QUEUEN_CASE(16, 1024, 8, 2);
+            }
+            return 0;
+        }
+#define QUEUE_CASE(G, T, NT, BPC) run("queue<" #G "," #T "> nt=" #NT " blocks/CU=" #BPC, cus * BPC, [&] { \
+    (void)hipMemsetAsync(counter, 0, 64 * 256, 0); \
+    hipLaunchKernelGGL((k_queue<G, T, NT>), dim3(cus * BPC), dim3(T), 0, 0, n, image, pix, atlas, lut, counter); })
+#define WQUEUE_CASE(W, NT, BPC) run("wqueue<" #W "> nt=" #NT " blocks/CU=" #BPC, cus * BPC, [&] { \
+    (void)hipMemsetAsync(counter, 0, 4, 0); \
+    hipLaunchKernelGGL((k_wqueue<W, NT>), dim3(cus * BPC), dim3(64 * W), 0, 0, n, image, pix, atlas, lut, counter); })
+        for (int rep = 0; rep < 2; ++rep) {
+            SHOT_CASE(8, 1024, false); SHOT_CASE(2, 512, false);
+            QUEUE_CASE(1, 256, true, 8); QUEUE_CASE(2, 512, true, 4); QUEUE_CASE(1, 512, true, 4); QUEUE_CASE(2, 256, true, 8);
+            QUEUE_CASE(4, 512, true, 4); QUEUE_CASE(2, 512, true, 2); QUEUE_CASE(2, 512, false, 4); QUEUE_CASE(8, 1024, true, 2);
+            WQUEUE_CASE(4, true, 8); WQUEUE_CASE(8, true, 4); WQUEUE_CASE(4, false, 8); WQUEUE_CASE(16, true, 2);
+        }
+        return 0;
+    }
     if (argc > 2) {          // tools/ubench_render <n> direct : the LDS-atlas one-shot shapes against atlas reads from L1
         for (int rep = 0; rep < 2; ++rep) {
             SHOT_CASE(8, 1024, false); SHOT_CASE(8, 1024, true);
