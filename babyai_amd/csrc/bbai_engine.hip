@@ -134,6 +134,10 @@ struct bbai_env {
                           //     lastStepMatch (babyai/levels/verifier.py:213-230); NULL = the normal mode
     uint8_t* tiles;       // [n][TILE_PITCH] fused tile plane of the CURRENT observations (allocated by bbai_set_atlas: pixel mode)
     bool tiles_valid;     // written by the last reset / step of every env
+    unsigned int* render_tickets;   // [64][64] ticket counters of k_render_q + its departure counter; zero between launches (the kernel leaves them so)
+    int render_queue;     // BBAI_RENDER_QUEUE / option "render_queue": -1 = by batch size (default), 0 = one-shot blocks only, m = queue shape m (render_launch)
+    int render_queue_bpc; // option "render_queue_bpc": persistent render blocks per CU (0 = 2048 threads' worth)
+    int n_cus;            // compute units of the device
     uint8_t* atlas;       // [n_tiles][192]
     uint8_t* lut;         // [2][256]
     int n_tiles;
@@ -808,6 +812,7 @@ __global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, Hot* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // k_render : encoded obs -> 56x56x3 pixels through the tile atlas
 // ------------------------------------------------------------------------------------------
+constexpr int RENDER_QUEUE_DEFAULT = 2;         // queue shape of render_launch used from 786 432 envs up
 constexpr int CHUNKS_PER_ROW = PIX * 3 / 8;       // 21 eight-byte chunks per pixel row
 constexpr int VEC_PER_ENV = PIX_BYTES / 16;       // 588 sixteen-byte stores per env
 
@@ -859,6 +864,82 @@ __global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_
             const uint64_t hi = render_chunk(s_atlas, t49, 2 * k + 1);
             u32x4 v = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
             __builtin_nontemporal_store(v, out + q);   // streaming output: keep it out of L2/MALL
+        }
+    }
+}
+
+// k_render_q: the same render from PERSISTENT blocks (the atlas is loaded into LDS once per block) that take their work from
+// atomic ticket counters, so that the chip's stores advance through the output as ONE compact window -- the order in which the
+// pure store stream is fastest (profiles/r03/NOTES.md section 13: stand-alone 1.60 ms against 1.74-1.77 for the one-shot
+// (1024, 8) shape at 1 048 576 envs; inside the step loop 1.61 against 1.71 ms).
+//   * a ticket = K consecutive G-env groups ("super-group"); the next ticket is taken while the first group of the current
+//     one is being staged, so its latency rides under the stores;
+//   * NC counters, 256 bytes apart, INTERLEAVED: ticket t of counter c is super-group t * NC + c, and a block uses counter
+//     blockIdx % NC (= its XCD for NC = 8: MI355X_MICROARCH.md "dequeue": one word serves ~88 tickets/us, "shard the head per
+//     XCD") -- the counters advance through the output together, so there is still one window, not NC of them (round 3's
+//     partitioned counters -- each its own NC-th of the batch -- lost that: 8 windows are free, 32 are not);
+//   * the counters clean up after themselves: the last block to leave (a departure counter) zeroes them for the next launch,
+//     so the step path carries no memset.
+// Tile rows and tickets are double-buffered: one barrier per group.
+template <int RENDER_GROUP, int RENDER_BLOCK, bool FROM_PLANE, int NC, int K>
+__global__ __launch_bounds__(RENDER_BLOCK) void k_render_q(int64_t n, const uint8_t* __restrict__ image,
+                                                           uint8_t* __restrict__ pixels, const uint8_t* __restrict__ atlas,
+                                                           const uint8_t* __restrict__ lut, int n_tiles, unsigned int* __restrict__ counters) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_atlas[MAX_TILES * TILE_BYTES];
+    __shared__ uint8_t s_lut[512];
+    __shared__ uint8_t s_tile[2][RENDER_GROUP * VIEW * VIEW + 8];
+    __shared__ unsigned int s_ticket[2];
+    for (int k = threadIdx.x; k < n_tiles * TILE_BYTES / 8; k += RENDER_BLOCK)
+        ((uint64_t*)s_atlas)[k] = ((const uint64_t*)atlas)[k];
+    for (int k = threadIdx.x; k < 512; k += RENDER_BLOCK) s_lut[k] = lut[k];
+    const int64_t all_groups = (n + RENDER_GROUP - 1) / RENDER_GROUP;
+    const int64_t n_super = (all_groups + K - 1) / K;
+    const unsigned int cidx = blockIdx.x % NC;
+    unsigned int* counter = counters + 64 * cidx;
+    int buf = 0, tp = 0;
+    if (threadIdx.x == 0) s_ticket[0] = atomicAdd(counter, 1u);
+    __syncthreads();
+    for (;;) {
+        const int64_t sg = (int64_t)s_ticket[tp] * NC + cidx;
+        if (sg >= n_super) break;
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            const int64_t grp = sg * K + kk;
+            if (grp >= all_groups) break;
+            const int64_t env0 = grp * RENDER_GROUP;
+            const int ne = (int)(n - env0 < RENDER_GROUP ? n - env0 : RENDER_GROUP);
+            for (int c = threadIdx.x; c < ne * VIEW * VIEW; c += RENDER_BLOCK) {
+                const int e = c / (VIEW * VIEW), cell = c - e * (VIEW * VIEW);
+                int key;
+                if (FROM_PLANE) {
+                    key = image[(env0 + e) * TILE_PITCH + cell];
+                } else {
+                    const uint8_t* o = image + (env0 + e) * OBS_BYTES + cell * 3;
+                    key = o[0] | (o[1] << 3) | (o[2] << 6);
+                }
+                s_tile[buf][c] = s_lut[(cell == 3 * VIEW + 6 ? 256 : 0) + key];
+            }
+            if (kk == 0 && threadIdx.x == 0) s_ticket[tp ^ 1] = atomicAdd(counter, 1u);      // the next ticket rides under this one's stores
+            __syncthreads();
+            u32x4* out = (u32x4*)(pixels + env0 * PIX_BYTES);
+            for (int q = threadIdx.x; q < ne * VEC_PER_ENV; q += RENDER_BLOCK) {
+                const int e = q / VEC_PER_ENV, k = q - e * VEC_PER_ENV;
+                const uint8_t* t49 = s_tile[buf] + e * (VIEW * VIEW);
+                const uint64_t lo = render_chunk(s_atlas, t49, 2 * k);
+                const uint64_t hi = render_chunk(s_atlas, t49, 2 * k + 1);
+                u32x4 v = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+                __builtin_nontemporal_store(v, out + q);
+            }
+            buf ^= 1;
+        }
+        tp ^= 1;
+    }
+    // every block has taken its last ticket before it arrives here (the failing ticket was read through LDS behind a barrier);
+    // the last one to arrive leaves all counters at zero for the next launch
+    if (threadIdx.x == 0) {
+        unsigned int* departed = counters + 64 * NC;
+        if (atomicAdd(departed, 1u) == gridDim.x - 1) {
+            for (int c = 0; c <= NC; ++c) atomicExch(counters + 64 * c, 0u);
         }
     }
 }
@@ -1074,6 +1155,7 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->counters, 128);
     alloc((void**)&e->total_resets, 16);
     alloc((void**)&e->atlas, MAX_TILES * TILE_BYTES);
+    alloc((void**)&e->render_tickets, 64 * 64 * 4);
     alloc((void**)&e->lut, 512);
     if (err != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "hipMalloc failed: %s", hipGetErrorString(err));
@@ -1101,6 +1183,12 @@ static int create_finish(bbai_env* e) {
     HIP_TRY(hipMemset(e->vset, 0, (size_t)n_envs * 64));
     HIP_TRY(hipMemset(e->counters, 0, 128));
     HIP_TRY(hipMemset(e->total_resets, 0, 16));
+    HIP_TRY(hipMemset(e->render_tickets, 0, 64 * 64 * 4));
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess) cus = 0;
+        e->n_cus = cus;
+    }
     if (e->lsm) HIP_TRY(hipMemset(e->lsm, 0, (size_t)n_envs));
     if (e->vplane) {
         HIP_TRY(hipMemset(e->vplane, 0, (size_t)n_envs * v_bytes(c)));
@@ -1130,6 +1218,8 @@ static int create_finish(bbai_env* e) {
         e->step_prio = sp ? atoi(sp) : 1;        // (never slower, GoTo 131 072 envs -2 %: profiles/r03/step_prio_ab.jsonl)
         const char* rv = getenv("BBAI_RENDER_GROUP");
         e->render_group = rv ? atoi(rv) : 0;
+        const char* qv = getenv("BBAI_RENDER_QUEUE");
+        e->render_queue = qv ? atoi(qv) : -1;
         const char* tv = getenv("BBAI_RENDER_TPB");
         e->render_tpb = tv ? atoi(tv) : 0;
     }
@@ -1150,7 +1240,7 @@ void bbai_destroy(bbai_env* e) {
     void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
     void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_list, e->win_count, e->reset_list, e->counters,
-                    e->total_resets, e->atlas, e->lut, e->tiles, e->vplane, e->fcache, e->lsm};
+                    e->total_resets, e->atlas, e->lut, e->tiles, e->vplane, e->fcache, e->lsm, e->render_tickets};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete e;
 }
@@ -1412,6 +1502,37 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
     // (round 3, from the tile plane: (512, 4) from 786 432 envs up -- 1.59 ms at 1 048 576 envs against 1.62-1.66 for
     // (1024, 8) and 1.81-1.85 for (512, 2), profiles/r03/render_fused_ab_1M.jsonl)
     const bool big = e->n >= 786432;
+    // Persistent blocks fed by ticket counters (k_render_q) from 786 432 envs up; one-shot blocks below, where the whole
+    // encoding is still in the memory-side cache and the (512, 2) one-shot shape wins.  BBAI_RENDER_QUEUE / option
+    // "render_queue": -1 = by batch size (default), 0 = never, m > 0 = queue shape m of the table below.
+    int qm = e->render_queue;
+    if (qm < 0) qm = big ? RENDER_QUEUE_DEFAULT : 0;
+    if (qm > 0) {
+        const int cus = e->n_cus > 0 ? e->n_cus : 256;
+#define RENDER_Q(GG, TT, NC, KK) do { \
+            const int64_t tickets = ((e->n + GG - 1) / GG + KK - 1) / KK; \
+            const int bpc = e->render_queue_bpc > 0 ? e->render_queue_bpc : 2048 / TT; \
+            const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)cus * bpc, tickets)); \
+            hipLaunchKernelGGL((k_render_q<GG, TT, FROM_PLANE, NC, KK>), dim3(blocks), dim3(TT), 0, (hipStream_t)stream, e->n, input, pixels, \
+                               e->atlas, e->lut, e->n_tiles, e->render_tickets); } while (0)
+        switch (qm) {
+        case 1: RENDER_Q(8, 1024, 1, 1); break;       // round 3's measurement: one counter, one group per ticket (ticket-bound at 1 M envs)
+        case 2: RENDER_Q(8, 1024, 8, 1); break;       // eight interleaved counters
+        case 3: RENDER_Q(8, 1024, 1, 2); break;       // two / four groups per ticket
+        case 4: RENDER_Q(8, 1024, 1, 4); break;
+        case 5: RENDER_Q(8, 1024, 8, 2); break;
+        case 6: RENDER_Q(4, 512, 8, 1); break;
+        case 7: RENDER_Q(2, 512, 8, 1); break;
+        case 8: RENDER_Q(4, 1024, 8, 1); break;
+        case 9: RENDER_Q(2, 256, 8, 1); break;
+        case 10: RENDER_Q(16, 1024, 8, 1); break;
+        case 11: RENDER_Q(4, 512, 8, 2); break;
+        default: RENDER_Q(8, 1024, 8, 1); break;
+        }
+#undef RENDER_Q
+        HIP_TRY(hipGetLastError());
+        return leave_call(e, (hipStream_t)stream);
+    }
     int G = e->render_group, T = e->render_tpb;
     if (G != 2 && G != 4 && G != 8) G = big ? (FROM_PLANE ? 4 : 8) : 2;
     if (T != 256 && T != 512 && T != 1024) T = big ? (FROM_PLANE ? 512 : 1024) : 512;
@@ -1763,6 +1884,39 @@ int bbai_set_done_actions(bbai_env* e, int enable) {
     return BBAI_OK;
 }
 int bbai_get_done_actions(bbai_env* e) { return e && e->lsm ? 1 : 0; }
+
+// Performance knobs by name (never semantics: every setting produces the same bytes).  What the BBAI_* environment variables
+// set at bbai_create, switchable on a live handle so that measurements can alternate settings inside ONE process on ONE box
+// (tools/ab.py).  Synchronises the device first.
+int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
+    if (!e || !name) ARG_FAIL("null handle or name");
+    ON_DEVICE(e->device);
+    HIP_TRY(hipDeviceSynchronize());
+    const int v = (int)value;
+    if (!strcmp(name, "render_queue")) e->render_queue = v;
+    else if (!strcmp(name, "render_queue_bpc")) e->render_queue_bpc = v;
+    else if (!strcmp(name, "render_group")) e->render_group = v;
+    else if (!strcmp(name, "render_tpb")) e->render_tpb = v;
+    else if (!strcmp(name, "step_prio")) e->step_prio = v;
+    else if (!strcmp(name, "pregen_group")) e->pregen_group = v;
+    else if (!strcmp(name, "pregen_blocks")) e->pregen_cap = std::max(64, v);
+    else if (!strcmp(name, "render_fused")) {
+        // keep (1) or drop (0) the fused tile plane of bbai_render_current; needs an installed atlas
+        if (v && !e->tiles) {
+            if (e->n_tiles <= 0) { snprintf(g_err, sizeof(g_err), "set_option(render_fused): no atlas installed"); return BBAI_ERR_STATE; }
+            HIP_TRY(hipMalloc((void**)&e->tiles, (size_t)e->n * TILE_PITCH));
+            HIP_TRY(hipMemset(e->tiles, 0, (size_t)e->n * TILE_PITCH));
+        } else if (!v && e->tiles) {
+            HIP_TRY(hipFree(e->tiles));
+            e->tiles = nullptr;
+        }
+        e->tiles_valid = false;
+    } else {
+        snprintf(g_err, sizeof(g_err), "set_option: unknown option '%s'", name);
+        return BBAI_ERR_ARG;
+    }
+    return BBAI_OK;
+}
 
 int bbai_profile(bbai_env* e, int enable) {
     if (!e) ARG_FAIL("null handle");

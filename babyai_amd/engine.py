@@ -80,6 +80,7 @@ def load_library():
     lib.bbai_bot_stats.argtypes = [P, P, P]
     lib.bbai_bot_rollout.argtypes = [P, I32, P, P, P, P, P, P, P, P, P, P]
     lib.bbai_set_done_actions.argtypes = [P, I32]
+    lib.bbai_set_option.argtypes = [P, ctypes.c_char_p, I64]
     lib.bbai_get_done_actions.argtypes = [P]
     _lib = lib
     return lib
@@ -91,6 +92,7 @@ EXPORTED_SYMBOLS = (
     "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures", "bbai_bot_act", "bbai_bot_stats",
     "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load", "bbai_profile", "bbai_profile_read", "bbai_gae", "bbai_tap",
     "bbai_tap_ids", "bbai_set_call_events", "bbai_render_current", "bbai_has_tile_plane", "bbai_bot_rollout", "bbai_set_done_actions", "bbai_get_done_actions",
+    "bbai_set_option",
 )
 
 
@@ -450,6 +452,14 @@ class BatchedBabyAIEnv(object):
         """Record the handle's completion event at the end of every call, so that a caller may destroy a stream it used
         for this env and come back on another one (include/bbai.h bbai_set_call_events; off by default: ~3 us per call)."""
         _check(self.lib, self.lib.bbai_set_call_events(self.handle, 1 if enable else 0), "bbai_set_call_events")
+
+    def set_option(self, name, value):
+        """A performance knob of the live handle by name (include/bbai.h bbai_set_option: launch shapes, render input,
+        priorities -- never semantics).  What measurements alternate inside one process (tools/ab.py)."""
+        _check(self.lib, self.lib.bbai_set_option(self.handle, name.encode(), int(value)), "bbai_set_option(%s)" % name)
+        if name == "render_fused":
+            self.render_fused = bool(self.lib.bbai_has_tile_plane(self.handle))
+            self._tiles_ok = False
 
     def profile(self, enable=True):
         """Bracket every k_step / k_consume / k_render launch with HIP events on its launch stream (bench.py)."""

@@ -212,6 +212,18 @@ int bbai_set_call_events(bbai_env* env, int enable);
 int bbai_set_done_actions(bbai_env* env, int enable);
 int bbai_get_done_actions(bbai_env* env);
 
+/* Performance knobs of a live handle, by name (what the BBAI_* environment variables set at bbai_create; the reference has
+ * no counterpart: these choose launch shapes and buffers, never results -- every setting yields the same bytes, which
+ * tests/test_gpu_parity.py::test_options_do_not_change_results checks).  Synchronises the device.  Names:
+ *   "render_queue"      -1 = by batch size (default), 0 = one-shot render blocks, m > 0 = persistent-block queue shape m
+ *   "render_queue_bpc"  persistent render blocks per CU (0 = 2048 threads' worth)
+ *   "render_group", "render_tpb"   envs / threads per one-shot render block (0 = by batch size)
+ *   "render_fused"      1 = keep the fused tile plane (bbai_render_current), 0 = drop it
+ *   "step_prio", "pregen_group", "pregen_blocks", "consume_fused"   as BBAI_STEP_PRIO / BBAI_PREGEN_GROUP / BBAI_PREGEN_BLOCKS /
+ *                       BBAI_CONSUME_FUSED
+ * BBAI_ERR_ARG for an unknown name. */
+int bbai_set_option(bbai_env* env, const char* name, int64_t value);
+
 /* Number of level generations (resets) performed so far, all envs. */
 int bbai_reset_count(bbai_env* env, uint64_t* out);
 

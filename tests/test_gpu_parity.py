@@ -1328,3 +1328,76 @@ def test_record_path_equals_window_plane_path(gpu, level, fused, monkeypatch):
     assert a.reset_count() == b.reset_count() and a.reset_count() > n
     a.close()
     b.close()
+
+
+N_QUEUE_SHAPES = 11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [0, 1])
+@pytest.mark.parametrize("n", [1, 9, 5003, 70001])
+def test_render_queue_equals_one_shot_render(gpu, n, fused):
+    """k_render_q (persistent blocks fed by ticket counters; the default from 786 432 envs up) against the one-shot k_render:
+    every pixel byte, every queue shape of render_launch, ragged last groups / tickets, fewer tickets than blocks, odd block
+    counts, from the encoding and from the fused tile plane, across resets -- and launch after launch, because the kernel
+    leaves its own ticket counters at zero for the next one."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    a = BatchedBabyAIEnv("BabyAI-GoToObjS6-v0", n, device=gpu, pixel=True, seeds=5)
+    b = BatchedBabyAIEnv("BabyAI-GoToObjS6-v0", n, device=gpu, pixel=True, seeds=5)
+    a.set_option("render_queue", 0)
+    if fused:
+        a.set_option("render_fused", 1)
+        b.set_option("render_fused", 1)
+    assert a.render_fused == bool(fused) and b.render_fused == bool(fused)
+    b.set_option("render_queue", 1)
+    oa, ob = a.reset(), b.reset()
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(1)
+    for t in range(4 * N_QUEUE_SHAPES):
+        assert torch.equal(oa["image"], ob["image"]), t
+        b.set_option("render_queue", 1 + t % N_QUEUE_SHAPES)
+        b.set_option("render_queue_bpc", (0, 1, 3, 0)[t // N_QUEUE_SHAPES])
+        act = torch.randint(0, 7, (n,), dtype=torch.uint8, device=gpu, generator=gen)
+        oa, _, _, _ = a.step(act)
+        ob, _, _, _ = b.step(act)
+    assert torch.equal(oa["image"], ob["image"])
+    # and through bbai_render of a stored encoding, every shape
+    pa = torch.zeros_like(a.pixels)
+    a.render_encoding(a.image, pa)
+    for mode in range(1, N_QUEUE_SHAPES + 2):
+        b.set_option("render_queue", mode)
+        pb = torch.zeros_like(b.pixels)
+        b.render_encoding(a.image, pb)
+        assert torch.equal(pa, pb), mode
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
+def test_options_do_not_change_results(gpu):
+    """include/bbai.h bbai_set_option: knobs choose launch shapes, never bytes.  One batch stepped with the defaults, one
+    with a different setting of every knob every few steps; unknown names are rejected."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv, EngineError
+    n = 3001
+    a = BatchedBabyAIEnv("BabyAI-PickupLoc-v0", n, device=gpu, pixel=True, seeds=11)
+    b = BatchedBabyAIEnv("BabyAI-PickupLoc-v0", n, device=gpu, pixel=True, seeds=11)
+    with pytest.raises(EngineError):
+        b.set_option("no_such_knob", 1)
+    oa, ob = a.reset(), b.reset()
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(3)
+    settings = [("step_prio", 0), ("pregen_group", 64), ("pregen_blocks", 64), ("render_group", 4), ("render_tpb", 256),
+                ("render_fused", 1), ("pregen_group", 16), ("render_fused", 0), ("render_queue", 6), ("pregen_group", 32), ("step_prio", 1)]
+    for t in range(20 * len(settings)):
+        assert torch.equal(oa["image"], ob["image"]) and torch.equal(a.image, b.image) and torch.equal(a.direction, b.direction), t
+        if t % 20 == 0:
+            b.set_option(*settings[t // 20])
+        act = torch.randint(0, 7, (n,), dtype=torch.uint8, device=gpu, generator=gen)
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(a.reward64, b.reward64) and torch.equal(da, db), t
+    assert a.reset_count() == b.reset_count() and a.reset_count() > 2 * n
+    a.close()
+    b.close()

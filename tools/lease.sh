@@ -1,0 +1,75 @@
+#!/bin/bash
+# tools/lease.sh -- everything that runs on the GPU box, ONE script for every lease (gpurun call).
+#
+#   gpurun --timeout 900 -- 'bash tools/lease.sh <tag> <job> [<job> ...]'
+#
+# Results go to gpurun_out/<tag>/ (merged back into the build container); what is kept is copied to profiles/<round>/ by hand
+# or by tools/summarize_profile.py.  A job is a function name below, optionally with arguments after colons
+# (ab:render1m  bench:C2).  Jobs run in the order given; a failing job does not stop the lease.
+TAG=$1; shift
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p $OUT
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+export TMPDIR=/tmp
+B="python $REPO/bench.py --steps 20 --warmup 5"
+
+suite() {            # the GPU test suite (optionally: -k expression)
+    cd $REPO
+    if [ -n "$1" ]; then timeout 1500 python -m pytest tests -m gpu -x -q -k "$1" > $OUT/gpu_tests.log 2>&1
+    else timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1; fi
+    echo "pytest rc=$?" >> $OUT/gpu_tests.log
+    tail -4 $OUT/gpu_tests.log
+}
+build() { cd $REPO && python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -3; }
+judged() {           # the driver's command
+    cd /tmp && timeout 600 $B > $OUT/bench_boss_pixel_1M.json 2> $OUT/bench_boss_pixel_1M.err
+    python $REPO/tools/summarize_profile.py --line $OUT/bench_boss_pixel_1M.json
+}
+trace() {            # rocprofv3 --kernel-trace --stats of the same command
+    cd /tmp && rm -rf $OUT/stats
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o boss -- $B --no-cpu-baseline --parity-envs 0 --no-extra-configs \
+        > $OUT/bench_boss_pixel_1M_under_rocprof.json 2> $OUT/rocprof_stats.log
+    find $OUT -name "*kernel_trace.csv" -size +20M -delete
+}
+pmc() {              # FETCH_SIZE / WRITE_SIZE, one pass each, no other tracing (gpurun refuses the combination)
+    cd /tmp && rm -rf $OUT/pmc_fetch $OUT/pmc_write
+    timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o boss -- $B --no-cpu-baseline --parity-envs 0 --min-seconds 0 --no-extra-configs > $OUT/rocprof_fetch.log 2>&1
+    timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o boss -- $B --no-cpu-baseline --parity-envs 0 --min-seconds 0 --no-extra-configs > $OUT/rocprof_write.log 2>&1
+    find $OUT -name "*kernel_trace.csv" -size +20M -delete
+}
+bench() {            # one BASELINE config as its own line: bench:C2 [extra args]
+    cd /tmp && timeout 600 python $REPO/bench.py --config $1 --no-extra-configs ${@:2} > $OUT/bench_$1.json 2>> $OUT/bench.err
+    python $REPO/tools/summarize_profile.py --line $OUT/bench_$1.json
+}
+ab() {               # tools/ab.py presets
+    cd /tmp
+    case $1 in
+    render1m)   timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 1048576 --pixel --steps 20 --blocks 8 --reps 3 --settings \
+                    render_queue=0 render_queue=1 render_queue=2 render_queue=3 render_queue=4 render_queue=5 render_queue=6 render_queue=7 render_queue=8 render_queue=10 render_queue=11 \
+                    render_queue=2,render_queue_bpc=1 \
+                    > $OUT/render_queue_ab_1M.jsonl 2> $OUT/ab.err; tail -1 $OUT/render_queue_ab_1M.jsonl ;;
+    render1m_fused) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 1048576 --pixel --steps 20 --blocks 8 --reps 3 --settings \
+                    render_fused=0,render_queue=0 render_fused=0,render_queue=-1 render_fused=1,render_queue=0 render_fused=1,render_queue=2 render_fused=1,render_queue=6 render_fused=1,render_queue=11 \
+                    > $OUT/render_fused_queue_ab_1M.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_fused_queue_ab_1M.jsonl ;;
+    render128k) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 131072 --pixel --steps 64 --blocks 8 --reps 3 --settings \
+                    render_queue=0 render_queue=2 render_queue=6 render_queue=7 render_queue=9 render_queue=11 \
+                    > $OUT/render_queue_ab_131072.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_131072.jsonl ;;
+    render512k) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 524288 --pixel --steps 32 --blocks 8 --reps 3 --settings \
+                    render_queue=0 render_queue=2 render_queue=6 render_queue=7 render_queue=11 \
+                    > $OUT/render_queue_ab_524288.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_524288.jsonl ;;
+    *)          # ab:<name>:<level>:<envs>:<steps>:<pixel 0|1>:<setting>:<setting>...   (settings use '/' for ',')
+                local name=$1 level=$2 envs=$3 steps=$4 pix=$5; shift 5
+                local sets=(); for s in "$@"; do sets+=("${s//\//,}"); done
+                timeout 600 python $REPO/tools/ab.py --tag $TAG --level $level --envs $envs $([ "$pix" = 1 ] && echo --pixel) --steps $steps --blocks 8 --reps 3 \
+                    --settings "${sets[@]}" > $OUT/ab_$name.jsonl 2>> $OUT/ab.err; tail -1 $OUT/ab_$name.jsonl ;;
+    esac
+}
+run() { cd $REPO && timeout 900 "$@"; }          # run:python:tools/x.py:arg ...
+
+for job in "$@"; do
+    IFS=':' read -r -a parts <<< "$job"
+    echo "=== $job ($(date +%T))"
+    "${parts[@]}"
+done
+echo "=== done ($(date +%T))"

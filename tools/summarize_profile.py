@@ -9,6 +9,14 @@ import os
 import shutil
 import sys
 
+if len(sys.argv) > 2 and sys.argv[1] == "--line":          # one-line digest of a bench.py JSON line (tools/lease.sh)
+    d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+    print(round(d["value"] / 1e6, 1), "M steps/s", round(d["ms_per_step"], 4), "ms/step", "frac", round(d["roofline"]["frac"], 3),
+          "of achievable", d["roofline"].get("frac_of_achievable"), "parity", (d.get("parity") or {}).get("mismatches_all_ranks"),
+          "kernels", d["roofline"]["kernel_avg_ms"], "cpu", (d.get("cpu_baseline") or {}).get("value"))
+    for name, c in sorted((d.get("configs") or {}).items()):
+        print("  ", name, json.dumps(c))
+    sys.exit(0)
 tag = sys.argv[1]
 src = os.path.join("gpurun_out", tag)
 dst = os.path.join("profiles", tag)
