@@ -49,21 +49,25 @@ def _s64(v):
 
 def actions_torch(seed, t0, t1, first, count, device):
     """uint8[t1 - t0, count] on `device`: the block of steps t0 .. t1-1 (int64 arithmetic wraps mod 2^64; logical
-    right shifts are emulated with a mask)."""
+    right shifts are emulated with a mask).  Evaluated for several steps at a time (<= 2^24 elements per pass: a long
+    run of a small shard is thousands of steps)."""
     import torch
     i = torch.arange(first, first + count, dtype=torch.int64, device=device)
-    base = i * _s64(_A)
+    base = (i * _s64(_A)).unsqueeze(0)
     out = torch.empty((t1 - t0, count), dtype=torch.uint8, device=device)
 
     def lsr(x, s):
         return (x >> s) & ((1 << (64 - s)) - 1)
 
-    for t in range(t0, t1):
-        x = base + _s64(t * _B + seed * _C)
+    chunk = max(1, (1 << 24) // max(1, count))
+    for c0 in range(t0, t1, chunk):
+        c1 = min(t1, c0 + chunk)
+        offs = torch.tensor([_s64(t * _B + seed * _C) for t in range(c0, c1)], dtype=torch.int64, device=device).unsqueeze(1)
+        x = base + offs
         x = x ^ lsr(x, 30)
         x = x * _s64(_M1)
         x = x ^ lsr(x, 27)
         x = x * _s64(_M2)
         x = x ^ lsr(x, 31)
-        out[t - t0] = ((lsr(x, 40) * 7) >> 24).to(torch.uint8)
+        out[c0 - t0:c1 - t0] = ((lsr(x, 40) * 7) >> 24).to(torch.uint8)
     return out

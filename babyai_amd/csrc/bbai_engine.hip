@@ -138,6 +138,7 @@ struct bbai_env {
     int render_queue;     // BBAI_RENDER_QUEUE / option "render_queue": -1 = by batch size (default), 0 = one-shot blocks only, m = queue shape m (render_launch)
     int render_queue_bpc; // option "render_queue_bpc": persistent render blocks per CU (0 = 2048 threads' worth)
     int n_cus;            // compute units of the device
+    int consume_fused;    // BBAI_CONSUME_FUSED / option "consume_fused": -1 = by batch size, 0 = k_consume launch, 1 = inside k_step
     uint8_t* atlas;       // [n_tiles][192]
     uint8_t* lut;         // [2][256]
     int n_tiles;
@@ -155,6 +156,8 @@ struct bbai_env {
 // k_step
 // ------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// batches up to this size consume finished envs inside k_step (use_fused_consume); above it the k_consume launch stays
+constexpr int64_t CONSUME_FUSED_MAX_ENVS = 524288;
 constexpr int MAX_PERIOD = 32;          // refill period B (ticks per look-ahead refill); ring depth D = 2B
 constexpr int WIN_STRIDE = 64;          // uint32 per window-count block (1 + MAX_PERIOD used)
 // envs (= threads) per k_step block.  The kernel is bound by its chain of dependent memory round trips, not by bytes or
@@ -325,22 +328,91 @@ __device__ __forceinline__ u32x4 v_segment(const LevelCfg& c, const uint8_t* __r
     return out;
 }
 
+// look-ahead slot -> live state of ONE env by ONE wave (k_consume: wave = env over the reset list; k_step<.., FUSE>: the wave that
+// stepped the env): coalesced record copy, SoA verifier view, first observation of the new episode (to `obs_dst`: the caller's
+// image row, or the block's LDS row in k_step), window plane + front cache, window bookkeeping for the batched refill.
+// `win_entry` = where this consumption is listed for k_pregen (NULL on reset(): the refill walks all envs).
+__device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_t env, int slot, int lane, uint8_t* __restrict__ recs,
+                                            Hot* __restrict__ hots, uint64_t* __restrict__ stales, const uint8_t* __restrict__ next_recs,
+                                            const Hot* __restrict__ next_hots, uint32_t* __restrict__ vheads, uint64_t* __restrict__ vsets,
+                                            int depth, uint8_t* __restrict__ pending, uint8_t* __restrict__ first_slot,
+                                            int32_t* __restrict__ win_entry, uint8_t* __restrict__ obs_dst, uint8_t* __restrict__ dirs,
+                                            uint8_t* __restrict__ tile_row /* or NULL */, uint8_t* __restrict__ vplane /* or NULL */,
+                                            uint16_t* __restrict__ fcache, uint8_t* __restrict__ lsm_arr /* or NULL */) {
+    const int nvec = c.rec_bytes >> 4;
+    const uint8_t* nrec = next_recs + ((int64_t)slot * n + env) * (int64_t)c.rec_bytes;
+    const u32x4* src = (const u32x4*)nrec;
+    u32x4* dst = (u32x4*)(recs + env * (int64_t)c.rec_bytes);
+    for (int k = lane; k < nvec; k += 64) dst[k] = src[k];
+    // the verifier's SoA view of the new program
+    const Prog* p = (const Prog*)(nrec + c.off_prog);
+    if (lane < 8) vsets[(int64_t)lane * n + env] = p->set[lane >> 1][lane & 1];
+    if (lane == 8) vheads[env] = vhead_pack(*p);
+    Hot h = next_hots[(int64_t)slot * n + env];
+    h.slot = (uint8_t)(slot + 1 == depth ? 0 : slot + 1);
+    // first observation of the new episode, straight from the slot (identical bytes to the live copy)
+    observe_wave(c, nrec, h, obs_dst, lane, tile_row);
+    if (vplane) {
+        // the new episode's window plane, straight from the slot; a start-carry object (it leaves the grid right after
+        // this first observation, below) is already shown as an empty cell
+        int sc = -1;
+        if (p->start_carry != NONE8) sc = e_index(c, nrec[c.off_pos + 2 * p->start_carry], nrec[c.off_pos + 2 * p->start_carry + 1]);
+        uint8_t* vrow = vplane + env * (int64_t)v_bytes(c);
+        const int nseg = v_nxo(c) * v_nyo(c) * 8;
+        // (read back from the slot -- L2 hits right after the copy above.  Parking the plane in LDS instead was measured
+        // and dropped: any LDS at all makes k_consume's blocks queue behind the generator's waves for it -- GoToLocal
+        // 65 536 envs: k_consume 14 -> 38 us, profiles/r03/NOTES.md)
+        for (int sg = lane; sg < nseg; sg += 64) *(u32x4*)(vrow + (sg >> 3) * VLINE + (sg & 7) * 16) = v_segment(c, nrec, sg >> 3, sg & 7, sc);
+        if (lane == 0) {
+            const int fi = e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir));
+            const uint32_t fe0 = fi == sc ? (uint32_t)E_EMPTY : nrec[fi];
+            const uint32_t ce0 = p->start_carry != NONE8 ? nrec[c.off_app + p->start_carry] : (uint32_t)E_EMPTY;
+            fcache[env] = (uint16_t)(fe0 | (ce0 << 8));
+        }
+    }
+    if (lane == 0) {
+        uint64_t stale0 = 0;
+        // PutNext*Carrying: the first observation above still shows the object on the grid (the reference builds
+        // it before handing the object to the agent, bonus_levels.py:821-829); now move it into the agent's hands
+        if (p->start_carry != NONE8) apply_start_carry(c, recs + env * (int64_t)c.rec_bytes, h, stale0, p->start_carry);
+        hots[env] = h;
+        stales[env] = stale0;
+        if (lsm_arr) lsm_arr[env] = 0;                  // fresh instruction objects: lastStepMatch = False (verifier.py:213-214)
+        dirs[env] = h.dir;
+        // window bookkeeping for the batched refill: first consumption in this window registers the env
+        const int pend = pending[env];
+        if (pend == 0) first_slot[env] = (uint8_t)slot;
+        if (win_entry) *win_entry = pend == 0 ? (int32_t)env : -1;
+        pending[env] = (uint8_t)(pend + 1);
+    }
+}
+
 // VP: the window comes from the env's V-plane line (ONE 128-byte line per step) and the transition's inputs -- the
 // appearance of the front cell and of the carried object -- from the 2-byte cache the previous step left (`fcache`), so a
 // plain move / turn touches no other record line; without VP both come out of the record (round 2's path: 2-3 lines for
 // the window + the lines of the front cell's id and the carried object's appearance).
-template <bool EMIT, bool VP>
+// FUSE: a wave whose envs finished consumes their look-ahead slots ITSELF (consume_env for every set bit of the wave's ballot,
+// the new episode's first observation straight into the block's LDS rows), instead of listing them for a k_consume launch:
+// on small shards that second launch costs as much as the step (profiles/r03: GoToLocal 65 536 envs k_step 21 us + k_consume
+// 18 us to reset 2 % of the envs).  `fuse` carries what k_consume's arguments carried.
+struct FuseArgs {
+    const uint8_t* next_recs; const Hot* next_hots; uint32_t* vheads_w; uint64_t* vsets_w; int depth, pos;
+    uint8_t* pending; uint8_t* first_slot; int32_t* win_list; uint32_t* win_count; unsigned long long* total_resets;
+};
+template <bool EMIT, bool VP, bool FUSE>
 __global__ __launch_bounds__(StepBlock<EMIT>::N, EMIT ? 4 : 1) void k_step(LevelCfg c, int64_t n, uint8_t* __restrict__ recs,
                                                      Hot* __restrict__ hots, uint64_t* __restrict__ stales,
                                                      const uint32_t* __restrict__ vheads, const uint64_t* __restrict__ vsets,
-                                                     const uint8_t* __restrict__ actions, uint8_t* __restrict__ image,
+                                                     const uint8_t* __restrict__ actions, uint8_t* image /* read (frozen envs re-emit) AND written: no restrict */,
                                                      uint8_t* __restrict__ dirs, float* __restrict__ rewards,
                                                      double* __restrict__ rewards64, uint8_t* __restrict__ dones, int auto_reset,
                                                      int32_t* __restrict__ reset_list, uint32_t* __restrict__ counters,
                                                      uint8_t* __restrict__ tiles /* EMIT: [n][TILE_PITCH] render input */, int prio,
                                                      uint8_t* __restrict__ vplane, uint16_t* __restrict__ fcache,
-                                                     uint8_t* __restrict__ lsm_arr /* NULL, or the done-action mode's per-env bits */) {
+                                                     uint8_t* __restrict__ lsm_arr /* NULL, or the done-action mode's per-env bits */,
+                                                     FuseArgs fuse) {
     constexpr int STEP_BLOCK = StepBlock<EMIT>::N;
+    static_assert(!FUSE || (STEP_BLOCK == 64 && !EMIT), "the in-wave consume relies on the block being one wave (LDS rows ordered by program order)");
     // the block's observation rows at the OUTPUT pitch of 147 bytes (bbai_step.hpp RowPacker), 16 bytes of front padding
     __shared__ __attribute__((aligned(16))) uint8_t s_obs[ROWS_FRONT + STEP_BLOCK * OBS_BYTES + 16];
     uint8_t* const s_rows = s_obs + ROWS_FRONT;
@@ -350,6 +422,7 @@ __global__ __launch_bounds__(StepBlock<EMIT>::N, EMIT ? 4 : 1) void k_step(Level
     const int64_t env = env0 + threadIdx.x;
     const bool active = env < n;
     bool want_reset = false;
+    int my_slot = 0;
     if (active) {
         // everything the step needs from the SoA arrays in ONE memory round trip, before the frozen test (the loads the
         // branch would otherwise delay are a second round trip on every step's critical path)
@@ -363,6 +436,7 @@ __global__ __launch_bounds__(StepBlock<EMIT>::N, EMIT ? 4 : 1) void k_step(Level
         asm volatile("" : "+v"(hv), "+v"(stale), "+v"(vp.head), "+v"(vp.set00), "+v"(action), "+v"(fc));
         Hot h;
         __builtin_memcpy(&h, &hv, sizeof(h));
+        my_slot = h.slot;
         uint8_t* rec = recs + env * (int64_t)c.rec_bytes;
         if (!h.frozen) {
             double reward = 0.0;
@@ -447,9 +521,28 @@ __global__ __launch_bounds__(StepBlock<EMIT>::N, EMIT ? 4 : 1) void k_step(Level
             int lane = threadIdx.x & 63;
             int leader = __ffsll((long long)bal) - 1;
             uint32_t basei = 0;
-            if (lane == leader) basei = atomicAdd(&counters[0], (uint32_t)__popcll(bal));
+            // (FUSE: the tick's count lives in the window's count block -- what k_consume would have written there at the end)
+            if (lane == leader) basei = atomicAdd(FUSE ? &fuse.win_count[1 + fuse.pos] : &counters[0], (uint32_t)__popcll(bal));
             basei = __shfl(basei, leader);
             if (want_reset) reset_list[basei + __popcll(bal & ((1ull << lane) - 1))] = (int32_t)env;
+            if (FUSE) {
+                // Everything this wave stored to the records, window planes and SoA entries of these envs must have landed
+                // before other lanes overwrite them (a terminal pickup patches the record the consume is about to replace).
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == leader) atomicAdd(fuse.total_resets, (unsigned long long)__popcll(bal));
+                int64_t wbase = 0;          // this tick's entries go behind those of the window's earlier ticks
+                for (int j = 0; j < fuse.pos; ++j) wbase += (int64_t)fuse.win_count[1 + j];
+                uint32_t k = 0;
+                while (bal) {
+                    const int src = __ffsll((long long)bal) - 1;
+                    bal &= bal - 1;
+                    const int slot = __shfl(my_slot, src);
+                    consume_env(c, n, env0 + src, slot, lane, recs, hots, stales, fuse.next_recs, fuse.next_hots, fuse.vheads_w, fuse.vsets_w,
+                                fuse.depth, fuse.pending, fuse.first_slot, fuse.win_list + wbase + basei + k, s_rows + src * OBS_BYTES, dirs, nullptr,
+                                VP ? vplane : nullptr, fcache, lsm_arr);
+                    ++k;
+                }
+            }
         }
     }
     __syncthreads();
@@ -660,55 +753,11 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
     for (int j = 0; j < pos; ++j) base += (int64_t)win_count[1 + j];
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
-    const int nvec = c.rec_bytes >> 4;
     for (int64_t it = wave; it < count; it += nwaves) {
         const int64_t env = all ? it : (int64_t)reset_list[it];
-        const int slot = hots[env].slot;
-        const uint8_t* nrec = next_recs + ((int64_t)slot * n + env) * (int64_t)c.rec_bytes;
-        const u32x4* src = (const u32x4*)nrec;
-        u32x4* dst = (u32x4*)(recs + env * (int64_t)c.rec_bytes);
-        for (int k = lane; k < nvec; k += 64) dst[k] = src[k];
-        // the verifier's SoA view of the new program
-        const Prog* p = (const Prog*)(nrec + c.off_prog);
-        if (lane < 8) vsets[(int64_t)lane * n + env] = p->set[lane >> 1][lane & 1];
-        if (lane == 8) vheads[env] = vhead_pack(*p);
-        Hot h = next_hots[(int64_t)slot * n + env];
-        h.slot = (uint8_t)(slot + 1 == depth ? 0 : slot + 1);
-        // first observation of the new episode, straight from the slot (identical bytes to the live copy)
-        observe_wave(c, nrec, h, image + env * OBS_BYTES, lane, tiles ? tiles + env * TILE_PITCH : nullptr);
-        if (vplane) {
-            // the new episode's window plane, straight from the slot; a start-carry object (it leaves the grid right after
-            // this first observation, below) is already shown as an empty cell
-            int sc = -1;
-            if (p->start_carry != NONE8) sc = e_index(c, nrec[c.off_pos + 2 * p->start_carry], nrec[c.off_pos + 2 * p->start_carry + 1]);
-            uint8_t* vrow = vplane + env * (int64_t)v_bytes(c);
-            const int nseg = v_nxo(c) * v_nyo(c) * 8;
-            // (read back from the slot -- L2 hits right after the copy above.  Parking the plane in LDS instead was measured
-            // and dropped: any LDS at all makes k_consume's blocks queue behind the generator's waves for it -- GoToLocal
-            // 65 536 envs: k_consume 14 -> 38 us, profiles/r03/NOTES.md)
-            for (int sg = lane; sg < nseg; sg += 64) *(u32x4*)(vrow + (sg >> 3) * VLINE + (sg & 7) * 16) = v_segment(c, nrec, sg >> 3, sg & 7, sc);
-            if (lane == 0) {
-                const int fi = e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir));
-                const uint32_t fe0 = fi == sc ? (uint32_t)E_EMPTY : nrec[fi];
-                const uint32_t ce0 = p->start_carry != NONE8 ? nrec[c.off_app + p->start_carry] : (uint32_t)E_EMPTY;
-                fcache[env] = (uint16_t)(fe0 | (ce0 << 8));
-            }
-        }
-        if (lane == 0) {
-            uint64_t stale0 = 0;
-            // PutNext*Carrying: the first observation above still shows the object on the grid (the reference builds
-            // it before handing the object to the agent, bonus_levels.py:821-829); now move it into the agent's hands
-            if (p->start_carry != NONE8) apply_start_carry(c, recs + env * (int64_t)c.rec_bytes, h, stale0, p->start_carry);
-            hots[env] = h;
-            stales[env] = stale0;
-            if (lsm_arr) lsm_arr[env] = 0;                  // fresh instruction objects: lastStepMatch = False (verifier.py:213-214)
-            dirs[env] = h.dir;
-            // window bookkeeping for the batched refill: first consumption in this window registers the env
-            const int pend = pending[env];
-            if (pend == 0) first_slot[env] = (uint8_t)slot;
-            if (!all) win_list[base + it] = pend == 0 ? (int32_t)env : -1;
-            pending[env] = (uint8_t)(pend + 1);
-        }
+        consume_env(c, n, env, hots[env].slot, lane, recs, hots, stales, next_recs, next_hots, vheads, vsets, depth, pending, first_slot,
+                    all ? nullptr : win_list + base + it, image + env * OBS_BYTES, dirs, tiles ? tiles + env * TILE_PITCH : nullptr, vplane, fcache,
+                    lsm_arr);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(total_resets, (unsigned long long)count);
@@ -812,7 +861,7 @@ __global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, Hot* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // k_render : encoded obs -> 56x56x3 pixels through the tile atlas
 // ------------------------------------------------------------------------------------------
-constexpr int RENDER_QUEUE_DEFAULT = 2;         // queue shape of render_launch used from 786 432 envs up
+constexpr int RENDER_QUEUE_DEFAULT = 1;         // queue shape of render_launch used from 786 432 envs up
 constexpr int CHUNKS_PER_ROW = PIX * 3 / 8;       // 21 eight-byte chunks per pixel row
 constexpr int VEC_PER_ENV = PIX_BYTES / 16;       // 588 sixteen-byte stores per env
 
@@ -1220,6 +1269,8 @@ static int create_finish(bbai_env* e) {
         e->render_group = rv ? atoi(rv) : 0;
         const char* qv = getenv("BBAI_RENDER_QUEUE");
         e->render_queue = qv ? atoi(qv) : -1;
+        const char* cf = getenv("BBAI_CONSUME_FUSED");
+        e->consume_fused = cf ? atoi(cf) : -1;
         const char* tv = getenv("BBAI_RENDER_TPB");
         e->render_tpb = tv ? atoi(tv) : 0;
     }
@@ -1248,7 +1299,7 @@ void bbai_destroy(bbai_env* e) {
 }  // extern "C"
 
 // k_pregen is instantiated per level family so that a launch carries only that family's mission code, and per group
-// width G (envs per wave = 64 / G; BBAI_PREGEN_GROUP, default 16)
+// width G (envs per wave = 64 / G; BBAI_PREGEN_GROUP, default 32: two envs per wave)
 template <int G>
 static void launch_pregen_g(const bbai_env* e, unsigned groups, const int32_t* win_list, const uint32_t* win_count, int all,
                             uint8_t* pending, const uint8_t* first_slot) {
@@ -1306,6 +1357,18 @@ static int leave_call(bbai_env* e, hipStream_t s) {
     if (e->call_events) HIP_TRY(hipEventRecord(e->ev_switch, s));
     return BBAI_OK;
 }
+// enter_call / leave_call as a scope: once a call has entered, EVERY exit path -- also the error returns after work was
+// already enqueued -- records the handle's completion event (call_events mode), so that a later call on another stream
+// never waits for less than the handle really enqueued.  `return scope.leave();` on the success path reports a failing
+// event record; the destructor covers the others.
+struct CallScope {
+    bbai_env* e; hipStream_t s; int rc; bool open;
+    CallScope(bbai_env* e_, hipStream_t s_) : e(e_), s(s_), rc(enter_call(e_, s_)), open(false) { open = rc == BBAI_OK; }
+    int leave() { open = false; return leave_call(e, s); }
+    ~CallScope() { if (open) (void)leave_call(e, s); }
+    CallScope(const CallScope&) = delete;
+    CallScope& operator=(const CallScope&) = delete;
+};
 
 // bbai_profile: bracket a launch with an event pair (ring of PROF_RING pairs per kernel; a pair is folded into the sums
 // when its slot comes round again, i.e. long after it completed, or when the totals are read)
@@ -1333,13 +1396,19 @@ struct ProfScope {
     }
 };
 
-// main stream: slots -> live state (+ first obs); side stream: refill the consumed slots.
-static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_t* dirs, int all) {
-    const int D = e->depth, B = e->period;
-    const int64_t w = e->tick / B;                   // window of this consume-tick
-    const int wb = (int)(w % 3);                     // its buffer (pending / first_slot / list / count / event)
-    const int pos = (int)(e->tick % B);
-    if (pos == 0) {
+// A consume-tick (one reset() or one auto-resetting step) in three parts: window_begin -- at the first tick of a window the
+// stream waits for the refill that filled the slots consumed from now on; the consume itself -- k_consume over the reset list,
+// or, fused, inside k_step (which therefore has to be launched AFTER window_begin); window_end -- the mission tokens of the new
+// episodes and, at the last tick of a window, ONE refill launch on the look-ahead stream for everything the window consumed.
+struct TickPos { int wb, pos; };
+static TickPos tick_pos(const bbai_env* e) {
+    const int64_t w = e->tick / e->period;           // window of this consume-tick
+    return {(int)(w % 3), (int)(e->tick % e->period)};      // its buffer (pending / first_slot / list / count / event), its place in the window
+}
+static int window_begin(bbai_env* e, hipStream_t s) {
+    const int B = e->period;
+    const int64_t w = e->tick / B;
+    if (e->tick % B == 0) {
         // Window start: the slots consumed from now on were refilled by window w-2 at the latest (buffer (w+1)%3):
         // wait for that refill; its buffer becomes the one window w+1 will use, so clear its count.
         const int ob = (int)((w + 1) % 3);
@@ -1347,21 +1416,20 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
         HIP_TRY(hipMemsetAsync(e->win_count + WIN_STRIDE * ob, 0, WIN_STRIDE * 4, s));
         e->win_all[ob] = 0;
     }
-    if (all) e->win_all[wb] = 1;
+    return BBAI_OK;
+}
+static int window_end(bbai_env* e, hipStream_t s, int all, bool fused) {
+    const int B = e->period;
+    const TickPos tp = tick_pos(e);
+    const int wb = tp.wb, pos = tp.pos;
     const int64_t hint = all ? e->n : std::max<int64_t>(e->n / 64, 64);
-    {
-    ProfScope prof_(e, 1, s);
-    hipLaunchKernelGGL(k_consume, dim3((unsigned)std::min<int64_t>((hint + 3) / 4, 8192)), dim3(256), 0, s, e->cfg, e->n, e->rec,
-                       e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, e->reset_list, e->counters + 16 * e->step_parity, all,
-                       e->total_resets, D, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n,
-                       e->win_list + (size_t)wb * e->period * e->n, e->win_count + WIN_STRIDE * wb, pos, image, dirs,
-                       e->counters + 16 * (e->step_parity ^ 1), e->tiles, e->step_prio, e->vplane, e->fcache, e->lsm);
-    }
-    if (e->tokens)
+    if (e->tokens)     // (fused: the tick's count is the window's count entry, which k_step's waves added up)
         hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n, e->rec,
-                           e->tokens, e->reset_list, e->counters + 16 * e->step_parity, all);
-    e->step_parity ^= 1;
-    e->next_counter_clean = true;
+                           e->tokens, e->reset_list, fused ? e->win_count + WIN_STRIDE * wb + 1 + pos : e->counters + 16 * e->step_parity, all);
+    if (!fused) {
+        e->step_parity ^= 1;
+        e->next_counter_clean = true;
+    }
     HIP_TRY(hipGetLastError());
     if (pos == B - 1) {
         // Window end: one refill launch for everything consumed in the window, on the look-ahead stream.
@@ -1376,6 +1444,23 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
     }
     e->tick++;
     return BBAI_OK;
+}
+// main stream: slots -> live state (+ first obs) by k_consume; side stream: refill the consumed slots.
+static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_t* dirs, int all) {
+    { int rc = window_begin(e, s); if (rc != BBAI_OK) return rc; }
+    const TickPos tp = tick_pos(e);
+    const int wb = tp.wb, pos = tp.pos;
+    if (all) e->win_all[wb] = 1;
+    const int64_t hint = all ? e->n : std::max<int64_t>(e->n / 64, 64);
+    {
+    ProfScope prof_(e, 1, s);
+    hipLaunchKernelGGL(k_consume, dim3((unsigned)std::min<int64_t>((hint + 3) / 4, 8192)), dim3(256), 0, s, e->cfg, e->n, e->rec,
+                       e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, e->reset_list, e->counters + 16 * e->step_parity, all,
+                       e->total_resets, e->depth, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n,
+                       e->win_list + (size_t)wb * e->period * e->n, e->win_count + WIN_STRIDE * wb, pos, image, dirs,
+                       e->counters + 16 * (e->step_parity ^ 1), e->tiles, e->step_prio, e->vplane, e->fcache, e->lsm);
+    }
+    return window_end(e, s, all, false);
 }
 
 int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
@@ -1413,34 +1498,55 @@ int bbai_reset(bbai_env* e, uint8_t* image, uint8_t* dirs, void* stream) {
     if (!e->seeded) { snprintf(g_err, sizeof(g_err), "reset before seed"); return BBAI_ERR_STATE; }
     ON_DEVICE(e->device);
     hipStream_t s = (hipStream_t)stream;
-    int rc = enter_call(e, s);
-    if (rc != BBAI_OK) return rc;
-    rc = consume_and_refill(e, s, image, dirs, 1);
+    CallScope call(e, s);
+    if (call.rc != BBAI_OK) return call.rc;
+    int rc = consume_and_refill(e, s, image, dirs, 1);
     if (rc != BBAI_OK) return rc;
     e->live = true;
     e->tiles_valid = e->tiles != nullptr;
-    return leave_call(e, s);
+    return call.leave();
 }
 
 // k_step (+ the consume / refill of the envs it finished) on stream s; the caller has entered the call
+static bool use_fused_consume(const bbai_env* e) {
+    // option "consume_fused" / BBAI_CONSUME_FUSED: 1 = the stepping wave consumes its finished envs itself, 0 = k_consume launch,
+    // -1 (default) = by batch size (CONSUME_FUSED_MAX_ENVS).  Never with the fused tile plane (that k_step keeps 256-thread blocks).
+    if (e->tiles) return false;
+    if (e->consume_fused >= 0) return e->consume_fused != 0;
+    return e->n <= CONSUME_FUSED_MAX_ENVS;
+}
 static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64,
                        uint8_t* dones, int auto_reset, hipStream_t s) {
+    const bool fused = auto_reset && use_fused_consume(e);
     int32_t* list = e->reset_list;
     uint32_t* counter = e->counters + 16 * e->step_parity;
-    if (!e->next_counter_clean) HIP_TRY(hipMemsetAsync(counter, 0, 4, s));   // (k_consume of the previous step zeroes it)
-    e->next_counter_clean = false;
+    FuseArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    if (fused) {
+        { int rc = window_begin(e, s); if (rc != BBAI_OK) return rc; }        // the slots this step's waves consume have landed
+        const TickPos tp = tick_pos(e);
+        fa.next_recs = e->next_rec; fa.next_hots = e->next_hot; fa.vheads_w = e->vhead; fa.vsets_w = e->vset; fa.depth = e->depth; fa.pos = tp.pos;
+        fa.pending = e->pending + (size_t)tp.wb * e->n; fa.first_slot = e->first_slot + (size_t)tp.wb * e->n;
+        fa.win_list = e->win_list + (size_t)tp.wb * e->period * e->n; fa.win_count = e->win_count + WIN_STRIDE * tp.wb;
+        fa.total_resets = e->total_resets;
+        e->next_counter_clean = false;      // (a later unfused step clears its ping-pong counter itself)
+    } else {
+        if (!e->next_counter_clean) HIP_TRY(hipMemsetAsync(counter, 0, 4, s));   // (k_consume of the previous step zeroes it)
+        e->next_counter_clean = false;
+    }
     {
         ProfScope prof_(e, 0, s);
-#define STEP_LAUNCH(EM, VV) hipLaunchKernelGGL((k_step<EM, VV>), dim3((unsigned)((e->n + StepBlock<EM>::N - 1) / StepBlock<EM>::N)), dim3(StepBlock<EM>::N), 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, \
-                                               image, dirs, rewards, rewards64, dones, auto_reset, list, counter, e->tiles, e->step_prio, e->vplane, e->fcache, e->lsm)
-        if (e->tiles) { if (e->vplane) STEP_LAUNCH(true, true); else STEP_LAUNCH(true, false); }
-        else { if (e->vplane) STEP_LAUNCH(false, true); else STEP_LAUNCH(false, false); }
+#define STEP_LAUNCH(EM, VV, FF) hipLaunchKernelGGL((k_step<EM, VV, FF>), dim3((unsigned)((e->n + StepBlock<EM>::N - 1) / StepBlock<EM>::N)), dim3(StepBlock<EM>::N), 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, \
+                                               image, dirs, rewards, rewards64, dones, auto_reset, list, counter, e->tiles, e->step_prio, e->vplane, e->fcache, e->lsm, fa)
+        if (e->tiles) { if (e->vplane) STEP_LAUNCH(true, true, false); else STEP_LAUNCH(true, false, false); }
+        else if (fused) { if (e->vplane) STEP_LAUNCH(false, true, true); else STEP_LAUNCH(false, false, true); }
+        else { if (e->vplane) STEP_LAUNCH(false, true, false); else STEP_LAUNCH(false, false, false); }
 #undef STEP_LAUNCH
         e->tiles_valid = e->tiles != nullptr;
     }
     HIP_TRY(hipGetLastError());
     // the number of finished envs is only known on the device: fixed grids, device-side count
-    if (auto_reset) { int rc = consume_and_refill(e, s, image, dirs, 0); if (rc != BBAI_OK) return rc; }
+    if (auto_reset) { int rc = fused ? window_end(e, s, 0, true) : consume_and_refill(e, s, image, dirs, 0); if (rc != BBAI_OK) return rc; }
     return BBAI_OK;
 }
 
@@ -1454,9 +1560,10 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
     }
     ON_DEVICE(e->device);
     hipStream_t s = (hipStream_t)stream;
-    { int rc = enter_call(e, s); if (rc != BBAI_OK) return rc; }
+    CallScope call(e, s);
+    if (call.rc != BBAI_OK) return call.rc;
     { int rc = step_launch(e, actions, image, dirs, rewards, rewards64, dones, auto_reset, s); if (rc != BBAI_OK) return rc; }
-    return leave_call(e, s);
+    return call.leave();
 }
 
 int bbai_set_atlas(bbai_env* e, const uint8_t* tiles, int n_tiles, const uint8_t* lut) {
@@ -1496,7 +1603,8 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
     // threads, 8 envs per barrier pair, 64 envs per block): 1 048 576 envs 1.80-1.85 vs 1.99-2.15 ms per step on the slow
     // boxes, 131 072 envs 0.224 vs 0.267-0.282.  Every block pays the 11 KB atlas load into LDS (L2 hits).
     // BBAI_RENDER_GROUP / BBAI_RENDER_TPB override (experiments).
-    { int rc = enter_call(e, (hipStream_t)stream); if (rc != BBAI_OK) return rc; }
+    CallScope call(e, (hipStream_t)stream);
+    if (call.rc != BBAI_OK) return call.rc;
     {
     ProfScope prof_(e, 2, (hipStream_t)stream);
     // (round 3, from the tile plane: (512, 4) from 786 432 envs up -- 1.59 ms at 1 048 576 envs against 1.62-1.66 for
@@ -1527,11 +1635,16 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
         case 9: RENDER_Q(2, 256, 8, 1); break;
         case 10: RENDER_Q(16, 1024, 8, 1); break;
         case 11: RENDER_Q(4, 512, 8, 2); break;
+        case 12: RENDER_Q(8, 1024, 2, 1); break;
+        case 13: RENDER_Q(16, 1024, 1, 1); break;
+        case 14: RENDER_Q(12, 1024, 1, 1); break;
+        case 15: RENDER_Q(8, 512, 1, 1); break;
+        case 16: RENDER_Q(4, 512, 1, 2); break;
         default: RENDER_Q(8, 1024, 8, 1); break;
         }
 #undef RENDER_Q
         HIP_TRY(hipGetLastError());
-        return leave_call(e, (hipStream_t)stream);
+        return call.leave();
     }
     int G = e->render_group, T = e->render_tpb;
     if (G != 2 && G != 4 && G != 8) G = big ? (FROM_PLANE ? 4 : 8) : 2;
@@ -1544,7 +1657,7 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
 #undef RENDER_LAUNCH
     }
     HIP_TRY(hipGetLastError());
-    return leave_call(e, (hipStream_t)stream);
+    return call.leave();
 }
 
 extern "C" {
@@ -1677,10 +1790,39 @@ int bbai_checkpoint_load(bbai_env* e, const void* host_buf, int64_t bytes) {
     CkptHeader h;
     memcpy(&h, host_buf, sizeof(h));
     if (h.magic != 0x42424149434b5054ull || h.version != 1) ARG_FAIL("not a bbai checkpoint");
-    if (h.n != e->n || memcmp(&h.cfg, &e->cfg, sizeof(LevelCfg)) != 0 || h.depth != e->depth || h.period != e->period)
-        ARG_FAIL("checkpoint was taken from a different level / batch size / look-ahead depth (BBAI_LOOKAHEAD)");
+    if (h.n != e->n || memcmp(&h.cfg, &e->cfg, sizeof(LevelCfg)) != 0 || h.period < 1 || h.period > MAX_PERIOD || h.depth != 2 * h.period)
+        ARG_FAIL("checkpoint was taken from a different level / batch size");
     ON_DEVICE(e->device);
     HIP_TRY(hipDeviceSynchronize());
+    if (h.period != e->period) {
+        // The handle chose its look-ahead period from the memory that was free when it was created (bbai_create); the blob's
+        // ring has the saving handle's.  The ring is part of the state: take the blob's shape.
+        const size_t D = (size_t)h.depth, slot_bytes = (size_t)e->n * e->cfg.rec_bytes;
+        (void)hipFree(e->next_rec); (void)hipFree(e->next_hot); (void)hipFree(e->win_list);
+        e->next_rec = nullptr; e->next_hot = nullptr; e->win_list = nullptr;
+        hipError_t r1 = hipMalloc((void**)&e->next_rec, D * slot_bytes);
+        hipError_t r2 = r1 == hipSuccess ? hipMalloc((void**)&e->next_hot, D * (size_t)e->n * sizeof(Hot)) : r1;
+        hipError_t r3 = r2 == hipSuccess ? hipMalloc((void**)&e->win_list, 3 * (size_t)h.period * (size_t)e->n * 4) : r2;
+        if (r3 != hipSuccess) {
+            // leave a consistent (unseeded) handle behind: the old shape again
+            (void)hipGetLastError();
+            if (e->next_rec) (void)hipFree(e->next_rec);
+            if (e->next_hot) (void)hipFree(e->next_hot);
+            e->next_rec = nullptr; e->next_hot = nullptr;
+            const size_t D0 = (size_t)e->depth;
+            if (hipMalloc((void**)&e->next_rec, D0 * slot_bytes) != hipSuccess || hipMalloc((void**)&e->next_hot, D0 * (size_t)e->n * sizeof(Hot)) != hipSuccess ||
+                hipMalloc((void**)&e->win_list, 3 * (size_t)e->period * (size_t)e->n * 4) != hipSuccess) {
+                snprintf(g_err, sizeof(g_err), "checkpoint_load: out of memory re-shaping the look-ahead ring; the handle is unusable");
+                e->seeded = e->live = false;
+                return BBAI_ERR_NOMEM;
+            }
+            e->seeded = e->live = false;
+            snprintf(g_err, sizeof(g_err), "checkpoint_load: no memory for the checkpoint's look-ahead ring (period %d); seed the handle again", h.period);
+            return BBAI_ERR_NOMEM;
+        }
+        e->period = h.period;
+        e->depth = h.depth;
+    }
     if (h.bot_stack && (!e->bot_state || e->bot_stack != h.bot_stack)) {
         if (e->bot_state) ARG_FAIL("the handle's expert uses a different stack capacity (BBAI_BOT_STACK)");
         int rc = bot_alloc(e, h.bot_stack);
@@ -1774,9 +1916,10 @@ int bbai_bot_act(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions, voi
     if (!e->live) { snprintf(g_err, sizeof(g_err), "bot_act before reset"); return BBAI_ERR_STATE; }
     ON_DEVICE(e->device);
     hipStream_t s = (hipStream_t)stream;
-    { int rc = enter_call(e, s); if (rc != BBAI_OK) return rc; }
+    CallScope call(e, s);
+    if (call.rc != BBAI_OK) return call.rc;
     { int rc = bot_launch(e, prev_actions, actions, BOT_DEAD, nullptr, s); if (rc != BBAI_OK) return rc; }
-    return leave_call(e, s);
+    return call.leave();
 }
 
 // T expert decisions + steps with no host round trip in between (the inner loop of generate_demos).
@@ -1788,7 +1931,8 @@ int bbai_bot_rollout(bbai_env* e, int T, uint8_t* image, uint8_t* dirs, uint8_t*
     if (tokens_out && !e->tokens) { snprintf(g_err, sizeof(g_err), "bot_rollout: tokens_out needs a registered token buffer (bbai_set_token_buffer)"); return BBAI_ERR_STATE; }
     ON_DEVICE(e->device);
     hipStream_t s = (hipStream_t)stream;
-    { int rc = enter_call(e, s); if (rc != BBAI_OK) return rc; }
+    CallScope call(e, s);
+    if (call.rc != BBAI_OK) return call.rc;
     const size_t n = (size_t)e->n;
     for (int t = 0; t < T; ++t) {
         // what the expert decides on: the observation (and mission) BEFORE the step
@@ -1800,7 +1944,7 @@ int bbai_bot_rollout(bbai_env* e, int T, uint8_t* image, uint8_t* dirs, uint8_t*
         rc = step_launch(e, actions_out + (size_t)t * n, image, dirs, rewards_out + (size_t)t * n, nullptr, dones_out + (size_t)t * n, 1, s);
         if (rc != BBAI_OK) return rc;
     }
-    return leave_call(e, s);
+    return call.leave();
 }
 
 #if defined(BBAI_BOT_PROF)
@@ -1900,6 +2044,7 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     else if (!strcmp(name, "step_prio")) e->step_prio = v;
     else if (!strcmp(name, "pregen_group")) e->pregen_group = v;
     else if (!strcmp(name, "pregen_blocks")) e->pregen_cap = std::max(64, v);
+    else if (!strcmp(name, "consume_fused")) e->consume_fused = v;
     else if (!strcmp(name, "render_fused")) {
         // keep (1) or drop (0) the fused tile plane of bbai_render_current; needs an installed atlas
         if (v && !e->tiles) {

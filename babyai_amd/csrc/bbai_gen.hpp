@@ -12,7 +12,7 @@
 //   RoomGrid / MiniGridEnv placement helpers      gym_minigrid (absent dependency), restated
 //                                                 per SURVEY.md Appendix B3-B7
 //
-// Execution model: ONE LANE GROUP = ONE ENV, Ctx::kLanes lanes wide (device: 16 -> four envs per wavefront, k_pregen in
+// Execution model: ONE LANE GROUP = ONE ENV, Ctx::kLanes lanes wide (device: 32 -> two envs per wavefront by default, 16 / 64 selectable, k_pregen in
 // bbai_engine.hip; host: 1).  Inside a group control flow is uniform (every lane runs the same scalar program on the
 // same RNG draws); the working set (MT state, both grid planes, room / object tables) sits in LDS, one GenWork per
 // group; the group's lanes split the data-parallel parts (MT twist, grid fill, reachability rows, record write-out).

@@ -19,6 +19,8 @@ def generate_demos(env_name, n_episodes, seed, device="cuda:0", batch=32768, fil
                    rollout=None):
     """`batch` streams run side by side on the device; a batch lasts as long as its slowest stream (the expert's decision
     kernel has a latency of about a millisecond whatever the batch size), so large batches are what makes this fast.
+    Memory: with the device rollout a batch keeps ~225 bytes per stream and step on the device until its last stream is
+    solved (0.95 GB per 128 steps at 32 768 streams, bounded by half of the free device memory: RuntimeError beyond).
 
     rollout: True = the per-step loop runs on the device (`bbai_bot_rollout`, history kept there, spans gathered there);
     False = one host round trip per step (rounds 1-2).  Same demonstrations either way.  None picks by what was measured
@@ -126,7 +128,18 @@ def _generate_batch(env_name, seed, n, device, filter_steps, pack, max_steps, de
     span = np.full((n, 2), -1, dtype=np.int64)     # [first, last] step of the stream's first solved episode
     open_ = np.ones(n, dtype=bool)                 # streams still looking for it
     g0 = 0
+    # The history stays on the device until every stream has its episode: 225 bytes per env-step (image 147, tokens 72, 6 flags),
+    # ~0.95 GB per 128-step chunk of 32 768 streams.  A stream the expert never solves would otherwise grow it up to the step
+    # budget (64 x max_steps) and end in a device out-of-memory error instead of the RuntimeError below: bound it by half of
+    # the memory that is free now.
+    free_b, _ = torch.cuda.mem_get_info(env.device)
+    chunk_bytes = chunk * n * (147 + 72 + 6 + 4)
+    max_chunks = max(2, int(free_b // 2 // max(1, chunk_bytes)))
     while open_.any() and g0 < budget:
+        if len(hist) >= max_chunks:
+            env.close()
+            raise RuntimeError("no solvable episode found for %d stream(s) within the history memory budget (%d chunks of %d steps x %d "
+                               "streams = %.1f GB on the device): use a smaller `batch`" % (int(open_.sum()), len(hist), chunk, n, len(hist) * chunk_bytes / 1e9))
         r = env.bot_rollout(chunk, tokens=True)
         hist.append(r)
         scan_chunk(r["done"].cpu().numpy(), r["gave_up"].cpu().numpy(), r["reward"].cpu().numpy(), g0, filter_steps, last_done, open_, span)

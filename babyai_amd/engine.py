@@ -291,6 +291,12 @@ class BatchedBabyAIEnv(object):
             lo, hi = (int(v) for v in torch.stack([actions.min(), actions.max()]).tolist())
             if hi > self.RESET_ENV or lo < 0:
                 raise AssertionError("unknown action")
+        if actions.dtype != torch.uint8:
+            # a wider integer must not WRAP into a valid action on its way to a byte (263 -> 7 = RESET_ENV, 256 -> 0 = left):
+            # everything outside 0..255 becomes 255, which include/bbai.h defines -- like every unknown action -- as `done`
+            if actions.dtype.is_floating_point or actions.dtype == torch.bool:
+                raise TypeError("actions must be an integer tensor, got %s" % actions.dtype)
+            actions = torch.where((actions < 0) | (actions > 255), torch.full_like(actions, 255), actions)
         if actions.dtype != torch.uint8 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
         if actions.numel() != self.num_envs:

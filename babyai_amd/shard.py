@@ -169,12 +169,18 @@ def gather_to_rank0(tensor, dist, via_all_gather=False):
     return None
 
 
-def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None, after_block=None, before_block=None, local_out=None):
+def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None, after_block=None, before_block=None, local_out=None,
+                 barrier_out=None):
     """The measured loop.  `actions`: uint8[warmup + blocks*steps, E] resident on the env's device.  `warmup` untimed
-    steps, then `blocks` timed blocks of EXACTLY `steps` steps, each bracketed by ranks.barrier() on both sides and
-    reduced with max over ranks.  `after_step(t)` (t = index into `actions`) runs inside the timed region (parity tap,
-    digests), `before_block(i)` / `after_block(i)` between blocks (untimed).  Returns the list of per-block seconds (max over ranks);
-    `local_out` (a list) receives this rank's own per-block seconds."""
+    steps, then `blocks` timed blocks of EXACTLY `steps` steps.  Every block is bracketed by ranks.barrier() (device idle,
+    barrier, device idle) on both sides; a rank's clock runs from the end of the opening barrier until ITS OWN device is
+    idle again, and the block's time is the MAX of those over the ranks.  The closing barrier and the max-reduce happen
+    after every clock has stopped: with several ranks they cost O(100 us) of collective + host synchronisation, which is
+    not part of any rank's steps (a block of 20 steps of a 131 072-env shard lasts 4.5 ms).  What the closing barrier
+    costs -- waiting for the slowest rank included -- goes to `barrier_out` (max over ranks, seconds per block).
+    `after_step(t)` (t = index into `actions`) runs inside the timed region (parity tap, digests), `before_block(i)` /
+    `after_block(i)` between blocks (untimed).  Returns the list of per-block seconds (max over ranks); `local_out`
+    (a list) receives this rank's own per-block seconds."""
     import time
     t = 0
     for _ in range(warmup):
@@ -194,10 +200,14 @@ def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None, af
                 after_step(t)
             t += 1
         ranks._sync()
-        if local_out is not None:
-            local_out.append(time.perf_counter() - t0)       # this rank's own device went idle (before the barrier)
+        mine = time.perf_counter() - t0                      # this rank's own device went idle: its clock stops here
         ranks.barrier()
-        out.append(ranks.max(time.perf_counter() - t0))
+        closing = time.perf_counter() - t0 - mine
+        if local_out is not None:
+            local_out.append(mine)
+        out.append(ranks.max(mine))
+        if barrier_out is not None:
+            barrier_out.append(ranks.max(closing))
         if after_block:
             after_block(len(out) - 1)
     return out

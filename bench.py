@@ -19,8 +19,9 @@ N GPUs (`scaling: "strong"`; 131 072 envs per GPU at N = 8).  `--weak` keeps 1 0
 (`scaling: "weak"`); `--envs` sets the per-GPU count by hand.
 
 What one run proves about itself (all in the one JSON line rank 0 prints):
-  * timing      W warmup steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize and max-reduced
-                over ranks, repeated until >= --min-seconds of timed work.  Blocks alternate between PLAIN (nothing but
+  * timing      W warmup steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both sides; a rank's
+                clock stops when its own device is idle, the block is the max over ranks (the closing barrier itself is
+                reported as timing.barrier_ms, not timed); repeated until >= --min-seconds of timed work.  Blocks alternate between PLAIN (nothing but
                 the steps and the parity tap) and PROFILED (every kernel launch bracketed by a HIP event pair on its
                 launch stream).  `value` / `ms_per_step` = median plain block; `roofline` = the profiled blocks, whose own
                 median step time is reported next to it (`timing.profiled_block_ms`), so that the kernel times add up to
@@ -35,6 +36,12 @@ What one run proves about itself (all in the one JSON line rank 0 prints):
                 spread: shard.scattered_ids) at EVERY step (image, direction, f64 reward bits, done; pixels of 64) are
                 tapped inside the timed region and re-derived afterwards by the CPU oracle from the seeds and the action
                 stream: `parity.mismatches_all_ranks` must be 0 (exit code 3 otherwise; 4 when the checker itself broke).
+  * configs     after the headline's timed region, the default single-GPU run puts every other BASELINE.json config through
+                the SAME loop on the same GPU -- C2 GoToLocal 65 536, C3 PickupLoc 262 144, C4 GoTo 1 048 576 (and its 131 072-env
+                8-GPU shard), encoded BossLevel 1 048 576: >= --extra-seconds of timed work each, alternating plain / profiled
+                blocks, 256 scattered envs tapped at every step and re-derived by the oracle.  `configs` in the line;
+                a mismatch there exits 3 like one in the headline.  --no-extra-configs skips them.
+  * setup_ms    what is outside the metric: bbai_create, bbai_seed (incl. the first fill of the look-ahead rings), first reset.
   * cpu_baseline  the oracle on the usable host cores over the same seeds and action stream (rank 0; a reported
                 baseline), with the measured reference/port ratio of the build container when it is on file.
 
@@ -135,6 +142,11 @@ def parse_args(argv=None):
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (test rigs: ranks may share a GPU)")
     ap.add_argument("--share-device", action="store_true", help="test rigs only: every rank uses cuda:0")
     ap.add_argument("--own-stream", action="store_true", help="run the rollout on a stream of its own instead of torch's default (NULL) stream")
+    ap.add_argument("--no-extra-configs", action="store_true", help="only the headline workload (default: the default single-GPU run also measures BASELINE configs C2-C4 and encoded BossLevel)")
+    ap.add_argument("--extra-configs", action="store_true", help="measure the other configs with --gpus N > 1 too (sharded over the N ranks)")
+    ap.add_argument("--extra-seconds", type=float, default=0.3, help="timed work per extra config")
+    ap.add_argument("--extra-parity-envs", type=int, default=256)
+    ap.add_argument("--extra-parity-budget", type=int, default=300000, help="oracle env-steps per extra config")
     ap.add_argument("--dump-digest", default=None, help="write per-env output digests of this rank to <prefix>.rank<r>.npy")
     args = ap.parse_args(argv)
     if args.gpus < 1:
@@ -178,81 +190,40 @@ def self_launch(args):
     return subprocess.call(cmd, env=env, cwd=os.getcwd())
 
 
-def main():
-    args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(args))
-    env_world = int(os.environ.get("WORLD_SIZE", "1"))
-    if env_world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; start with --nproc-per-node == --gpus "
-                         "(or run plain `python bench.py --gpus N`, which launches the ranks itself)" % (args.gpus, env_world))
-    level, pixel, E, total_envs, scaling = resolve_workload(args)
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
 
-    # the CPU legs' worker pool is forked BEFORE the GPU runtime and the process group exist (oracle/cpu_baseline.py
-    # make_pool): it idles through the timed region and is only fed afterwards.  Rank 0 also runs the CPU baseline and
-    # gets the larger share of the node's cores; the other ranks keep two workers each for their parity replay.
-    pool = None
-    pool_size = 0
-    if args.parity_envs or not args.no_cpu_baseline:
-        from oracle import cpu_baseline            # outside the timed region: checker / reported baseline only
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-        cores = cpu_baseline.usable_cores()
-        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
-            pool_size = max(2, cores - 2 * (local_world - 1))
-        else:
-            pool_size = 2
-        pool = cpu_baseline.make_pool(pool_size)
 
-    import numpy as np
-    import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (no CPU path)")
-    if not args.share_device and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", env_world)):
-        raise SystemExit("bench.py: %d ranks on this node but only %d GPUs visible (one rank per GPU; test rigs: --share-device "
-                         "--dist-backend gloo)" % (env_world, torch.cuda.device_count()))
-    from babyai_amd import shard
+class Ctx(object):
+    """What every measurement of a run shares: torch, the process group, the device, the CPU worker pool."""
+    pass
+
+
+def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, PP, parity_budget, after_seed=None, digest=None):
+    """One workload through the measured loop (babyai_amd/shard.py timed_blocks): create + seed + reset the shard (timed:
+    `setup_ms`), W warmup steps and ONE K-step probe block, then as many further K-step blocks as make `min_seconds`,
+    alternately plain and profiled, with the outputs of P scattered envs (pixels of PP) tapped at every step.  Returns a
+    dict with the block times, the per-kernel HIP-event times, the device logs for the oracle replay and the counters; the
+    env is closed."""
+    import time
+    torch, shard, ranks, dev, args = ctx.torch, ctx.shard, ctx.ranks, ctx.dev, ctx.args
     from babyai_amd.action_stream import actions_torch
-    ranks = shard.Ranks.from_env(args.dist_backend, args.share_device)
-    rank, world, dev = ranks.rank, ranks.world, ranks.device
-    if world != args.gpus:
-        raise SystemExit("bench.py: the live process group has %d ranks, --gpus asked for %d" % (world, args.gpus))
-    group = ranks.describe()
-    if group["allreduce_of_ones"] != world or (not args.share_device and group["distinct_devices"] != world):
-        raise SystemExit("bench.py: process group check failed: %r" % (group,))
-
-    import __graft_entry__
-    if rank == 0:
-        __graft_entry__.build()
-    ranks.barrier()
     from babyai_amd.engine import BatchedBabyAIEnv
-
-    first, count = shard.shard_range(total_envs, world, rank)
+    first, count = shard.shard_range(total_envs, ranks.world, ranks.rank)
     assert count == E
-    if args.own_stream:
-        torch.cuda.set_stream(torch.cuda.Stream(dev))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     env = BatchedBabyAIEnv("BabyAI-%s-v0" % level, E, device=dev, pixel=pixel)
-    env.seed(shard.shard_seeds(args.seed, total_envs, world, rank))
-    K, W = args.steps, args.warmup
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    env.seed(shard.shard_seeds(args.seed, total_envs, ranks.world, ranks.rank))       # synchronous (include/bbai.h bbai_seed)
+    t2 = time.perf_counter()
+    if after_seed:
+        after_seed()
 
-    achievable = achievable_bandwidth(torch, dev) if rank == 0 else None
-
-    # clock ramp: a cold GPU spends its first second or so below its sustained clocks; keep it busy with an
-    # untimed fill stream before the (short) warmup so the timed region sees steady-state clocks
-    if args.prewarm_seconds > 0:
-        import time
-        scratch = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
-        t_end = time.perf_counter() + args.prewarm_seconds
-        while time.perf_counter() < t_end:
-            for _ in range(20):
-                scratch.fill_(1)
-            torch.cuda.synchronize()
-        del scratch
-
-    P = min(args.parity_envs, E)
-    if world > 1 and P:
-        P = max(min(128, E), P // world)      # every rank's host cores are shared by all ranks of the node
-    PP = min(args.parity_pixel_envs, P) if pixel else 0
-    digest = shard.EnvDigest(E, dev, 147) if args.dump_digest else None
+    P = min(P, E)
+    PP = min(PP, P) if pixel else 0
 
     # the tapped envs: scattered over the shard; the ones whose pixels are checked too come first in the log rows and
     # are themselves a spread (both ends included)
@@ -282,12 +253,19 @@ def main():
         env.tap(lg["image"][obs_row], lg["direction"][obs_row], lg["reward64"][row], lg["done"][row],
                 lg["pixels"][obs_row] if "pixels" in lg else None, ids=lg["ids"])
 
-    # phase 1: reset, W warmup steps and ONE K-step block; its time decides how many further blocks make --min-seconds
+    # phase 1: reset, W warmup steps and ONE K-step block; its time decides how many further blocks make min_seconds
     S1 = W + K
     actions1 = actions_torch(args.action_seed, 0, S1, first, E, dev)        # resident before the timed region
     ids1, PP1 = tap_ids(P, PP)
     log1 = make_log(S1, True, ids1, PP1)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
     env.reset()
+    torch.cuda.synchronize()
+    t4 = time.perf_counter()
+    setup_ms = {"create": (t1 - t0) * 1e3, "seed": (t2 - t1) * 1e3, "first_reset": (t4 - t3) * 1e3,
+                "note": "bbai_create (allocation + clearing), bbai_seed (sha512 + MT19937 init + the first D levels of every env's "
+                        "look-ahead ring) and the first reset() with its observation (+ render); outside the metric"}
     if log1 is not None:
         log1["image"][0].copy_(env.image[log1["ids"]])
         log1["direction"][0].copy_(env.direction[log1["ids"]])
@@ -302,7 +280,7 @@ def main():
 
     torch.cuda.synchronize()
     blocks = shard.timed_blocks(env, actions1, W, K, 1, ranks, after1)
-    want = int(min(args.max_blocks, max(0, -(-args.min_seconds // blocks[0]))))
+    want = int(min(max_blocks, max(0, -(-min_seconds // blocks[0]))))
     want = int(ranks.max(want))
     if want == 1:
         want = 2                                      # one plain and one profiled block at least
@@ -310,8 +288,8 @@ def main():
     # phase-1 block was only the probe
     S2 = want * K
     ids2, PP2, sel2 = ids1, PP1, None
-    if P and (S1 + S2) * P > args.parity_budget:      # long run: every step of FEWER envs in phase 2 -- a spread of phase 1's
-        P2 = max(min(16, P), args.parity_budget // (S1 + S2))
+    if P and (S1 + S2) * P > parity_budget:      # long run: every step of FEWER envs in phase 2 -- a spread of phase 1's
+        P2 = max(min(16, P), parity_budget // (S1 + S2))
         PP2 = min(PP1, P2)
         pix_rows = sorted(set((PP1 - 1) * k // max(1, PP2 - 1) for k in range(PP2))) if PP2 else []
         n_rest = len(ids1) - PP1
@@ -322,8 +300,7 @@ def main():
     resets0 = env.reset_count()
     env.profile(True)              # per-kernel HIP event pairs on the launch stream (include/bbai.h bbai_profile) ...
     env.profile_pause()            # ... in the odd blocks only
-    local_blocks = []
-    profiled = []
+    local_blocks, barrier_s, profiled = [], [], []
     if want:
         actions2 = actions_torch(args.action_seed, S1, S1 + S2, first, E, dev)
         log2 = make_log(S2, False, ids2, PP2)
@@ -341,55 +318,175 @@ def main():
                 env.profile_pause()
 
         torch.cuda.synchronize()
-        all_blocks = shard.timed_blocks(env, actions2, 0, K, want, ranks, after2, before_block=before_block, local_out=local_blocks)
+        all_blocks = shard.timed_blocks(env, actions2, 0, K, want, ranks, after2, before_block=before_block, local_out=local_blocks,
+                                        barrier_out=barrier_s)
         env.profile_pause()
         blocks = all_blocks[0::2]
         profiled = all_blocks[1::2]
         local_blocks = local_blocks[0::2]
+        del actions2
     resets = ranks.sum(env.reset_count() - resets0)
-    S = S1 + S2
-
     if not want:                    # single-block run: nothing was bracketed; time a few untimed steps
         env.profile(True)
         for t in range(4):
             env.step(actions1[t])
         torch.cuda.synchronize()
-    kernel_ms = {k: v[0] for k, v in env.profile_read().items() if v[0] is not None}
-    kernel_launches = {k: v[1] for k, v in env.profile_read().items() if v[0] is not None}
+    prof = env.profile_read()
     env.profile(False)
+    m = {"level": level, "pixel": pixel, "E": E, "total_envs": total_envs, "first": first, "K": K, "W": W, "S1": S1, "S2": S2, "want": want,
+         "blocks": blocks, "profiled": profiled, "local_blocks": local_blocks, "barrier_s": barrier_s,
+         "kernel_ms": {k: v[0] for k, v in prof.items() if v[0] is not None},
+         "kernel_launches": {k: v[1] for k, v in prof.items() if v[0] is not None},
+         "resets": resets, "setup_ms": setup_ms, "render_fused": getattr(env, "render_fused", False),
+         "log1": log1, "log2": log2, "ids2": ids2, "PP1": PP1, "PP2": PP2, "sel2": sel2, "env": env}
+    return m
 
-    def median(xs):
-        xs = sorted(xs)
-        return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
+
+def replay(ctx, m):
+    """Outside the timed region: the oracle re-derives what the tap recorded (oracle/cpu_baseline.py parity_replay)."""
+    torch, np = ctx.torch, ctx.np
+    log1, log2, sel2, PP1, PP2, ids2 = m["log1"], m["log2"], m["sel2"], m["PP1"], m["PP2"], m["ids2"]
+    if log1 is None:
+        return None
+    try:
+        host = {}
+        for k in log1:
+            if k == "ids" or (k == "pixels" and not PP2):
+                continue
+            a = log1[k]
+            if sel2 is not None:                    # phase 2 followed a subset: the checked envs are that subset, all steps
+                rows = [r for r in sel2 if r < PP1] if k == "pixels" else sel2
+                a = a[:, torch.as_tensor(rows, dtype=torch.int64, device=ctx.dev)]
+            host[k] = np.concatenate([a.cpu().numpy()] + ([log2[k].cpu().numpy()] if log2 is not None else []))
+        par = ctx.cpu_baseline.parity_replay(m["level"], host, ctx.args.seed, ctx.args.action_seed, m["first"], PP2,
+                                             env_ids=[m["first"] + i for i in ids2], pool=ctx.pool)
+    except Exception as exc:
+        par = {"error": repr(exc), "mismatches": None}          # the CHECKER broke: reported, not a parity verdict
+    return par
+
+
+def roofline_of(m):
+    """(dominant kernel, algorithmic bytes per launch, bytes per env-step, its avg ms, GB/s, ceiling key)"""
+    E = m["E"]
+    if m["pixel"]:
+        dom, alg_bytes, bps, key = "k_render", E * (147 + 9408), 9496, "fill_GBs"        # reads the encoding, writes the pixels: a pure store stream
+    else:
+        dom, alg_bytes, bps, key = "k_step", E * 235, 235, "copy_GBs"                    # reads and writes mixed
+    dom_ms = m["kernel_ms"][dom]
+    return dom, alg_bytes, bps, dom_ms, alg_bytes / (dom_ms * 1e-3) / 1e9, key
+
+
+# what the one JSON line carries next to the headline: every other BASELINE.json config on this GPU (world == 1), measured by
+# the same loop.  steps = steps per block (a block must last milliseconds for a host clock); C4 is quoted on 8 GPUs --
+# its total fits one, so the single-GPU line runs the total, and the per-GPU shard of the 8-GPU job next to it.
+EXTRA_CONFIGS = [
+    ("C2", dict(level="GoToLocal", total=65536, pixel=False, steps=256, ref="BASELINE.json configs[1]; babyai/levels/iclr19_levels.py:105-124")),
+    ("C3", dict(level="PickupLoc", total=262144, pixel=False, steps=128, ref="BASELINE.json configs[2]; iclr19_levels.py:494-515")),
+    ("C4", dict(level="GoTo", total=1048576, pixel=False, steps=32, ref="BASELINE.json configs[3] (1 048 576 envs, here on ONE GPU); iclr19_levels.py:224-257")),
+    ("C4-shard", dict(level="GoTo", total=131072, pixel=False, steps=128, ref="one GPU's share of configs[3] on 8 GPUs")),
+    ("C5-encoded", dict(level="BossLevel", total=1048576, pixel=False, steps=32, ref="the headline's level with 7x7x3 encoded observations (k_step's own roofline)")),
+]
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; start with --nproc-per-node == --gpus "
+                         "(or run plain `python bench.py --gpus N`, which launches the ranks itself)" % (args.gpus, env_world))
+    level, pixel, E, total_envs, scaling = resolve_workload(args)
+
+    # the CPU legs' worker pool is forked BEFORE the GPU runtime and the process group exist (oracle/cpu_baseline.py
+    # make_pool): it idles through the timed region and is only fed afterwards.  Rank 0 also runs the CPU baseline and
+    # gets the larger share of the node's cores; the other ranks keep two workers each for their parity replay.
+    pool = None
+    pool_size = 0
+    cpu_baseline = None
+    if args.parity_envs or not args.no_cpu_baseline:
+        from oracle import cpu_baseline            # outside the timed region: checker / reported baseline only
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        cores = cpu_baseline.usable_cores()
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            pool_size = max(2, cores - 2 * (local_world - 1))
+        else:
+            pool_size = 2
+        pool = cpu_baseline.make_pool(pool_size)
+
+    import time
+    t_start = time.perf_counter()
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (no CPU path)")
+    if not args.share_device and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", env_world)):
+        raise SystemExit("bench.py: %d ranks on this node but only %d GPUs visible (one rank per GPU; test rigs: --share-device "
+                         "--dist-backend gloo)" % (env_world, torch.cuda.device_count()))
+    from babyai_amd import shard
+    ranks = shard.Ranks.from_env(args.dist_backend, args.share_device)
+    rank, world, dev = ranks.rank, ranks.world, ranks.device
+    if world != args.gpus:
+        raise SystemExit("bench.py: the live process group has %d ranks, --gpus asked for %d" % (world, args.gpus))
+    group = ranks.describe()
+    if group["allreduce_of_ones"] != world or (not args.share_device and group["distinct_devices"] != world):
+        raise SystemExit("bench.py: process group check failed: %r" % (group,))
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    ranks.barrier()
+
+    if args.own_stream:
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
+    ctx = Ctx()
+    ctx.torch, ctx.np, ctx.shard, ctx.ranks, ctx.dev, ctx.args, ctx.pool, ctx.cpu_baseline = torch, np, shard, ranks, dev, args, pool, cpu_baseline
+    K, W = args.steps, args.warmup
+    state = {"achievable": None}
+
+    def after_seed():
+        state["achievable"] = achievable_bandwidth(torch, dev) if rank == 0 else None
+        # clock ramp: a cold GPU spends its first second or so below its sustained clocks; keep it busy with an
+        # untimed fill stream before the (short) warmup so the timed region sees steady-state clocks
+        if args.prewarm_seconds > 0:
+            scratch = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+            t_end = time.perf_counter() + args.prewarm_seconds
+            while time.perf_counter() < t_end:
+                for _ in range(20):
+                    scratch.fill_(1)
+                torch.cuda.synchronize()
+            del scratch
+
+    P = min(args.parity_envs, E)
+    if world > 1 and P:
+        P = max(min(128, E), P // world)      # every rank's host cores are shared by all ranks of the node
+    digest = shard.EnvDigest(E, dev, 147) if args.dump_digest else None
+    m = measure(ctx, level, pixel, E, total_envs, K, W, args.min_seconds, args.max_blocks, P, args.parity_pixel_envs, args.parity_budget,
+                after_seed=after_seed, digest=digest)
+    env = m["env"]
+    achievable = state["achievable"]
+    blocks, profiled, local_blocks = m["blocks"], m["profiled"], m["local_blocks"]
+    kernel_ms, kernel_launches = m["kernel_ms"], m["kernel_launches"]
+    S, want = m["S1"] + m["S2"], m["want"]
 
     bs = sorted(blocks)
     med = median(blocks)
     value = K * E * world / med
     per_rank_ms = ranks.gather_objects(median(local_blocks) / K * 1e3 if local_blocks else None)
-    if pixel:
-        dom, alg_bytes = "k_render", E * (147 + 9408)          # reads the encoding, writes the pixels
-        dom_ms = kernel_ms["k_render"]
-        bytes_per_step = 9496
-        ceiling_key = "fill_GBs"                                # a pure store stream
-    else:
-        dom, alg_bytes = "k_step", E * 235
-        dom_ms = kernel_ms["k_step"]
-        bytes_per_step = 235
-        ceiling_key = "copy_GBs"                                # reads and writes mixed
-    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    dom, alg_bytes, bytes_per_step, dom_ms, achieved, ceiling_key = roofline_of(m)
     # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate
-    # runs; tools/gpu_profile.sh -> tools/summarize_profile.py -> profiles/pmc_latest.json).  Counters cannot be
+    # runs; tools/lease.sh pmc -> tools/summarize_profile.py -> profiles/pmc_latest.json).  Counters cannot be
     # collected inside this process: the committed summary is quoted with its provenance, and only while the kernel
     # sources still hash to what was profiled on this exact workload.
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        key = next((k for k in pmc["kernels"] if k == dom or k.startswith(dom + "<")), None)      # k_render is a template
+        key = next((k for k in pmc["kernels"] if k == dom or k.startswith(dom + "<") or k.startswith(dom + "_q<")), None)      # k_render / k_render_q are templates
         if pmc.get("level") == level and pmc.get("envs") == E and key:
             kk = pmc["kernels"][key]
             fetch = kk.get("FETCH_SIZE_corrected", 2 * kk["FETCH_SIZE"])      # gfx950: FETCH_SIZE tallies 128-B requests as 64 B
             traffic = {"bytes": fetch + kk["WRITE_SIZE"], "fetch_corrected": fetch, "fetch_raw": kk["FETCH_SIZE"], "write": kk["WRITE_SIZE"],
-                       "correction": "FETCH_SIZE x 2 (MI355X_MICROARCH.md, calibrated on k_render's known byte counts)",
+                       "kernel": key, "correction": "FETCH_SIZE x 2 (MI355X_MICROARCH.md, calibrated on k_render's known byte counts)",
                        "source": "profiles/pmc_latest.json", "commit": pmc.get("commit"), "csrc_sha": pmc.get("csrc_sha"),
                        "current": pmc.get("csrc_sha") == csrc_sha()}
             if not traffic["current"]:
@@ -403,9 +500,9 @@ def main():
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": "BabyAI-%s-v0 %s obs, %d envs in total = %d per GPU x %d, random actions, auto-reset" % (
             level, "56x56x3 pixel (RGBImgPartialObsWrapper)" if pixel else "7x7x3 encoded", total_envs, E, world),
-            "envs_per_gpu": E, "total_envs": total_envs, "resets_in_timed_region": resets,
+            "envs_per_gpu": E, "total_envs": total_envs, "resets_in_timed_region": m["resets"],
             "parallelism": "env-shards x%d, no collective" % world,
-            "render_input": (("fused tile plane (BBAI_RENDER_FUSED=1)" if getattr(env, "render_fused", False) else "the step's 147-byte encoding") if pixel else None),
+            "render_input": (("fused tile plane (BBAI_RENDER_FUSED=1)" if m["render_fused"] else "the step's 147-byte encoding") if pixel else None),
             "actions": "counter-based (action_seed %d, step, global env index), uniform over 7" % args.action_seed},
         "rccl": dict(group, per_rank_ms_per_step=per_rank_ms,
                      per_rank_ms_per_step_min=min(per_rank_ms) if all(v is not None for v in per_rank_ms) else None,
@@ -414,12 +511,16 @@ def main():
         "timing": {"blocks": len(blocks), "steps_per_block": K, "block_ms": {"min": bs[0] * 1e3, "median": med * 1e3, "max": bs[-1] * 1e3},
                    "timed_seconds": sum(blocks) + sum(profiled), "value_from": "median plain block", "value_at_min": K * E * world / bs[0],
                    "value_at_max": K * E * world / bs[-1],
+                   "clock": "per block: opening barrier -> K steps -> this rank's device idle; the block = max over ranks; the closing barrier "
+                            "and the max-reduce run after every rank's clock has stopped (barrier_ms)",
+                   "barrier_ms": {"median": median(m["barrier_s"]) * 1e3, "max": max(m["barrier_s"]) * 1e3} if m["barrier_s"] else None,
                    "profiled_blocks": len(profiled),
                    "profiled_block_ms": {"min": min(profiled) * 1e3, "median": prof_med * 1e3, "max": max(profiled) * 1e3} if profiled else None,
                    "profiled_ms_per_step": prof_med / K * 1e3 if profiled else None,
                    "event_pairs_cost_us_per_step": (prof_med - med) / K * 1e6 if profiled else None,
                    "note": "plain and profiled blocks alternate; kernel_avg_ms are the profiled blocks' launches and add up to (at most) "
                            "profiled_ms_per_step"},
+        "setup_ms": m["setup_ms"],
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic["bytes"] if traffic else None, "traffic_provenance": traffic,
@@ -428,7 +529,7 @@ def main():
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
                      "whole_step_alg_GBs": value / world * bytes_per_step / 1e9,
                      "kernel_avg_ms": kernel_ms, "kernel_launches": kernel_launches, "measured_on": "rank 0"},
-        "parity": None, "cpu_baseline": None,
+        "parity": None, "cpu_baseline": None, "configs": None,
         "build": {"commit": git_head(), "csrc_sha": csrc_sha()},
     }
     # the OPTIONAL gather of the encoded observations to rank 0 (north_star: "only an optional xGMI gather of obs to
@@ -438,7 +539,6 @@ def main():
             src = env.image if args.dist_backend == "nccl" else env.image.cpu()
             shard.gather_to_rank0(src, ranks.dist, via_all_gather=True)
             ranks.barrier()
-            import time
             t0 = time.perf_counter()
             for _ in range(5):
                 shard.gather_to_rank0(src, ranks.dist, via_all_gather=True)
@@ -452,24 +552,34 @@ def main():
     torch.cuda.synchronize()
     if args.dump_digest:
         np.save("%s.rank%d.npy" % (args.dump_digest, rank), digest.numpy())
-    # ---- outside the timed region: the oracle re-derives what the tap recorded --------------------------------------
+    env.close()
+    m["env"] = None
+
+    # ---- the other BASELINE configs, same loop, same GPU (world == 1 unless --extra-configs) -----------------------------------
+    extras = []
+    run_extras = (not args.no_extra_configs) and (world == 1 or args.extra_configs) and args.config is None and \
+        args.envs is None and args.total_envs is None and not args.weak and args.level == "BossLevel" and not args.no_pixel
+    if run_extras:
+        for name, c in EXTRA_CONFIGS:
+            if c["total"] % world:
+                continue
+            try:
+                mc = measure(ctx, c["level"], c["pixel"], c["total"] // world, c["total"], c["steps"], 16, args.extra_seconds, 64,
+                             args.extra_parity_envs, 0, args.extra_parity_budget)
+                mc["env"].close()
+                mc["env"] = None
+                extras.append((name, c, mc))
+            except Exception as exc:
+                extras.append((name, c, {"error": repr(exc)}))
+            torch.cuda.empty_cache()
+
+    # ---- outside the timed region: the oracle re-derives what the taps recorded --------------------------------------
     exit_code = 0
-    if log1 is not None:
-        try:
-            host = {}
-            for k in log1:
-                if k == "ids" or (k == "pixels" and not PP2):
-                    continue
-                a = log1[k]
-                if sel2 is not None:                    # phase 2 followed a subset: the checked envs are that subset, all steps
-                    rows = [r for r in sel2 if r < PP1] if k == "pixels" else sel2
-                    a = a[:, torch.as_tensor(rows, dtype=torch.int64, device=dev)]
-                host[k] = np.concatenate([a.cpu().numpy()] + ([log2[k].cpu().numpy()] if log2 is not None else []))
-            par = cpu_baseline.parity_replay(level, host, args.seed, args.action_seed, first, PP2, env_ids=[first + i for i in ids2], pool=pool)
-        except Exception as exc:
-            par = {"error": repr(exc), "mismatches": None}          # the CHECKER broke: reported, not a parity verdict
+    par = replay(ctx, m)
+    if par is not None:
         bad = ranks.sum(par["mismatches"] or 0)
         broken = ranks.sum(1 if par["mismatches"] is None else 0)
+        ids2 = m["ids2"]
         if rank == 0:
             par["mismatches_all_ranks"] = None if broken else bad       # never readable as "0 mismatches" when nothing was checked
             par["checker_errors_all_ranks"] = broken
@@ -482,19 +592,53 @@ def main():
             exit_code = 4
         elif bad:
             exit_code = 3                   # a fast kernel whose results differ from the oracle's is not done
+    if extras:
+        cfgs = {}
+        for name, c, mc in extras:
+            if "error" in mc:
+                cfgs[name] = {"error": mc["error"]}
+                exit_code = exit_code or 4
+                continue
+            pc = replay(ctx, mc)
+            bad = ranks.sum((pc or {}).get("mismatches") or 0)
+            broken = ranks.sum(1 if (pc is not None and pc["mismatches"] is None) else 0)
+            if broken:
+                exit_code = exit_code or 4
+            elif bad:
+                exit_code = 3
+            cdom, calg, cbps, cdom_ms, cach, _ = roofline_of(mc)
+            cmed = median(mc["blocks"])
+            Kc, Ec = mc["K"], mc["E"]
+            cfgs[name] = {
+                "workload": "BabyAI-%s-v0 7x7x3 encoded obs, %d envs in total = %d per GPU x %d, random actions, auto-reset" % (c["level"], c["total"], Ec, world),
+                "reference": c["ref"], "value": Kc * Ec * world / cmed, "unit": "env-steps/s", "ms_per_step": cmed / Kc * 1e3,
+                "steps_per_block": Kc, "blocks": len(mc["blocks"]), "timed_seconds": sum(mc["blocks"]) + sum(mc["profiled"]),
+                "block_ms": {"min": min(mc["blocks"]) * 1e3, "median": cmed * 1e3, "max": max(mc["blocks"]) * 1e3},
+                "kernel_avg_ms": mc["kernel_ms"],
+                "roofline": {"kernel": cdom, "alg_bytes_per_launch": calg, "avg_launch_ms": cdom_ms, "achieved": cach, "unit": "GB/s",
+                             "frac": cach / HBM_PEAK_GBS, "whole_step_alg_GBs": Kc * Ec / cmed * cbps / 1e9},
+                "resets": mc["resets"], "resets_per_step": mc["resets"] / float(mc["S2"] or 1), "setup_ms": {k: v for k, v in mc["setup_ms"].items() if k != "note"},
+                "parity": None if pc is None else {"envs": pc.get("envs"), "steps": pc.get("steps"), "mismatches": None if broken else bad,
+                                                   "first_mismatch": pc.get("first_mismatch"), "seconds": pc.get("seconds"), "error": pc.get("error"),
+                                                   "env_selection": "scattered over the shard (shard.scattered_ids), every step"},
+            }
+        out["configs"] = cfgs
     ranks.barrier()
     if rank == 0 and not args.no_cpu_baseline:
         try:
             cb = cpu_baseline.run(level, pixel, args.cpu_baseline_seconds, args.seed, args.action_seed, pool=pool, cores=pool_size)
             cb.update(cpu_baseline.reference_over_port(level, pixel))
             out["cpu_baseline"] = cb
+            for name, c, mc in extras:          # the port's speed on the other configs, converted with the ratio on file (no extra CPU time here)
+                if out["configs"] and name in out["configs"] and "error" not in out["configs"][name]:
+                    out["configs"][name]["cpu_reference_over_port"] = cpu_baseline.reference_over_port(c["level"], c["pixel"]) or None
         except Exception as exc:      # the baseline is a reported number, never the product path
             out["cpu_baseline"] = {"error": repr(exc)}
     if pool is not None:
         pool.terminate()
+    out["wall_seconds"] = time.perf_counter() - t_start
     if rank == 0:
         print(json.dumps(out), flush=True)
-    env.close()
     ranks.barrier()
     ranks.close()
     sys.exit(exit_code)

@@ -126,8 +126,9 @@ int bbai_get_programs(bbai_env* env, int64_t first, int64_t count, uint8_t* prog
 /* Checkpoint / resume of a whole batch (the reference checkpoints only its model, babyai/utils/model.py:29-32; an
  * auto-resetting env batch additionally needs its RNG streams): the blob holds the live state, every env's MT19937
  * stream, the look-ahead ring with its window bookkeeping, the counters and -- when bbai_bot_act has been used -- the
- * expert's plans.  Loading it into a fresh handle of the same level, batch size and BBAI_LOOKAHEAD continues the run
- * bit-identically, auto-resets included (tests/test_gpu_parity.py::test_checkpoint_resume_*).  Synchronous, host buffers.
+ * expert's plans.  Loading it into a fresh handle of the same level and batch size continues the run
+ * bit-identically, auto-resets included (tests/test_gpu_parity.py::test_checkpoint_resume_*); a handle whose look-ahead
+ * period differs (it is chosen from the free memory at bbai_create unless BBAI_LOOKAHEAD pins it) takes the blob's ring shape.  Synchronous, host buffers.
  * Caller-owned buffers are not part of the blob: keep the last observation next to it if it is needed before the next
  * step, and register the token buffer again after a load (bbai_set_token_buffer refills every row of a live handle). */
 int64_t bbai_checkpoint_bytes(bbai_env* env);

@@ -80,10 +80,35 @@ def _worker(rank, world, port, q):
     local = []
     shard.timed_blocks(env, actions_torch(ASEED, 100, 104, first, count, "cpu"), 0, 2, 2, ranks, local_out=local,
                        before_block=lambda i: local.append(("before", i)))
+    # the clock of a block stops when the rank's own device is idle: a rank that dawdles INSIDE the closing barrier must not
+    # lengthen the block (its delay shows up in barrier_out); a rank whose STEPS are slow must (max over ranks)
+    import time
+
+    class SlowBarrier(object):
+        def __init__(self, inner):
+            self.inner = inner
+            self.calls = 0
+
+        def __getattr__(self, k):
+            return getattr(self.inner, k)
+
+        def barrier(self):
+            self.calls += 1
+            if self.inner.rank == 1 and self.calls % 2 == 0:        # the CLOSING barrier of every block
+                time.sleep(0.4)
+            self.inner.barrier()
+
+    class SlowSteps(object):
+        def step(self, a):
+            if rank == 1:
+                time.sleep(0.05)
+
+    bar, own = [], []
+    quick = shard.timed_blocks(SlowSteps(), actions_torch(ASEED, 0, 4, first, count, "cpu"), 0, 2, 2, SlowBarrier(ranks), barrier_out=bar, local_out=own)
     t = ranks.max(0.5 + rank)
     n = ranks.sum(count)
     if rank == 0:
-        q.put((full_img.numpy(), full_dig.numpy(), blocks, t, n, group, local))
+        q.put((full_img.numpy(), full_dig.numpy(), blocks, t, n, group, local, (quick, bar, own)))
     ranks.barrier()
     ranks.close()
 
@@ -98,7 +123,7 @@ def test_two_rank_gloo_shards_equal_the_unsharded_run():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    full_img, full_dig, blocks, t, n, group, local = q.get(timeout=300)
+    full_img, full_dig, blocks, t, n, group, local, (quick, bar, own) = q.get(timeout=300)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -110,4 +135,8 @@ def test_two_rank_gloo_shards_equal_the_unsharded_run():
     assert np.array_equal(full_dig, dig.h.numpy())              # ... at every step, every output (running digests)
     assert len(blocks) == BLOCKS and all(b > 0 for b in blocks)
     assert t == 1.5                                             # max over ranks
+    # rank 1 steps 2 x 50 ms per block and then sleeps 400 ms in the closing barrier; rank 0 does nothing
+    assert all(0.09 < b < 0.3 for b in quick), quick            # the block = the slowest rank's STEPS, not its barrier nap
+    assert all(b > 0.35 for b in bar), bar                      # ... which is reported on its own
+    assert all(o < 0.05 for o in own), own                      # rank 0's own clock
     assert n == TOTAL

@@ -447,13 +447,16 @@ def test_evaluate_policy_tensor_path(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", ["0", "1"])
 @pytest.mark.parametrize("period", ["1", "2", "8"])
-def test_autoreset_with_interleaved_resets(gpu, period, monkeypatch):
+def test_autoreset_with_interleaved_resets(gpu, period, fused, monkeypatch):
     """Auto-reset stepping with explicit reset() calls thrown in, for several refill periods (BBAI_LOOKAHEAD):
-    the look-ahead ring must hand every env its stream's levels in order whatever the window phase."""
+    the look-ahead ring must hand every env its stream's levels in order whatever the window phase -- with the finished
+    envs consumed by a k_consume launch (0) and inside k_step by the wave that stepped them (1)."""
     import torch
     from babyai_amd.engine import BatchedBabyAIEnv
     monkeypatch.setenv("BBAI_LOOKAHEAD", period)
+    monkeypatch.setenv("BBAI_CONSUME_FUSED", fused)
     n = 64
     env = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=9)     # tiny level: episodes of a few steps
     refs = _oracle_envs("GoToObjS4", [9 + i for i in range(n)])
@@ -797,8 +800,9 @@ def test_bot_device_equals_host_build(gpu, level, n, steps):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", ["0", "1"])
 @pytest.mark.parametrize("lookahead", [None, "2"])
-def test_very_short_episodes_every_window_tick(gpu, lookahead, monkeypatch):
+def test_very_short_episodes_every_window_tick(gpu, lookahead, fused, monkeypatch):
     """Expert-driven GoToObjS4: episodes of 1-4 steps, so roughly a third of the batch finishes on EVERY step and an env
     finishes several times within one look-ahead window (regression: the window's refill list must hold one entry
     per (tick, finished env), not one per env).  Every env against the host build, bot and env in lockstep."""
@@ -808,6 +812,7 @@ def test_very_short_episodes_every_window_tick(gpu, lookahead, monkeypatch):
     from hostsim_util import HostBot, HostEnv
     if lookahead:
         monkeypatch.setenv("BBAI_LOOKAHEAD", lookahead)
+    monkeypatch.setenv("BBAI_CONSUME_FUSED", fused)       # k_consume launch / consumed inside k_step
     level, n, base = "GoToObjS4", 768, 52000
     env = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=base)
     env.reset()
@@ -985,6 +990,41 @@ def test_checkpoint_resume_is_bit_identical(gpu, level, lookahead, use_bot, monk
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("save_period,load_period", [("8", "2"), ("2", None), (None, "4")])
+def test_checkpoint_loads_into_a_handle_with_another_lookahead_period(gpu, save_period, load_period, monkeypatch):
+    """The look-ahead period is chosen from the memory that is free at bbai_create (or pinned by BBAI_LOOKAHEAD): two
+    identically configured handles may differ in it.  The ring travels in the blob, so the loading handle takes the
+    blob's shape and continues bit-identically."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    n = 300
+    if save_period:
+        monkeypatch.setenv("BBAI_LOOKAHEAD", save_period)
+    a = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=77)
+    monkeypatch.delenv("BBAI_LOOKAHEAD", raising=False)
+    a.reset()
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(6)
+    acts = torch.randint(0, 3, (120, n), dtype=torch.uint8, device=gpu, generator=gen)
+    for t in range(21):
+        a.step(acts[t])
+    blob = a.save_checkpoint()
+    if load_period:
+        monkeypatch.setenv("BBAI_LOOKAHEAD", load_period)
+    b = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=1)        # seeded with something else, other ring shape
+    b.reset()
+    b.load_checkpoint(blob)
+    for t in range(21, 120):
+        a.step(acts[t])
+        b.step(acts[t])
+        assert torch.equal(a.image, b.image) and torch.equal(a.reward64, b.reward64) and torch.equal(a.done, b.done), t
+    assert a.reset_count() == b.reset_count() and a.reset_count() > 5 * n
+    assert len(b.save_checkpoint()) == len(blob)
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("lookahead,first_leg", [("2", 3), ("2", 5), ("4", 6), ("4", 9), ("8", 13), ("8", 21)])
 def test_reseed_in_the_middle_of_a_window(gpu, lookahead, first_leg, monkeypatch):
     """seed() on an engine that stopped `first_leg` auto-reset steps into a run -- not a multiple of the refill period, so
@@ -1149,6 +1189,14 @@ def test_unknown_actions_are_defined_and_can_be_rejected(gpu):
         b.step(torch.where(swap, junk, acts))                 # every `done` replaced by an arbitrary byte 8..255
         assert torch.equal(a.image, b.image) and torch.equal(a.reward64, b.reward64) and torch.equal(a.done, b.done)
     assert a.reset_count() == b.reset_count() > n
+    # a WIDER integer tensor must not wrap into a valid action on its way to a byte: 263 (= 7 mod 256: the per-env reset),
+    # 256 (= 0: turn left), -1, 2**40 + 2 all behave like `done`
+    wide = torch.tensor([263, 256, -1, 2 ** 40 + 2], dtype=torch.int64, device=gpu).repeat(n // 4)
+    a.step(torch.full((n,), 6, dtype=torch.uint8, device=gpu))
+    b.step(wide)
+    assert torch.equal(a.image, b.image) and torch.equal(a.reward64, b.reward64) and torch.equal(a.done, b.done)
+    with pytest.raises(TypeError):
+        b.step(torch.zeros(n, dtype=torch.float32, device=gpu))
     bad = torch.zeros(n, dtype=torch.uint8, device=gpu)
     bad[n // 2] = 9
     with pytest.raises(AssertionError, match="unknown action"):
@@ -1330,7 +1378,7 @@ def test_record_path_equals_window_plane_path(gpu, level, fused, monkeypatch):
     b.close()
 
 
-N_QUEUE_SHAPES = 11
+N_QUEUE_SHAPES = 16
 
 
 @pytest.mark.gpu
@@ -1389,7 +1437,8 @@ def test_options_do_not_change_results(gpu):
     gen = torch.Generator(device=gpu)
     gen.manual_seed(3)
     settings = [("step_prio", 0), ("pregen_group", 64), ("pregen_blocks", 64), ("render_group", 4), ("render_tpb", 256),
-                ("render_fused", 1), ("pregen_group", 16), ("render_fused", 0), ("render_queue", 6), ("pregen_group", 32), ("step_prio", 1)]
+                ("render_fused", 1), ("consume_fused", 1), ("pregen_group", 16), ("render_fused", 0), ("consume_fused", 0),
+                ("render_queue", 6), ("pregen_group", 32), ("step_prio", 1), ("consume_fused", 1), ("consume_fused", -1)]
     for t in range(20 * len(settings)):
         assert torch.equal(oa["image"], ob["image"]) and torch.equal(a.image, b.image) and torch.equal(a.direction, b.direction), t
         if t % 20 == 0:

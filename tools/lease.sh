@@ -52,11 +52,15 @@ ab() {               # tools/ab.py presets
     render1m_fused) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 1048576 --pixel --steps 20 --blocks 8 --reps 3 --settings \
                     render_fused=0,render_queue=0 render_fused=0,render_queue=-1 render_fused=1,render_queue=0 render_fused=1,render_queue=2 render_fused=1,render_queue=6 render_fused=1,render_queue=11 \
                     > $OUT/render_fused_queue_ab_1M.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_fused_queue_ab_1M.jsonl ;;
+    render1m_b) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 1048576 --pixel --steps 20 --blocks 8 --reps 3 --settings \
+                    render_queue=0 render_queue=1 render_queue=3 render_queue=12 render_queue=13 render_queue=14 render_queue=15 render_queue=16 \
+                    render_queue=1,render_queue_bpc=1 render_queue=1,render_queue_bpc=3 render_fused=1,render_queue=1 render_fused=1,render_queue=15 \
+                    > $OUT/render_queue_ab_1M_b.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_1M_b.jsonl ;;
     render128k) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 131072 --pixel --steps 64 --blocks 8 --reps 3 --settings \
-                    render_queue=0 render_queue=2 render_queue=6 render_queue=7 render_queue=9 render_queue=11 \
+                    render_queue=0 render_queue=1 render_queue=15 render_queue=16 \
                     > $OUT/render_queue_ab_131072.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_131072.jsonl ;;
     render512k) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 524288 --pixel --steps 32 --blocks 8 --reps 3 --settings \
-                    render_queue=0 render_queue=2 render_queue=6 render_queue=7 render_queue=11 \
+                    render_queue=0 render_queue=1 render_queue=15 render_queue=16 \
                     > $OUT/render_queue_ab_524288.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_524288.jsonl ;;
     *)          # ab:<name>:<level>:<envs>:<steps>:<pixel 0|1>:<setting>:<setting>...   (settings use '/' for ',')
                 local name=$1 level=$2 envs=$3 steps=$4 pix=$5; shift 5
