@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--settings", nargs="+", required=True)
+    ap.add_argument("--base", default="", help="options applied before every setting (so that a setting only names what it changes)")
     ap.add_argument("--tag", default=None)
     args = ap.parse_args()
 
@@ -92,7 +93,7 @@ def main():
     for rep in range(args.reps):
         for name, opts, envs in settings:
             env = get_env(envs)
-            for k, v in opts:
+            for k, v in parse_setting(args.base)[0] + opts:
                 env.set_option(k, v)
             for _ in range(args.settle):
                 step(env)

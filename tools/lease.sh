@@ -45,14 +45,14 @@ bench() {            # one BASELINE config as its own line: bench:C2 [extra args
 ab() {               # tools/ab.py presets
     cd /tmp
     case $1 in
-    render1m)   timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 1048576 --pixel --steps 20 --blocks 8 --reps 3 --settings \
+    render1m)   timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 1048576 --pixel --steps 20 --blocks 8 --reps 3 --base render_fused=0,render_queue_bpc=0 --settings \
                     render_queue=0 render_queue=1 render_queue=2 render_queue=3 render_queue=4 render_queue=5 render_queue=6 render_queue=7 render_queue=8 render_queue=10 render_queue=11 \
                     render_queue=2,render_queue_bpc=1 \
                     > $OUT/render_queue_ab_1M.jsonl 2> $OUT/ab.err; tail -1 $OUT/render_queue_ab_1M.jsonl ;;
-    render1m_fused) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 1048576 --pixel --steps 20 --blocks 8 --reps 3 --settings \
+    render1m_fused) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 1048576 --pixel --steps 20 --blocks 8 --reps 3 --base render_fused=0,render_queue_bpc=0 --settings \
                     render_fused=0,render_queue=0 render_fused=0,render_queue=-1 render_fused=1,render_queue=0 render_fused=1,render_queue=2 render_fused=1,render_queue=6 render_fused=1,render_queue=11 \
                     > $OUT/render_fused_queue_ab_1M.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_fused_queue_ab_1M.jsonl ;;
-    render1m_b) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 1048576 --pixel --steps 20 --blocks 8 --reps 3 --settings \
+    render1m_b) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 1048576 --pixel --steps 20 --blocks 8 --reps 3 --base render_fused=0,render_queue_bpc=0 --settings \
                     render_queue=0 render_queue=1 render_queue=3 render_queue=12 render_queue=13 render_queue=14 render_queue=15 render_queue=16 \
                     render_queue=1,render_queue_bpc=1 render_queue=1,render_queue_bpc=3 render_fused=1,render_queue=1 render_fused=1,render_queue=15 \
                     > $OUT/render_queue_ab_1M_b.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_1M_b.jsonl ;;
@@ -65,7 +65,7 @@ ab() {               # tools/ab.py presets
     *)          # ab:<name>:<level>:<envs>:<steps>:<pixel 0|1>:<setting>:<setting>...   (settings use '/' for ',')
                 local name=$1 level=$2 envs=$3 steps=$4 pix=$5; shift 5
                 local sets=(); for s in "$@"; do sets+=("${s//\//,}"); done
-                timeout 600 python $REPO/tools/ab.py --tag $TAG --level $level --envs $envs $([ "$pix" = 1 ] && echo --pixel) --steps $steps --blocks 8 --reps 3 \
+                timeout 600 python $REPO/tools/ab.py --tag $TAG --level $level --envs $envs $([ "$pix" = 1 ] && echo --pixel) --steps $steps --blocks 8 --reps 3 --base "$AB_BASE" \
                     --settings "${sets[@]}" > $OUT/ab_$name.jsonl 2>> $OUT/ab.err; tail -1 $OUT/ab_$name.jsonl ;;
     esac
 }
