@@ -136,7 +136,9 @@ struct bbai_env {
     bool tiles_valid;     // written by the last reset / step of every env
     unsigned int* render_tickets;   // [64][64] ticket counters of k_render_q + its departure counter; zero between launches (the kernel leaves them so)
     int render_queue;     // BBAI_RENDER_QUEUE / option "render_queue": -1 = by batch size (default), 0 = one-shot blocks only, m = queue shape m (render_launch)
-    int render_queue_bpc; // option "render_queue_bpc": persistent render blocks per CU (0 = 2048 threads' worth)
+    int render_queue_bpc; // option "render_queue_bpc": persistent render blocks per CU (0 = 1024 threads' worth: ONE 1024-thread block per CU --
+                          // profiles/r04/render_queue_ab_1M_b.jsonl: k_render 1.50 ms against 1.61 with two)
+    int render_queue_blocks;   // option "render_queue_blocks": their total number (0 = by render_queue_bpc)
     int n_cus;            // compute units of the device
     int consume_fused;    // BBAI_CONSUME_FUSED / option "consume_fused": -1 = by batch size, 0 = k_consume launch, 1 = inside k_step
     uint8_t* atlas;       // [n_tiles][192]
@@ -156,8 +158,6 @@ struct bbai_env {
 // k_step
 // ------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// batches up to this size consume finished envs inside k_step (use_fused_consume); above it the k_consume launch stays
-constexpr int64_t CONSUME_FUSED_MAX_ENVS = 524288;
 constexpr int MAX_PERIOD = 32;          // refill period B (ticks per look-ahead refill); ring depth D = 2B
 constexpr int WIN_STRIDE = 64;          // uint32 per window-count block (1 + MAX_PERIOD used)
 // envs (= threads) per k_step block.  The kernel is bound by its chain of dependent memory round trips, not by bytes or
@@ -268,11 +268,11 @@ __device__ __forceinline__ void encode_view(const uint32_t* cp, const uint32_t* 
     o.finish();
 }
 
-// Wave-cooperative observation of ONE env (used where a wave owns an env: k_consume): lane l < 49 owns view cell
+// Wave-cooperative observation of ONE env (used where a wave owns an env: consume_env): lane l < 49 owns view cell
 // (vi, vj) = (l % 7, l / 7); the opacity mask of the whole view is one ballot; every lane runs the 7-row
-// visibility sweep on it and writes its own three bytes.
-__device__ __forceinline__ void observe_wave(const LevelCfg& c, const uint8_t* __restrict__ rec, const Hot& h,
-                                             uint8_t* __restrict__ dst, int lane, uint8_t* __restrict__ tile_row /* or NULL */) {
+// visibility sweep on it and writes its own three bytes.  In two halves so that the caller can put other memory traffic
+// between the cell load and its use: observe_fetch returns the lane's cell, observe_emit does the rest.
+__device__ __forceinline__ int observe_fetch(const LevelCfg& c, const uint8_t* __restrict__ rec, const Hot& h, int lane) {
     const int vi = lane % VIEW, vj = lane / VIEW;
     int e = E_EMPTY;
     if (lane < VIEW * VIEW) {
@@ -280,6 +280,11 @@ __device__ __forceinline__ void observe_wave(const LevelCfg& c, const uint8_t* _
         view_to_world(h.ax, h.ay, h.dir, vi, vj, x, y);
         e = rec[e_index(c, x, y)];
     }
+    return e;
+}
+__device__ __forceinline__ void observe_emit(const LevelCfg& c, const uint8_t* __restrict__ rec, const Hot& h, int e,
+                                             uint8_t* __restrict__ dst, int lane, uint8_t* __restrict__ tile_row /* or NULL */) {
+    const int vi = lane % VIEW, vj = lane / VIEW;
     const unsigned long long opaque = __ballot(lane < VIEW * VIEW && e_opaque(e));
     uint32_t opq[VIEW], vis[VIEW];
 #pragma unroll
@@ -332,6 +337,11 @@ __device__ __forceinline__ u32x4 v_segment(const LevelCfg& c, const uint8_t* __r
 // stepped the env): coalesced record copy, SoA verifier view, first observation of the new episode (to `obs_dst`: the caller's
 // image row, or the block's LDS row in k_step), window plane + front cache, window bookkeeping for the batched refill.
 // `win_entry` = where this consumption is listed for k_pregen (NULL on reset(): the refill walks all envs).
+// The job is a handful of kilobytes per env, so what it costs is its chain of dependent memory round trips (a reset-heavy small
+// shard pays it on every step): everything that depends on nothing but the slot is LOADED FIRST, in batches that are all in
+// flight together (pose, program, the record's 16-byte vectors, the window plane's row segments), the one load that needs the
+// new pose (the view cell) goes out as soon as the pose is there, and the stores follow.  Round 3's form (load - store pairs
+// in loops) was ten round trips long.
 __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_t env, int slot, int lane, uint8_t* __restrict__ recs,
                                             Hot* __restrict__ hots, uint64_t* __restrict__ stales, const uint8_t* __restrict__ next_recs,
                                             const Hot* __restrict__ next_hots, uint32_t* __restrict__ vheads, uint64_t* __restrict__ vsets,
@@ -341,46 +351,69 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
                                             uint16_t* __restrict__ fcache, uint8_t* __restrict__ lsm_arr /* or NULL */) {
     const int nvec = c.rec_bytes >> 4;
     const uint8_t* nrec = next_recs + ((int64_t)slot * n + env) * (int64_t)c.rec_bytes;
-    const u32x4* src = (const u32x4*)nrec;
-    u32x4* dst = (u32x4*)(recs + env * (int64_t)c.rec_bytes);
-    for (int k = lane; k < nvec; k += 64) dst[k] = src[k];
-    // the verifier's SoA view of the new program
-    const Prog* p = (const Prog*)(nrec + c.off_prog);
-    if (lane < 8) vsets[(int64_t)lane * n + env] = p->set[lane >> 1][lane & 1];
-    if (lane == 8) vheads[env] = vhead_pack(*p);
     Hot h = next_hots[(int64_t)slot * n + env];
+    const Prog* p = (const Prog*)(nrec + c.off_prog);
+    const int start_carry = p->start_carry;
+    const uint64_t pset = lane < 8 ? p->set[lane >> 1][lane & 1] : 0ull;
+    const uint32_t vh = vhead_pack(*p);
+    const int pend = lane == 0 ? (int)pending[env] : 0;
     h.slot = (uint8_t)(slot + 1 == depth ? 0 : slot + 1);
-    // first observation of the new episode, straight from the slot (identical bytes to the live copy)
-    observe_wave(c, nrec, h, obs_dst, lane, tile_row);
-    if (vplane) {
-        // the new episode's window plane, straight from the slot; a start-carry object (it leaves the grid right after
-        // this first observation, below) is already shown as an empty cell
-        int sc = -1;
-        if (p->start_carry != NONE8) sc = e_index(c, nrec[c.off_pos + 2 * p->start_carry], nrec[c.off_pos + 2 * p->start_carry + 1]);
-        uint8_t* vrow = vplane + env * (int64_t)v_bytes(c);
-        const int nseg = v_nxo(c) * v_nyo(c) * 8;
-        // (read back from the slot -- L2 hits right after the copy above.  Parking the plane in LDS instead was measured
-        // and dropped: any LDS at all makes k_consume's blocks queue behind the generator's waves for it -- GoToLocal
-        // 65 536 envs: k_consume 14 -> 38 us, profiles/r03/NOTES.md)
-        for (int sg = lane; sg < nseg; sg += 64) *(u32x4*)(vrow + (sg >> 3) * VLINE + (sg & 7) * 16) = v_segment(c, nrec, sg >> 3, sg & 7, sc);
-        if (lane == 0) {
-            const int fi = e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir));
-            const uint32_t fe0 = fi == sc ? (uint32_t)E_EMPTY : nrec[fi];
-            const uint32_t ce0 = p->start_carry != NONE8 ? nrec[c.off_app + p->start_carry] : (uint32_t)E_EMPTY;
-            fcache[env] = (uint16_t)(fe0 | (ce0 << 8));
+    // the view cell of the new pose (the one load that needs the pose)
+    const int e_view = observe_fetch(c, nrec, h, lane);
+    // record: slot -> live copy
+    {
+        const u32x4* src = (const u32x4*)nrec;
+        u32x4* dst = (u32x4*)(recs + env * (int64_t)c.rec_bytes);
+        constexpr int CPB = 2;
+        for (int k0 = lane; k0 < nvec; k0 += 64 * CPB) {
+            u32x4 buf[CPB];
+#pragma unroll
+            for (int j = 0; j < CPB; ++j) if (k0 + 64 * j < nvec) buf[j] = src[k0 + 64 * j];
+#pragma unroll
+            for (int j = 0; j < CPB; ++j) if (k0 + 64 * j < nvec) dst[k0 + 64 * j] = buf[j];
         }
     }
+    // the new episode's window plane, straight from the slot (L2 hits next to the copy above.  Parking the plane in LDS was
+    // measured and dropped in round 3: any LDS at all makes k_consume's blocks queue behind the generator's waves for it)
+    uint8_t* vrow = vplane ? vplane + env * (int64_t)v_bytes(c) : nullptr;
+    if (vplane) {
+        const int nseg = v_nxo(c) * v_nyo(c) * 8;
+        constexpr int SGB = 4;
+        for (int s0 = lane; s0 < nseg; s0 += 64 * SGB) {
+            u32x4 seg[SGB];
+#pragma unroll
+            for (int j = 0; j < SGB; ++j) { const int sg = s0 + 64 * j; if (sg < nseg) seg[j] = v_segment(c, nrec, sg >> 3, sg & 7, -1); }
+#pragma unroll
+            for (int j = 0; j < SGB; ++j) { const int sg = s0 + 64 * j; if (sg < nseg) *(u32x4*)(vrow + (sg >> 3) * VLINE + (sg & 7) * 16) = seg[j]; }
+        }
+    }
+    // the verifier's SoA view of the new program
+    if (lane < 8) vsets[(int64_t)lane * n + env] = pset;
+    if (lane == 8) vheads[env] = vh;
+    // first observation of the new episode, straight from the slot (identical bytes to the live copy)
+    observe_emit(c, nrec, h, e_view, obs_dst, lane, tile_row);
     if (lane == 0) {
         uint64_t stale0 = 0;
+        uint32_t fe0 = nrec[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))], ce0 = E_EMPTY;
         // PutNext*Carrying: the first observation above still shows the object on the grid (the reference builds
-        // it before handing the object to the agent, bonus_levels.py:821-829); now move it into the agent's hands
-        if (p->start_carry != NONE8) apply_start_carry(c, recs + env * (int64_t)c.rec_bytes, h, stale0, p->start_carry);
+        // it before handing the object to the agent, bonus_levels.py:821-829); now move it into the agent's hands.  In the
+        // window plane (and the front cache) its cell is empty from the start.
+        if (start_carry != NONE8) {
+            const int sx = nrec[c.off_pos + 2 * start_carry], sy = nrec[c.off_pos + 2 * start_carry + 1];
+            if (vplane) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the segment stores of every lane have landed; the patch goes over them
+                v_patch(c, vrow, sx, sy, E_EMPTY);
+            }
+            if (e_index(c, sx, sy) == e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))) fe0 = E_EMPTY;
+            ce0 = nrec[c.off_app + start_carry];
+            apply_start_carry(c, recs + env * (int64_t)c.rec_bytes, h, stale0, start_carry);
+        }
+        if (vplane) fcache[env] = (uint16_t)(fe0 | (ce0 << 8));
         hots[env] = h;
         stales[env] = stale0;
         if (lsm_arr) lsm_arr[env] = 0;                  // fresh instruction objects: lastStepMatch = False (verifier.py:213-214)
         dirs[env] = h.dir;
         // window bookkeeping for the batched refill: first consumption in this window registers the env
-        const int pend = pending[env];
         if (pend == 0) first_slot[env] = (uint8_t)slot;
         if (win_entry) *win_entry = pend == 0 ? (int32_t)env : -1;
         pending[env] = (uint8_t)(pend + 1);
@@ -1167,15 +1200,16 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
         // window lasts as long as its slowest level (hundreds of microseconds to milliseconds: rejection sampling has a
         // heavy tail) and has to land within one window, so B ticks of the step path must outlast it or the step stream
         // waits: default = the longest period of 32, 16, 8, 4, 2 whose ring fits the cap.  The cap is BBAI_RING_GIB
-        // (default 16 GiB) but never more than a quarter of the memory that is FREE right now (several handles or ranks
+        // (default 64 GiB -- the part has 288 GB; round 4: 1 048 576 GoTo envs waited for refills at period 4, the 16-GiB cap of
+        // rounds 1-3) but never more than a quarter of the memory that is FREE right now (several handles or ranks
         // on one device, smaller parts), and an allocation that fails all the same is retried with half the period: a
-        // shorter period only costs speed, never correctness.  (131072 GoTo envs -> 32; 1M BossLevel envs -> 4.)
+        // shorter period only costs speed, never correctness.  (131072 GoTo envs -> 32; 1M BossLevel envs -> 16.)
         const char* ev = getenv("BBAI_LOOKAHEAD");
         const char* gv = getenv("BBAI_RING_GIB");
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)64 << 30;
         const size_t slot_bytes = (size_t)n_envs * c.rec_bytes;
-        const size_t cap = std::min((size_t)(gv ? std::max(1, atoi(gv)) : 16) << 30, free_b / 4);
+        const size_t cap = std::min((size_t)(gv ? std::max(1, atoi(gv)) : 64) << 30, free_b / 4);
         int b = 2;
         if (ev) b = atoi(ev);
         else for (int cand = MAX_PERIOD; cand >= 2; cand >>= 1) if (slot_bytes * 2 * (size_t)cand <= cap) { b = cand; break; }
@@ -1513,7 +1547,12 @@ static bool use_fused_consume(const bbai_env* e) {
     // -1 (default) = by batch size (CONSUME_FUSED_MAX_ENVS).  Never with the fused tile plane (that k_step keeps 256-thread blocks).
     if (e->tiles) return false;
     if (e->consume_fused >= 0) return e->consume_fused != 0;
-    return e->n <= CONSUME_FUSED_MAX_ENVS;
+    // Measured (profiles/r04/consume_fused_ab.jsonl, ms per step unfused -> fused): the mazes win -- GoTo 131 072 envs 0.046 -> 0.041,
+    // GoTo 1 048 576 0.245 -> 0.211, BossLevel encoded 1 048 576 0.137 -> 0.125, pixels 1.718 -> 1.710 -- their episodes last hundreds of steps,
+    // few waves have a finished env and one launch per step disappears; the single rooms lose -- GoToLocal 65 536 0.035 -> 0.054, PickupLoc
+    // 262 144 0.085 -> 0.143 -- 2 % of the envs finish on every step, so most waves carry a reset or two and do them one after the
+    // other behind their own step, where k_consume's waves do them all at once.
+    return e->cfg.num_rows * e->cfg.num_cols > 1;
 }
 static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64,
                        uint8_t* dones, int auto_reset, hipStream_t s) {
@@ -1619,8 +1658,8 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
         const int cus = e->n_cus > 0 ? e->n_cus : 256;
 #define RENDER_Q(GG, TT, NC, KK) do { \
             const int64_t tickets = ((e->n + GG - 1) / GG + KK - 1) / KK; \
-            const int bpc = e->render_queue_bpc > 0 ? e->render_queue_bpc : 2048 / TT; \
-            const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)cus * bpc, tickets)); \
+            const int64_t want = e->render_queue_blocks > 0 ? e->render_queue_blocks : (e->render_queue_bpc > 0 ? (int64_t)cus * e->render_queue_bpc : (int64_t)cus * 1024 / TT); \
+            const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, tickets)); \
             hipLaunchKernelGGL((k_render_q<GG, TT, FROM_PLANE, NC, KK>), dim3(blocks), dim3(TT), 0, (hipStream_t)stream, e->n, input, pixels, \
                                e->atlas, e->lut, e->n_tiles, e->render_tickets); } while (0)
         switch (qm) {
@@ -1640,6 +1679,8 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
         case 14: RENDER_Q(12, 1024, 1, 1); break;
         case 15: RENDER_Q(8, 512, 1, 1); break;
         case 16: RENDER_Q(4, 512, 1, 2); break;
+        case 17: RENDER_Q(8, 256, 1, 1); break;
+        case 18: RENDER_Q(16, 1024, 1, 2); break;
         default: RENDER_Q(8, 1024, 8, 1); break;
         }
 #undef RENDER_Q
@@ -2039,6 +2080,7 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     const int v = (int)value;
     if (!strcmp(name, "render_queue")) e->render_queue = v;
     else if (!strcmp(name, "render_queue_bpc")) e->render_queue_bpc = v;
+    else if (!strcmp(name, "render_queue_blocks")) e->render_queue_blocks = v;
     else if (!strcmp(name, "render_group")) e->render_group = v;
     else if (!strcmp(name, "render_tpb")) e->render_tpb = v;
     else if (!strcmp(name, "step_prio")) e->step_prio = v;

@@ -217,7 +217,7 @@ int bbai_get_done_actions(bbai_env* env);
  * no counterpart: these choose launch shapes and buffers, never results -- every setting yields the same bytes, which
  * tests/test_gpu_parity.py::test_options_do_not_change_results checks).  Synchronises the device.  Names:
  *   "render_queue"      -1 = by batch size (default), 0 = one-shot render blocks, m > 0 = persistent-block queue shape m
- *   "render_queue_bpc"  persistent render blocks per CU (0 = 2048 threads' worth)
+ *   "render_queue_bpc", "render_queue_blocks"   persistent render blocks per CU (0 = 1024 threads' worth) / in total (0 = per CU)
  *   "render_group", "render_tpb"   envs / threads per one-shot render block (0 = by batch size)
  *   "render_fused"      1 = keep the fused tile plane (bbai_render_current), 0 = drop it
  *   "step_prio", "pregen_group", "pregen_blocks", "consume_fused"   as BBAI_STEP_PRIO / BBAI_PREGEN_GROUP / BBAI_PREGEN_BLOCKS /

@@ -110,20 +110,25 @@ def run(level="BossLevel", pixel=True, seconds=12.0, seed_base=0, action_seed=12
 
 
 def reference_over_port(level, pixel):
-    """The measured speed ratio reference / port for this workload, from profiles/r03/cpu_port_vs_reference.json (taken in
+    """The measured speed ratio reference / port for this workload, from profiles/r0N/cpu_port_vs_reference.json (taken in
     the build container, where /root/reference can be imported: tools/cpu_port_vs_reference.py -- same seeds, same actions,
     equal output digests).  The reference tree never reaches the GPU box, so the bench line carries the port's figure and
     this ratio to convert it.  {} when no measurement is on file for the workload."""
     import json
-    path = os.path.join(_ROOT, "profiles", "r03", "cpu_port_vs_reference.json")
-    try:
-        with open(path) as f:
-            table = json.load(f)
-        row = table["workloads"]["%s/%s" % (level, "pixel" if pixel else "encoded")]
-    except (OSError, ValueError, KeyError):
+    table = row = rel = None
+    for rnd in ("r04", "r03"):                              # the latest measurement on file
+        rel = "profiles/%s/cpu_port_vs_reference.json" % rnd
+        try:
+            with open(os.path.join(_ROOT, rel)) as f:
+                table = json.load(f)
+            row = table["workloads"]["%s/%s" % (level, "pixel" if pixel else "encoded")]
+            break
+        except (OSError, ValueError, KeyError):
+            row = None
+    if row is None:
         return {}
     return {"reference_over_port": row["reference_over_port"],
-            "reference_over_port_provenance": {"file": "profiles/r03/cpu_port_vs_reference.json", "digest_equal": row["digest_equal"],
+            "reference_over_port_provenance": {"file": rel, "digest_equal": row["digest_equal"],
                                                "reference_steps_per_s": row["reference_steps_per_s"], "port_steps_per_s": row["port_steps_per_s"],
                                                "steps": row["steps"], "where": table.get("where"), "commit": table.get("commit")}}
 

@@ -1378,7 +1378,7 @@ def test_record_path_equals_window_plane_path(gpu, level, fused, monkeypatch):
     b.close()
 
 
-N_QUEUE_SHAPES = 16
+N_QUEUE_SHAPES = 18
 
 
 @pytest.mark.gpu
@@ -1406,6 +1406,7 @@ def test_render_queue_equals_one_shot_render(gpu, n, fused):
         assert torch.equal(oa["image"], ob["image"]), t
         b.set_option("render_queue", 1 + t % N_QUEUE_SHAPES)
         b.set_option("render_queue_bpc", (0, 1, 3, 0)[t // N_QUEUE_SHAPES])
+        b.set_option("render_queue_blocks", (0, 0, 0, 77)[t // N_QUEUE_SHAPES])
         act = torch.randint(0, 7, (n,), dtype=torch.uint8, device=gpu, generator=gen)
         oa, _, _, _ = a.step(act)
         ob, _, _, _ = b.step(act)

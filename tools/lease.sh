@@ -56,6 +56,11 @@ ab() {               # tools/ab.py presets
                     render_queue=0 render_queue=1 render_queue=3 render_queue=12 render_queue=13 render_queue=14 render_queue=15 render_queue=16 \
                     render_queue=1,render_queue_bpc=1 render_queue=1,render_queue_bpc=3 render_fused=1,render_queue=1 render_fused=1,render_queue=15 \
                     > $OUT/render_queue_ab_1M_b.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_1M_b.jsonl ;;
+    render1m_c) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 1048576 --pixel --steps 20 --blocks 8 --reps 3 --base render_fused=0,render_queue_bpc=0,render_queue_blocks=0 --settings \
+                    render_queue=0 render_queue=1 render_queue=1,render_queue_blocks=512 render_queue=1,render_queue_blocks=192 render_queue=1,render_queue_blocks=128 \
+                    render_queue=3 render_queue=13 render_queue=18 render_queue=14 render_queue=15 render_queue=15,render_queue_blocks=256 render_queue=17 render_queue=17,render_queue_blocks=512 \
+                    render_queue=17,render_queue_blocks=256 render_queue=3,render_queue_blocks=192 render_queue=13,render_queue_blocks=192 \
+                    > $OUT/render_queue_ab_1M_c.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_1M_c.jsonl ;;
     render128k) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 131072 --pixel --steps 64 --blocks 8 --reps 3 --settings \
                     render_queue=0 render_queue=1 render_queue=15 render_queue=16 \
                     > $OUT/render_queue_ab_131072.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_131072.jsonl ;;
@@ -68,6 +73,47 @@ ab() {               # tools/ab.py presets
                 timeout 600 python $REPO/tools/ab.py --tag $TAG --level $level --envs $envs $([ "$pix" = 1 ] && echo --pixel) --steps $steps --blocks 8 --reps 3 --base "$AB_BASE" \
                     --settings "${sets[@]}" > $OUT/ab_$name.jsonl 2>> $OUT/ab.err; tail -1 $OUT/ab_$name.jsonl ;;
     esac
+}
+sq() {               # SQ counter pass over the headline bench: where the waves of k_render / k_step spend their cycles
+    cd /tmp && rm -rf $OUT/pmc_sq
+    timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU \
+        --kernel-trace --output-format csv -d $OUT/pmc_sq -o boss -- python $REPO/bench.py --steps 8 --warmup 2 --no-cpu-baseline --parity-envs 0 --min-seconds 0 --no-extra-configs ${@} > $OUT/rocprof_sq.log 2>&1
+    python - <<PY | tee $OUT/sq_counters.txt
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for path in glob.glob("$OUT/pmc_sq/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if k.startswith(("k_render", "k_step", "k_consume")):
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in agg.items():
+    print(k, {c: round(sorted(v)[len(v) // 2]) for c, v in d.items()}, "launches", len(next(iter(d.values()))))
+PY
+    find $OUT -name "*.csv" -size +20M -delete
+}
+botbench() {         # expert-driven env-steps/s per config (tools/bot_bench.py)
+    cd /tmp
+    for cfg in "GoToLocal 65536 200" "PickupLoc 262144 100" "GoTo 131072 100" "BossLevel 262144 60" "BossLevel 1048576 30"; do
+        timeout 300 python $REPO/tools/bot_bench.py $cfg 2>> $OUT/bot_bench.err | tail -1 | tee -a $OUT/bot_bench.jsonl
+    done
+}
+soak() {             # scattered envs of large batches vs the oracle over many steps (tools/gpu_soak.py)
+    cd $REPO && timeout 900 python - > $OUT/soak_random.txt 2>&1 <<PY
+import sys
+sys.path.insert(0, "$REPO/tools"); sys.path.insert(0, "$REPO")
+import gpu_soak
+bad = 0
+for level, n, T in (("BossLevel", 1048576, 200), ("GoToLocal", 65536, 400), ("PickupLoc", 262144, 300), ("GoTo", 131072, 300), ("PutNextS5N2Carrying", 65536, 300), ("KeyInBox", 65536, 300), ("SynthSeq", 131072, 200)):
+    bad += gpu_soak.soak(level, n, T, 48, 12345)
+print("soak mismatches:", bad)
+PY
+    tail -4 $OUT/soak_random.txt
+}
+ubench() {           # the microbenchmarks DESIGN.md quotes (built here: hipcc is on the box)
+    cd $REPO && for u in gather render fetchcal; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/ubench_$u tools/ubench_$u.hip 2>/dev/null; done
+    timeout 120 python tools/membw.py > $OUT/membw.json 2> $OUT/membw.err
+    timeout 300 /tmp/ubench_render ${1:-1048576} ${2:-queue} > $OUT/ubench_render_${2:-queue}.jsonl 2> $OUT/ubench_render.err
+    cat $OUT/membw.json; tail -30 $OUT/ubench_render_${2:-queue}.jsonl
 }
 run() { cd $REPO && timeout 900 "$@"; }          # run:python:tools/x.py:arg ...
 
