@@ -104,6 +104,7 @@ struct bbai_env {
     uint32_t* win_count;  // [3][WIN_STRIDE]: [1 + pos] = finished envs of tick `pos` of the window
     int win_all[3];       // window contained a reset() of every env: refill iterates all envs
     int32_t* reset_list;  // [n]     envs finished by the current step (k_step -> k_consume / k_tokens)
+    uint8_t* reset_slot;  // [n]     ... and the look-ahead slot each of them consumes (spares k_consume one dependent round trip)
     uint32_t* counters;   // [2][16] [p][0] = reset list length; ping-pong by step parity so that k_consume can zero the
                           //         other one for the next step (no memset launch on the step path)
     int step_parity;
@@ -158,6 +159,21 @@ struct bbai_env {
 // k_step
 // ------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Sum of the first `upto` (<= 64) per-tick counts of a window's count block (entries [1 ..]): ONE load per lane and a wave
+// reduction.  (As a scalar loop this was `upto` dependent memory round trips -- up to 31 of them, ~15 us, at the top of every
+// k_consume / k_pregen wave: most of what a small shard's k_consume launch cost in rounds 1-3.)  Call with the full wave active.
+__device__ __forceinline__ int64_t win_prefix(const uint32_t* __restrict__ win_count, int upto) {
+    const int lane = (int)threadIdx.x & 63;
+    uint32_t lo = lane < upto ? win_count[1 + lane] : 0u, hi = 0u;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const uint32_t l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+        const uint32_t sum = lo + l2;
+        hi += h2 + (sum < lo ? 1u : 0u);
+        lo = sum;
+    }
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
 constexpr int MAX_PERIOD = 32;          // refill period B (ticks per look-ahead refill); ring depth D = 2B
 constexpr int WIN_STRIDE = 64;          // uint32 per window-count block (1 + MAX_PERIOD used)
 // envs (= threads) per k_step block.  The kernel is bound by its chain of dependent memory round trips, not by bytes or
@@ -317,17 +333,17 @@ __device__ __forceinline__ u32x4 v_segment(const LevelCfg& c, const uint8_t* __r
     const int nxo = v_nxo(c);
     const int yo = line / nxo, xo = line - yo * nxo;
     const int prow = 2 * yo + r, pcol = 8 * xo;
-    uint32_t w[4] = {0, 0, 0, 0};
-    if (prow < c.EH) {
-        const int base = prow * c.ES + pcol;
+    const int base = prow * c.ES + pcol;
+    uint32_t w[4];
+    // branch-free: a dword outside the plane is read at offset 0 and replaced by zero, so the four loads (and those of the
+    // caller's other segments) are in flight together -- as conditional loads each one was its own round trip
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
-            if (pcol + 4 * d < c.ES) {
-                uint32_t v = *(const uint32_t*)(E + base + 4 * d);
-                const int k = sc - (base + 4 * d);
-                if (k >= 0 && k < 4) v = (v & ~(0xFFu << (8 * k))) | ((uint32_t)E_EMPTY << (8 * k));
-                w[d] = v;
-            }
+    for (int d = 0; d < 4; ++d) {
+        const bool ok = prow < c.EH && pcol + 4 * d < c.ES;
+        uint32_t v = *(const uint32_t*)(E + (ok ? base + 4 * d : 0));
+        const int k = sc - (base + 4 * d);
+        if (k >= 0 && k < 4) v = (v & ~(0xFFu << (8 * k))) | ((uint32_t)E_EMPTY << (8 * k));
+        w[d] = ok ? v : 0u;
     }
     u32x4 out = {w[0], w[1], w[2], w[3]};
     return out;
@@ -360,6 +376,7 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
     h.slot = (uint8_t)(slot + 1 == depth ? 0 : slot + 1);
     // the view cell of the new pose (the one load that needs the pose)
     const int e_view = observe_fetch(c, nrec, h, lane);
+    uint32_t fe0 = nrec[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];       // (the front cell for the cache: with the view cells, not behind everything)
     // record: slot -> live copy
     {
         const u32x4* src = (const u32x4*)nrec;
@@ -368,7 +385,8 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
         for (int k0 = lane; k0 < nvec; k0 += 64 * CPB) {
             u32x4 buf[CPB];
 #pragma unroll
-            for (int j = 0; j < CPB; ++j) if (k0 + 64 * j < nvec) buf[j] = src[k0 + 64 * j];
+            for (int j = 0; j < CPB; ++j) buf[j] = src[k0 + 64 * j < nvec ? k0 + 64 * j : nvec - 1];
+            asm volatile("" : "+v"(buf[0]), "+v"(buf[1]));       // (both loads in flight before the first store: the scheduler otherwise pairs them load - store - load - store)
 #pragma unroll
             for (int j = 0; j < CPB; ++j) if (k0 + 64 * j < nvec) dst[k0 + 64 * j] = buf[j];
         }
@@ -382,7 +400,7 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
         for (int s0 = lane; s0 < nseg; s0 += 64 * SGB) {
             u32x4 seg[SGB];
 #pragma unroll
-            for (int j = 0; j < SGB; ++j) { const int sg = s0 + 64 * j; if (sg < nseg) seg[j] = v_segment(c, nrec, sg >> 3, sg & 7, -1); }
+            for (int j = 0; j < SGB; ++j) { const int sg = s0 + 64 * j < nseg ? s0 + 64 * j : nseg - 1; seg[j] = v_segment(c, nrec, sg >> 3, sg & 7, -1); }
 #pragma unroll
             for (int j = 0; j < SGB; ++j) { const int sg = s0 + 64 * j; if (sg < nseg) *(u32x4*)(vrow + (sg >> 3) * VLINE + (sg & 7) * 16) = seg[j]; }
         }
@@ -394,7 +412,7 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
     observe_emit(c, nrec, h, e_view, obs_dst, lane, tile_row);
     if (lane == 0) {
         uint64_t stale0 = 0;
-        uint32_t fe0 = nrec[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))], ce0 = E_EMPTY;
+        uint32_t ce0 = E_EMPTY;
         // PutNext*Carrying: the first observation above still shows the object on the grid (the reference builds
         // it before handing the object to the agent, bonus_levels.py:821-829); now move it into the agent's hands.  In the
         // window plane (and the front cache) its cell is empty from the start.
@@ -439,7 +457,7 @@ __global__ __launch_bounds__(StepBlock<EMIT>::N, EMIT ? 4 : 1) void k_step(Level
                                                      const uint8_t* __restrict__ actions, uint8_t* image /* read (frozen envs re-emit) AND written: no restrict */,
                                                      uint8_t* __restrict__ dirs, float* __restrict__ rewards,
                                                      double* __restrict__ rewards64, uint8_t* __restrict__ dones, int auto_reset,
-                                                     int32_t* __restrict__ reset_list, uint32_t* __restrict__ counters,
+                                                     int32_t* __restrict__ reset_list, uint8_t* __restrict__ reset_slot, uint32_t* __restrict__ counters,
                                                      uint8_t* __restrict__ tiles /* EMIT: [n][TILE_PITCH] render input */, int prio,
                                                      uint8_t* __restrict__ vplane, uint16_t* __restrict__ fcache,
                                                      uint8_t* __restrict__ lsm_arr /* NULL, or the done-action mode's per-env bits */,
@@ -557,14 +575,17 @@ __global__ __launch_bounds__(StepBlock<EMIT>::N, EMIT ? 4 : 1) void k_step(Level
             // (FUSE: the tick's count lives in the window's count block -- what k_consume would have written there at the end)
             if (lane == leader) basei = atomicAdd(FUSE ? &fuse.win_count[1 + fuse.pos] : &counters[0], (uint32_t)__popcll(bal));
             basei = __shfl(basei, leader);
-            if (want_reset) reset_list[basei + __popcll(bal & ((1ull << lane) - 1))] = (int32_t)env;
+            if (want_reset) {
+                const uint32_t at = basei + __popcll(bal & ((1ull << lane) - 1));
+                reset_list[at] = (int32_t)env;
+                if (!FUSE) reset_slot[at] = (uint8_t)my_slot;
+            }
             if (FUSE) {
                 // Everything this wave stored to the records, window planes and SoA entries of these envs must have landed
                 // before other lanes overwrite them (a terminal pickup patches the record the consume is about to replace).
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == leader) atomicAdd(fuse.total_resets, (unsigned long long)__popcll(bal));
-                int64_t wbase = 0;          // this tick's entries go behind those of the window's earlier ticks
-                for (int j = 0; j < fuse.pos; ++j) wbase += (int64_t)fuse.win_count[1 + j];
+                const int64_t wbase = win_prefix(fuse.win_count, fuse.pos);          // this tick's entries go behind those of the window's earlier ticks
                 uint32_t k = 0;
                 while (bal) {
                     const int src = __ffsll((long long)bal) - 1;
@@ -648,8 +669,11 @@ struct GroupCtx {
 // group's LDS block, then one ATTEMPT of the generator's rejection loop per trip of the main loop (Gen::attempt) -- a
 // group whose attempt was accepted writes the level out and goes on to its next level / env while its neighbours retry,
 // so the wave only idles lanes inside an attempt, never across attempts.
+#ifndef BBAI_PREGEN_WAVES
+#define BBAI_PREGEN_WAVES 2        // minimum waves per SIMD the register allocation has to allow (experiment builds: 3, 4)
+#endif
 template <int KIND, int G>
-__global__ __launch_bounds__(64, 2) void k_pregen(LevelCfg c, int64_t n, uint8_t* __restrict__ next_recs,
+__global__ __launch_bounds__(64, BBAI_PREGEN_WAVES) void k_pregen(LevelCfg c, int64_t n, uint8_t* __restrict__ next_recs,
                                                   Hot* __restrict__ next_hots, uint32_t* __restrict__ mts,
                                                   int32_t* __restrict__ mtis, const int32_t* __restrict__ win_list,
                                                   const uint32_t* __restrict__ win_count, int all, int depth,
@@ -662,10 +686,7 @@ __global__ __launch_bounds__(64, 2) void k_pregen(LevelCfg c, int64_t n, uint8_t
     GenWork& w = ws[threadIdx.x / G];
     const int lane = ctx.lane();
     int64_t count = n;
-    if (!all) {                                          // window list = concatenated per-tick lists
-        count = 0;
-        for (int j = 0; j < MAX_PERIOD; ++j) count += (int64_t)win_count[1 + j];
-    }
+    if (!all) count = win_prefix(win_count, MAX_PERIOD);     // window list = concatenated per-tick lists
     int64_t it = (int64_t)blockIdx.x * NG + threadIdx.x / G;
     const int64_t stride = (int64_t)gridDim.x * NG;
     // the group's current env
@@ -684,12 +705,19 @@ __global__ __launch_bounds__(64, 2) void k_pregen(LevelCfg c, int64_t n, uint8_t
                 break;
             }
             if (have) {
+                // the env's generator state: all of its loads in flight together (MT19937 words, position, first slot) -- as a
+                // load - store loop this was five dependent round trips before the first draw
                 const uint32_t* mt = mts + env * MT_N;
-                ctx.sync();
-                for (int k = lane; k < MT_N; k += G) w.mt[k] = mt[k];
-                ctx.sync();
+                constexpr int MTQ = (MT_N + G - 1) / G;
+                uint32_t mtw[MTQ];
+#pragma unroll
+                for (int q = 0; q < MTQ; ++q) { const int k = lane + q * G; mtw[q] = mt[k < MT_N ? k : MT_N - 1]; }
                 mti = mtis[env];
                 slot = first_slot[env];
+                ctx.sync();
+#pragma unroll
+                for (int q = 0; q < MTQ; ++q) { const int k = lane + q * G; if (k < MT_N) w.mt[k] = mtw[q]; }
+                ctx.sync();
                 const int prev = slot == 0 ? depth - 1 : slot - 1;          // holds the level generated just before
                 last_locked = next_hots[(int64_t)prev * n + env].last_locked;   // LevelGen.locked_room survives episodes
                 last_locked = last_locked == NONE8 ? -1 : last_locked;
@@ -770,7 +798,7 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
                                                  uint64_t* __restrict__ stales, const uint8_t* __restrict__ next_recs,
                                                  const Hot* __restrict__ next_hots, uint32_t* __restrict__ vheads,
                                                  uint64_t* __restrict__ vsets, const int32_t* __restrict__ reset_list,
-                                                 const uint32_t* __restrict__ counter, int all,
+                                                 const uint8_t* __restrict__ reset_slot, const uint32_t* __restrict__ counter, int all,
                                                  unsigned long long* __restrict__ total_resets, int depth,
                                                  uint8_t* __restrict__ pending, uint8_t* __restrict__ first_slot,
                                                  int32_t* __restrict__ win_list, uint32_t* __restrict__ win_count, int pos,
@@ -782,13 +810,13 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
     const int64_t count = all ? n : (int64_t)counter[0];
     // this tick's entries go behind those of the window's earlier ticks (their counts were written by earlier
     // launches); no atomics: an env appears at most once per tick, repeats within the window are marked -1
-    int64_t base = 0;
-    for (int j = 0; j < pos; ++j) base += (int64_t)win_count[1 + j];
+    const int64_t base = win_prefix(win_count, pos);
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
     for (int64_t it = wave; it < count; it += nwaves) {
         const int64_t env = all ? it : (int64_t)reset_list[it];
-        consume_env(c, n, env, hots[env].slot, lane, recs, hots, stales, next_recs, next_hots, vheads, vsets, depth, pending, first_slot,
+        const int slot = all ? (int)hots[env].slot : (int)reset_slot[it];       // (k_step listed it next to the env: no round trip through the env's state)
+        consume_env(c, n, env, slot, lane, recs, hots, stales, next_recs, next_hots, vheads, vsets, depth, pending, first_slot,
                     all ? nullptr : win_list + base + it, image + env * OBS_BYTES, dirs, tiles ? tiles + env * TILE_PITCH : nullptr, vplane, fcache,
                     lsm_arr);
     }
@@ -1235,6 +1263,7 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
         if (dv && dv[0]) alloc((void**)&e->lsm, (size_t)n_envs);
     }
     alloc((void**)&e->reset_list, (size_t)n_envs * 4);
+    alloc((void**)&e->reset_slot, (size_t)n_envs);
     alloc((void**)&e->counters, 128);
     alloc((void**)&e->total_resets, 16);
     alloc((void**)&e->atlas, MAX_TILES * TILE_BYTES);
@@ -1325,7 +1354,7 @@ void bbai_destroy(bbai_env* e) {
     void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
     void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_list, e->win_count, e->reset_list, e->counters,
-                    e->total_resets, e->atlas, e->lut, e->tiles, e->vplane, e->fcache, e->lsm, e->render_tickets};
+                    e->total_resets, e->atlas, e->lut, e->tiles, e->vplane, e->fcache, e->lsm, e->render_tickets, e->reset_slot};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete e;
 }
@@ -1489,7 +1518,7 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
     {
     ProfScope prof_(e, 1, s);
     hipLaunchKernelGGL(k_consume, dim3((unsigned)std::min<int64_t>((hint + 3) / 4, 8192)), dim3(256), 0, s, e->cfg, e->n, e->rec,
-                       e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, e->reset_list, e->counters + 16 * e->step_parity, all,
+                       e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, e->reset_list, e->reset_slot, e->counters + 16 * e->step_parity, all,
                        e->total_resets, e->depth, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n,
                        e->win_list + (size_t)wb * e->period * e->n, e->win_count + WIN_STRIDE * wb, pos, image, dirs,
                        e->counters + 16 * (e->step_parity ^ 1), e->tiles, e->step_prio, e->vplane, e->fcache, e->lsm);
@@ -1576,7 +1605,7 @@ static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint
     {
         ProfScope prof_(e, 0, s);
 #define STEP_LAUNCH(EM, VV, FF) hipLaunchKernelGGL((k_step<EM, VV, FF>), dim3((unsigned)((e->n + StepBlock<EM>::N - 1) / StepBlock<EM>::N)), dim3(StepBlock<EM>::N), 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, \
-                                               image, dirs, rewards, rewards64, dones, auto_reset, list, counter, e->tiles, e->step_prio, e->vplane, e->fcache, e->lsm, fa)
+                                               image, dirs, rewards, rewards64, dones, auto_reset, list, e->reset_slot, counter, e->tiles, e->step_prio, e->vplane, e->fcache, e->lsm, fa)
         if (e->tiles) { if (e->vplane) STEP_LAUNCH(true, true, false); else STEP_LAUNCH(true, false, false); }
         else if (fused) { if (e->vplane) STEP_LAUNCH(false, true, true); else STEP_LAUNCH(false, false, true); }
         else { if (e->vplane) STEP_LAUNCH(false, true, false); else STEP_LAUNCH(false, false, false); }

@@ -30,7 +30,7 @@ def parse_setting(text):
         if not kv:
             continue
         k, v = kv.split("=")
-        if k.startswith("env:"):
+        if k.startswith("env:") or k.startswith("env."):      # ("env." for tools/lease.sh, whose job syntax owns the colon)
             envs[k[4:]] = v
         else:
             opts.append((k, int(v)))

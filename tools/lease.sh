@@ -61,6 +61,13 @@ ab() {               # tools/ab.py presets
                     render_queue=3 render_queue=13 render_queue=18 render_queue=14 render_queue=15 render_queue=15,render_queue_blocks=256 render_queue=17 render_queue=17,render_queue_blocks=512 \
                     render_queue=17,render_queue_blocks=256 render_queue=3,render_queue_blocks=192 render_queue=13,render_queue_blocks=192 \
                     > $OUT/render_queue_ab_1M_c.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_1M_c.jsonl ;;
+    render1m_d) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 1048576 --pixel --steps 20 --blocks 8 --reps 3 --base render_fused=0,render_queue_bpc=0,render_queue_blocks=0 --settings \
+                    render_queue=0 render_queue=1 render_queue=2 render_queue=12 render_queue=14 render_queue=1,render_queue_blocks=224 render_queue=1,render_queue_blocks=320 render_fused=1,render_queue=1 \
+                    > $OUT/render_queue_ab_1M_d.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_1M_d.jsonl ;;
+    render256k) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 262144 --pixel --steps 48 --blocks 8 --reps 3 --settings \
+                    render_queue=0 render_queue=1 > $OUT/render_queue_ab_262144.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_262144.jsonl ;;
+    render384k) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 393216 --pixel --steps 48 --blocks 8 --reps 3 --settings \
+                    render_queue=0 render_queue=1 > $OUT/render_queue_ab_393216.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_393216.jsonl ;;
     render128k) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 131072 --pixel --steps 64 --blocks 8 --reps 3 --settings \
                     render_queue=0 render_queue=1 render_queue=15 render_queue=16 \
                     > $OUT/render_queue_ab_131072.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_131072.jsonl ;;
@@ -71,7 +78,7 @@ ab() {               # tools/ab.py presets
                 local name=$1 level=$2 envs=$3 steps=$4 pix=$5; shift 5
                 local sets=(); for s in "$@"; do sets+=("${s//\//,}"); done
                 timeout 600 python $REPO/tools/ab.py --tag $TAG --level $level --envs $envs $([ "$pix" = 1 ] && echo --pixel) --steps $steps --blocks 8 --reps 3 --base "$AB_BASE" \
-                    --settings "${sets[@]}" > $OUT/ab_$name.jsonl 2>> $OUT/ab.err; tail -1 $OUT/ab_$name.jsonl ;;
+                    --settings "${sets[@]}" > $OUT/ab_$name$AB_SUFFIX.jsonl 2>> $OUT/ab.err; tail -1 $OUT/ab_$name$AB_SUFFIX.jsonl ;;
     esac
 }
 sq() {               # SQ counter pass over the headline bench: where the waves of k_render / k_step spend their cycles
@@ -114,6 +121,13 @@ ubench() {           # the microbenchmarks DESIGN.md quotes (built here: hipcc i
     timeout 120 python tools/membw.py > $OUT/membw.json 2> $OUT/membw.err
     timeout 300 /tmp/ubench_render ${1:-1048576} ${2:-queue} > $OUT/ubench_render_${2:-queue}.jsonl 2> $OUT/ubench_render.err
     cat $OUT/membw.json; tail -30 $OUT/ubench_render_${2:-queue}.jsonl
+}
+lib() {              # the same ab spec under two engine builds, alternated twice: lib:<other.so>:<ab args as for ab:>
+    local other=$1; shift
+    for rep in 1 2; do
+        echo "--- default build"; AB_SUFFIX=_default_$rep ab "$@"
+        echo "--- $other"; BBAI_ENGINE_LIB=$REPO/$other AB_SUFFIX=_other_$rep ab "$@"
+    done
 }
 run() { cd $REPO && timeout 900 "$@"; }          # run:python:tools/x.py:arg ...
 
