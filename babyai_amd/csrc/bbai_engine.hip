@@ -133,8 +133,6 @@ struct bbai_env {
     uint16_t* fcache;     // [n] appearance of the front cell (low byte) and of the carried object (high byte) after the last step
     uint8_t* lsm;         // [n] done-action verifier mode only (BABYAI_DONE_ACTIONS / bbai_set_done_actions): bit k = leaf k's
                           //     lastStepMatch (babyai/levels/verifier.py:213-230); NULL = the normal mode
-    uint8_t* tiles;       // [n][TILE_PITCH] fused tile plane of the CURRENT observations (allocated by bbai_set_atlas: pixel mode)
-    bool tiles_valid;     // written by the last reset / step of every env
     unsigned int* render_tickets;   // [64][64] ticket counters of k_render_q + its departure counter; zero between launches (the kernel leaves them so)
     int render_queue;     // BBAI_RENDER_QUEUE / option "render_queue": -1 = by batch size (default), 0 = one-shot blocks only, m = queue shape m (render_launch)
     int render_queue_bpc; // option "render_queue_bpc": persistent render blocks per CU (0 = 1024 threads' worth: ONE 1024-thread block per CU --
@@ -177,20 +175,14 @@ __device__ __forceinline__ int64_t win_prefix(const uint32_t* __restrict__ win_c
 constexpr int MAX_PERIOD = 32;          // refill period B (ticks per look-ahead refill); ring depth D = 2B
 constexpr int WIN_STRIDE = 64;          // uint32 per window-count block (1 + MAX_PERIOD used)
 // envs (= threads) per k_step block.  The kernel is bound by its chain of dependent memory round trips, not by bytes or
-// instructions, and the block is what waits at its two barriers for its slowest wave: ONE wave per block (64) measured
-// against 128 / 256 (profiles/r03/step_variants_ab.jsonl: BossLevel encoded 1 048 576 envs k_step 0.130 -> 0.124 -> 0.111 ms,
+// instructions, and a block is what waits at its barriers for its slowest wave: ONE wave per block (64) measured against
+// 128 / 256 in round 3 (profiles/r03/step_variants_ab.jsonl: BossLevel encoded 1 048 576 envs k_step 0.130 -> 0.124 -> 0.111 ms,
 // PickupLoc 262 144 0.071 -> 0.061 -> 0.051, GoTo 131 072 0.0212 -> 0.0192 -> 0.0184, GoToLocal 65 536 0.0244 -> 0.0216 -> 0.0214).
-// With the fused tile-plane pass (pixel batches from 786 432 envs) the size makes no difference -- step_block_pixel_ab.jsonl:
-// 1.853-1.861 / 1.857-1.871 / 1.865-1.879 ms per step for 256 / 128 / 64 -- and that path stays at 256.
-#ifndef BBAI_STEP_BLOCK
-#define BBAI_STEP_BLOCK 64
+// Since round 4 the kernel RELIES on it: the LDS traffic of a block is ordered by the wave's program order alone.
+constexpr int STEP_BLOCK = 64;
+#ifndef BBAI_STEP_WAVES
+#define BBAI_STEP_WAVES 5          // minimum waves per SIMD the register allocation of k_step has to allow (96 VGPRs; LDS: 3.6 KB per wave)
 #endif
-#ifndef BBAI_STEP_BLOCK_FUSED
-#define BBAI_STEP_BLOCK_FUSED 256
-#endif
-template <bool EMIT> struct StepBlock { static constexpr int N = EMIT ? BBAI_STEP_BLOCK_FUSED : BBAI_STEP_BLOCK; };
-static_assert(StepBlock<false>::N % 64 == 0 && StepBlock<true>::N % 64 == 0 && StepBlock<false>::N <= 1024 && StepBlock<true>::N <= 1024,
-              "whole waves; 64 rows of 147 B keep every block's span 16-byte aligned");
 // BBAI_PREFETCH_ID=1 (experiment): the id-plane entry of the front cell fetched WITH the window.  Measured slower everywhere
 // (step_variants_ab.jsonl: BossLevel encoded 1M k_step 0.130 -> 0.148 ms, GoTo 131 072 0.021 -> 0.028): one more line per
 // env-step costs more than the verifier's occasional extra round trip.  Off.
@@ -201,19 +193,15 @@ static_assert(StepBlock<false>::N % 64 == 0 && StepBlock<true>::N % 64 == 0 && S
 // Observation with the 7x7 window staged in LDS (the k_step path).  49 scattered byte loads per lane keep the
 // texture-address unit busy for most of k_step (tools/step_ab.py ablation), so the window is fetched in WORLD
 // orientation as 7 rows x 3 aligned dwords, byte-aligned with v_alignbyte, parked in 56 dword-aligned bytes inside the
-// lane's own LDS obs row (`scr`, bbai_step.hpp row_scratch), and read back in VIEW orientation (rotation = per-direction
+// lane's own LDS scratch (`scr`, WIN_SCRATCH bytes), and read back in VIEW orientation (rotation = per-direction
 // address arithmetic on ds_read_u8).  All of a lane's reads precede its writes and lanes only touch bytes of their own
 // row, so no barrier is needed here.
-// `mb` (optional, EMIT): the same view as ONE byte per cell -- the appearance byte where the cell is visible, 0 where it is
-// not -- 49 bytes in view order [vi][vj] + 3 zero bytes: the pixel render's input (TILE_PITCH bytes per env).
 // The window's rows come from `q` (first aligned dword of row 0), `rstride` dwords apart, `off` = byte offset of the
 // window's first column inside that dword: the record's appearance plane (rstride = ES / 4) or the env's V-plane line
 // (rstride = 4).  `ce` = appearance of what the agent carries (E_EMPTY: nothing).  `fe2` receives the appearance of the
 // cell in front of the agent (view cell (3, 5)) for the verifier and the next step's transition.
-constexpr int TILE_PITCH = 52;
-// Two halves, so that the verifier (which only needs fe2) can run between them while nothing of the 37-dword encoding is
-// live yet: view_cells fetches and rotates the window (cp = the 49 cells, vis = visibility rows), encode_view writes the
-// encoding (and the plane row) from them.
+// Two halves, so that the verifier (which only needs fe2) can run between them: view_cells fetches and rotates the window
+// (cp = the 49 cells, vis = visibility rows), mask_cells zeroes the invisible ones (what the block stages in LDS).
 // window_fetch issues the loads (7 rows x 3 dwords: one dwordx3 each); view_cells consumes them.  k_step puts the rare
 // object actions (pickup / drop / toggle: dependent record loads and stores) BETWEEN the two, so their memory round trips
 // overlap the window's instead of preceding it.  Such an action changes exactly one cell of the window that was fetched
@@ -255,12 +243,9 @@ __device__ __forceinline__ void view_cells(const uint32_t* wd, int off, int dir,
         cp[idx >> 2] = (cp[idx >> 2] & ~(0xFFu << (8 * (idx & 3)))) | (ce << (8 * (idx & 3)));
     }
 }
-// Four cells at a time: a dword of (visibility-masked) appearance bytes e0..e3 becomes the 12 encoding bytes
-// t0 c0 s0 t1 | c1 s1 t2 c2 | s2 t3 c3 s3 (type = e & 7, colour = (e >> 3) & 7, state = e >> 6) with three field extractions on
-// the whole dword and six byte permutes (v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first,
-// 0x0C is zero) -- 11 instructions per four cells instead of ~55 shifting every channel byte into place on its own.
-template <bool EMIT>
-__device__ __forceinline__ void encode_view(const uint32_t* cp, const uint32_t* vis, RowPacker o, uint32_t* mb) {
+// The view with its invisible cells zeroed: 13 dwords of appearance bytes in view order [vi][vj] (49 bytes + 3 zero bytes) --
+// what the block stages in LDS; a zero cell encodes as (0, 0, 0) like the reference's invisible cell.
+__device__ __forceinline__ void mask_cells(const uint32_t* cp, const uint32_t* vis, uint32_t* xm) {
 #pragma unroll
     for (int k = 0; k < 13; ++k) {
         // the cells of this dword that are visible: byte b <- bit (idx / 7) of vis[idx % 7], idx = 4k + b
@@ -270,18 +255,8 @@ __device__ __forceinline__ void encode_view(const uint32_t* cp, const uint32_t* 
             const int idx = 4 * k + b;
             if (idx < VIEW * VIEW) m |= (uint32_t)__builtin_amdgcn_sbfe((int)vis[idx % VIEW], idx / VIEW, 1) & (0xFFu << (8 * b));   // v_bfe_i32: 0 / ~0
         }
-        const uint32_t x = cp[k] & m;
-        if (EMIT) mb[k] = x;               // the plane row = the view with the invisible cells zeroed
-        const uint32_t t = x & 0x07070707u, c = (x >> 3) & 0x07070707u, st = (x >> 6) & 0x03030303u;
-        if (k < 12) {
-            o.put(3 * k, __builtin_amdgcn_perm(__builtin_amdgcn_perm(t, c, 0x050C0004u), st, 0x07000504u));
-            o.put(3 * k + 1, __builtin_amdgcn_perm(__builtin_amdgcn_perm(c, st, 0x060C0105u), t, 0x07020504u));
-            o.put(3 * k + 2, __builtin_amdgcn_perm(__builtin_amdgcn_perm(st, t, 0x070C0306u), c, 0x07030504u));
-        } else {
-            o.put(36, (t & 0xFFu) | ((c & 0xFFu) << 8) | ((st & 0xFFu) << 16));   // cell 48: three bytes, the row's last dword
-        }
+        xm[k] = cp[k] & m;
     }
-    o.finish();
 }
 
 // Wave-cooperative observation of ONE env (used where a wave owns an env: consume_env): lane l < 49 owns view cell
@@ -299,7 +274,8 @@ __device__ __forceinline__ int observe_fetch(const LevelCfg& c, const uint8_t* _
     return e;
 }
 __device__ __forceinline__ void observe_emit(const LevelCfg& c, const uint8_t* __restrict__ rec, const Hot& h, int e,
-                                             uint8_t* __restrict__ dst, int lane, uint8_t* __restrict__ tile_row /* or NULL */) {
+                                             uint8_t* __restrict__ dst /* 147-byte encoding, or NULL */, int lane,
+                                             uint8_t* __restrict__ cell_row /* 49 masked appearance bytes (k_step's LDS staging), or NULL */) {
     const int vi = lane % VIEW, vj = lane / VIEW;
     const unsigned long long opaque = __ballot(lane < VIEW * VIEW && e_opaque(e));
     uint32_t opq[VIEW], vis[VIEW];
@@ -312,9 +288,11 @@ __device__ __forceinline__ void observe_emit(const LevelCfg& c, const uint8_t* _
 #pragma unroll
         for (int r = 0; r < VIEW; ++r) row = (vj == r) ? vis[r] : row;
         const bool v = row >> vi & 1;
-        uint8_t* o = dst + (vi * VIEW + vj) * 3;
-        o[0] = v ? e_type(e) : 0; o[1] = v ? e_color(e) : 0; o[2] = v ? e_state(e) : 0;
-        if (tile_row) tile_row[vi * VIEW + vj] = v ? (uint8_t)e : (uint8_t)0;
+        if (dst) {
+            uint8_t* o = dst + (vi * VIEW + vj) * 3;
+            o[0] = v ? e_type(e) : 0; o[1] = v ? e_color(e) : 0; o[2] = v ? e_state(e) : 0;
+        }
+        if (cell_row) cell_row[vi * VIEW + vj] = v ? (uint8_t)e : (uint8_t)0;
     }
 }
 
@@ -350,8 +328,9 @@ __device__ __forceinline__ u32x4 v_segment(const LevelCfg& c, const uint8_t* __r
 }
 
 // look-ahead slot -> live state of ONE env by ONE wave (k_consume: wave = env over the reset list; k_step<.., FUSE>: the wave that
-// stepped the env): coalesced record copy, SoA verifier view, first observation of the new episode (to `obs_dst`: the caller's
-// image row, or the block's LDS row in k_step), window plane + front cache, window bookkeeping for the batched refill.
+// stepped the env): coalesced record copy, SoA verifier view, first observation of the new episode (k_consume: the 147-byte
+// encoding to `obs_dst`, the caller's image row; k_step: the 49 masked cells to `cell_row`, the env's row of the block's LDS
+// staging), window plane + front cache, window bookkeeping for the batched refill.
 // `win_entry` = where this consumption is listed for k_pregen (NULL on reset(): the refill walks all envs).
 // The job is a handful of kilobytes per env, so what it costs is its chain of dependent memory round trips (a reset-heavy small
 // shard pays it on every step): everything that depends on nothing but the slot is LOADED FIRST, in batches that are all in
@@ -362,8 +341,8 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
                                             Hot* __restrict__ hots, uint64_t* __restrict__ stales, const uint8_t* __restrict__ next_recs,
                                             const Hot* __restrict__ next_hots, uint32_t* __restrict__ vheads, uint64_t* __restrict__ vsets,
                                             int depth, uint8_t* __restrict__ pending, uint8_t* __restrict__ first_slot,
-                                            int32_t* __restrict__ win_entry, uint8_t* __restrict__ obs_dst, uint8_t* __restrict__ dirs,
-                                            uint8_t* __restrict__ tile_row /* or NULL */, uint8_t* __restrict__ vplane /* or NULL */,
+                                            int32_t* __restrict__ win_entry, uint8_t* __restrict__ obs_dst /* or NULL */, uint8_t* __restrict__ dirs,
+                                            uint8_t* __restrict__ cell_row /* or NULL */, uint8_t* __restrict__ vplane /* or NULL */,
                                             uint16_t* __restrict__ fcache, uint8_t* __restrict__ lsm_arr /* or NULL */) {
     const int nvec = c.rec_bytes >> 4;
     const uint8_t* nrec = next_recs + ((int64_t)slot * n + env) * (int64_t)c.rec_bytes;
@@ -409,7 +388,7 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
     if (lane < 8) vsets[(int64_t)lane * n + env] = pset;
     if (lane == 8) vheads[env] = vh;
     // first observation of the new episode, straight from the slot (identical bytes to the live copy)
-    observe_emit(c, nrec, h, e_view, obs_dst, lane, tile_row);
+    observe_emit(c, nrec, h, e_view, obs_dst, lane, cell_row);
     if (lane == 0) {
         uint64_t stale0 = 0;
         uint32_t ce0 = E_EMPTY;
@@ -438,42 +417,49 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
     }
 }
 
+// wave-local ordering point for the block's LDS traffic (the block is one wave: no workgroup barrier needed)
+__device__ __forceinline__ void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // VP: the window comes from the env's V-plane line (ONE 128-byte line per step) and the transition's inputs -- the
 // appearance of the front cell and of the carried object -- from the 2-byte cache the previous step left (`fcache`), so a
 // plain move / turn touches no other record line; without VP both come out of the record (round 2's path: 2-3 lines for
 // the window + the lines of the front cell's id and the carried object's appearance).
 // FUSE: a wave whose envs finished consumes their look-ahead slots ITSELF (consume_env for every set bit of the wave's ballot,
-// the new episode's first observation straight into the block's LDS rows), instead of listing them for a k_consume launch:
-// on small shards that second launch costs as much as the step (profiles/r03: GoToLocal 65 536 envs k_step 21 us + k_consume
-// 18 us to reset 2 % of the envs).  `fuse` carries what k_consume's arguments carried.
+// the new episode's first observation straight into the block's LDS cells), instead of listing them for a k_consume launch.
+// `fuse` carries what k_consume's arguments carried.
 struct FuseArgs {
     const uint8_t* next_recs; const Hot* next_hots; uint32_t* vheads_w; uint64_t* vsets_w; int depth, pos;
     uint8_t* pending; uint8_t* first_slot; int32_t* win_list; uint32_t* win_count; unsigned long long* total_resets;
 };
-template <bool EMIT, bool VP, bool FUSE>
-__global__ __launch_bounds__(StepBlock<EMIT>::N, EMIT ? 4 : 1) void k_step(LevelCfg c, int64_t n, uint8_t* __restrict__ recs,
+template <bool VP, bool FUSE>
+__global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c, int64_t n, uint8_t* __restrict__ recs,
                                                      Hot* __restrict__ hots, uint64_t* __restrict__ stales,
                                                      const uint32_t* __restrict__ vheads, const uint64_t* __restrict__ vsets,
                                                      const uint8_t* __restrict__ actions, uint8_t* image /* read (frozen envs re-emit) AND written: no restrict */,
                                                      uint8_t* __restrict__ dirs, float* __restrict__ rewards,
                                                      double* __restrict__ rewards64, uint8_t* __restrict__ dones, int auto_reset,
                                                      int32_t* __restrict__ reset_list, uint8_t* __restrict__ reset_slot, uint32_t* __restrict__ counters,
-                                                     uint8_t* __restrict__ tiles /* EMIT: [n][TILE_PITCH] render input */, int prio,
-                                                     uint8_t* __restrict__ vplane, uint16_t* __restrict__ fcache,
+                                                     int prio, uint8_t* __restrict__ vplane, uint16_t* __restrict__ fcache,
                                                      uint8_t* __restrict__ lsm_arr /* NULL, or the done-action mode's per-env bits */,
                                                      FuseArgs fuse) {
-    constexpr int STEP_BLOCK = StepBlock<EMIT>::N;
-    static_assert(!FUSE || (STEP_BLOCK == 64 && !EMIT), "the in-wave consume relies on the block being one wave (LDS rows ordered by program order)");
-    // the block's observation rows at the OUTPUT pitch of 147 bytes (bbai_step.hpp RowPacker), 16 bytes of front padding
-    __shared__ __attribute__((aligned(16))) uint8_t s_obs[ROWS_FRONT + STEP_BLOCK * OBS_BYTES + 16];
-    uint8_t* const s_rows = s_obs + ROWS_FRONT;
+    // ONE LDS area, three uses in program order (bbai_step.hpp "staged as CELLS"): the lanes' window scratch (64 x 56 B), then the
+    // block's dense cell stream (64 x 49 B), then the transposition buffer of the copy-out (3072 B)
+    __shared__ __attribute__((aligned(16))) uint8_t s_buf[CELLS_FRONT + STEP_BLOCK * WIN_SCRATCH + 16];
+    uint8_t* const s_cells = s_buf + CELLS_FRONT;
     if (prio) __builtin_amdgcn_s_setprio(3);            // the look-ahead generator's waves share the CUs: issue ours first
-    uint32_t mb[13];
+    const int lane = (int)threadIdx.x;
     const int64_t env0 = (int64_t)blockIdx.x * STEP_BLOCK;
-    const int64_t env = env0 + threadIdx.x;
+    const int64_t env = env0 + lane;
     const bool active = env < n;
     bool want_reset = false;
     int my_slot = 0;
+    uint32_t xm[13];                                    // the lane's 49 view cells, invisible ones zeroed (+ 3 zero bytes)
+#pragma unroll
+    for (int k = 0; k < 13; ++k) xm[k] = 0;
     if (active) {
         // everything the step needs from the SoA arrays in ONE memory round trip, before the frozen test (the loads the
         // branch would otherwise delay are a second round trip on every step's critical path)
@@ -529,7 +515,7 @@ __global__ __launch_bounds__(StepBlock<EMIT>::N, EMIT ? 4 : 1) void k_step(Level
             }
             int fe2;
             uint32_t cp[13], vis[VIEW];
-            view_cells(wd, txm & 3, dir, (uint32_t)ce, nfe, s_rows + row_scratch(threadIdx.x), cp, vis, fe2);
+            view_cells(wd, txm & 3, dir, (uint32_t)ce, nfe, s_cells + WIN_SCRATCH * lane, cp, vis, fe2);
             // "env.reset() for THIS env, now" (A_RESET_ENV, bbai_step.hpp): the episode ends with done = 1, reward = 0
             const bool done = action == A_RESET_ENV ? true : finish_step(c, r, h, stale, action, fe2, reward, lsm_arr ? &lsm : nullptr, idf);
             if (lsm_arr) lsm_arr[env] = (uint8_t)lsm;
@@ -542,9 +528,10 @@ __global__ __launch_bounds__(StepBlock<EMIT>::N, EMIT ? 4 : 1) void k_step(Level
             if (rewards64) rewards64[env] = reward;        // the reference's Python float, bit for bit (levelgen.py:59-61)
             dones[env] = done ? 1 : 0;
             dirs[env] = h.dir;
-            encode_view<EMIT>(cp, vis, RowPacker(s_rows, threadIdx.x), mb);
+            mask_cells(cp, vis, xm);
         }
-        // frozen envs keep re-emitting their last outputs: copy them through LDS unchanged
+        // frozen envs keep re-emitting their last outputs: their cells are re-derived from the (caller-kept) encoding --
+        // appearance = type | colour << 3 | state << 6, and an invisible cell's (0, 0, 0) is the zero cell it came from
         else {
             if (h.frozen == 2 && auto_reset) {      // level the generator gave up on (last-resort guard): skip to the next one
                 rewards[env] = 0.0f;
@@ -553,23 +540,26 @@ __global__ __launch_bounds__(StepBlock<EMIT>::N, EMIT ? 4 : 1) void k_step(Level
                 want_reset = true;
             }
             const uint8_t* src = image + env * OBS_BYTES;
-            for (int b = 0; b < OBS_BYTES; ++b) s_rows[threadIdx.x * OBS_BYTES + b] = src[b];
-            if (EMIT) {      // the plane row of a frozen env is re-derived from its (caller-kept) encoding: type | colour << 3 | state << 6
+            for (int idx = 0; idx < VIEW * VIEW; ++idx) {
+                const uint32_t key = src[3 * idx] | (src[3 * idx + 1] << 3) | (src[3 * idx + 2] << 6);
 #pragma unroll
-                for (int k = 0; k < 13; ++k) mb[k] = 0;
-                for (int idx = 0; idx < VIEW * VIEW; ++idx) {
-                    const uint32_t key = src[3 * idx] | (src[3 * idx + 1] << 3) | (src[3 * idx + 2] << 6);
-#pragma unroll
-                    for (int k = 0; k < 13; ++k) mb[k] |= (idx >> 2) == k ? key << (8 * (idx & 3)) : 0u;
-                }
+                for (int k = 0; k < 13; ++k) xm[k] |= (idx >> 2) == k ? key << (8 * (idx & 3)) : 0u;
             }
         }
+    }
+    // Both branches are behind us: every lane's window scratch has been written and read back, and the LDS area becomes the
+    // block's dense cell stream (a lane's 49 bytes overlap OTHER lanes' scratch: this must not move into the branches above)
+    lds_sync();
+    if (active) {
+        CellPacker o(s_cells, lane);
+#pragma unroll
+        for (int k = 0; k < 13; ++k) o.put(k, xm[k]);
+        o.finish();
     }
     // compact finished envs into the reset list: one atomic per wave
     {
         unsigned long long bal = __ballot(want_reset);
         if (bal) {
-            int lane = threadIdx.x & 63;
             int leader = __ffsll((long long)bal) - 1;
             uint32_t basei = 0;
             // (FUSE: the tick's count lives in the window's count block -- what k_consume would have written there at the end)
@@ -591,50 +581,55 @@ __global__ __launch_bounds__(StepBlock<EMIT>::N, EMIT ? 4 : 1) void k_step(Level
                     const int src = __ffsll((long long)bal) - 1;
                     bal &= bal - 1;
                     const int slot = __shfl(my_slot, src);
+                    // (the new episode's first observation: 49 cells over the finished env's row of the stream)
                     consume_env(c, n, env0 + src, slot, lane, recs, hots, stales, fuse.next_recs, fuse.next_hots, fuse.vheads_w, fuse.vsets_w,
-                                fuse.depth, fuse.pending, fuse.first_slot, fuse.win_list + wbase + basei + k, s_rows + src * OBS_BYTES, dirs, nullptr,
+                                fuse.depth, fuse.pending, fuse.first_slot, fuse.win_list + wbase + basei + k, nullptr, dirs, s_cells + src * CELL_ROW,
                                 VP ? vplane : nullptr, fcache, lsm_arr);
                     ++k;
                 }
             }
         }
     }
-    __syncthreads();
-    // the block's contiguous obs span leaves as it lies in LDS: 16 bytes per lane per store (256 x 147 B = 2352 x 16 B; the
-    // span of every full block starts 16-byte aligned in the output).  The last, partial block ends with a byte tail.
+    lds_sync();
+    // Copy-out.  The block's cells are one dense stream (cell i of the stream -> output bytes 3 i .. 3 i + 2), its output one
+    // contiguous span of nb x 147 bytes that starts 16-byte aligned for every full block.  A lane takes CHUNKS of 16 cells
+    // (one aligned ds_read_b128) and expands each into 48 output bytes; per round of 64 chunks the 3072 bytes go through the
+    // (now free) LDS area once more so that every store instruction of the wave writes 1 KiB of consecutive bytes.
     const int64_t nb = n - env0 < STEP_BLOCK ? n - env0 : STEP_BLOCK;      // envs in this block
     const int total = (int)nb * OBS_BYTES;
+    const int nchunks = ((int)nb * CELL_ROW + 15) >> 4;                    // 196 for a full block: 3 rounds of 64 + one of 4
+    constexpr int ROUNDS = (STEP_BLOCK * CELL_ROW / 16 + 63) / 64;         // 4
+    u32x4 cin[ROUNDS];
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) {
+        const int ch = lane + 64 * i;
+        cin[i] = *(const u32x4*)(s_cells + 16 * (ch < nchunks ? ch : 0));   // (cells past the block's last one expand into bytes >= total: never stored)
+    }
+    lds_sync();                                                            // all cells are in registers: the area is the transposition buffer now
     uint8_t* out = image + env0 * OBS_BYTES;
-    {
-        // (a caller's buffer that is not 16-byte aligned -- a row of a [T][n][147] history with odd n -- gets dwords or bytes)
-        const int al = (int)((uintptr_t)out & 15);
+    const int al = (int)((uintptr_t)out & 15);      // (a caller's buffer that is not 16-byte aligned -- a row of a [T][n][147] history with odd n -- gets dwords or bytes)
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) {
+        if (64 * i >= nchunks) break;
+        uint32_t o[12];
+        expand_cells4(cin[i].x, o); expand_cells4(cin[i].y, o + 3); expand_cells4(cin[i].z, o + 6); expand_cells4(cin[i].w, o + 9);
+        u32x4* t = (u32x4*)(s_cells + 48 * lane);
+        { u32x4 v0 = {o[0], o[1], o[2], o[3]}, v1 = {o[4], o[5], o[6], o[7]}, v2 = {o[8], o[9], o[10], o[11]}; t[0] = v0; t[1] = v1; t[2] = v2; }
+        lds_sync();
+        const int bytes = total - 3072 * i < 3072 ? total - 3072 * i : 3072;      // this round's share of the span
+        uint8_t* dst = out + 3072 * i;
         int done_bytes = 0;
         if (al == 0) {
-            const int nvec = total >> 4;
-            const u32x4* s128 = (const u32x4*)s_rows;
-            for (int v = threadIdx.x; v < nvec; v += STEP_BLOCK) ((u32x4*)out)[v] = s128[v];     // (non-temporal here: measured, no effect -- profiles/r03/NOTES.md)
+            const int nvec = bytes >> 4;
+            for (int v = lane; v < nvec; v += 64) ((u32x4*)dst)[v] = ((const u32x4*)s_cells)[v];
             done_bytes = nvec << 4;
         } else if ((al & 3) == 0) {
-            const int ndw = total >> 2;
-            const uint32_t* s32 = (const uint32_t*)s_rows;
-            for (int d = threadIdx.x; d < ndw; d += STEP_BLOCK) ((uint32_t*)out)[d] = s32[d];
+            const int ndw = bytes >> 2;
+            for (int d = lane; d < ndw; d += 64) ((uint32_t*)dst)[d] = ((const uint32_t*)s_cells)[d];
             done_bytes = ndw << 2;
         }
-        for (int b = done_bytes + threadIdx.x; b < total; b += STEP_BLOCK) out[b] = s_rows[b];
-    }
-    if (EMIT) {
-        // second pass through the same LDS: the block's tile-plane rows (52 B per env, LDS pitch == output pitch) leave as
-        // one contiguous dword span, written LAST so that the render finds them in the memory-side cache
-        __syncthreads();
-        uint32_t* s32 = (uint32_t*)s_obs;
-        if (active) {
-#pragma unroll
-            for (int k = 0; k < 13; ++k) s32[threadIdx.x * 13 + k] = mb[k];
-        }
-        __syncthreads();
-        uint32_t* tout = (uint32_t*)(tiles + env0 * TILE_PITCH);
-        const int tdw = (int)nb * 13;
-        for (int d = threadIdx.x; d < tdw; d += STEP_BLOCK) tout[d] = s32[d];
+        for (int b = done_bytes + lane; b < bytes; b += 64) dst[b] = s_cells[b];
+        lds_sync();                                                        // before the next round overwrites the buffer
     }
 }
 
@@ -669,11 +664,15 @@ struct GroupCtx {
 // group's LDS block, then one ATTEMPT of the generator's rejection loop per trip of the main loop (Gen::attempt) -- a
 // group whose attempt was accepted writes the level out and goes on to its next level / env while its neighbours retry,
 // so the wave only idles lanes inside an attempt, never across attempts.
+// Minimum waves per SIMD the generator's register allocation has to allow.  4 (<= 128 VGPRs) instead of the 3 the compiler
+// settles on by itself (131-135 VGPRs at two envs per wave): PickupLoc 262 144 envs 0.0939 -> 0.0877 ms per step, the GoTo family
+// already fits (profiles/r04/pregen_waves_per_simd_ab.jsonl).  The bonus family would spill (167 VGPRs) and four envs per wave
+// need 200: those keep 2.
 #ifndef BBAI_PREGEN_WAVES
-#define BBAI_PREGEN_WAVES 2        // minimum waves per SIMD the register allocation has to allow (experiment builds: 3, 4)
+#define BBAI_PREGEN_WAVES 4
 #endif
 template <int KIND, int G>
-__global__ __launch_bounds__(64, BBAI_PREGEN_WAVES) void k_pregen(LevelCfg c, int64_t n, uint8_t* __restrict__ next_recs,
+__global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_WAVES) void k_pregen(LevelCfg c, int64_t n, uint8_t* __restrict__ next_recs,
                                                   Hot* __restrict__ next_hots, uint32_t* __restrict__ mts,
                                                   int32_t* __restrict__ mtis, const int32_t* __restrict__ win_list,
                                                   const uint32_t* __restrict__ win_count, int all, int depth,
@@ -803,7 +802,7 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
                                                  uint8_t* __restrict__ pending, uint8_t* __restrict__ first_slot,
                                                  int32_t* __restrict__ win_list, uint32_t* __restrict__ win_count, int pos,
                                                  uint8_t* __restrict__ image, uint8_t* __restrict__ dirs,
-                                                 uint32_t* __restrict__ other_counter, uint8_t* __restrict__ tiles /* or NULL */, int prio,
+                                                 uint32_t* __restrict__ other_counter, int prio,
                                                  uint8_t* __restrict__ vplane /* or NULL */, uint16_t* __restrict__ fcache,
                                                  uint8_t* __restrict__ lsm_arr /* or NULL */) {
     if (prio) __builtin_amdgcn_s_setprio(3);
@@ -817,7 +816,7 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
         const int64_t env = all ? it : (int64_t)reset_list[it];
         const int slot = all ? (int)hots[env].slot : (int)reset_slot[it];       // (k_step listed it next to the env: no round trip through the env's state)
         consume_env(c, n, env, slot, lane, recs, hots, stales, next_recs, next_hots, vheads, vsets, depth, pending, first_slot,
-                    all ? nullptr : win_list + base + it, image + env * OBS_BYTES, dirs, tiles ? tiles + env * TILE_PITCH : nullptr, vplane, fcache,
+                    all ? nullptr : win_list + base + it, image + env * OBS_BYTES, dirs, nullptr, vplane, fcache,
                     lsm_arr);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -922,7 +921,7 @@ __global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, Hot* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // k_render : encoded obs -> 56x56x3 pixels through the tile atlas
 // ------------------------------------------------------------------------------------------
-constexpr int RENDER_QUEUE_DEFAULT = 1;         // queue shape of render_launch used from 786 432 envs up
+constexpr int RENDER_QUEUE_DEFAULT = 1;         // queue shape of render_launch used from 262 144 envs up
 constexpr int CHUNKS_PER_ROW = PIX * 3 / 8;       // 21 eight-byte chunks per pixel row
 constexpr int VEC_PER_ENV = PIX_BYTES / 16;       // 588 sixteen-byte stores per env
 
@@ -935,9 +934,10 @@ __device__ __forceinline__ uint64_t render_chunk(const uint8_t* s_atlas, const u
     return *(const uint64_t*)(s_atlas + tile * TILE_BYTES + ty * 24 + part * 8);
 }
 
-// FROM_PLANE: `image` is the fused tile plane ([n][TILE_PITCH], one masked appearance byte per cell, written by k_step /
-// k_consume) instead of the 147-byte encoding: a third of the input bytes, and the last thing the step wrote.
-template <int RENDER_GROUP, int RENDER_BLOCK, bool FROM_PLANE>     // envs per block iteration (between two barriers); threads per block
+// (Round 3's alternative input -- a fused tile plane, one masked appearance byte per cell, left behind by k_step -- was measured
+// once more with the ticket queue in round 4 (profiles/r04/render_queue_counters_1M_lease_d.jsonl: k_render 1.503 vs 1.505 ms, k_step
+// + 0.02 ms) and removed.)
+template <int RENDER_GROUP, int RENDER_BLOCK>     // envs per block iteration (between two barriers); threads per block
 __global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_t* __restrict__ image,
                                                          uint8_t* __restrict__ pixels, const uint8_t* __restrict__ atlas,
                                                          const uint8_t* __restrict__ lut, int n_tiles) {
@@ -955,13 +955,8 @@ __global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_
         // encoded cell -> atlas tile, once per cell (49 per env)
         for (int c = threadIdx.x; c < ne * VIEW * VIEW; c += RENDER_BLOCK) {
             const int e = c / (VIEW * VIEW), cell = c - e * (VIEW * VIEW);
-            int key;
-            if (FROM_PLANE) {
-                key = image[(env0 + e) * TILE_PITCH + cell];
-            } else {
-                const uint8_t* o = image + (env0 + e) * OBS_BYTES + cell * 3;
-                key = o[0] | (o[1] << 3) | (o[2] << 6);
-            }
+            const uint8_t* o = image + (env0 + e) * OBS_BYTES + cell * 3;
+            const int key = o[0] | (o[1] << 3) | (o[2] << 6);
             s_tile[c] = s_lut[(cell == 3 * VIEW + 6 ? 256 : 0) + key];
         }
         __syncthreads();
@@ -978,20 +973,18 @@ __global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_
     }
 }
 
-// k_render_q: the same render from PERSISTENT blocks (the atlas is loaded into LDS once per block) that take their work from
-// atomic ticket counters, so that the chip's stores advance through the output as ONE compact window -- the order in which the
-// pure store stream is fastest (profiles/r03/NOTES.md section 13: stand-alone 1.60 ms against 1.74-1.77 for the one-shot
-// (1024, 8) shape at 1 048 576 envs; inside the step loop 1.61 against 1.71 ms).
-//   * a ticket = K consecutive G-env groups ("super-group"); the next ticket is taken while the first group of the current
-//     one is being staged, so its latency rides under the stores;
-//   * NC counters, 256 bytes apart, INTERLEAVED: ticket t of counter c is super-group t * NC + c, and a block uses counter
-//     blockIdx % NC (= its XCD for NC = 8: MI355X_MICROARCH.md "dequeue": one word serves ~88 tickets/us, "shard the head per
-//     XCD") -- the counters advance through the output together, so there is still one window, not NC of them (round 3's
-//     partitioned counters -- each its own NC-th of the batch -- lost that: 8 windows are free, 32 are not);
+// k_render_q: the same render from PERSISTENT blocks (the atlas is loaded into LDS once per block) that take their work from an
+// atomic ticket counter, so that the chip's stores advance through the output as ONE compact, evenly paced window -- the order
+// in which the pure store stream is fastest (render_launch has the measurements).
+//   * a ticket = K consecutive G-env groups; the next ticket is taken while the first group of the current one is being
+//     staged, so its latency rides under the stores;
+//   * NC counters, 256 bytes apart, INTERLEAVED: ticket t of counter c is super-group t * NC + c, a block uses counter
+//     blockIdx % NC (= its XCD for NC = 8).  Shipped: NC = 1, K = 1 -- more counters or bigger tickets relieve the ticket rate
+//     (~88 M/s per address) and measure SLOWER: the counters drift apart, the window widens;
 //   * the counters clean up after themselves: the last block to leave (a departure counter) zeroes them for the next launch,
 //     so the step path carries no memset.
 // Tile rows and tickets are double-buffered: one barrier per group.
-template <int RENDER_GROUP, int RENDER_BLOCK, bool FROM_PLANE, int NC, int K>
+template <int RENDER_GROUP, int RENDER_BLOCK, int NC, int K>
 __global__ __launch_bounds__(RENDER_BLOCK) void k_render_q(int64_t n, const uint8_t* __restrict__ image,
                                                            uint8_t* __restrict__ pixels, const uint8_t* __restrict__ atlas,
                                                            const uint8_t* __restrict__ lut, int n_tiles, unsigned int* __restrict__ counters) {
@@ -1020,13 +1013,8 @@ __global__ __launch_bounds__(RENDER_BLOCK) void k_render_q(int64_t n, const uint
             const int ne = (int)(n - env0 < RENDER_GROUP ? n - env0 : RENDER_GROUP);
             for (int c = threadIdx.x; c < ne * VIEW * VIEW; c += RENDER_BLOCK) {
                 const int e = c / (VIEW * VIEW), cell = c - e * (VIEW * VIEW);
-                int key;
-                if (FROM_PLANE) {
-                    key = image[(env0 + e) * TILE_PITCH + cell];
-                } else {
-                    const uint8_t* o = image + (env0 + e) * OBS_BYTES + cell * 3;
-                    key = o[0] | (o[1] << 3) | (o[2] << 6);
-                }
+                const uint8_t* o = image + (env0 + e) * OBS_BYTES + cell * 3;
+                const int key = o[0] | (o[1] << 3) | (o[2] << 6);
                 s_tile[buf][c] = s_lut[(cell == 3 * VIEW + 6 ? 256 : 0) + key];
             }
             if (kk == 0 && threadIdx.x == 0) s_ticket[tp ^ 1] = atomicAdd(counter, 1u);      // the next ticket rides under this one's stores
@@ -1354,7 +1342,7 @@ void bbai_destroy(bbai_env* e) {
     void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
     void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_list, e->win_count, e->reset_list, e->counters,
-                    e->total_resets, e->atlas, e->lut, e->tiles, e->vplane, e->fcache, e->lsm, e->render_tickets, e->reset_slot};
+                    e->total_resets, e->atlas, e->lut, e->vplane, e->fcache, e->lsm, e->render_tickets, e->reset_slot};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete e;
 }
@@ -1521,7 +1509,7 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
                        e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, e->reset_list, e->reset_slot, e->counters + 16 * e->step_parity, all,
                        e->total_resets, e->depth, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n,
                        e->win_list + (size_t)wb * e->period * e->n, e->win_count + WIN_STRIDE * wb, pos, image, dirs,
-                       e->counters + 16 * (e->step_parity ^ 1), e->tiles, e->step_prio, e->vplane, e->fcache, e->lsm);
+                       e->counters + 16 * (e->step_parity ^ 1), e->step_prio, e->vplane, e->fcache, e->lsm);
     }
     return window_end(e, s, all, false);
 }
@@ -1566,15 +1554,13 @@ int bbai_reset(bbai_env* e, uint8_t* image, uint8_t* dirs, void* stream) {
     int rc = consume_and_refill(e, s, image, dirs, 1);
     if (rc != BBAI_OK) return rc;
     e->live = true;
-    e->tiles_valid = e->tiles != nullptr;
     return call.leave();
 }
 
 // k_step (+ the consume / refill of the envs it finished) on stream s; the caller has entered the call
 static bool use_fused_consume(const bbai_env* e) {
     // option "consume_fused" / BBAI_CONSUME_FUSED: 1 = the stepping wave consumes its finished envs itself, 0 = k_consume launch,
-    // -1 (default) = by batch size (CONSUME_FUSED_MAX_ENVS).  Never with the fused tile plane (that k_step keeps 256-thread blocks).
-    if (e->tiles) return false;
+    // -1 (default) = by level family.
     if (e->consume_fused >= 0) return e->consume_fused != 0;
     // Measured (profiles/r04/consume_fused_ab.jsonl, ms per step unfused -> fused): the mazes win -- GoTo 131 072 envs 0.046 -> 0.041,
     // GoTo 1 048 576 0.245 -> 0.211, BossLevel encoded 1 048 576 0.137 -> 0.125, pixels 1.718 -> 1.710 -- their episodes last hundreds of steps,
@@ -1604,13 +1590,11 @@ static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint
     }
     {
         ProfScope prof_(e, 0, s);
-#define STEP_LAUNCH(EM, VV, FF) hipLaunchKernelGGL((k_step<EM, VV, FF>), dim3((unsigned)((e->n + StepBlock<EM>::N - 1) / StepBlock<EM>::N)), dim3(StepBlock<EM>::N), 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, \
-                                               image, dirs, rewards, rewards64, dones, auto_reset, list, e->reset_slot, counter, e->tiles, e->step_prio, e->vplane, e->fcache, e->lsm, fa)
-        if (e->tiles) { if (e->vplane) STEP_LAUNCH(true, true, false); else STEP_LAUNCH(true, false, false); }
-        else if (fused) { if (e->vplane) STEP_LAUNCH(false, true, true); else STEP_LAUNCH(false, false, true); }
-        else { if (e->vplane) STEP_LAUNCH(false, true, false); else STEP_LAUNCH(false, false, false); }
+#define STEP_LAUNCH(VV, FF) hipLaunchKernelGGL((k_step<VV, FF>), dim3((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), dim3(STEP_BLOCK), 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, \
+                                           image, dirs, rewards, rewards64, dones, auto_reset, list, e->reset_slot, counter, e->step_prio, e->vplane, e->fcache, e->lsm, fa)
+        if (fused) { if (e->vplane) STEP_LAUNCH(true, true); else STEP_LAUNCH(false, true); }
+        else { if (e->vplane) STEP_LAUNCH(true, false); else STEP_LAUNCH(false, false); }
 #undef STEP_LAUNCH
-        e->tiles_valid = e->tiles != nullptr;
     }
     HIP_TRY(hipGetLastError());
     // the number of finished envs is only known on the device: fixed grids, device-side count
@@ -1640,87 +1624,66 @@ int bbai_set_atlas(bbai_env* e, const uint8_t* tiles, int n_tiles, const uint8_t
     HIP_TRY(hipMemcpy(e->atlas, tiles, (size_t)n_tiles * TILE_BYTES, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->lut, lut, 512, hipMemcpyHostToDevice));
     e->n_tiles = n_tiles;
-    // Pixel mode with BBAI_RENDER_FUSED=1: from now on reset / step also keep the fused tile plane of the current observations
-    // (bbai_render_current).  OFF by default since the end of round 3.  What was measured, always inside the step loop at
-    // 1 048 576 envs, modes alternated within one lease:
-    //   * mid round 3 (profiles/r03/render_fused_ab_*.jsonl): render from the plane with (512, 4) blocks 1.59 ms against 1.68 ms
-    //     from the encoding with (1024, 8), step 1.78 against 1.85 ms; at 131 072 envs the plane only costs (0.243 vs 0.231 ms);
-    //   * end of round 3, two other boxes, with the one-wave-per-block k_step of the encoded path (the fused pass keeps 256-thread
-    //     blocks and costs k_step 0.02 ms): profiles/r03/render_fused_ab_final.jsonl 1.868 / 1.869 / 1.868 ms per step from the
-    //     plane against 1.821 / 1.828 / 1.819 from the encoding (k_render 1.73 ms either way);
-    //     render_fused_by_step_build.jsonl: from the encoding ahead in three of four pairs, with this and the previous k_step.
-    // The plane pays on boxes where the render's input residency matters (k_render 1.59) and costs on those where the store
-    // stream alone decides (k_render 1.73): six boxes of the second kind in a row decided the default.
-    const char* fv = getenv("BBAI_RENDER_FUSED");
-    const bool want = fv && atoi(fv) != 0;
-    if (!e->tiles && want) {
-        HIP_TRY(hipMalloc((void**)&e->tiles, (size_t)e->n * TILE_PITCH));
-        HIP_TRY(hipMemset(e->tiles, 0, (size_t)e->n * TILE_PITCH));
-        e->tiles_valid = false;
-    }
     return BBAI_OK;
 }
 
 }  // extern "C"
 
-template <bool FROM_PLANE>
 static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, void* stream) {
-    // Launch shape: ONE G-env group (G x 9.4 KB of pixels) per one-shot block of T threads.  Chosen by wall-clock step time
-    // inside the real bench, shapes alternated within one lease, on fast and slow boxes (profiles/r02/render_shape_*.jsonl,
-    // render_tpb_*.jsonl): (T, G) = (1024, 8) from 786 432 envs up, (512, 2) below.  Against round 1's looped shape (256
-    // threads, 8 envs per barrier pair, 64 envs per block): 1 048 576 envs 1.80-1.85 vs 1.99-2.15 ms per step on the slow
-    // boxes, 131 072 envs 0.224 vs 0.267-0.282.  Every block pays the 11 KB atlas load into LDS (L2 hits).
-    // BBAI_RENDER_GROUP / BBAI_RENDER_TPB override (experiments).
     CallScope call(e, (hipStream_t)stream);
     if (call.rc != BBAI_OK) return call.rc;
     {
     ProfScope prof_(e, 2, (hipStream_t)stream);
-    // (round 3, from the tile plane: (512, 4) from 786 432 envs up -- 1.59 ms at 1 048 576 envs against 1.62-1.66 for
-    // (1024, 8) and 1.81-1.85 for (512, 2), profiles/r03/render_fused_ab_1M.jsonl)
+    // From 262 144 envs up: k_render_q -- ONE persistent 1024-thread block per CU, 8-env groups handed out by ONE ticket
+    // counter.  Everything below was measured inside the step loop, settings alternated in one process (tools/ab.py),
+    // 1 048 576 BossLevel envs, k_render ms per launch (profiles/r04/render_queue_*.jsonl; four leases = four boxes):
+    //   one-shot (1024, 8) blocks (rounds 2-3)                         1.64 - 1.72
+    //   queue, two blocks per CU, one counter (round 3's lead)         1.60 - 1.61
+    //   queue, ONE block per CU (256 blocks), one counter              1.50            <- shipped: 6.67 TB/s, 0.83 of peak
+    //   ... 192 / 224 / 320 / 512 blocks                               1.66 / 1.53 / 1.51 / 1.64;   128: 2.14
+    //   ... two / eight interleaved counters                           1.56 / 1.69 - 1.77
+    //   ... 2 groups per ticket, 12- / 16-env groups                   1.60 / 1.55 - 1.58 / 1.61
+    //   ... 512- / 256-thread blocks (8-env groups)                    1.61 - 1.63 / 1.57 (512 blocks)
+    // One counter serves ~88 M tickets/s (131 072 tickets = 1.49 ms): the shipped shape runs AT the ticket rate, and every
+    // way of relieving it (more counters, bigger tickets) is slower -- the single counter is what keeps the chip's stores one
+    // compact, evenly paced window.  By batch size (queue vs the one-shot shape of that size, ms per step): 131 072 envs
+    // 0.221 vs 0.214, 262 144 0.414 vs 0.418, 393 216 0.614 vs 0.639, 524 288 0.809 vs 0.848 -- below 262 144 the whole
+    // encoding is still in the memory-side cache and short-lived (512, 2) blocks win.
+    // BBAI_RENDER_QUEUE / option "render_queue": -1 = by batch size (default), 0 = never, m > 0 = queue shape m of the table below.
     const bool big = e->n >= 786432;
-    // Persistent blocks fed by ticket counters (k_render_q) from 786 432 envs up; one-shot blocks below, where the whole
-    // encoding is still in the memory-side cache and the (512, 2) one-shot shape wins.  BBAI_RENDER_QUEUE / option
-    // "render_queue": -1 = by batch size (default), 0 = never, m > 0 = queue shape m of the table below.
     int qm = e->render_queue;
-    if (qm < 0) qm = big ? RENDER_QUEUE_DEFAULT : 0;
+    if (qm < 0) qm = e->n >= 262144 ? RENDER_QUEUE_DEFAULT : 0;
     if (qm > 0) {
         const int cus = e->n_cus > 0 ? e->n_cus : 256;
 #define RENDER_Q(GG, TT, NC, KK) do { \
             const int64_t tickets = ((e->n + GG - 1) / GG + KK - 1) / KK; \
             const int64_t want = e->render_queue_blocks > 0 ? e->render_queue_blocks : (e->render_queue_bpc > 0 ? (int64_t)cus * e->render_queue_bpc : (int64_t)cus * 1024 / TT); \
             const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, tickets)); \
-            hipLaunchKernelGGL((k_render_q<GG, TT, FROM_PLANE, NC, KK>), dim3(blocks), dim3(TT), 0, (hipStream_t)stream, e->n, input, pixels, \
+            hipLaunchKernelGGL((k_render_q<GG, TT, NC, KK>), dim3(blocks), dim3(TT), 0, (hipStream_t)stream, e->n, input, pixels, \
                                e->atlas, e->lut, e->n_tiles, e->render_tickets); } while (0)
-        switch (qm) {
-        case 1: RENDER_Q(8, 1024, 1, 1); break;       // round 3's measurement: one counter, one group per ticket (ticket-bound at 1 M envs)
-        case 2: RENDER_Q(8, 1024, 8, 1); break;       // eight interleaved counters
-        case 3: RENDER_Q(8, 1024, 1, 2); break;       // two / four groups per ticket
-        case 4: RENDER_Q(8, 1024, 1, 4); break;
-        case 5: RENDER_Q(8, 1024, 8, 2); break;
-        case 6: RENDER_Q(4, 512, 8, 1); break;
-        case 7: RENDER_Q(2, 512, 8, 1); break;
-        case 8: RENDER_Q(4, 1024, 8, 1); break;
-        case 9: RENDER_Q(2, 256, 8, 1); break;
-        case 10: RENDER_Q(16, 1024, 8, 1); break;
-        case 11: RENDER_Q(4, 512, 8, 2); break;
-        case 12: RENDER_Q(8, 1024, 2, 1); break;
-        case 13: RENDER_Q(16, 1024, 1, 1); break;
-        case 14: RENDER_Q(12, 1024, 1, 1); break;
-        case 15: RENDER_Q(8, 512, 1, 1); break;
-        case 16: RENDER_Q(4, 512, 1, 2); break;
-        case 17: RENDER_Q(8, 256, 1, 1); break;
-        case 18: RENDER_Q(16, 1024, 1, 2); break;
-        default: RENDER_Q(8, 1024, 8, 1); break;
+        switch (qm) {          // (shapes other than 1 stay for measurements: tests/test_gpu_parity.py checks every one byte for byte)
+        default:
+        case 1: RENDER_Q(8, 1024, 1, 1); break;       // shipped
+        case 2: RENDER_Q(8, 1024, 8, 1); break;       // eight / two interleaved counters
+        case 3: RENDER_Q(8, 1024, 2, 1); break;
+        case 4: RENDER_Q(8, 1024, 1, 2); break;       // two groups per ticket
+        case 5: RENDER_Q(12, 1024, 1, 1); break;      // bigger groups
+        case 6: RENDER_Q(16, 1024, 1, 1); break;
+        case 7: RENDER_Q(8, 512, 1, 1); break;        // smaller blocks
+        case 8: RENDER_Q(8, 256, 1, 1); break;
+        case 9: RENDER_Q(2, 512, 8, 1); break;        // small groups need more counters (524 288 tickets)
         }
 #undef RENDER_Q
         HIP_TRY(hipGetLastError());
         return call.leave();
     }
+    // Below: ONE G-env group per one-shot block of T threads, (512, 2) (round 2: profiles/r02/render_shape_*.jsonl; (1024, 8) from
+    // 786 432 envs when the queue is switched off).  BBAI_RENDER_GROUP / BBAI_RENDER_TPB override (experiments).
     int G = e->render_group, T = e->render_tpb;
-    if (G != 2 && G != 4 && G != 8) G = big ? (FROM_PLANE ? 4 : 8) : 2;
-    if (T != 256 && T != 512 && T != 1024) T = big ? (FROM_PLANE ? 512 : 1024) : 512;
+    if (G != 2 && G != 4 && G != 8) G = big ? 8 : 2;
+    if (T != 256 && T != 512 && T != 1024) T = big ? 1024 : 512;
     const dim3 grid((unsigned)((e->n + G - 1) / G));
-#define RENDER_LAUNCH(GG, TT) hipLaunchKernelGGL((k_render<GG, TT, FROM_PLANE>), grid, dim3(TT), 0, (hipStream_t)stream, e->n, input, pixels, e->atlas, e->lut, e->n_tiles)
+#define RENDER_LAUNCH(GG, TT) hipLaunchKernelGGL((k_render<GG, TT>), grid, dim3(TT), 0, (hipStream_t)stream, e->n, input, pixels, e->atlas, e->lut, e->n_tiles)
 #define RENDER_G(GG) do { if (T == 1024) RENDER_LAUNCH(GG, 1024); else if (T == 512) RENDER_LAUNCH(GG, 512); else RENDER_LAUNCH(GG, 256); } while (0)
     if (G == 2) RENDER_G(2); else if (G == 4) RENDER_G(4); else RENDER_G(8);
 #undef RENDER_G
@@ -1736,16 +1699,7 @@ int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream
     if (!e || !image || !pixels) ARG_FAIL("null handle or buffer");
     if (e->n_tiles <= 0) { snprintf(g_err, sizeof(g_err), "render before set_atlas"); return BBAI_ERR_STATE; }
     ON_DEVICE(e->device);
-    return render_launch<false>(e, image, pixels, stream);
-}
-
-// The pixels of the CURRENT observation of every env, from the tile plane the last reset / step left behind.
-int bbai_render_current(bbai_env* e, uint8_t* pixels, void* stream) {
-    if (!e || !pixels) ARG_FAIL("null handle or buffer");
-    if (e->n_tiles <= 0) { snprintf(g_err, sizeof(g_err), "render before set_atlas"); return BBAI_ERR_STATE; }
-    if (!e->tiles || !e->tiles_valid) { snprintf(g_err, sizeof(g_err), "render_current: no reset / step since set_atlas (or BBAI_RENDER_FUSED=0)"); return BBAI_ERR_STATE; }
-    ON_DEVICE(e->device);
-    return render_launch<true>(e, e->tiles, pixels, stream);
+    return render_launch(e, image, pixels, stream);
 }
 
 // Register (or clear with NULL) a caller-owned uint8[n][72] device buffer that the engine keeps filled with the
@@ -1791,7 +1745,6 @@ int bbai_import_state(bbai_env* e, int64_t first, int64_t count, const uint8_t* 
     if (rec) HIP_TRY(hipMemcpy(e->rec + first * e->cfg.rec_bytes, rec, (size_t)count * e->cfg.rec_bytes, hipMemcpyHostToDevice));
     if (hot) HIP_TRY(hipMemcpy(e->hot + first, hot, (size_t)count * sizeof(Hot), hipMemcpyHostToDevice));
     if (stale) HIP_TRY(hipMemcpy(e->stale + first, stale, (size_t)count * 8, hipMemcpyHostToDevice));
-    e->tiles_valid = false;             // (the plane describes observations; the next reset / step rewrites it)
     if (e->lsm && count > 0) HIP_TRY(hipMemset(e->lsm + first, 0, (size_t)count));     // (not part of the exported state: lastStepMatch = False)
     if (rec && count > 0) {
         hipLaunchKernelGGL(k_sync_prog, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, e->cfg, e->n, first, count, e->rec,
@@ -1914,7 +1867,6 @@ int bbai_checkpoint_load(bbai_env* e, const void* host_buf, int64_t bytes) {
     const uint8_t* src = (const uint8_t*)host_buf + sizeof(CkptHeader);
     for (int i = 0; i < k; ++i) { HIP_TRY(hipMemcpy(seg[i].p, src, seg[i].bytes, hipMemcpyHostToDevice)); src += seg[i].bytes; }
     e->step_parity = h.step_parity; e->next_counter_clean = h.next_counter_clean != 0; e->seeded = h.seeded != 0; e->live = h.live != 0;
-    e->tiles_valid = false;
     for (int i = 0; i < 3; ++i) e->win_all[i] = h.win_all[i];
     e->tick = h.tick;
     // the refill events of the saved run completed before the save: re-record them on the (idle) look-ahead stream
@@ -2084,7 +2036,6 @@ int bbai_set_call_events(bbai_env* e, int enable) {
     return BBAI_OK;
 }
 
-int bbai_has_tile_plane(bbai_env* e) { return e && e->tiles ? 1 : 0; }
 
 // The reference's BABYAI_DONE_ACTIONS verifier mode for this handle (on by default iff that variable was non-empty at
 // bbai_create, as the reference reads it at import).  Switching it resets every env's lastStepMatch bits.
@@ -2116,18 +2067,7 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     else if (!strcmp(name, "pregen_group")) e->pregen_group = v;
     else if (!strcmp(name, "pregen_blocks")) e->pregen_cap = std::max(64, v);
     else if (!strcmp(name, "consume_fused")) e->consume_fused = v;
-    else if (!strcmp(name, "render_fused")) {
-        // keep (1) or drop (0) the fused tile plane of bbai_render_current; needs an installed atlas
-        if (v && !e->tiles) {
-            if (e->n_tiles <= 0) { snprintf(g_err, sizeof(g_err), "set_option(render_fused): no atlas installed"); return BBAI_ERR_STATE; }
-            HIP_TRY(hipMalloc((void**)&e->tiles, (size_t)e->n * TILE_PITCH));
-            HIP_TRY(hipMemset(e->tiles, 0, (size_t)e->n * TILE_PITCH));
-        } else if (!v && e->tiles) {
-            HIP_TRY(hipFree(e->tiles));
-            e->tiles = nullptr;
-        }
-        e->tiles_valid = false;
-    } else {
+    else {
         snprintf(g_err, sizeof(g_err), "set_option: unknown option '%s'", name);
         return BBAI_ERR_ARG;
     }

@@ -306,14 +306,17 @@ BB_HD void process_vis_rows(const uint32_t opq[VIEW], uint32_t vis[VIEW]) {
     }
 }
 
-// ---- k_step's observation rows in LDS, packed at the OUTPUT pitch ----------------------------------------------------------
-// A block's 256 observations leave as one contiguous span of 256 x 147 bytes.  With the rows parked in LDS at that same
-// 147-byte pitch the copy-out is a plain 16-byte-per-lane stream (ds_read_b128 -> global_store_dwordx4); parked at a
-// dword-aligned 148-byte pitch instead (round 2 / early round 3) every output dword had to be re-assembled from three LDS
-// dwords -- 26 VALU instructions per dword, a third of k_step's vector work.  The price is paid once per lane here: the
-// lane's 37 encoding dwords are shifted by its row's byte phase (one v_alignbyte_b32 each) and written as ALIGNED dwords;
-// the first and last bytes of a row share a dword with the neighbouring rows and go out as byte writes, so lanes never
-// touch each other's bytes and no barrier is needed before the block-wide one.
+// ---- k_step's observations in LDS: staged as CELLS, expanded on the way out -------------------------------------------
+// A block's 64 observations leave as one contiguous span of 64 x 147 bytes, and 147 = 49 cells x 3 channel bytes.  Round 3
+// parked the finished 147-byte rows in LDS (RowPacker: 9.4 KB per wave, 37 shifted dwords per lane, ~500 VALU per lane for the
+// byte-granular encoding).  Round 4 parks the 49 masked appearance bytes per env instead (3.1 KB per wave), back to back at
+// a 49-byte pitch, so that the block's cells form ONE dense stream in which cell i becomes output bytes 3 i .. 3 i + 2 whatever
+// env it belongs to: sixteen cells (one aligned ds_read_b128) expand into 48 output bytes (three dwordx4) with the same
+// byte-permute trick, per CHUNK instead of per lane-row -- a third of the packing work, the encode on aligned data, and an LDS
+// footprint that no longer limits how many waves a CU holds.
+// CellPacker: the lane's 13 cell dwords (49 bytes + 3 zero bytes) shifted by the row's byte phase and written as aligned
+// dwords; the first and last bytes of a row share a dword with the neighbouring rows and go out as byte writes, so lanes never
+// touch each other's bytes.
 BB_HD uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t s) {     // ({hi, lo} >> 8 s) & 0xFFFFFFFF, s = 0..3
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_alignbyte(hi, lo, s);
@@ -321,41 +324,66 @@ BB_HD uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t s) {     // ({hi, 
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (s & 3)));
 #endif
 }
-constexpr int ROWS_FRONT = 16;       // bytes in front of row 0 (row 0's "previous dword" exists; keeps the span 16-byte aligned)
-struct RowPacker {
-    uint8_t* p;          // dword j of the lane's shifted stream lives at p + 4 j
+// v_perm_b32: byte i of the result = byte sel[i] of {a, b} (0-3: b, 4-7: a), 0x0C = zero
+BB_HD uint32_t perm_b32(uint32_t a, uint32_t b, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(a, b, sel);
+#else
+    const uint64_t src = ((uint64_t)a << 32) | b;
+    uint32_t out = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t k = (sel >> (8 * i)) & 0xFFu;
+        const uint32_t byte = k < 8 ? (uint32_t)(src >> (8 * k)) & 0xFFu : 0u;      // (only 0..7 and 0x0C are used)
+        out |= byte << (8 * i);
+    }
+    return out;
+#endif
+}
+constexpr int CELL_ROW = VIEW * VIEW;    // 49 cells = 49 staged bytes per env
+constexpr int CELLS_FRONT = 16;          // bytes in front of row 0 (row 0's "previous dword" exists; keeps the stream 16-byte aligned)
+struct CellPacker {
+    uint8_t* p;          // LDS dword j of the lane's shifted stream lives at p + 4 j
     uint32_t prev, s;
     int shp;             // 1..4: bytes of the row's first LDS dword that belong to the previous row
-    // `rows` = LDS byte ROWS_FRONT of the block's row area (16-byte aligned), row r = bytes [147 r, 147 r + 147)
-    BB_HD RowPacker(uint8_t* rows, int r) {
-        const int base = r * OBS_BYTES;
+    // `rows` = the block's cell area (16-byte aligned), row r = bytes [49 r, 49 r + 49)
+    BB_HD CellPacker(uint8_t* rows, int r) {
+        const int base = r * CELL_ROW;
         shp = (base & 3) ? (base & 3) : 4;
         p = rows + (base - shp);
         s = (uint32_t)(4 - shp);
         prev = 0;
     }
-    // dword j of the row (j = 0..36, in order; dword 36 = the last three bytes + one zero byte)
+    // dword j of the row (j = 0..12, in order; dword 12 = cell 48 + three zero bytes)
     BB_HD void put(int j, uint32_t d) {
         const uint32_t w = align_bytes(d, prev, s);
-        if (j == 0) {        // stream bytes 0 .. 3 - shp, at byte positions shp .. 3
+        if (j == 0) {            // row bytes 0 .. 3 - shp, at byte positions shp .. 3
             if (shp <= 1) p[1] = (uint8_t)(w >> 8);
             if (shp <= 2) p[2] = (uint8_t)(w >> 16);
             if (shp <= 3) p[3] = (uint8_t)(w >> 24);
-        } else {
+        } else if (j < 12) {
             *(uint32_t*)(p + 4 * j) = w;
+        } else {                 // LDS dword 12 = row bytes 48 - shp .. 51 - shp: the row ends at byte 48
+            uint8_t* q = p + 48;
+            if (shp >= 3) *(uint32_t*)q = w;
+            else { q[0] = (uint8_t)w; q[1] = (uint8_t)(w >> 8); if (shp == 2) q[2] = (uint8_t)(w >> 16); }
         }
         prev = d;
     }
-    BB_HD void finish() {    // stream bytes 148 - shp .. 146: the shp - 1 low bytes of dword 37
-        const uint32_t w = align_bytes(0u, prev, s);
-        uint8_t* q = p + 4 * 37;
-        if (shp >= 2) q[0] = (uint8_t)w;
-        if (shp >= 3) q[1] = (uint8_t)(w >> 8);
-        if (shp >= 4) q[2] = (uint8_t)(w >> 16);
+    BB_HD void finish() {        // shp == 4: the row's last byte (cell 48) is the first byte of LDS dword 13
+        if (shp == 4) p[52] = (uint8_t)align_bytes(0u, prev, s);
     }
 };
-// the lane's 56 bytes of dword-aligned scratch (the 7x7 window in world orientation) inside its own row
-BB_HD int row_scratch(int r) { return (r * OBS_BYTES + 88 + 3) & ~3; }
+// Four cells e0..e3 (one dword of appearance bytes, invisible cells already zero) -> their 12 encoding bytes
+// t0 c0 s0 t1 | c1 s1 t2 c2 | s2 t3 c3 s3 (type = e & 7, colour = (e >> 3) & 7, state = e >> 6): three field extractions on the
+// whole dword and six byte permutes.
+BB_HD void expand_cells4(uint32_t x, uint32_t* o) {
+    const uint32_t t = x & 0x07070707u, c = (x >> 3) & 0x07070707u, st = (x >> 6) & 0x03030303u;
+    o[0] = perm_b32(perm_b32(t, c, 0x050C0004u), st, 0x07000504u);
+    o[1] = perm_b32(perm_b32(c, st, 0x060C0105u), t, 0x07020504u);
+    o[2] = perm_b32(perm_b32(st, t, 0x070C0306u), c, 0x07030504u);
+}
+// the lane's 56 bytes of dword-aligned window scratch (the 7x7 window in world orientation), used before the cells are staged
+constexpr int WIN_SCRATCH = 56;
 
 // World cell shown at view cell (vi, vj): pos + f*(6-vj) + r*(vi-3), r = (-f.y, f.x).
 BB_HD void view_to_world(int ax, int ay, int dir, int vi, int vj, int& x, int& y) {

@@ -58,8 +58,6 @@ def load_library():
     lib.bbai_step.argtypes = [P, P, P, P, P, P, P, I32, P]
     lib.bbai_set_atlas.argtypes = [P, P, I32, P]
     lib.bbai_render.argtypes = [P, P, P, P]
-    lib.bbai_render_current.argtypes = [P, P, P]
-    lib.bbai_has_tile_plane.argtypes = [P]
     lib.bbai_set_token_buffer.argtypes = [P, P]
     lib.bbai_export_state.argtypes = [P, I64, I64, P, P, P]
     lib.bbai_import_state.argtypes = [P, I64, I64, P, P, P]
@@ -91,7 +89,7 @@ EXPORTED_SYMBOLS = (
     "bbai_reset", "bbai_step", "bbai_set_atlas", "bbai_render", "bbai_set_token_buffer", "bbai_export_state", "bbai_import_state",
     "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures", "bbai_bot_act", "bbai_bot_stats",
     "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load", "bbai_profile", "bbai_profile_read", "bbai_gae", "bbai_tap",
-    "bbai_tap_ids", "bbai_set_call_events", "bbai_render_current", "bbai_has_tile_plane", "bbai_bot_rollout", "bbai_set_done_actions", "bbai_get_done_actions",
+    "bbai_tap_ids", "bbai_set_call_events", "bbai_bot_rollout", "bbai_set_done_actions", "bbai_get_done_actions",
     "bbai_set_option",
 )
 
@@ -199,7 +197,6 @@ class BatchedBabyAIEnv(object):
             self.reward64 = torch.zeros((n,), dtype=torch.float64, device=self.device)
             self.done = torch.zeros((n,), dtype=torch.uint8, device=self.device)
             self.pixels = None
-            self.render_fused = False
             if self.pixel:
                 self.pixels = torch.zeros((n, PIX, PIX, 3), dtype=torch.uint8, device=self.device)
                 atlas = np.load(ATLAS_PATH)
@@ -207,10 +204,7 @@ class BatchedBabyAIEnv(object):
                 lut = np.ascontiguousarray(atlas["lut"], dtype=np.uint8)
                 _check(self.lib, self.lib.bbai_set_atlas(self.handle, tiles.ctypes.data, tiles.shape[0],
                                                           lut.ctypes.data), "bbai_set_atlas")
-                # BBAI_RENDER_FUSED=1: the engine keeps a fused tile plane and renders from it (include/bbai.h bbai_render_current)
-                self.render_fused = bool(self.lib.bbai_has_tile_plane(self.handle))
         self._missions = None
-        self._tiles_ok = False         # the engine's tile plane describes the observation about to be rendered (set by reset / step)
         self._obs_version = 0
         self.kernel_events = None      # bench.py: list of (tag, start_event, end_event) when enabled
         self.num_actions = 7
@@ -253,11 +247,8 @@ class BatchedBabyAIEnv(object):
         img = self.image
         if self.pixel:
             ev = self._ev_begin()
-            if self.render_fused and self._tiles_ok:       # from the tile plane the reset / step just wrote (include/bbai.h bbai_render_current)
-                _check(self.lib, self.lib.bbai_render_current(self.handle, self.pixels.data_ptr(), self._stream()), "bbai_render_current")
-            else:
-                _check(self.lib, self.lib.bbai_render(self.handle, self.image.data_ptr(), self.pixels.data_ptr(),
-                                                       self._stream()), "bbai_render")
+            _check(self.lib, self.lib.bbai_render(self.handle, self.image.data_ptr(), self.pixels.data_ptr(),
+                                                   self._stream()), "bbai_render")
             self._ev_end("render", ev)
             img = self.pixels
         self._obs_version += 1
@@ -276,7 +267,6 @@ class BatchedBabyAIEnv(object):
     def reset(self):
         _check(self.lib, self.lib.bbai_reset(self.handle, self.image.data_ptr(), self.direction.data_ptr(),
                                               self._stream()), "bbai_reset")
-        self._tiles_ok = True
         return self._obs()
 
     def step(self, actions, validate=None):
@@ -308,7 +298,6 @@ class BatchedBabyAIEnv(object):
                                              self.done.data_ptr(),
                                              1 if self.auto_reset else 0, self._stream()), "bbai_step")
         self._ev_end("step", ev)
-        self._tiles_ok = True
         return self._obs(), self.reward, self.done, {}
 
     # ---- state access -------------------------------------------------------------------
@@ -349,7 +338,6 @@ class BatchedBabyAIEnv(object):
         assert rec.shape == (count, self.cfg.rec_bytes) and hot.shape == (count, 16) and stale.shape == (count,)
         _check(self.lib, self.lib.bbai_import_state(self.handle, first, count, rec.ctypes.data, hot.ctypes.data,
                                                      stale.ctypes.data), "bbai_import_state")
-        self._tiles_ok = False
 
     def save_checkpoint(self):
         """The whole batch as one host blob (np.uint8): live state, RNG streams, look-ahead ring, window bookkeeping,
@@ -364,7 +352,6 @@ class BatchedBabyAIEnv(object):
         is not part of the blob: callers that need it keep `image` / `direction` next to it (or step once)."""
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         _check(self.lib, self.lib.bbai_checkpoint_load(self.handle, blob.ctypes.data, blob.size), "bbai_checkpoint_load")
-        self._tiles_ok = False
         if getattr(self, "instr", None) is not None:        # refill the caller-owned token rows from the loaded programs
             _check(self.lib, self.lib.bbai_set_token_buffer(self.handle, self.instr.data_ptr()), "bbai_set_token_buffer")
 
@@ -425,7 +412,6 @@ class BatchedBabyAIEnv(object):
                                                     out["image"].data_ptr(), out["direction"].data_ptr(), tok_ptr,
                                                     out["action"].data_ptr(), out["reward"].data_ptr(), out["done"].data_ptr(),
                                                     out["gave_up"].data_ptr(), self._stream()), "bbai_bot_rollout")
-        self._tiles_ok = True
         self._obs_version += 1
         return out
 
@@ -463,10 +449,7 @@ class BatchedBabyAIEnv(object):
         """A performance knob of the live handle by name (include/bbai.h bbai_set_option: launch shapes, render input,
         priorities -- never semantics).  What measurements alternate inside one process (tools/ab.py)."""
         _check(self.lib, self.lib.bbai_set_option(self.handle, name.encode(), int(value)), "bbai_set_option(%s)" % name)
-        if name == "render_fused":
-            self.render_fused = bool(self.lib.bbai_has_tile_plane(self.handle))
-            self._tiles_ok = False
-
+    
     def profile(self, enable=True):
         """Bracket every k_step / k_consume / k_render launch with HIP events on its launch stream (bench.py)."""
         _check(self.lib, self.lib.bbai_profile(self.handle, 1 if enable else 0), "bbai_profile")

@@ -98,16 +98,6 @@ int bbai_step(bbai_env* env, const uint8_t* actions_dev, uint8_t* image_dev, uin
  * scripts/train_rl.py:57-58): encoded obs uint8[N][147] -> pixels uint8[N][56][56][3].
  * The tile atlas must have been installed with bbai_set_atlas. */
 int bbai_set_atlas(bbai_env* env, const uint8_t* tiles_host, int n_tiles, const uint8_t* lut_host /* [2][256] */);
-/* The same wrapper applied to the CURRENT observation of every env (what a training / evaluation loop renders after
- * each reset / step), from a fused tile plane: with BBAI_RENDER_FUSED=1 in the environment at bbai_set_atlas, bbai_reset /
- * bbai_step also leave a 52-byte tile plane per env behind (one masked appearance byte per view cell, written last), and
- * this entry renders from it -- a third of the input bytes of bbai_render(image), still in the memory-side cache.
- * Byte-identical to bbai_render of the image the same call wrote.  Off by default: it pays on some boxes of the pool and
- * costs on others (profiles/r03/NOTES.md sections 5 and 12).  BBAI_ERR_STATE when the handle keeps no plane, or no reset /
- * step has happened since the atlas was installed (or after import / checkpoint_load). */
-int bbai_render_current(bbai_env* env, uint8_t* pixels_dev, void* stream);
-/* 1 when the handle keeps the tile plane (BBAI_RENDER_FUSED=1 at bbai_set_atlas), else 0: use bbai_render. */
-int bbai_has_tile_plane(bbai_env* env);
 int bbai_render(bbai_env* env, const uint8_t* image_dev, uint8_t* pixels_dev, void* stream);
 
 /* Mission text as token ids, device-resident (replaces the per-step regex tokenisation of every mission in
@@ -219,7 +209,6 @@ int bbai_get_done_actions(bbai_env* env);
  *   "render_queue"      -1 = by batch size (default), 0 = one-shot render blocks, m > 0 = persistent-block queue shape m
  *   "render_queue_bpc", "render_queue_blocks"   persistent render blocks per CU (0 = 1024 threads' worth) / in total (0 = per CU)
  *   "render_group", "render_tpb"   envs / threads per one-shot render block (0 = by batch size)
- *   "render_fused"      1 = keep the fused tile plane (bbai_render_current), 0 = drop it
  *   "step_prio", "pregen_group", "pregen_blocks", "consume_fused"   as BBAI_STEP_PRIO / BBAI_PREGEN_GROUP / BBAI_PREGEN_BLOCKS /
  *                       BBAI_CONSUME_FUSED
  * BBAI_ERR_ARG for an unknown name. */

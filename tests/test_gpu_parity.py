@@ -1224,46 +1224,32 @@ def test_unknown_actions_are_defined_and_can_be_rejected(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("auto_reset", [True, False])
-def test_render_current_equals_render_of_the_encoding(gpu, auto_reset, monkeypatch):
-    """bbai_render_current (pixels from the tile plane that reset / step leave behind: one masked appearance byte per view
-    cell) against bbai_render (pixels from the 147-byte encoding the same call wrote), every step, through auto-resets and
-    -- ManyEnvs mode -- frozen envs, whose plane rows are re-derived from their encoding."""
-    import ctypes
+@pytest.mark.parametrize("n", [5000, 64, 37])
+def test_frozen_envs_re_emit_their_observation_through_the_cell_stream(gpu, n):
+    """ManyEnvs mode (babyai/evaluate.py:73-81): a finished env is frozen and keeps re-emitting its last observation.  k_step
+    stages every block's observations as 49-byte cell rows and expands them on the way out (bbai_step.hpp); a frozen lane
+    re-derives its cells from the caller-kept encoding.  Every frozen env's image, direction and pixels must stay byte for
+    byte what they were at its terminal step while its neighbours keep moving -- ragged last block included."""
     import torch
-    from babyai_amd.engine import BatchedBabyAIEnv, _check
-    n = 5000                                          # not a multiple of the step block: ragged last block
-    monkeypatch.setenv("BBAI_RENDER_FUSED", "1")      # (small batches do not keep the plane by default)
-    env = BatchedBabyAIEnv("BabyAI-GoToObjS6-v0" if auto_reset else "BabyAI-PickupLoc-v0", n, device=gpu, pixel=True, seeds=77,
-                           auto_reset=auto_reset)
-    assert env.render_fused
-    other = torch.zeros_like(env.pixels)
+    from babyai_amd.engine import BatchedBabyAIEnv
+    env = BatchedBabyAIEnv("BabyAI-PickupLoc-v0", n, device=gpu, pixel=True, seeds=77, auto_reset=False)
+    env.reset()
     gen = torch.Generator(device=gpu)
     gen.manual_seed(3)
-
-    def check(tag):
-        _check(env.lib, env.lib.bbai_render(env.handle, env.image.data_ptr(), other.data_ptr(), env._stream()), "bbai_render")
-        assert torch.equal(env.pixels, other), tag
-
-    env.reset()
-    check("reset")
+    frozen = torch.zeros(n, dtype=torch.bool, device=gpu)
+    keep_img, keep_pix, keep_dir = env.image.clone(), env.pixels.clone(), env.direction.clone()
     for t in range(140):
         env.step(torch.randint(0, 7, (n,), dtype=torch.uint8, device=gpu, generator=gen))
-        check(t)
-    if auto_reset:
-        assert env.reset_count() > 2 * n
-    else:
-        assert int(env.done.sum()) > n // 2               # most envs sat frozen for a while
-        env.reset()
-        check("second reset")
-    # the plane is not part of a checkpoint: after a load the binding renders from the encoding until the next step
-    blob = env.save_checkpoint()
-    env.load_checkpoint(blob)
-    assert not env._tiles_ok
-    rc = env.lib.bbai_render_current(env.handle, other.data_ptr(), env._stream())
-    assert rc == -3                                        # BBAI_ERR_STATE, not stale pixels
+        assert torch.equal(env.image[frozen], keep_img[frozen]) and torch.equal(env.pixels[frozen], keep_pix[frozen]), t
+        assert torch.equal(env.direction[frozen], keep_dir[frozen]), t
+        newly = env.done.bool() & ~frozen
+        keep_img[newly], keep_pix[newly], keep_dir[newly] = env.image[newly], env.pixels[newly], env.direction[newly]
+        frozen |= newly
+        assert torch.equal(env.done.bool(), frozen), t             # a frozen env keeps reporting done
+    assert int(frozen.sum()) > n // 2                             # most envs sat frozen for a while
+    env.reset()
     env.step(torch.randint(0, 7, (n,), dtype=torch.uint8, device=gpu, generator=gen))
-    check("after load")
+    assert int(env.done.sum()) < n // 4                           # a fresh episode everywhere
     env.close()
 
 
@@ -1352,17 +1338,17 @@ def test_step_writes_observations_into_unaligned_caller_buffers(gpu, offset):
 @pytest.mark.parametrize("level", ["BossLevel", "PutNextS6N3Carrying", "KeyInBox"])
 def test_record_path_equals_window_plane_path(gpu, level, fused, monkeypatch):
     """BBAI_VPLANE=0 (the step's window and front cell come out of the record's appearance plane: round 2's path, kept for
-    A/B measurements) against the default window-plane path, with and without the fused tile-plane pass -- all four
-    k_step instantiations: same observations, rewards, dones and pixels at every step, object actions included."""
+    A/B measurements) against the default window-plane path, with the finished envs consumed by k_consume and inside
+    k_step -- all four k_step instantiations: same observations, rewards, dones and pixels at every step, object actions
+    included."""
     import torch
     from babyai_amd.engine import BatchedBabyAIEnv
     n, steps = 1500, 120
-    monkeypatch.setenv("BBAI_RENDER_FUSED", fused)
+    monkeypatch.setenv("BBAI_CONSUME_FUSED", fused)
     a = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=31, pixel=True)
     monkeypatch.setenv("BBAI_VPLANE", "0")
     b = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=31, pixel=True)
     monkeypatch.delenv("BBAI_VPLANE")
-    assert a.render_fused == (fused == "1") and b.render_fused == (fused == "1")
     oa, ob = a.reset(), b.reset()
     gen = torch.Generator(device=gpu)
     gen.manual_seed(8)
@@ -1378,26 +1364,21 @@ def test_record_path_equals_window_plane_path(gpu, level, fused, monkeypatch):
     b.close()
 
 
-N_QUEUE_SHAPES = 18
+N_QUEUE_SHAPES = 9
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", [0, 1])
 @pytest.mark.parametrize("n", [1, 9, 5003, 70001])
-def test_render_queue_equals_one_shot_render(gpu, n, fused):
+def test_render_queue_equals_one_shot_render(gpu, n):
     """k_render_q (persistent blocks fed by ticket counters; the default from 786 432 envs up) against the one-shot k_render:
     every pixel byte, every queue shape of render_launch, ragged last groups / tickets, fewer tickets than blocks, odd block
-    counts, from the encoding and from the fused tile plane, across resets -- and launch after launch, because the kernel
-    leaves its own ticket counters at zero for the next one."""
+    counts, across resets -- and launch after launch, because the kernel leaves its own ticket counters at zero for the
+    next one."""
     import torch
     from babyai_amd.engine import BatchedBabyAIEnv
     a = BatchedBabyAIEnv("BabyAI-GoToObjS6-v0", n, device=gpu, pixel=True, seeds=5)
     b = BatchedBabyAIEnv("BabyAI-GoToObjS6-v0", n, device=gpu, pixel=True, seeds=5)
     a.set_option("render_queue", 0)
-    if fused:
-        a.set_option("render_fused", 1)
-        b.set_option("render_fused", 1)
-    assert a.render_fused == bool(fused) and b.render_fused == bool(fused)
     b.set_option("render_queue", 1)
     oa, ob = a.reset(), b.reset()
     gen = torch.Generator(device=gpu)
@@ -1438,7 +1419,7 @@ def test_options_do_not_change_results(gpu):
     gen = torch.Generator(device=gpu)
     gen.manual_seed(3)
     settings = [("step_prio", 0), ("pregen_group", 64), ("pregen_blocks", 64), ("render_group", 4), ("render_tpb", 256),
-                ("render_fused", 1), ("consume_fused", 1), ("pregen_group", 16), ("render_fused", 0), ("consume_fused", 0),
+                ("consume_fused", 1), ("pregen_group", 16), ("render_queue", 1), ("consume_fused", 0),
                 ("render_queue", 6), ("pregen_group", 32), ("step_prio", 1), ("consume_fused", 1), ("consume_fused", -1)]
     for t in range(20 * len(settings)):
         assert torch.equal(oa["image"], ob["image"]) and torch.equal(a.image, b.image) and torch.equal(a.direction, b.direction), t

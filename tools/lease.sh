@@ -45,35 +45,11 @@ bench() {            # one BASELINE config as its own line: bench:C2 [extra args
 ab() {               # tools/ab.py presets
     cd /tmp
     case $1 in
-    render1m)   timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 1048576 --pixel --steps 20 --blocks 8 --reps 3 --base render_fused=0,render_queue_bpc=0 --settings \
-                    render_queue=0 render_queue=1 render_queue=2 render_queue=3 render_queue=4 render_queue=5 render_queue=6 render_queue=7 render_queue=8 render_queue=10 render_queue=11 \
-                    render_queue=2,render_queue_bpc=1 \
-                    > $OUT/render_queue_ab_1M.jsonl 2> $OUT/ab.err; tail -1 $OUT/render_queue_ab_1M.jsonl ;;
-    render1m_fused) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 1048576 --pixel --steps 20 --blocks 8 --reps 3 --base render_fused=0,render_queue_bpc=0 --settings \
-                    render_fused=0,render_queue=0 render_fused=0,render_queue=-1 render_fused=1,render_queue=0 render_fused=1,render_queue=2 render_fused=1,render_queue=6 render_fused=1,render_queue=11 \
-                    > $OUT/render_fused_queue_ab_1M.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_fused_queue_ab_1M.jsonl ;;
-    render1m_b) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 1048576 --pixel --steps 20 --blocks 8 --reps 3 --base render_fused=0,render_queue_bpc=0 --settings \
-                    render_queue=0 render_queue=1 render_queue=3 render_queue=12 render_queue=13 render_queue=14 render_queue=15 render_queue=16 \
-                    render_queue=1,render_queue_bpc=1 render_queue=1,render_queue_bpc=3 render_fused=1,render_queue=1 render_fused=1,render_queue=15 \
-                    > $OUT/render_queue_ab_1M_b.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_1M_b.jsonl ;;
-    render1m_c) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 1048576 --pixel --steps 20 --blocks 8 --reps 3 --base render_fused=0,render_queue_bpc=0,render_queue_blocks=0 --settings \
-                    render_queue=0 render_queue=1 render_queue=1,render_queue_blocks=512 render_queue=1,render_queue_blocks=192 render_queue=1,render_queue_blocks=128 \
-                    render_queue=3 render_queue=13 render_queue=18 render_queue=14 render_queue=15 render_queue=15,render_queue_blocks=256 render_queue=17 render_queue=17,render_queue_blocks=512 \
-                    render_queue=17,render_queue_blocks=256 render_queue=3,render_queue_blocks=192 render_queue=13,render_queue_blocks=192 \
-                    > $OUT/render_queue_ab_1M_c.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_1M_c.jsonl ;;
-    render1m_d) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 1048576 --pixel --steps 20 --blocks 8 --reps 3 --base render_fused=0,render_queue_bpc=0,render_queue_blocks=0 --settings \
-                    render_queue=0 render_queue=1 render_queue=2 render_queue=12 render_queue=14 render_queue=1,render_queue_blocks=224 render_queue=1,render_queue_blocks=320 render_fused=1,render_queue=1 \
-                    > $OUT/render_queue_ab_1M_d.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_1M_d.jsonl ;;
-    render256k) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 262144 --pixel --steps 48 --blocks 8 --reps 3 --settings \
-                    render_queue=0 render_queue=1 > $OUT/render_queue_ab_262144.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_262144.jsonl ;;
-    render384k) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 393216 --pixel --steps 48 --blocks 8 --reps 3 --settings \
-                    render_queue=0 render_queue=1 > $OUT/render_queue_ab_393216.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_393216.jsonl ;;
-    render128k) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 131072 --pixel --steps 64 --blocks 8 --reps 3 --settings \
-                    render_queue=0 render_queue=1 render_queue=15 render_queue=16 \
-                    > $OUT/render_queue_ab_131072.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_131072.jsonl ;;
-    render512k) timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs 524288 --pixel --steps 32 --blocks 8 --reps 3 --settings \
-                    render_queue=0 render_queue=1 render_queue=15 render_queue=16 \
-                    > $OUT/render_queue_ab_524288.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_524288.jsonl ;;
+    render)     # ab:render:<envs>:<steps per block>  -- the render queue shapes of render_launch against the one-shot shape, in the step loop
+                timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs ${2:-1048576} --pixel --steps ${3:-20} --blocks 8 --reps 3 \
+                    --base render_queue_bpc=0,render_queue_blocks=0 --settings render_queue=0 render_queue=1 render_queue=2 render_queue=3 render_queue=4 render_queue=5 \
+                    render_queue=6 render_queue=7 render_queue=8 render_queue=1,render_queue_bpc=2 render_queue=1,render_queue_blocks=224 \
+                    > $OUT/render_queue_ab_${2:-1048576}.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_${2:-1048576}.jsonl ;;
     *)          # ab:<name>:<level>:<envs>:<steps>:<pixel 0|1>:<setting>:<setting>...   (settings use '/' for ',')
                 local name=$1 level=$2 envs=$3 steps=$4 pix=$5; shift 5
                 local sets=(); for s in "$@"; do sets+=("${s//\//,}"); done
