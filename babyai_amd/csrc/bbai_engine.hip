@@ -139,6 +139,7 @@ struct bbai_env {
                           // profiles/r04/render_queue_ab_1M_b.jsonl: k_render 1.50 ms against 1.61 with two)
     int render_queue_blocks;   // option "render_queue_blocks": their total number (0 = by render_queue_bpc)
     int n_cus;            // compute units of the device
+    int done_action_enum; // option "done_action_enum": done-action mode only -- bbai_step's `done` actions count as the enum member (verifier.py:543-545)
     int consume_fused;    // BBAI_CONSUME_FUSED / option "consume_fused": -1 = by batch size, 0 = k_consume launch, 1 = inside k_step
     uint8_t* atlas;       // [n_tiles][192]
     uint8_t* lut;         // [2][256]
@@ -178,11 +179,11 @@ constexpr int WIN_STRIDE = 64;          // uint32 per window-count block (1 + MA
 // instructions, and a block is what waits at its barriers for its slowest wave: ONE wave per block (64) measured against
 // 128 / 256 in round 3 (profiles/r03/step_variants_ab.jsonl: BossLevel encoded 1 048 576 envs k_step 0.130 -> 0.124 -> 0.111 ms,
 // PickupLoc 262 144 0.071 -> 0.061 -> 0.051, GoTo 131 072 0.0212 -> 0.0192 -> 0.0184, GoToLocal 65 536 0.0244 -> 0.0216 -> 0.0214).
-// Since round 4 the kernel RELIES on it: the LDS traffic of a block is ordered by the wave's program order alone.
+// The in-wave consume (FUSE) RELIES on it: the LDS traffic of a block is ordered by the wave's program order alone.
 constexpr int STEP_BLOCK = 64;
 #ifndef BBAI_STEP_WAVES
-#define BBAI_STEP_WAVES 5          // minimum waves per SIMD the register allocation of k_step has to allow (96 VGPRs; LDS: 3.6 KB per wave)
-#endif
+#define BBAI_STEP_WAVES 1          // minimum waves per SIMD the register allocation of k_step has to allow (106 VGPRs = 4 waves; forcing 5 spills:
+#endif                             // profiles/r04/NOTES.md section 6)
 // BBAI_PREFETCH_ID=1 (experiment): the id-plane entry of the front cell fetched WITH the window.  Measured slower everywhere
 // (step_variants_ab.jsonl: BossLevel encoded 1M k_step 0.130 -> 0.148 ms, GoTo 131 072 0.021 -> 0.028): one more line per
 // env-step costs more than the verifier's occasional extra round trip.  Off.
@@ -193,15 +194,16 @@ constexpr int STEP_BLOCK = 64;
 // Observation with the 7x7 window staged in LDS (the k_step path).  49 scattered byte loads per lane keep the
 // texture-address unit busy for most of k_step (tools/step_ab.py ablation), so the window is fetched in WORLD
 // orientation as 7 rows x 3 aligned dwords, byte-aligned with v_alignbyte, parked in 56 dword-aligned bytes inside the
-// lane's own LDS scratch (`scr`, WIN_SCRATCH bytes), and read back in VIEW orientation (rotation = per-direction
+// lane's own LDS obs row (`scr`, bbai_step.hpp row_scratch), and read back in VIEW orientation (rotation = per-direction
 // address arithmetic on ds_read_u8).  All of a lane's reads precede its writes and lanes only touch bytes of their own
 // row, so no barrier is needed here.
 // The window's rows come from `q` (first aligned dword of row 0), `rstride` dwords apart, `off` = byte offset of the
 // window's first column inside that dword: the record's appearance plane (rstride = ES / 4) or the env's V-plane line
 // (rstride = 4).  `ce` = appearance of what the agent carries (E_EMPTY: nothing).  `fe2` receives the appearance of the
 // cell in front of the agent (view cell (3, 5)) for the verifier and the next step's transition.
-// Two halves, so that the verifier (which only needs fe2) can run between them: view_cells fetches and rotates the window
-// (cp = the 49 cells, vis = visibility rows), mask_cells zeroes the invisible ones (what the block stages in LDS).
+// Two halves, so that the verifier (which only needs fe2) can run between them while nothing of the 37-dword encoding is
+// live yet: view_cells fetches and rotates the window (cp = the 49 cells, vis = visibility rows), encode_view writes the
+// encoding from them.
 // window_fetch issues the loads (7 rows x 3 dwords: one dwordx3 each); view_cells consumes them.  k_step puts the rare
 // object actions (pickup / drop / toggle: dependent record loads and stores) BETWEEN the two, so their memory round trips
 // overlap the window's instead of preceding it.  Such an action changes exactly one cell of the window that was fetched
@@ -243,9 +245,11 @@ __device__ __forceinline__ void view_cells(const uint32_t* wd, int off, int dir,
         cp[idx >> 2] = (cp[idx >> 2] & ~(0xFFu << (8 * (idx & 3)))) | (ce << (8 * (idx & 3)));
     }
 }
-// The view with its invisible cells zeroed: 13 dwords of appearance bytes in view order [vi][vj] (49 bytes + 3 zero bytes) --
-// what the block stages in LDS; a zero cell encodes as (0, 0, 0) like the reference's invisible cell.
-__device__ __forceinline__ void mask_cells(const uint32_t* cp, const uint32_t* vis, uint32_t* xm) {
+// Four cells at a time: a dword of (visibility-masked) appearance bytes e0..e3 becomes the 12 encoding bytes
+// t0 c0 s0 t1 | c1 s1 t2 c2 | s2 t3 c3 s3 (type = e & 7, colour = (e >> 3) & 7, state = e >> 6) with three field extractions on
+// the whole dword and six byte permutes (v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first,
+// 0x0C is zero) -- 11 instructions per four cells instead of ~55 shifting every channel byte into place on its own.
+__device__ __forceinline__ void encode_view(const uint32_t* cp, const uint32_t* vis, RowPacker o) {
 #pragma unroll
     for (int k = 0; k < 13; ++k) {
         // the cells of this dword that are visible: byte b <- bit (idx / 7) of vis[idx % 7], idx = 4k + b
@@ -255,8 +259,17 @@ __device__ __forceinline__ void mask_cells(const uint32_t* cp, const uint32_t* v
             const int idx = 4 * k + b;
             if (idx < VIEW * VIEW) m |= (uint32_t)__builtin_amdgcn_sbfe((int)vis[idx % VIEW], idx / VIEW, 1) & (0xFFu << (8 * b));   // v_bfe_i32: 0 / ~0
         }
-        xm[k] = cp[k] & m;
+        const uint32_t x = cp[k] & m;
+        const uint32_t t = x & 0x07070707u, c = (x >> 3) & 0x07070707u, st = (x >> 6) & 0x03030303u;
+        if (k < 12) {
+            o.put(3 * k, __builtin_amdgcn_perm(__builtin_amdgcn_perm(t, c, 0x050C0004u), st, 0x07000504u));
+            o.put(3 * k + 1, __builtin_amdgcn_perm(__builtin_amdgcn_perm(c, st, 0x060C0105u), t, 0x07020504u));
+            o.put(3 * k + 2, __builtin_amdgcn_perm(__builtin_amdgcn_perm(st, t, 0x070C0306u), c, 0x07030504u));
+        } else {
+            o.put(36, (t & 0xFFu) | ((c & 0xFFu) << 8) | ((st & 0xFFu) << 16));   // cell 48: three bytes, the row's last dword
+        }
     }
+    o.finish();
 }
 
 // Wave-cooperative observation of ONE env (used where a wave owns an env: consume_env): lane l < 49 owns view cell
@@ -274,8 +287,7 @@ __device__ __forceinline__ int observe_fetch(const LevelCfg& c, const uint8_t* _
     return e;
 }
 __device__ __forceinline__ void observe_emit(const LevelCfg& c, const uint8_t* __restrict__ rec, const Hot& h, int e,
-                                             uint8_t* __restrict__ dst /* 147-byte encoding, or NULL */, int lane,
-                                             uint8_t* __restrict__ cell_row /* 49 masked appearance bytes (k_step's LDS staging), or NULL */) {
+                                             uint8_t* __restrict__ dst, int lane) {
     const int vi = lane % VIEW, vj = lane / VIEW;
     const unsigned long long opaque = __ballot(lane < VIEW * VIEW && e_opaque(e));
     uint32_t opq[VIEW], vis[VIEW];
@@ -288,11 +300,8 @@ __device__ __forceinline__ void observe_emit(const LevelCfg& c, const uint8_t* _
 #pragma unroll
         for (int r = 0; r < VIEW; ++r) row = (vj == r) ? vis[r] : row;
         const bool v = row >> vi & 1;
-        if (dst) {
-            uint8_t* o = dst + (vi * VIEW + vj) * 3;
-            o[0] = v ? e_type(e) : 0; o[1] = v ? e_color(e) : 0; o[2] = v ? e_state(e) : 0;
-        }
-        if (cell_row) cell_row[vi * VIEW + vj] = v ? (uint8_t)e : (uint8_t)0;
+        uint8_t* o = dst + (vi * VIEW + vj) * 3;
+        o[0] = v ? e_type(e) : 0; o[1] = v ? e_color(e) : 0; o[2] = v ? e_state(e) : 0;
     }
 }
 
@@ -328,9 +337,8 @@ __device__ __forceinline__ u32x4 v_segment(const LevelCfg& c, const uint8_t* __r
 }
 
 // look-ahead slot -> live state of ONE env by ONE wave (k_consume: wave = env over the reset list; k_step<.., FUSE>: the wave that
-// stepped the env): coalesced record copy, SoA verifier view, first observation of the new episode (k_consume: the 147-byte
-// encoding to `obs_dst`, the caller's image row; k_step: the 49 masked cells to `cell_row`, the env's row of the block's LDS
-// staging), window plane + front cache, window bookkeeping for the batched refill.
+// stepped the env): coalesced record copy, SoA verifier view, first observation of the new episode (to `obs_dst`: the caller's
+// image row, or the block's LDS row in k_step), window plane + front cache, window bookkeeping for the batched refill.
 // `win_entry` = where this consumption is listed for k_pregen (NULL on reset(): the refill walks all envs).
 // The job is a handful of kilobytes per env, so what it costs is its chain of dependent memory round trips (a reset-heavy small
 // shard pays it on every step): everything that depends on nothing but the slot is LOADED FIRST, in batches that are all in
@@ -341,8 +349,8 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
                                             Hot* __restrict__ hots, uint64_t* __restrict__ stales, const uint8_t* __restrict__ next_recs,
                                             const Hot* __restrict__ next_hots, uint32_t* __restrict__ vheads, uint64_t* __restrict__ vsets,
                                             int depth, uint8_t* __restrict__ pending, uint8_t* __restrict__ first_slot,
-                                            int32_t* __restrict__ win_entry, uint8_t* __restrict__ obs_dst /* or NULL */, uint8_t* __restrict__ dirs,
-                                            uint8_t* __restrict__ cell_row /* or NULL */, uint8_t* __restrict__ vplane /* or NULL */,
+                                            int32_t* __restrict__ win_entry, uint8_t* __restrict__ obs_dst, uint8_t* __restrict__ dirs,
+                                            uint8_t* __restrict__ vplane /* or NULL */,
                                             uint16_t* __restrict__ fcache, uint8_t* __restrict__ lsm_arr /* or NULL */) {
     const int nvec = c.rec_bytes >> 4;
     const uint8_t* nrec = next_recs + ((int64_t)slot * n + env) * (int64_t)c.rec_bytes;
@@ -388,7 +396,7 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
     if (lane < 8) vsets[(int64_t)lane * n + env] = pset;
     if (lane == 8) vheads[env] = vh;
     // first observation of the new episode, straight from the slot (identical bytes to the live copy)
-    observe_emit(c, nrec, h, e_view, obs_dst, lane, cell_row);
+    observe_emit(c, nrec, h, e_view, obs_dst, lane);
     if (lane == 0) {
         uint64_t stale0 = 0;
         uint32_t ce0 = E_EMPTY;
@@ -417,19 +425,12 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
     }
 }
 
-// wave-local ordering point for the block's LDS traffic (the block is one wave: no workgroup barrier needed)
-__device__ __forceinline__ void lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
 // VP: the window comes from the env's V-plane line (ONE 128-byte line per step) and the transition's inputs -- the
 // appearance of the front cell and of the carried object -- from the 2-byte cache the previous step left (`fcache`), so a
 // plain move / turn touches no other record line; without VP both come out of the record (round 2's path: 2-3 lines for
 // the window + the lines of the front cell's id and the carried object's appearance).
 // FUSE: a wave whose envs finished consumes their look-ahead slots ITSELF (consume_env for every set bit of the wave's ballot,
-// the new episode's first observation straight into the block's LDS cells), instead of listing them for a k_consume launch.
+// the new episode's first observation straight into the block's LDS rows), instead of listing them for a k_consume launch.
 // `fuse` carries what k_consume's arguments carried.
 struct FuseArgs {
     const uint8_t* next_recs; const Hot* next_hots; uint32_t* vheads_w; uint64_t* vsets_w; int depth, pos;
@@ -445,11 +446,11 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
                                                      int32_t* __restrict__ reset_list, uint8_t* __restrict__ reset_slot, uint32_t* __restrict__ counters,
                                                      int prio, uint8_t* __restrict__ vplane, uint16_t* __restrict__ fcache,
                                                      uint8_t* __restrict__ lsm_arr /* NULL, or the done-action mode's per-env bits */,
+                                                     int enum_done /* done-action mode: this step's `done` actions are the enum member (bbai_step.hpp verify_side) */,
                                                      FuseArgs fuse) {
-    // ONE LDS area, three uses in program order (bbai_step.hpp "staged as CELLS"): the lanes' window scratch (64 x 56 B), then the
-    // block's dense cell stream (64 x 49 B), then the transposition buffer of the copy-out (3072 B)
-    __shared__ __attribute__((aligned(16))) uint8_t s_buf[CELLS_FRONT + STEP_BLOCK * WIN_SCRATCH + 16];
-    uint8_t* const s_cells = s_buf + CELLS_FRONT;
+    // the block's observation rows at the OUTPUT pitch of 147 bytes (bbai_step.hpp RowPacker), 16 bytes of front padding
+    __shared__ __attribute__((aligned(16))) uint8_t s_obs[ROWS_FRONT + STEP_BLOCK * OBS_BYTES + 16];
+    uint8_t* const s_rows = s_obs + ROWS_FRONT;
     if (prio) __builtin_amdgcn_s_setprio(3);            // the look-ahead generator's waves share the CUs: issue ours first
     const int lane = (int)threadIdx.x;
     const int64_t env0 = (int64_t)blockIdx.x * STEP_BLOCK;
@@ -457,9 +458,6 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
     const bool active = env < n;
     bool want_reset = false;
     int my_slot = 0;
-    uint32_t xm[13];                                    // the lane's 49 view cells, invisible ones zeroed (+ 3 zero bytes)
-#pragma unroll
-    for (int k = 0; k < 13; ++k) xm[k] = 0;
     if (active) {
         // everything the step needs from the SoA arrays in ONE memory round trip, before the frozen test (the loads the
         // branch would otherwise delay are a second round trip on every step's critical path)
@@ -515,9 +513,9 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
             }
             int fe2;
             uint32_t cp[13], vis[VIEW];
-            view_cells(wd, txm & 3, dir, (uint32_t)ce, nfe, s_cells + WIN_SCRATCH * lane, cp, vis, fe2);
+            view_cells(wd, txm & 3, dir, (uint32_t)ce, nfe, s_rows + row_scratch(lane), cp, vis, fe2);
             // "env.reset() for THIS env, now" (A_RESET_ENV, bbai_step.hpp): the episode ends with done = 1, reward = 0
-            const bool done = action == A_RESET_ENV ? true : finish_step(c, r, h, stale, action, fe2, reward, lsm_arr ? &lsm : nullptr, idf);
+            const bool done = action == A_RESET_ENV ? true : finish_step(c, r, h, stale, action, fe2, reward, lsm_arr ? &lsm : nullptr, idf, enum_done != 0);
             if (lsm_arr) lsm_arr[env] = (uint8_t)lsm;
             if (done && !auto_reset) h.frozen = 1;
             want_reset = done && auto_reset;
@@ -528,10 +526,9 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
             if (rewards64) rewards64[env] = reward;        // the reference's Python float, bit for bit (levelgen.py:59-61)
             dones[env] = done ? 1 : 0;
             dirs[env] = h.dir;
-            mask_cells(cp, vis, xm);
+            encode_view(cp, vis, RowPacker(s_rows, lane));
         }
-        // frozen envs keep re-emitting their last outputs: their cells are re-derived from the (caller-kept) encoding --
-        // appearance = type | colour << 3 | state << 6, and an invisible cell's (0, 0, 0) is the zero cell it came from
+        // frozen envs keep re-emitting their last outputs: copy them through LDS unchanged
         else {
             if (h.frozen == 2 && auto_reset) {      // level the generator gave up on (last-resort guard): skip to the next one
                 rewards[env] = 0.0f;
@@ -540,21 +537,8 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
                 want_reset = true;
             }
             const uint8_t* src = image + env * OBS_BYTES;
-            for (int idx = 0; idx < VIEW * VIEW; ++idx) {
-                const uint32_t key = src[3 * idx] | (src[3 * idx + 1] << 3) | (src[3 * idx + 2] << 6);
-#pragma unroll
-                for (int k = 0; k < 13; ++k) xm[k] |= (idx >> 2) == k ? key << (8 * (idx & 3)) : 0u;
-            }
+            for (int b = 0; b < OBS_BYTES; ++b) s_rows[lane * OBS_BYTES + b] = src[b];
         }
-    }
-    // Both branches are behind us: every lane's window scratch has been written and read back, and the LDS area becomes the
-    // block's dense cell stream (a lane's 49 bytes overlap OTHER lanes' scratch: this must not move into the branches above)
-    lds_sync();
-    if (active) {
-        CellPacker o(s_cells, lane);
-#pragma unroll
-        for (int k = 0; k < 13; ++k) o.put(k, xm[k]);
-        o.finish();
     }
     // compact finished envs into the reset list: one atomic per wave
     {
@@ -581,55 +565,37 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
                     const int src = __ffsll((long long)bal) - 1;
                     bal &= bal - 1;
                     const int slot = __shfl(my_slot, src);
-                    // (the new episode's first observation: 49 cells over the finished env's row of the stream)
+                    // (the new episode's first observation goes over the finished env's row; LDS traffic of the one wave stays in program order)
                     consume_env(c, n, env0 + src, slot, lane, recs, hots, stales, fuse.next_recs, fuse.next_hots, fuse.vheads_w, fuse.vsets_w,
-                                fuse.depth, fuse.pending, fuse.first_slot, fuse.win_list + wbase + basei + k, nullptr, dirs, s_cells + src * CELL_ROW,
+                                fuse.depth, fuse.pending, fuse.first_slot, fuse.win_list + wbase + basei + k, s_rows + src * OBS_BYTES, dirs,
                                 VP ? vplane : nullptr, fcache, lsm_arr);
                     ++k;
                 }
             }
         }
     }
-    lds_sync();
-    // Copy-out.  The block's cells are one dense stream (cell i of the stream -> output bytes 3 i .. 3 i + 2), its output one
-    // contiguous span of nb x 147 bytes that starts 16-byte aligned for every full block.  A lane takes CHUNKS of 16 cells
-    // (one aligned ds_read_b128) and expands each into 48 output bytes; per round of 64 chunks the 3072 bytes go through the
-    // (now free) LDS area once more so that every store instruction of the wave writes 1 KiB of consecutive bytes.
+    __syncthreads();
+    // the block's contiguous obs span leaves as it lies in LDS: 16 bytes per lane per store (64 x 147 B = 588 x 16 B; the
+    // span of every full block starts 16-byte aligned in the output).  The last, partial block ends with a byte tail.
     const int64_t nb = n - env0 < STEP_BLOCK ? n - env0 : STEP_BLOCK;      // envs in this block
     const int total = (int)nb * OBS_BYTES;
-    const int nchunks = ((int)nb * CELL_ROW + 15) >> 4;                    // 196 for a full block: 3 rounds of 64 + one of 4
-    constexpr int ROUNDS = (STEP_BLOCK * CELL_ROW / 16 + 63) / 64;         // 4
-    u32x4 cin[ROUNDS];
-#pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) {
-        const int ch = lane + 64 * i;
-        cin[i] = *(const u32x4*)(s_cells + 16 * (ch < nchunks ? ch : 0));   // (cells past the block's last one expand into bytes >= total: never stored)
-    }
-    lds_sync();                                                            // all cells are in registers: the area is the transposition buffer now
     uint8_t* out = image + env0 * OBS_BYTES;
-    const int al = (int)((uintptr_t)out & 15);      // (a caller's buffer that is not 16-byte aligned -- a row of a [T][n][147] history with odd n -- gets dwords or bytes)
-#pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) {
-        if (64 * i >= nchunks) break;
-        uint32_t o[12];
-        expand_cells4(cin[i].x, o); expand_cells4(cin[i].y, o + 3); expand_cells4(cin[i].z, o + 6); expand_cells4(cin[i].w, o + 9);
-        u32x4* t = (u32x4*)(s_cells + 48 * lane);
-        { u32x4 v0 = {o[0], o[1], o[2], o[3]}, v1 = {o[4], o[5], o[6], o[7]}, v2 = {o[8], o[9], o[10], o[11]}; t[0] = v0; t[1] = v1; t[2] = v2; }
-        lds_sync();
-        const int bytes = total - 3072 * i < 3072 ? total - 3072 * i : 3072;      // this round's share of the span
-        uint8_t* dst = out + 3072 * i;
+    {
+        // (a caller's buffer that is not 16-byte aligned -- a row of a [T][n][147] history with odd n -- gets dwords or bytes)
+        const int al = (int)((uintptr_t)out & 15);
         int done_bytes = 0;
         if (al == 0) {
-            const int nvec = bytes >> 4;
-            for (int v = lane; v < nvec; v += 64) ((u32x4*)dst)[v] = ((const u32x4*)s_cells)[v];
+            const int nvec = total >> 4;
+            const u32x4* s128 = (const u32x4*)s_rows;
+            for (int v = lane; v < nvec; v += STEP_BLOCK) ((u32x4*)out)[v] = s128[v];     // (non-temporal here: measured, no effect -- profiles/r03/NOTES.md)
             done_bytes = nvec << 4;
         } else if ((al & 3) == 0) {
-            const int ndw = bytes >> 2;
-            for (int d = lane; d < ndw; d += 64) ((uint32_t*)dst)[d] = ((const uint32_t*)s_cells)[d];
+            const int ndw = total >> 2;
+            const uint32_t* s32 = (const uint32_t*)s_rows;
+            for (int d = lane; d < ndw; d += STEP_BLOCK) ((uint32_t*)out)[d] = s32[d];
             done_bytes = ndw << 2;
         }
-        for (int b = done_bytes + lane; b < bytes; b += 64) dst[b] = s_cells[b];
-        lds_sync();                                                        // before the next round overwrites the buffer
+        for (int b = done_bytes + lane; b < total; b += STEP_BLOCK) out[b] = s_rows[b];
     }
 }
 
@@ -816,7 +782,7 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
         const int64_t env = all ? it : (int64_t)reset_list[it];
         const int slot = all ? (int)hots[env].slot : (int)reset_slot[it];       // (k_step listed it next to the env: no round trip through the env's state)
         consume_env(c, n, env, slot, lane, recs, hots, stales, next_recs, next_hots, vheads, vsets, depth, pending, first_slot,
-                    all ? nullptr : win_list + base + it, image + env * OBS_BYTES, dirs, nullptr, vplane, fcache,
+                    all ? nullptr : win_list + base + it, image + env * OBS_BYTES, dirs, vplane, fcache,
                     lsm_arr);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1570,7 +1536,7 @@ static bool use_fused_consume(const bbai_env* e) {
     return e->cfg.num_rows * e->cfg.num_cols > 1;
 }
 static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64,
-                       uint8_t* dones, int auto_reset, hipStream_t s) {
+                       uint8_t* dones, int auto_reset, hipStream_t s, int enum_done) {
     const bool fused = auto_reset && use_fused_consume(e);
     int32_t* list = e->reset_list;
     uint32_t* counter = e->counters + 16 * e->step_parity;
@@ -1591,7 +1557,7 @@ static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint
     {
         ProfScope prof_(e, 0, s);
 #define STEP_LAUNCH(VV, FF) hipLaunchKernelGGL((k_step<VV, FF>), dim3((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), dim3(STEP_BLOCK), 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, \
-                                           image, dirs, rewards, rewards64, dones, auto_reset, list, e->reset_slot, counter, e->step_prio, e->vplane, e->fcache, e->lsm, fa)
+                                           image, dirs, rewards, rewards64, dones, auto_reset, list, e->reset_slot, counter, e->step_prio, e->vplane, e->fcache, e->lsm, enum_done, fa)
         if (fused) { if (e->vplane) STEP_LAUNCH(true, true); else STEP_LAUNCH(false, true); }
         else { if (e->vplane) STEP_LAUNCH(true, false); else STEP_LAUNCH(false, false); }
 #undef STEP_LAUNCH
@@ -1614,7 +1580,7 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
     hipStream_t s = (hipStream_t)stream;
     CallScope call(e, s);
     if (call.rc != BBAI_OK) return call.rc;
-    { int rc = step_launch(e, actions, image, dirs, rewards, rewards64, dones, auto_reset, s); if (rc != BBAI_OK) return rc; }
+    { int rc = step_launch(e, actions, image, dirs, rewards, rewards64, dones, auto_reset, s, e->done_action_enum); if (rc != BBAI_OK) return rc; }
     return call.leave();
 }
 
@@ -1963,7 +1929,8 @@ int bbai_bot_rollout(bbai_env* e, int T, uint8_t* image, uint8_t* dirs, uint8_t*
         if (tokens_out) HIP_TRY(hipMemcpyAsync(tokens_out + (size_t)t * n * TOK_MAX, e->tokens, n * TOK_MAX, hipMemcpyDeviceToDevice, s));
         int rc = bot_launch(e, nullptr, actions_out + (size_t)t * n, A_RESET_ENV, gave_up_out + (size_t)t * n, s);
         if (rc != BBAI_OK) return rc;
-        rc = step_launch(e, actions_out + (size_t)t * n, image, dirs, rewards_out + (size_t)t * n, nullptr, dones_out + (size_t)t * n, 1, s);
+        rc = step_launch(e, actions_out + (size_t)t * n, image, dirs, rewards_out + (size_t)t * n, nullptr, dones_out + (size_t)t * n, 1, s,
+                         1 /* the expert's `done` is the enum member (bot.py:593) */);
         if (rc != BBAI_OK) return rc;
     }
     return call.leave();
@@ -2067,6 +2034,7 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     else if (!strcmp(name, "pregen_group")) e->pregen_group = v;
     else if (!strcmp(name, "pregen_blocks")) e->pregen_cap = std::max(64, v);
     else if (!strcmp(name, "consume_fused")) e->consume_fused = v;
+    else if (!strcmp(name, "done_action_enum")) e->done_action_enum = v != 0;       // (the one SEMANTIC switch in this list: include/bbai.h bbai_set_done_actions)
     else {
         snprintf(g_err, sizeof(g_err), "set_option: unknown option '%s'", name);
         return BBAI_ERR_ARG;

@@ -111,39 +111,48 @@ BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale
 }
 
 // One side of a Seq (an ActionInstr, or an AndInstr of two).  bit_a/bit_b: And progress bits.
-// An AndInstr never reports failure (verifier.py:536-550); a lone ActionInstr passes it through.  (In done-action mode the
-// reference's AndInstr has a failure rule behind `action is self.env.actions.done`, verifier.py:543-545: an identity test
-// against the enum member that no int / numpy action ever passes -- every vectorised caller steps with ints,
-// babyai/rl/utils/penv.py:8 -- so a byte-action engine has nothing to restate there; oracle/levels.py keeps the test.)
-BB_HD int verify_side(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int base, int n, int bit_a, int action, int fe2, uint32_t* lsm, int idf) {
+// An AndInstr never reports failure (verifier.py:536-550) -- except in done-action mode for a `done` that IS the enum member
+// (verifier.py:543-545 `action is self.env.actions.done`): if both of its instructions just failed on it, so does the And.
+// An int 6 never passes that identity test (every vectorised caller of the reference steps with ints, penv.py:8); the
+// reference's own bot returns the member (bot.py:593, fed to env.step by scripts/make_agent_demos.py:93-107).  `enum_done`
+// says which kind this step's `done` actions are: bbai_bot_rollout (the expert's own actions) and the "done_action_enum"
+// option set it.  A lone ActionInstr passes its failure through.
+BB_HD int verify_side(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int base, int n, int bit_a, int action, int fe2, uint32_t* lsm, int idf,
+                      bool enum_done = false) {
     if (n == 1) return verify_leaf(c, r, h, stale, base, action, fe2, lsm, idf);
-    if (!(h.vstate >> bit_a & 1))
-        if (verify_leaf(c, r, h, stale, base, action, fe2, lsm, idf) == V_SUCCESS) h.vstate |= 1 << bit_a;
-    if (!(h.vstate >> (bit_a + 1) & 1))
-        if (verify_leaf(c, r, h, stale, base + 1, action, fe2, lsm, idf) == V_SUCCESS) h.vstate |= 1 << (bit_a + 1);
+    int sa = V_SUCCESS, sb = V_SUCCESS;              // (a side that succeeded earlier is not verified again: a_done stays 'success')
+    if (!(h.vstate >> bit_a & 1)) {
+        sa = verify_leaf(c, r, h, stale, base, action, fe2, lsm, idf);
+        if (sa == V_SUCCESS) h.vstate |= 1 << bit_a;
+    }
+    if (!(h.vstate >> (bit_a + 1) & 1)) {
+        sb = verify_leaf(c, r, h, stale, base + 1, action, fe2, lsm, idf);
+        if (sb == V_SUCCESS) h.vstate |= 1 << (bit_a + 1);
+    }
+    if (lsm && enum_done && action == A_DONE && sa == V_FAILURE && sb == V_FAILURE) return V_FAILURE;
     return (h.vstate >> bit_a & 3) == 3 ? V_SUCCESS : V_CONTINUE;
 }
 
-BB_HD int verify_root(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2, uint32_t* lsm, int idf) {
+BB_HD int verify_root(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2, uint32_t* lsm, int idf, bool enum_done = false) {
     const VProg* p = &r.prog;
-    if (p->root() == R_ACTION || p->root() == R_AND) return verify_side(c, r, h, stale, 0, p->n_a(), 1, action, fe2, lsm, idf);
+    if (p->root() == R_ACTION || p->root() == R_AND) return verify_side(c, r, h, stale, 0, p->n_a(), 1, action, fe2, lsm, idf, enum_done);
     // Before: a then b; After: b then a.  The second part is verified with the SAME action in
     // the step the first part completes (verifier.py:463-464,504-505); a failure of either part fails.
     const bool before = p->root() == R_BEFORE;
     const int b1 = before ? 0 : 2, n1 = before ? p->n_a() : p->n_b(), s1 = before ? 1 : 3;
     const int b2 = before ? 2 : 0, n2 = before ? p->n_b() : p->n_a(), s2 = before ? 3 : 1;
     if (!(h.vstate & 1)) {
-        int st = verify_side(c, r, h, stale, b1, n1, s1, action, fe2, lsm, idf);
+        int st = verify_side(c, r, h, stale, b1, n1, s1, action, fe2, lsm, idf, enum_done);
         if (st == V_FAILURE) return st;
         if (st != V_SUCCESS) {
             // strict Seq: completing the second part first fails (verifier.py:466-469,507-510); the probe IS a verify()
             // of the second part, with its side effects (preCarrying, And progress bits, lastStepMatch)
-            if (p->strict_seq() && verify_side(c, r, h, stale, b2, n2, s2, action, fe2, lsm, idf) == V_SUCCESS) return V_FAILURE;
+            if (p->strict_seq() && verify_side(c, r, h, stale, b2, n2, s2, action, fe2, lsm, idf, enum_done) == V_SUCCESS) return V_FAILURE;
             return st;
         }
         h.vstate |= 1;
     }
-    return verify_side(c, r, h, stale, b2, n2, s2, action, fe2, lsm, idf);
+    return verify_side(c, r, h, stale, b2, n2, s2, action, fe2, lsm, idf, enum_done);
 }
 
 // reward = 1 - 0.9 * (step_count / max_steps) in float64 (MiniGridEnv._reward, returned as a Python float at
@@ -229,8 +238,9 @@ BB_HD int apply_action(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t& sta
 
 // Second half: the instruction verifier and the episode end (RoomGridLevel.step, levelgen.py:56-66).  `fe2` = appearance
 // byte of the front cell of the pose AFTER the action.  Returns done; reward by reference.
-BB_HD bool finish_step(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2, double& reward, uint32_t* lsm = nullptr, int idf = -1) {
-    const int status = verify_root(c, r, h, stale, action, fe2, lsm, idf);
+BB_HD bool finish_step(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2, double& reward, uint32_t* lsm = nullptr, int idf = -1,
+                       bool enum_done = false) {
+    const int status = verify_root(c, r, h, stale, action, fe2, lsm, idf, enum_done);
     bool done = h.step >= h.max_steps;
     reward = 0.0;
     if (status == V_SUCCESS) { done = true; reward = success_reward(h.step, h.max_steps); }
@@ -240,19 +250,21 @@ BB_HD bool finish_step(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stal
 
 // MiniGridEnv.step + RoomGridLevel.step for one env, everything read from the record (host build, reference form of the
 // two halves above).  Returns done; reward by reference.
-BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, double& reward, uint32_t* lsm = nullptr) {
+BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, double& reward, uint32_t* lsm = nullptr,
+                    bool enum_done = false) {
     EnvRef r = env_ref(c, rec, vp);
     const int fe = r.E[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];
     int ce = h.carry != NONE8 ? r.app[h.carry] : (int)E_EMPTY;
     apply_action(c, r, h, stale, action, fe, ce);
     const int fe2 = r.E[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];
-    return finish_step(c, r, h, stale, action, fe2, reward, lsm);
+    return finish_step(c, r, h, stale, action, fe2, reward, lsm, -1, enum_done);
 }
 
 // The same step in k_step's order of operations: pose, then the front cell's id fetched BEFORE the object actions (with the
 // window, in the kernel) and corrected by what they wrote, then the verifier on that id.  The host build runs the golden
 // traces through this form too (tests/test_hostsim_golden.py), so the bookkeeping is checked without a GPU.
-BB_HD bool step_env_prefetch(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, double& reward, uint32_t* lsm = nullptr) {
+BB_HD bool step_env_prefetch(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, double& reward, uint32_t* lsm = nullptr,
+                             bool enum_done = false) {
     EnvRef r = env_ref(c, rec, vp);
     const int fe = r.E[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];
     int ce = h.carry != NONE8 ? r.app[h.carry] : (int)E_EMPTY;
@@ -264,16 +276,17 @@ BB_HD bool step_env_prefetch(const LevelCfg& c, uint8_t* rec, const VProg& vp, H
     const int nfe = apply_objects(c, r, h, stale, action, fe, ce, idf, &nid);
     if (nfe >= 0) fe2 = nfe;
     if (nid >= 0) idf = nid;
-    return finish_step(c, r, h, stale, action, fe2, reward, lsm, idf);
+    return finish_step(c, r, h, stale, action, fe2, reward, lsm, idf, enum_done);
 }
 
 // Not a MiniGrid action: "env.reset() for THIS env, now" -- what a ParallelEnv worker does on a `reset` command
 // (babyai/rl/utils/penv.py:12-14) and what make_agent_demos.py:84-88 does after a bot crash.  The episode ends with
 // done = 1, reward = 0 and (auto-reset) the next observation is the first one of the env's next level.
 constexpr int A_RESET_ENV = 7;
-BB_HD bool step_env_cmd(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, double& reward, uint32_t* lsm = nullptr) {
+BB_HD bool step_env_cmd(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, uint64_t& stale, int action, double& reward, uint32_t* lsm = nullptr,
+                        bool enum_done = false) {
     if (action == A_RESET_ENV) { reward = 0.0; return true; }
-    return step_env(c, rec, vp, h, stale, action, reward, lsm);
+    return step_env(c, rec, vp, h, stale, action, reward, lsm, enum_done);
 }
 
 // bonus_levels.py:821-829: right after reset (and after the first observation was produced) the object is taken
@@ -306,17 +319,14 @@ BB_HD void process_vis_rows(const uint32_t opq[VIEW], uint32_t vis[VIEW]) {
     }
 }
 
-// ---- k_step's observations in LDS: staged as CELLS, expanded on the way out -------------------------------------------
-// A block's 64 observations leave as one contiguous span of 64 x 147 bytes, and 147 = 49 cells x 3 channel bytes.  Round 3
-// parked the finished 147-byte rows in LDS (RowPacker: 9.4 KB per wave, 37 shifted dwords per lane, ~500 VALU per lane for the
-// byte-granular encoding).  Round 4 parks the 49 masked appearance bytes per env instead (3.1 KB per wave), back to back at
-// a 49-byte pitch, so that the block's cells form ONE dense stream in which cell i becomes output bytes 3 i .. 3 i + 2 whatever
-// env it belongs to: sixteen cells (one aligned ds_read_b128) expand into 48 output bytes (three dwordx4) with the same
-// byte-permute trick, per CHUNK instead of per lane-row -- a third of the packing work, the encode on aligned data, and an LDS
-// footprint that no longer limits how many waves a CU holds.
-// CellPacker: the lane's 13 cell dwords (49 bytes + 3 zero bytes) shifted by the row's byte phase and written as aligned
-// dwords; the first and last bytes of a row share a dword with the neighbouring rows and go out as byte writes, so lanes never
-// touch each other's bytes.
+// ---- k_step's observation rows in LDS, packed at the OUTPUT pitch ----------------------------------------------------------
+// A block's 256 observations leave as one contiguous span of 256 x 147 bytes.  With the rows parked in LDS at that same
+// 147-byte pitch the copy-out is a plain 16-byte-per-lane stream (ds_read_b128 -> global_store_dwordx4); parked at a
+// dword-aligned 148-byte pitch instead (round 2 / early round 3) every output dword had to be re-assembled from three LDS
+// dwords -- 26 VALU instructions per dword, a third of k_step's vector work.  The price is paid once per lane here: the
+// lane's 37 encoding dwords are shifted by its row's byte phase (one v_alignbyte_b32 each) and written as ALIGNED dwords;
+// the first and last bytes of a row share a dword with the neighbouring rows and go out as byte writes, so lanes never
+// touch each other's bytes and no barrier is needed before the block-wide one.
 BB_HD uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t s) {     // ({hi, lo} >> 8 s) & 0xFFFFFFFF, s = 0..3
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_alignbyte(hi, lo, s);
@@ -324,66 +334,41 @@ BB_HD uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t s) {     // ({hi, 
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (s & 3)));
 #endif
 }
-// v_perm_b32: byte i of the result = byte sel[i] of {a, b} (0-3: b, 4-7: a), 0x0C = zero
-BB_HD uint32_t perm_b32(uint32_t a, uint32_t b, uint32_t sel) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_perm(a, b, sel);
-#else
-    const uint64_t src = ((uint64_t)a << 32) | b;
-    uint32_t out = 0;
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t k = (sel >> (8 * i)) & 0xFFu;
-        const uint32_t byte = k < 8 ? (uint32_t)(src >> (8 * k)) & 0xFFu : 0u;      // (only 0..7 and 0x0C are used)
-        out |= byte << (8 * i);
-    }
-    return out;
-#endif
-}
-constexpr int CELL_ROW = VIEW * VIEW;    // 49 cells = 49 staged bytes per env
-constexpr int CELLS_FRONT = 16;          // bytes in front of row 0 (row 0's "previous dword" exists; keeps the stream 16-byte aligned)
-struct CellPacker {
-    uint8_t* p;          // LDS dword j of the lane's shifted stream lives at p + 4 j
+constexpr int ROWS_FRONT = 16;       // bytes in front of row 0 (row 0's "previous dword" exists; keeps the span 16-byte aligned)
+struct RowPacker {
+    uint8_t* p;          // dword j of the lane's shifted stream lives at p + 4 j
     uint32_t prev, s;
     int shp;             // 1..4: bytes of the row's first LDS dword that belong to the previous row
-    // `rows` = the block's cell area (16-byte aligned), row r = bytes [49 r, 49 r + 49)
-    BB_HD CellPacker(uint8_t* rows, int r) {
-        const int base = r * CELL_ROW;
+    // `rows` = LDS byte ROWS_FRONT of the block's row area (16-byte aligned), row r = bytes [147 r, 147 r + 147)
+    BB_HD RowPacker(uint8_t* rows, int r) {
+        const int base = r * OBS_BYTES;
         shp = (base & 3) ? (base & 3) : 4;
         p = rows + (base - shp);
         s = (uint32_t)(4 - shp);
         prev = 0;
     }
-    // dword j of the row (j = 0..12, in order; dword 12 = cell 48 + three zero bytes)
+    // dword j of the row (j = 0..36, in order; dword 36 = the last three bytes + one zero byte)
     BB_HD void put(int j, uint32_t d) {
         const uint32_t w = align_bytes(d, prev, s);
-        if (j == 0) {            // row bytes 0 .. 3 - shp, at byte positions shp .. 3
+        if (j == 0) {        // stream bytes 0 .. 3 - shp, at byte positions shp .. 3
             if (shp <= 1) p[1] = (uint8_t)(w >> 8);
             if (shp <= 2) p[2] = (uint8_t)(w >> 16);
             if (shp <= 3) p[3] = (uint8_t)(w >> 24);
-        } else if (j < 12) {
+        } else {
             *(uint32_t*)(p + 4 * j) = w;
-        } else {                 // LDS dword 12 = row bytes 48 - shp .. 51 - shp: the row ends at byte 48
-            uint8_t* q = p + 48;
-            if (shp >= 3) *(uint32_t*)q = w;
-            else { q[0] = (uint8_t)w; q[1] = (uint8_t)(w >> 8); if (shp == 2) q[2] = (uint8_t)(w >> 16); }
         }
         prev = d;
     }
-    BB_HD void finish() {        // shp == 4: the row's last byte (cell 48) is the first byte of LDS dword 13
-        if (shp == 4) p[52] = (uint8_t)align_bytes(0u, prev, s);
+    BB_HD void finish() {    // stream bytes 148 - shp .. 146: the shp - 1 low bytes of dword 37
+        const uint32_t w = align_bytes(0u, prev, s);
+        uint8_t* q = p + 4 * 37;
+        if (shp >= 2) q[0] = (uint8_t)w;
+        if (shp >= 3) q[1] = (uint8_t)(w >> 8);
+        if (shp >= 4) q[2] = (uint8_t)(w >> 16);
     }
 };
-// Four cells e0..e3 (one dword of appearance bytes, invisible cells already zero) -> their 12 encoding bytes
-// t0 c0 s0 t1 | c1 s1 t2 c2 | s2 t3 c3 s3 (type = e & 7, colour = (e >> 3) & 7, state = e >> 6): three field extractions on the
-// whole dword and six byte permutes.
-BB_HD void expand_cells4(uint32_t x, uint32_t* o) {
-    const uint32_t t = x & 0x07070707u, c = (x >> 3) & 0x07070707u, st = (x >> 6) & 0x03030303u;
-    o[0] = perm_b32(perm_b32(t, c, 0x050C0004u), st, 0x07000504u);
-    o[1] = perm_b32(perm_b32(c, st, 0x060C0105u), t, 0x07020504u);
-    o[2] = perm_b32(perm_b32(st, t, 0x070C0306u), c, 0x07030504u);
-}
-// the lane's 56 bytes of dword-aligned window scratch (the 7x7 window in world orientation), used before the cells are staged
-constexpr int WIN_SCRATCH = 56;
+// the lane's 56 bytes of dword-aligned scratch (the 7x7 window in world orientation) inside its own row
+BB_HD int row_scratch(int r) { return (r * OBS_BYTES + 88 + 3) & ~3; }
 
 // World cell shown at view cell (vi, vj): pos + f*(6-vj) + r*(vi-3), r = (-f.y, f.x).
 BB_HD void view_to_world(int ax, int ay, int dir, int vi, int vj, int& x, int& y) {

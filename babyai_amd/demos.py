@@ -70,6 +70,10 @@ def _generate_batch_stepwise(env_name, seed, n, device, filter_steps, pack, max_
     """One batch of streams, one host round trip per step (bbai_bot_act + bbai_step driven from here)."""
     import torch
     env = BatchedBabyAIEnv(env_name, n, device=device, seeds=[seed + k for k in range(n)], auto_reset=True)
+    if env.done_actions:
+        # BABYAI_DONE_ACTIONS: the actions below are the expert's own, and its `done` is the enum member (babyai/bot.py:593): AndInstr's
+        # identity-tested failure rule applies (verifier.py:543-545; include/bbai.h bbai_set_done_actions) -- as it does inside bbai_bot_rollout
+        env.set_option("done_action_enum", 1)
     obs = env.reset()
     mission = list(obs["mission"])
     # whole-batch history, one row per step; an episode is the slice [ep_start[i], t] of column i

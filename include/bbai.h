@@ -196,21 +196,27 @@ int bbai_set_call_events(bbai_env* env, int enable);
  * 'BABYAI_DONE_ACTIONS', False)`, :216-230 ActionInstr.verify): an action instruction succeeds only on a `done` action taken
  * right after the step that completed it, and a `done` action at any other time FAILS it (episode over, reward 0).  A handle
  * starts in that mode iff the variable is non-empty in the environment at bbai_create -- the reference reads it at import --
- * and this call switches it explicitly (every env's lastStepMatch is cleared; call it between episodes).  AndInstr's extra
- * failure rule (verifier.py:543-545) sits behind `action is self.env.actions.done`, an identity test no int action passes
- * (every vectorised caller of the reference steps with ints, babyai/rl/utils/penv.py:8): nothing to restate for byte
- * actions.  The per-env bits travel in checkpoints; bbai_import_state clears them.  tests/test_done_actions.py. */
+ * and this call switches it explicitly (every env's lastStepMatch is cleared; call it between episodes).
+ * AndInstr's extra failure rule (verifier.py:543-545: both of its instructions fail on a `done` => the And fails) sits behind
+ * `action is self.env.actions.done`, an IDENTITY test: an int 6 never passes it (every vectorised caller of the reference steps
+ * with ints, babyai/rl/utils/penv.py:8), the enum member does -- and the reference's own expert returns the member (babyai/bot.py:593,
+ * fed to env.step by scripts/make_agent_demos.py:93-107).  A byte cannot carry that difference, so the caller says which it is:
+ * bbai_bot_rollout applies the rule (its actions are the expert's), bbai_step applies it iff bbai_set_option(env,
+ * "done_action_enum", 1) -- for a loop that steps with what bbai_bot_act suggested.  Pinned by traces of the reference stepped with
+ * the enum member (tests/golden/done_actions_enum/, tests/test_done_actions.py).
+ * The per-env bits travel in checkpoints; bbai_import_state clears them. */
 int bbai_set_done_actions(bbai_env* env, int enable);
 int bbai_get_done_actions(bbai_env* env);
 
 /* Performance knobs of a live handle, by name (what the BBAI_* environment variables set at bbai_create; the reference has
- * no counterpart: these choose launch shapes and buffers, never results -- every setting yields the same bytes, which
+ * no counterpart: these choose launch shapes and buffers, never results -- every setting but the last yields the same bytes, which
  * tests/test_gpu_parity.py::test_options_do_not_change_results checks).  Synchronises the device.  Names:
  *   "render_queue"      -1 = by batch size (default), 0 = one-shot render blocks, m > 0 = persistent-block queue shape m
  *   "render_queue_bpc", "render_queue_blocks"   persistent render blocks per CU (0 = 1024 threads' worth) / in total (0 = per CU)
  *   "render_group", "render_tpb"   envs / threads per one-shot render block (0 = by batch size)
  *   "step_prio", "pregen_group", "pregen_blocks", "consume_fused"   as BBAI_STEP_PRIO / BBAI_PREGEN_GROUP / BBAI_PREGEN_BLOCKS /
  *                       BBAI_CONSUME_FUSED
+ *   "done_action_enum"  the one semantic switch, meaningful in done-action mode only: see bbai_set_done_actions
  * BBAI_ERR_ARG for an unknown name. */
 int bbai_set_option(bbai_env* env, const char* name, int64_t value);
 

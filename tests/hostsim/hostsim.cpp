@@ -92,6 +92,17 @@ int hs_step64_done(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale,
     VProg vp; vp.bind(vhead_pack(*p), sets, 1);
     return step_env_cmd(*cfg, rec, vp, *hot, *stale, action, *reward, lsm) ? 1 : 0;
 }
+// ... with this step's `done` counting as the ENUM member (verifier.py:543-545 `action is self.env.actions.done`); order: 0 = the
+// reference's order of operations, 1 = k_step's
+int hs_step64_done_enum(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int action, double* reward, uint32_t* lsm, int order) {
+    const Prog* p = (const Prog*)(rec + cfg->off_prog);
+    uint64_t sets[8];
+    for (int k = 0; k < 8; ++k) sets[k] = p->set[k >> 1][k & 1];
+    VProg vp; vp.bind(vhead_pack(*p), sets, 1);
+    if (action == A_RESET_ENV) { *reward = 0.0; return 1; }
+    return (order ? step_env_prefetch(*cfg, rec, vp, *hot, *stale, action, *reward, lsm, true)
+                  : step_env(*cfg, rec, vp, *hot, *stale, action, *reward, lsm, true)) ? 1 : 0;
+}
 int hs_step(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int action, float* reward) {
     double r = 0.0;
     const int d = hs_step64(cfg, rec, hot, stale, action, &r);
@@ -103,30 +114,21 @@ void hs_observe(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, uint8_t
     observe_env(*cfg, rec, *hot, out);
 }
 
-// ---- k_step's LDS staging (bbai_step.hpp CellPacker + expand_cells4), one lane at a time in the caller's lane order -------------
-// cells_in: [n][13] dwords (49 masked appearance bytes + three zero bytes each); lds: CELLS_FRONT + n * 56 + 16 bytes, pre-filled by
-// the caller; scratch_fill != 0 first scribbles over every lane's window scratch (the area's earlier use).  Then the copy-out as
-// the kernel does it: chunks of 16 cells of the dense stream -> 48 output bytes each, written to `out` (n * 147 bytes) at 48 * chunk.
-void hs_stage_cells(const uint32_t* cells_in, const int32_t* order, int n, uint8_t* lds, int scratch_fill, uint8_t* out) {
-    uint8_t* cells = lds + CELLS_FRONT;
+// ---- k_step's LDS row packing (bbai_step.hpp RowPacker), one lane at a time in the caller's lane order ---------------------
+// rows_in: [n][37] dwords (147 bytes + one pad byte each); lds: ROWS_FRONT + n * 147 + 16 bytes, pre-filled by the caller;
+// scratch_fill != 0 also scribbles over every lane's window scratch first (it must stay inside the lane's own row).
+void hs_pack_rows(const uint32_t* rows_in, const int32_t* order, int n, uint8_t* lds, int scratch_fill) {
+    uint8_t* rows = lds + ROWS_FRONT;
     if (scratch_fill)
-        for (int i = 0; i < n; ++i) memset(cells + WIN_SCRATCH * i, 0xEE, WIN_SCRATCH);
+        for (int i = 0; i < n; ++i) memset(rows + row_scratch(i), 0xEE, 56);
     for (int k = 0; k < n; ++k) {
         const int r = order[k];
-        CellPacker o(cells, r);
-        for (int j = 0; j < 13; ++j) o.put(j, cells_in[r * 13 + j]);
+        RowPacker o(rows, r);
+        for (int j = 0; j < 37; ++j) o.put(j, rows_in[r * 37 + j]);
         o.finish();
     }
-    if (!out) return;
-    const int total = n * OBS_BYTES, nchunks = (n * CELL_ROW + 15) >> 4;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        uint32_t x[4], o[12];
-        memcpy(x, cells + 16 * ch, 16);
-        for (int g = 0; g < 4; ++g) expand_cells4(x[g], o + 3 * g);
-        const int lo = 48 * ch, len = total - lo < 48 ? total - lo : 48;
-        memcpy(out + lo, o, (size_t)len);
-    }
 }
+int hs_row_scratch(int r) { return row_scratch(r); }
 
 // ---- the expert (bbai_bot.hpp) -------------------------------------------------------------------------------
 int hs_bot_state_bytes(int stack_cap) { return (int)bot_state_bytes(stack_cap); }

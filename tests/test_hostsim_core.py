@@ -112,33 +112,29 @@ def test_max_mission_tokens_bounds_every_level():
         assert longest <= bound <= 72, (name, longest, bound)
 
 
-def test_cell_staging_and_chunk_expansion_produce_the_encoding():
-    """k_step stages a block's observations in LDS as CELLS -- 49 masked appearance bytes per env at a 49-byte pitch
-    (bbai_step.hpp CellPacker: 13 dwords shifted by the row's byte phase, aligned dword writes + byte-sized head / tail pieces)
-    -- and expands the dense stream in chunks of 16 cells into 48 output bytes (expand_cells4).  Lanes run in any order, so
-    no lane may write a byte outside its own row, whatever the area held before (the window scratch), and the expanded
-    stream must be the 7x7x3 encoding (type, colour, state of every cell) of every env, ragged last chunk included."""
+def test_row_packer_lays_rows_out_at_the_output_pitch():
+    """k_step parks its 256 observation rows in LDS at the 147-byte OUTPUT pitch (bbai_step.hpp RowPacker): every lane
+    shifts its 37 dwords by the row's byte phase and writes aligned dwords + byte-sized head / tail pieces.  Lanes run in
+    any order without a barrier, so no lane may write a byte outside its own row -- including its window scratch."""
     import ctypes
     import numpy as np
     from hostsim_util import lib
     L = lib()
-    L.hs_stage_cells.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.hs_pack_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    L.hs_row_scratch.argtypes = [ctypes.c_int]
     rng = np.random.RandomState(7)
-    for trial, n in enumerate((64, 64, 64, 1, 2, 3, 5, 17, 63, 64)):
-        cells = rng.randint(0, 256, size=(n, 52)).astype(np.uint8)
-        cells[:, 49:] = 0                                  # dword 12 = cell 48 + three zero bytes
+    n = 256
+    for trial in range(8):
+        rows = rng.randint(0, 256, size=(n, 148)).astype(np.uint8)
+        rows[:, 147] = 0                                   # dword 36 = three bytes + a zero byte
         order = rng.permutation(n).astype(np.int32)
-        lds = np.full(16 + 64 * 56 + 16, 0xA5, np.uint8)
-        out = np.full(n * 147 + 48, 0x5A, np.uint8)
-        L.hs_stage_cells(np.ascontiguousarray(cells).view(np.uint32).ctypes.data, order.ctypes.data, n, lds.ctypes.data, trial & 1, out.ctypes.data)
-        assert np.array_equal(lds[16:16 + n * 49].reshape(n, 49), cells[:, :49])
-        assert (lds[:16] == 0xA5).all()                                     # nothing before row 0
-        if not (trial & 1):
-            assert (lds[16 + n * 49:] == 0xA5).all()                        # ... or after the last row
-        e = cells[:, :49]
-        want = np.stack([e & 7, (e >> 3) & 7, e >> 6], axis=-1).reshape(n, 147)
-        assert np.array_equal(out[:n * 147].reshape(n, 147), want)
-        assert (out[n * 147:] == 0x5A).all()
+        lds = np.full(16 + n * 147 + 16, 0xA5, np.uint8)
+        L.hs_pack_rows(np.ascontiguousarray(rows).view(np.uint32).ctypes.data, order.ctypes.data, n, lds.ctypes.data, trial & 1)
+        assert np.array_equal(lds[16:16 + n * 147].reshape(n, 147), rows[:, :147])
+        assert (lds[:16] == 0xA5).all() and (lds[16 + n * 147:] == 0xA5).all()     # nothing before row 0 / after row 255
+    for r in range(n):
+        s = L.hs_row_scratch(r)
+        assert s % 4 == 0 and r * 147 <= s and s + 56 <= (r + 1) * 147
 
 
 @pytest.mark.parametrize("name", sorted(LEVELS))

@@ -12,6 +12,11 @@ Protocol = tools/gen_golden.py's (a ParallelEnv worker: seed, reset, step, reset
 expert most of the time -- so that instructions do get completed -- a `done` action with probability 0.22 (right after a
 completed instruction it ends the episode with success, anywhere else with failure), uniformly random otherwise.  Actions
 are passed as plain ints, like every vectorised caller of the reference does (babyai/rl/utils/penv.py:8).
+
+`--enum`: the same protocol on the levels whose missions contain AndInstr, with every `done` passed as the ENUM MEMBER
+`env.actions.done` -- what the reference's own expert returns (babyai/bot.py:593) and scripts/make_agent_demos.py:93-107 feeds to
+env.step.  Only then does AndInstr's failure rule (verifier.py:543-545, `action is self.env.actions.done`) fire.  Fixtures:
+tests/golden/done_actions_enum/ (pin oracle, host build and -- bbai_set_option "done_action_enum" -- the HIP engine).
 """
 import os
 import signal
@@ -47,7 +52,9 @@ PLAN = [
     ("PickupDistDebug", 6, 200),
     ("ActionObjDoor", 6, 200),
 ]
-SEED_BASE = 7000
+PLAN_ENUM = [("GoToSeq", 8, 500), ("SynthSeq", 8, 500), ("BossLevel", 8, 700), ("MiniBossLevel", 8, 500)]
+ENUM = "--enum" in sys.argv
+SEED_BASE = 7000 + (500 if ENUM else 0)
 
 
 class BotTimeout(BaseException):
@@ -116,7 +123,7 @@ def trace(name, n_envs, n_steps):
         for i, e in enumerate(envs):
             a = drivers[i].act()
             actions[t, i] = a
-            o, r, d, _ = e.step(int(a))
+            o, r, d, _ = e.step(e.actions.done if (ENUM and a == 6) else int(a))
             reward64[t, i] = r
             done[t, i] = d
             if d:
@@ -124,7 +131,7 @@ def trace(name, n_envs, n_steps):
                 missions.append((t + 1, i, o['mission']))
                 drivers[i].new_episode()
             image[t + 1, i] = o['image']; direction[t + 1, i] = o['direction']
-    out_dir = os.path.join(ROOT, 'tests', 'golden', 'done_actions')
+    out_dir = os.path.join(ROOT, 'tests', 'golden', 'done_actions_enum' if ENUM else 'done_actions')
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, name + '.npz')
     np.savez_compressed(out, level=name, seeds=seeds, actions=actions, image=image, direction=direction, reward64=reward64,
@@ -138,7 +145,7 @@ def trace(name, n_envs, n_steps):
 
 
 if __name__ == '__main__':
-    only = set(sys.argv[1:])
-    for p in PLAN:
+    only = set(a for a in sys.argv[1:] if not a.startswith("--"))
+    for p in (PLAN_ENUM if ENUM else PLAN):
         if not only or p[0] in only:
             trace(*p)
