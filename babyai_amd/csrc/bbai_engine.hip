@@ -1638,6 +1638,8 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
         case 7: RENDER_Q(8, 512, 1, 1); break;        // smaller blocks
         case 8: RENDER_Q(8, 256, 1, 1); break;
         case 9: RENDER_Q(2, 512, 8, 1); break;        // small groups need more counters (524 288 tickets)
+        case 10: RENDER_Q(9, 1024, 1, 1); break;      // just above the shipped group: a little more work per ticket
+        case 11: RENDER_Q(10, 1024, 1, 1); break;
         }
 #undef RENDER_Q
         HIP_TRY(hipGetLastError());

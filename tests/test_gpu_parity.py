@@ -1364,7 +1364,7 @@ def test_record_path_equals_window_plane_path(gpu, level, fused, monkeypatch):
     b.close()
 
 
-N_QUEUE_SHAPES = 9
+N_QUEUE_SHAPES = 11
 
 
 @pytest.mark.gpu

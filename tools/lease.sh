@@ -48,7 +48,7 @@ ab() {               # tools/ab.py presets
     render)     # ab:render:<envs>:<steps per block>  -- the render queue shapes of render_launch against the one-shot shape, in the step loop
                 timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs ${2:-1048576} --pixel --steps ${3:-20} --blocks 8 --reps 3 \
                     --base render_queue_bpc=0,render_queue_blocks=0 --settings render_queue=0 render_queue=1 render_queue=2 render_queue=3 render_queue=4 render_queue=5 \
-                    render_queue=6 render_queue=7 render_queue=8 render_queue=1,render_queue_bpc=2 render_queue=1,render_queue_blocks=224 \
+                    render_queue=6 render_queue=7 render_queue=8 render_queue=10 render_queue=11 render_queue=1,render_queue_bpc=2 render_queue=1,render_queue_blocks=224 \
                     > $OUT/render_queue_ab_${2:-1048576}.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_${2:-1048576}.jsonl ;;
     *)          # ab:<name>:<level>:<envs>:<steps>:<pixel 0|1>:<setting>:<setting>...   (settings use '/' for ',')
                 local name=$1 level=$2 envs=$3 steps=$4 pix=$5; shift 5
