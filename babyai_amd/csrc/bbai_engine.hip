@@ -138,6 +138,7 @@ struct bbai_env {
     int render_queue_bpc; // option "render_queue_bpc": persistent render blocks per CU (0 = 1024 threads' worth: ONE 1024-thread block per CU --
                           // profiles/r04/render_queue_ab_1M_b.jsonl: k_render 1.50 ms against 1.61 with two)
     int render_queue_blocks;   // option "render_queue_blocks": their total number (0 = by render_queue_bpc)
+    int render_pace;      // option "render_pace" (experiment): 1/16 ns of wall clock per render ticket, 0 = tickets are taken as fast as the counter serves them
     int n_cus;            // compute units of the device
     int done_action_enum; // option "done_action_enum": done-action mode only -- bbai_step's `done` actions count as the enum member (verifier.py:543-545)
     int consume_fused;    // BBAI_CONSUME_FUSED / option "consume_fused": -1 = by batch size, 0 = k_consume launch, 1 = inside k_step
@@ -953,11 +954,13 @@ __global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_
 template <int RENDER_GROUP, int RENDER_BLOCK, int NC, int K>
 __global__ __launch_bounds__(RENDER_BLOCK) void k_render_q(int64_t n, const uint8_t* __restrict__ image,
                                                            uint8_t* __restrict__ pixels, const uint8_t* __restrict__ atlas,
-                                                           const uint8_t* __restrict__ lut, int n_tiles, unsigned int* __restrict__ counters) {
+                                                           const uint8_t* __restrict__ lut, int n_tiles, unsigned int* __restrict__ counters,
+                                                           int pace_x16 /* experiment: 0, or 1/16 ns of wall clock per ticket (render_launch) */) {
     __shared__ __attribute__((aligned(16))) uint8_t s_atlas[MAX_TILES * TILE_BYTES];
     __shared__ uint8_t s_lut[512];
     __shared__ uint8_t s_tile[2][RENDER_GROUP * VIEW * VIEW + 8];
     __shared__ unsigned int s_ticket[2];
+    __shared__ unsigned long long s_origin;
     for (int k = threadIdx.x; k < n_tiles * TILE_BYTES / 8; k += RENDER_BLOCK)
         ((uint64_t*)s_atlas)[k] = ((const uint64_t*)atlas)[k];
     for (int k = threadIdx.x; k < 512; k += RENDER_BLOCK) s_lut[k] = lut[k];
@@ -966,11 +969,20 @@ __global__ __launch_bounds__(RENDER_BLOCK) void k_render_q(int64_t n, const uint
     const unsigned int cidx = blockIdx.x % NC;
     unsigned int* counter = counters + 64 * cidx;
     int buf = 0, tp = 0;
-    if (threadIdx.x == 0) s_ticket[0] = atomicAdd(counter, 1u);
+    if (threadIdx.x == 0) {
+        const unsigned int t0 = atomicAdd(counter, 1u);
+        s_ticket[0] = t0;
+        // time-paced tickets (experiment): ticket sg is not started before origin + sg x pace; the 100-MHz constant clock in 1/16 ns
+        s_origin = __builtin_amdgcn_s_memrealtime() * 160ull - ((unsigned long long)t0 * NC + cidx) * (unsigned long long)pace_x16;
+    }
     __syncthreads();
     for (;;) {
         const int64_t sg = (int64_t)s_ticket[tp] * NC + cidx;
         if (sg >= n_super) break;
+        if (pace_x16) {
+            const unsigned long long due = s_origin + (unsigned long long)sg * (unsigned long long)pace_x16;
+            while (__builtin_amdgcn_s_memrealtime() * 160ull < due) __builtin_amdgcn_s_sleep(1);
+        }
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) {
             const int64_t grp = sg * K + kk;
@@ -1626,7 +1638,7 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
             const int64_t want = e->render_queue_blocks > 0 ? e->render_queue_blocks : (e->render_queue_bpc > 0 ? (int64_t)cus * e->render_queue_bpc : (int64_t)cus * 1024 / TT); \
             const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, tickets)); \
             hipLaunchKernelGGL((k_render_q<GG, TT, NC, KK>), dim3(blocks), dim3(TT), 0, (hipStream_t)stream, e->n, input, pixels, \
-                               e->atlas, e->lut, e->n_tiles, e->render_tickets); } while (0)
+                               e->atlas, e->lut, e->n_tiles, e->render_tickets, e->render_pace); } while (0)
         switch (qm) {          // (shapes other than 1 stay for measurements: tests/test_gpu_parity.py checks every one byte for byte)
         default:
         case 1: RENDER_Q(8, 1024, 1, 1); break;       // shipped
@@ -2030,6 +2042,7 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     if (!strcmp(name, "render_queue")) e->render_queue = v;
     else if (!strcmp(name, "render_queue_bpc")) e->render_queue_bpc = v;
     else if (!strcmp(name, "render_queue_blocks")) e->render_queue_blocks = v;
+    else if (!strcmp(name, "render_pace")) e->render_pace = v < 0 ? 0 : v;
     else if (!strcmp(name, "render_group")) e->render_group = v;
     else if (!strcmp(name, "render_tpb")) e->render_tpb = v;
     else if (!strcmp(name, "step_prio")) e->step_prio = v;
