@@ -138,7 +138,9 @@ struct bbai_env {
     int render_queue_bpc; // option "render_queue_bpc": persistent render blocks per CU (0 = 1024 threads' worth: ONE 1024-thread block per CU --
                           // profiles/r04/render_queue_ab_1M_b.jsonl: k_render 1.50 ms against 1.61 with two)
     int render_queue_blocks;   // option "render_queue_blocks": their total number (0 = by render_queue_bpc)
-    int render_pace;      // option "render_pace" (experiment): 1/16 ns of wall clock per render ticket, 0 = tickets are taken as fast as the counter serves them
+    int render_pace;      // option "render_pace": 1/16 ns of wall clock per render ticket; 0 = as fast as the counter serves them; -1 (default) = from
+                          // the calibrated fill rate (render_launch)
+    double fill_GBs;      // plain store stream of this device (calibrate_fill, at bbai_set_atlas for batches that render through the queue); 0 = not measured
     int n_cus;            // compute units of the device
     int done_action_enum; // option "done_action_enum": done-action mode only -- bbai_step's `done` actions count as the enum member (verifier.py:543-545)
     int consume_fused;    // BBAI_CONSUME_FUSED / option "consume_fused": -1 = by batch size, 0 = k_consume launch, 1 = inside k_step
@@ -888,7 +890,10 @@ __global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, Hot* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // k_render : encoded obs -> 56x56x3 pixels through the tile atlas
 // ------------------------------------------------------------------------------------------
-constexpr int RENDER_QUEUE_DEFAULT = 1;         // queue shape of render_launch used from 262 144 envs up
+constexpr int RENDER_QUEUE_DEFAULT = 1;         // queue shape of render_launch used from RENDER_QUEUE_MIN_ENVS up
+constexpr int RENDER_QUEUE_PACED = 3;           // ... with time-paced tickets: (1024, 8) blocks, two interleaved counters
+constexpr int64_t RENDER_QUEUE_MIN_ENVS = 262144;
+constexpr double RENDER_PACE_FRACTION = 0.987;  // tickets are paced at this fraction of the calibrated fill rate (profiles/r04/NOTES.md section 1)
 constexpr int CHUNKS_PER_ROW = PIX * 3 / 8;       // 21 eight-byte chunks per pixel row
 constexpr int VEC_PER_ENV = PIX_BYTES / 16;       // 588 sixteen-byte stores per env
 
@@ -1063,6 +1068,12 @@ __global__ __launch_bounds__(64) void k_tokens(LevelCfg c, int64_t n, const uint
         else if (p->root == R_AFTER) { o.put(32); o.put(24); tok_side(o, p, 2, p->n_b); }    // after you
         while (o.n < TOK_MAX) o.p[o.n++] = 0;
     }
+}
+
+// one 4-KiB span per 256-thread block, 16 bytes per lane: the plain store stream (calibrate_fill)
+__global__ __launch_bounds__(256) void k_fill16(u32x4* __restrict__ out, int64_t nvec) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q < nvec) { u32x4 v = {1u, 2u, 3u, (uint32_t)q}; __builtin_nontemporal_store(v, out + q); }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1298,6 +1309,8 @@ static int create_finish(bbai_env* e) {
         e->render_group = rv ? atoi(rv) : 0;
         const char* qv = getenv("BBAI_RENDER_QUEUE");
         e->render_queue = qv ? atoi(qv) : -1;
+        const char* pv2 = getenv("BBAI_RENDER_PACE");
+        e->render_pace = pv2 ? atoi(pv2) : -1;
         const char* cf = getenv("BBAI_CONSUME_FUSED");
         e->consume_fused = cf ? atoi(cf) : -1;
         const char* tv = getenv("BBAI_RENDER_TPB");
@@ -1596,12 +1609,41 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
     return call.leave();
 }
 
+// What a plain store stream reaches on this device, GB/s: 1 GiB written by one-shot 4-KiB blocks (the shape in which the pure
+// store stream is fastest: profiles/r02/ubench_store.txt), a few passes, HIP events.  The render paces its tickets just below
+// this rate (render_launch).  Synchronous; the scratch buffer is freed again.
+static int calibrate_fill(bbai_env* e) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    size_t bytes = (size_t)1 << 30;
+    while (bytes > ((size_t)64 << 20) && bytes > free_b / 4) bytes >>= 1;
+    void* buf = nullptr;
+    if (hipMalloc(&buf, bytes) != hipSuccess) { (void)hipGetLastError(); e->fill_GBs = 0; return BBAI_OK; }     // (no calibration: the counter-paced shape)
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+    const int64_t nvec = (int64_t)(bytes >> 4);
+    const dim3 grid((unsigned)((nvec + 255) / 256));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_fill16, grid, dim3(256), 0, 0, (u32x4*)buf, nvec);
+    HIP_TRY(hipEventRecord(a, 0));
+    const int passes = 6;
+    for (int i = 0; i < passes; ++i) hipLaunchKernelGGL(k_fill16, grid, dim3(256), 0, 0, (u32x4*)buf, nvec);
+    HIP_TRY(hipEventRecord(b, 0));
+    HIP_TRY(hipEventSynchronize(b));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipFree(buf);
+    e->fill_GBs = ms > 0 ? (double)bytes * passes / (ms * 1e-3) / 1e9 : 0;
+    return BBAI_OK;
+}
+
 int bbai_set_atlas(bbai_env* e, const uint8_t* tiles, int n_tiles, const uint8_t* lut) {
     if (!e || !tiles || !lut || n_tiles < 1 || n_tiles > MAX_TILES) ARG_FAIL("null pointer or tile count out of range");
     ON_DEVICE(e->device);
     HIP_TRY(hipMemcpy(e->atlas, tiles, (size_t)n_tiles * TILE_BYTES, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->lut, lut, 512, hipMemcpyHostToDevice));
     e->n_tiles = n_tiles;
+    if (e->n >= RENDER_QUEUE_MIN_ENVS && e->fill_GBs == 0) { int rc = calibrate_fill(e); if (rc != BBAI_OK) return rc; }
     return BBAI_OK;
 }
 
@@ -1630,7 +1672,14 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
     // BBAI_RENDER_QUEUE / option "render_queue": -1 = by batch size (default), 0 = never, m > 0 = queue shape m of the table below.
     const bool big = e->n >= 786432;
     int qm = e->render_queue;
-    if (qm < 0) qm = e->n >= 262144 ? RENDER_QUEUE_DEFAULT : 0;
+    int pace = e->render_pace;
+    if (qm < 0) {
+        qm = e->n >= RENDER_QUEUE_MIN_ENVS ? RENDER_QUEUE_DEFAULT : 0;
+        // time-paced tickets when the device's fill rate is known: two interleaved counters serve tickets twice as fast as the chip
+        // can store them, and the wall clock admits them at RENDER_PACE_FRACTION of the fill rate
+        if (qm == RENDER_QUEUE_DEFAULT && pace < 0 && e->fill_GBs > 0) qm = RENDER_QUEUE_PACED;
+    }
+    if (pace < 0) pace = (qm == RENDER_QUEUE_PACED && e->fill_GBs > 0) ? (int)(16.0 * 8 * PIX_BYTES / (RENDER_PACE_FRACTION * e->fill_GBs) + 0.5) : 0;
     if (qm > 0) {
         const int cus = e->n_cus > 0 ? e->n_cus : 256;
 #define RENDER_Q(GG, TT, NC, KK) do { \
@@ -1638,7 +1687,7 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
             const int64_t want = e->render_queue_blocks > 0 ? e->render_queue_blocks : (e->render_queue_bpc > 0 ? (int64_t)cus * e->render_queue_bpc : (int64_t)cus * 1024 / TT); \
             const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, tickets)); \
             hipLaunchKernelGGL((k_render_q<GG, TT, NC, KK>), dim3(blocks), dim3(TT), 0, (hipStream_t)stream, e->n, input, pixels, \
-                               e->atlas, e->lut, e->n_tiles, e->render_tickets, e->render_pace); } while (0)
+                               e->atlas, e->lut, e->n_tiles, e->render_tickets, pace); } while (0)
         switch (qm) {          // (shapes other than 1 stay for measurements: tests/test_gpu_parity.py checks every one byte for byte)
         default:
         case 1: RENDER_Q(8, 1024, 1, 1); break;       // shipped
@@ -2042,7 +2091,7 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     if (!strcmp(name, "render_queue")) e->render_queue = v;
     else if (!strcmp(name, "render_queue_bpc")) e->render_queue_bpc = v;
     else if (!strcmp(name, "render_queue_blocks")) e->render_queue_blocks = v;
-    else if (!strcmp(name, "render_pace")) e->render_pace = v < 0 ? 0 : v;
+    else if (!strcmp(name, "render_pace")) e->render_pace = v < 0 ? -1 : v;
     else if (!strcmp(name, "render_group")) e->render_group = v;
     else if (!strcmp(name, "render_tpb")) e->render_tpb = v;
     else if (!strcmp(name, "step_prio")) e->step_prio = v;
@@ -2052,6 +2101,33 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     else if (!strcmp(name, "done_action_enum")) e->done_action_enum = v != 0;       // (the one SEMANTIC switch in this list: include/bbai.h bbai_set_done_actions)
     else {
         snprintf(g_err, sizeof(g_err), "set_option: unknown option '%s'", name);
+        return BBAI_ERR_ARG;
+    }
+    return BBAI_OK;
+}
+
+// Read back a knob or a measured quantity: the names of bbai_set_option, plus "fill_GBs" (the calibrated plain store stream,
+// 0 = not measured) and "render_pace_effective" (1/16 ns per render ticket the next bbai_render will use, 0 = unpaced).
+int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
+    if (!e || !name || !out) ARG_FAIL("null handle, name or output");
+    if (!strcmp(name, "render_queue")) *out = e->render_queue;
+    else if (!strcmp(name, "render_queue_bpc")) *out = e->render_queue_bpc;
+    else if (!strcmp(name, "render_queue_blocks")) *out = e->render_queue_blocks;
+    else if (!strcmp(name, "render_pace")) *out = e->render_pace;
+    else if (!strcmp(name, "render_group")) *out = e->render_group;
+    else if (!strcmp(name, "render_tpb")) *out = e->render_tpb;
+    else if (!strcmp(name, "step_prio")) *out = e->step_prio;
+    else if (!strcmp(name, "pregen_group")) *out = e->pregen_group;
+    else if (!strcmp(name, "pregen_blocks")) *out = e->pregen_cap;
+    else if (!strcmp(name, "consume_fused")) *out = e->consume_fused;
+    else if (!strcmp(name, "done_action_enum")) *out = e->done_action_enum;
+    else if (!strcmp(name, "lookahead_period")) *out = e->period;
+    else if (!strcmp(name, "fill_GBs")) *out = (int64_t)(e->fill_GBs + 0.5);
+    else if (!strcmp(name, "render_pace_effective")) {
+        const bool paced = e->render_queue < 0 ? (e->n >= RENDER_QUEUE_MIN_ENVS && e->render_pace < 0 && e->fill_GBs > 0) : (e->render_queue == RENDER_QUEUE_PACED && e->fill_GBs > 0);
+        *out = e->render_pace >= 0 ? e->render_pace : (paced ? (int64_t)(16.0 * 8 * PIX_BYTES / (RENDER_PACE_FRACTION * e->fill_GBs) + 0.5) : 0);
+    } else {
+        snprintf(g_err, sizeof(g_err), "get_option: unknown option '%s'", name);
         return BBAI_ERR_ARG;
     }
     return BBAI_OK;

@@ -79,6 +79,7 @@ def load_library():
     lib.bbai_bot_rollout.argtypes = [P, I32, P, P, P, P, P, P, P, P, P, P]
     lib.bbai_set_done_actions.argtypes = [P, I32]
     lib.bbai_set_option.argtypes = [P, ctypes.c_char_p, I64]
+    lib.bbai_get_option.argtypes = [P, ctypes.c_char_p, ctypes.POINTER(I64)]
     lib.bbai_get_done_actions.argtypes = [P]
     _lib = lib
     return lib
@@ -90,7 +91,7 @@ EXPORTED_SYMBOLS = (
     "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures", "bbai_bot_act", "bbai_bot_stats",
     "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load", "bbai_profile", "bbai_profile_read", "bbai_gae", "bbai_tap",
     "bbai_tap_ids", "bbai_set_call_events", "bbai_bot_rollout", "bbai_set_done_actions", "bbai_get_done_actions",
-    "bbai_set_option",
+    "bbai_set_option", "bbai_get_option",
 )
 
 
@@ -450,6 +451,12 @@ class BatchedBabyAIEnv(object):
         priorities -- never semantics).  What measurements alternate inside one process (tools/ab.py)."""
         _check(self.lib, self.lib.bbai_set_option(self.handle, name.encode(), int(value)), "bbai_set_option(%s)" % name)
     
+    def get_option(self, name):
+        """A knob of the live handle, or a measured quantity ("fill_GBs", "render_pace_effective", "lookahead_period")."""
+        v = ctypes.c_int64(0)
+        _check(self.lib, self.lib.bbai_get_option(self.handle, name.encode(), ctypes.byref(v)), "bbai_get_option(%s)" % name)
+        return int(v.value)
+
     def profile(self, enable=True):
         """Bracket every k_step / k_consume / k_render launch with HIP events on its launch stream (bench.py)."""
         _check(self.lib, self.lib.bbai_profile(self.handle, 1 if enable else 0), "bbai_profile")
