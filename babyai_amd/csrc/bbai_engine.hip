@@ -138,9 +138,10 @@ struct bbai_env {
     int render_queue_bpc; // option "render_queue_bpc": persistent render blocks per CU (0 = 1024 threads' worth: ONE 1024-thread block per CU --
                           // profiles/r04/render_queue_ab_1M_b.jsonl: k_render 1.50 ms against 1.61 with two)
     int render_queue_blocks;   // option "render_queue_blocks": their total number (0 = by render_queue_bpc)
-    int render_pace;      // option "render_pace": 1/16 ns of wall clock per render ticket; 0 = as fast as the counter serves them; -1 (default) = from
-                          // the calibrated fill rate (render_launch)
-    double fill_GBs;      // plain store stream of this device (calibrate_fill, at bbai_set_atlas for batches that render through the queue); 0 = not measured
+    int render_pace;      // option "render_pace": 1/16 ns of wall clock per render ticket; 0 = as fast as the counter serves them; -1 (default) = tuned
+                          // on the handle's first render (tune_render_pace)
+    int pace_tuned;       // the tuned pace (1/16 ns per ticket), 0 = not tuned yet
+    float pace_probe_ms[16];   // what the tuner measured: ms per launch at RENDER_PACE_PROBES[k] (0 = not probed)
     int n_cus;            // compute units of the device
     int done_action_enum; // option "done_action_enum": done-action mode only -- bbai_step's `done` actions count as the enum member (verifier.py:543-545)
     int consume_fused;    // BBAI_CONSUME_FUSED / option "consume_fused": -1 = by batch size, 0 = k_consume launch, 1 = inside k_step
@@ -893,7 +894,7 @@ __global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, Hot* __restrict__ 
 constexpr int RENDER_QUEUE_DEFAULT = 1;         // queue shape of render_launch used from RENDER_QUEUE_MIN_ENVS up
 constexpr int RENDER_QUEUE_PACED = 3;           // ... with time-paced tickets: (1024, 8) blocks, two interleaved counters
 constexpr int64_t RENDER_QUEUE_MIN_ENVS = 262144;
-constexpr double RENDER_PACE_FRACTION = 0.987;  // tickets are paced at this fraction of the calibrated fill rate (profiles/r04/NOTES.md section 1)
+
 constexpr int CHUNKS_PER_ROW = PIX * 3 / 8;       // 21 eight-byte chunks per pixel row
 constexpr int VEC_PER_ENV = PIX_BYTES / 16;       // 588 sixteen-byte stores per env
 
@@ -1068,12 +1069,6 @@ __global__ __launch_bounds__(64) void k_tokens(LevelCfg c, int64_t n, const uint
         else if (p->root == R_AFTER) { o.put(32); o.put(24); tok_side(o, p, 2, p->n_b); }    // after you
         while (o.n < TOK_MAX) o.p[o.n++] = 0;
     }
-}
-
-// one 4-KiB span per 256-thread block, 16 bytes per lane: the plain store stream (calibrate_fill)
-__global__ __launch_bounds__(256) void k_fill16(u32x4* __restrict__ out, int64_t nvec) {
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (q < nvec) { u32x4 v = {1u, 2u, 3u, (uint32_t)q}; __builtin_nontemporal_store(v, out + q); }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1609,45 +1604,56 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
     return call.leave();
 }
 
-// What a plain store stream reaches on this device, GB/s: 1 GiB written by one-shot 4-KiB blocks (the shape in which the pure
-// store stream is fastest: profiles/r02/ubench_store.txt), a few passes, HIP events.  The render paces its tickets just below
-// this rate (render_launch).  Synchronous; the scratch buffer is freed again.
-static int calibrate_fill(bbai_env* e) {
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-    size_t bytes = (size_t)1 << 30;
-    while (bytes > ((size_t)64 << 20) && bytes > free_b / 4) bytes >>= 1;
-    void* buf = nullptr;
-    if (hipMalloc(&buf, bytes) != hipSuccess) { (void)hipGetLastError(); e->fill_GBs = 0; return BBAI_OK; }     // (no calibration: the counter-paced shape)
-    hipEvent_t a, b;
-    HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
-    const int64_t nvec = (int64_t)(bytes >> 4);
-    const dim3 grid((unsigned)((nvec + 255) / 256));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_fill16, grid, dim3(256), 0, 0, (u32x4*)buf, nvec);
-    HIP_TRY(hipEventRecord(a, 0));
-    const int passes = 6;
-    for (int i = 0; i < passes; ++i) hipLaunchKernelGGL(k_fill16, grid, dim3(256), 0, 0, (u32x4*)buf, nvec);
-    HIP_TRY(hipEventRecord(b, 0));
-    HIP_TRY(hipEventSynchronize(b));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    (void)hipFree(buf);
-    e->fill_GBs = ms > 0 ? (double)bytes * passes / (ms * 1e-3) / 1e9 : 0;
-    return BBAI_OK;
-}
-
 int bbai_set_atlas(bbai_env* e, const uint8_t* tiles, int n_tiles, const uint8_t* lut) {
     if (!e || !tiles || !lut || n_tiles < 1 || n_tiles > MAX_TILES) ARG_FAIL("null pointer or tile count out of range");
     ON_DEVICE(e->device);
     HIP_TRY(hipMemcpy(e->atlas, tiles, (size_t)n_tiles * TILE_BYTES, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->lut, lut, 512, hipMemcpyHostToDevice));
     e->n_tiles = n_tiles;
-    if (e->n >= RENDER_QUEUE_MIN_ENVS && e->fill_GBs == 0) { int rc = calibrate_fill(e); if (rc != BBAI_OK) return rc; }
     return BBAI_OK;
 }
 
 }  // extern "C"
+
+// The pace of the render's tickets, tuned on the real launch.  k_render_q at the rate of ONE ticket counter (11.4 ns per 8-env ticket
+// = 6.6 TB/s) beats every unpaced shape because the counter PACES the chip's stores (render_launch); the best pace is a little
+// faster -- just below what the device's store stream sustains (profiles/r04/render_pace_ab_*.jsonl, two boxes: 11.0-11.06 ns,
+// k_render 1.50 -> 1.466 / 1.482 ms) -- slower costs 8 us per 1/16 ns, faster falls off a cliff into the unpaced regime
+// (+ 20-40 us).  Boxes differ by a few per cent in store bandwidth, so the handle measures: its first render is repeated (the render
+// is idempotent) at paces from slow to fast, three launches each, timed with HIP events ON THE CALLER'S STREAM (which this one call
+// therefore synchronises); it keeps the fastest and backs off by one step.  ~30 launches, once per handle.
+constexpr int RENDER_PACE_PROBES[] = {186, 183, 180, 178, 176, 174, 172, 170, 168, 166};       // 1/16 ns per ticket: 11.6 ... 10.4 ns
+static int tune_render_pace(bbai_env* e, const uint8_t* input, uint8_t* pixels, hipStream_t s) {
+    const int cus = e->n_cus > 0 ? e->n_cus : 256;
+    const int64_t tickets = (e->n + 7) / 8;
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, tickets));
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+    auto run = [&](int pace, float* ms) -> int {
+        HIP_TRY(hipEventRecord(a, s));
+        hipLaunchKernelGGL((k_render_q<8, 1024, 2, 1>), dim3(blocks), dim3(1024), 0, s, e->n, input, pixels, e->atlas, e->lut, e->n_tiles, e->render_tickets, pace);
+        HIP_TRY(hipEventRecord(b, s));
+        HIP_TRY(hipEventSynchronize(b));
+        HIP_TRY(hipEventElapsedTime(ms, a, b));
+        return BBAI_OK;
+    };
+    float warm = 0;
+    { int rc = run(RENDER_PACE_PROBES[0], &warm); if (rc != BBAI_OK) return rc; }
+    int best = -1, worse = 0;
+    float best_ms = 1e30f;
+    constexpr int NP = (int)(sizeof(RENDER_PACE_PROBES) / sizeof(int));
+    for (int k = 0; k < NP && worse < 2; ++k) {
+        float ms = 1e30f;
+        for (int r = 0; r < 3; ++r) { float t = 0; int rc = run(RENDER_PACE_PROBES[k], &t); if (rc != BBAI_OK) return rc; ms = std::min(ms, t); }
+        e->pace_probe_ms[k] = ms;
+        if (ms < best_ms) { best_ms = ms; best = k; worse = 0; } else ++worse;       // (two probes past the minimum: over the cliff, stop)
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    HIP_TRY(hipGetLastError());
+    // one step back towards the slow side: the loop's conditions (k_step before, the generator next to it) are not the idle chip's
+    e->pace_tuned = best <= 0 ? RENDER_PACE_PROBES[0] : RENDER_PACE_PROBES[best] + 1;
+    return BBAI_OK;
+}
 
 static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, void* stream) {
     CallScope call(e, (hipStream_t)stream);
@@ -1675,11 +1681,14 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
     int pace = e->render_pace;
     if (qm < 0) {
         qm = e->n >= RENDER_QUEUE_MIN_ENVS ? RENDER_QUEUE_DEFAULT : 0;
-        // time-paced tickets when the device's fill rate is known: two interleaved counters serve tickets twice as fast as the chip
-        // can store them, and the wall clock admits them at RENDER_PACE_FRACTION of the fill rate
-        if (qm == RENDER_QUEUE_DEFAULT && pace < 0 && e->fill_GBs > 0) qm = RENDER_QUEUE_PACED;
+        // Time-paced tickets (the default): two interleaved counters serve tickets twice as fast as the chip can store them, and
+        // the wall clock admits one per `pace` -- tuned ONCE per handle, on this first launch itself (tune_render_pace).
+        if (qm == RENDER_QUEUE_DEFAULT && pace < 0) {
+            if (!e->pace_tuned) { int rc = tune_render_pace(e, input, pixels, (hipStream_t)stream); if (rc != BBAI_OK) return rc; }
+            if (e->pace_tuned > 0) { qm = RENDER_QUEUE_PACED; pace = e->pace_tuned; }
+        }
     }
-    if (pace < 0) pace = (qm == RENDER_QUEUE_PACED && e->fill_GBs > 0) ? (int)(16.0 * 8 * PIX_BYTES / (RENDER_PACE_FRACTION * e->fill_GBs) + 0.5) : 0;
+    if (pace < 0) pace = 0;
     if (qm > 0) {
         const int cus = e->n_cus > 0 ? e->n_cus : 256;
 #define RENDER_Q(GG, TT, NC, KK) do { \
@@ -2092,6 +2101,7 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     else if (!strcmp(name, "render_queue_bpc")) e->render_queue_bpc = v;
     else if (!strcmp(name, "render_queue_blocks")) e->render_queue_blocks = v;
     else if (!strcmp(name, "render_pace")) e->render_pace = v < 0 ? -1 : v;
+    else if (!strcmp(name, "render_pace_retune")) e->pace_tuned = 0;           // (the next default render tunes again)
     else if (!strcmp(name, "render_group")) e->render_group = v;
     else if (!strcmp(name, "render_tpb")) e->render_tpb = v;
     else if (!strcmp(name, "step_prio")) e->step_prio = v;
@@ -2106,8 +2116,9 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     return BBAI_OK;
 }
 
-// Read back a knob or a measured quantity: the names of bbai_set_option, plus "fill_GBs" (the calibrated plain store stream,
-// 0 = not measured) and "render_pace_effective" (1/16 ns per render ticket the next bbai_render will use, 0 = unpaced).
+// Read back a knob or a measured quantity: the names of bbai_set_option, plus "render_pace_effective" (1/16 ns per render ticket in
+// use: the option, or what the handle's first render tuned; 0 = unpaced / not tuned yet), "render_pace_probe_us_<k>" (the tuner's k-th
+// probe: pace << 32 | microseconds per launch) and "lookahead_period".
 int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     if (!e || !name || !out) ARG_FAIL("null handle, name or output");
     if (!strcmp(name, "render_queue")) *out = e->render_queue;
@@ -2122,10 +2133,11 @@ int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     else if (!strcmp(name, "consume_fused")) *out = e->consume_fused;
     else if (!strcmp(name, "done_action_enum")) *out = e->done_action_enum;
     else if (!strcmp(name, "lookahead_period")) *out = e->period;
-    else if (!strcmp(name, "fill_GBs")) *out = (int64_t)(e->fill_GBs + 0.5);
-    else if (!strcmp(name, "render_pace_effective")) {
-        const bool paced = e->render_queue < 0 ? (e->n >= RENDER_QUEUE_MIN_ENVS && e->render_pace < 0 && e->fill_GBs > 0) : (e->render_queue == RENDER_QUEUE_PACED && e->fill_GBs > 0);
-        *out = e->render_pace >= 0 ? e->render_pace : (paced ? (int64_t)(16.0 * 8 * PIX_BYTES / (RENDER_PACE_FRACTION * e->fill_GBs) + 0.5) : 0);
+    else if (!strcmp(name, "render_pace_effective")) *out = e->render_pace >= 0 ? e->render_pace : ((e->render_queue < 0 && e->n >= RENDER_QUEUE_MIN_ENVS) ? e->pace_tuned : 0);
+    else if (!strncmp(name, "render_pace_probe_us_", 21)) {          // what the tuner measured at RENDER_PACE_PROBES[k]: microseconds per launch (0 = not probed)
+        const int k = atoi(name + 21);
+        if (k < 0 || k >= (int)(sizeof(RENDER_PACE_PROBES) / sizeof(int))) ARG_FAIL("probe index out of range");
+        *out = (int64_t)(e->pace_probe_ms[k] * 1000.0f + 0.5f) | ((int64_t)RENDER_PACE_PROBES[k] << 32);
     } else {
         snprintf(g_err, sizeof(g_err), "get_option: unknown option '%s'", name);
         return BBAI_ERR_ARG;

@@ -336,9 +336,15 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
     render_cfg = None
     if pixel:
         pace = env.get_option("render_pace_effective")
-        render_cfg = {"calibrated_fill_GBs": env.get_option("fill_GBs"), "ticket_pace_ns": pace / 16.0 if pace else None,
-                      "note": "k_render_q admits one 8-env ticket per ticket_pace_ns of wall clock, just below the device's plain store stream "
-                              "(calibrated once per handle at bbai_set_atlas); null = tickets as fast as the counter serves them"}
+        probes = []
+        for k in range(10):
+            v = env.get_option("render_pace_probe_us_%d" % k)
+            if v & 0xFFFFFFFF:
+                probes.append({"pace_ns": (v >> 32) / 16.0, "us_per_launch": v & 0xFFFFFFFF})
+        render_cfg = {"ticket_pace_ns": pace / 16.0 if pace else None, "tuner_probes": probes,
+                      "note": "k_render_q admits one 8-env ticket per ticket_pace_ns of wall clock, just below what the device's store stream "
+                              "sustains; tuned once per handle on its first render (idempotent re-renders, slow to fast, fastest + one step back); "
+                              "null = tickets as fast as the counter serves them"}
     m = {"level": level, "pixel": pixel, "E": E, "total_envs": total_envs, "first": first, "K": K, "W": W, "S1": S1, "S2": S2, "want": want,
          "blocks": blocks, "profiled": profiled, "local_blocks": local_blocks, "barrier_s": barrier_s,
          "kernel_ms": {k: v[0] for k, v in prof.items() if v[0] is not None},

@@ -120,7 +120,7 @@ def main():
                     "profiled_ms_per_step": round(median(prof), 5) if prof else None, "kernel_avg_ms": km,
                     "resets_per_step": (env.reset_count() - r0) / (args.blocks * K)}
             if args.pixel:
-                line["fill_GBs"], line["render_pace_effective_x16"] = env.get_option("fill_GBs"), env.get_option("render_pace_effective")
+                line["render_pace_effective_x16"] = env.get_option("render_pace_effective")
             print(json.dumps(line), flush=True)
             results.setdefault(name, []).append(line)
     rank = sorted(((median([l["ms_per_step"] for l in ls]), n) for n, ls in results.items()))

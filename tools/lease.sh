@@ -55,7 +55,7 @@ ab() {               # tools/ab.py presets
                     --base render_queue=-1,render_queue_bpc=0,render_queue_blocks=0,render_pace=-1 --settings render_queue=1,render_pace=0 render_pace=-1 render_queue=3,render_pace=0 \
                     render_queue=3,render_pace=182 render_queue=3,render_pace=179 render_queue=3,render_pace=177 render_queue=3,render_pace=175 render_queue=3,render_pace=173 \
                     render_queue=3,render_pace=171 render_queue=1,render_pace=186 render_queue=3,render_pace=176,render_queue_bpc=2 \
-                    > $OUT/render_pace_ab_${2:-1048576}.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_pace_ab_${2:-1048576}.jsonl; grep -o '"fill_GBs": [0-9]*, "render_pace_effective_x16": [0-9]*' $OUT/render_pace_ab_${2:-1048576}.jsonl | sort | uniq -c ;;
+                    > $OUT/render_pace_ab_${2:-1048576}.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_pace_ab_${2:-1048576}.jsonl; grep -o '"setting": "[^"]*"\|"render_pace_effective_x16": [0-9]*' $OUT/render_pace_ab_${2:-1048576}.jsonl | sort | uniq -c ;;
     *)          # ab:<name>:<level>:<envs>:<steps>:<pixel 0|1>:<setting>:<setting>...   (settings use '/' for ',')
                 local name=$1 level=$2 envs=$3 steps=$4 pix=$5; shift 5
                 local sets=(); for s in "$@"; do sets+=("${s//\//,}"); done
