@@ -1615,14 +1615,18 @@ int bbai_set_atlas(bbai_env* e, const uint8_t* tiles, int n_tiles, const uint8_t
 
 }  // extern "C"
 
-// The pace of the render's tickets, tuned on the real launch.  k_render_q at the rate of ONE ticket counter (11.4 ns per 8-env ticket
-// = 6.6 TB/s) beats every unpaced shape because the counter PACES the chip's stores (render_launch); the best pace is a little
-// faster -- just below what the device's store stream sustains (profiles/r04/render_pace_ab_*.jsonl, two boxes: 11.0-11.06 ns,
-// k_render 1.50 -> 1.466 / 1.482 ms) -- slower costs 8 us per 1/16 ns, faster falls off a cliff into the unpaced regime
-// (+ 20-40 us).  Boxes differ by a few per cent in store bandwidth, so the handle measures: its first render is repeated (the render
-// is idempotent) at paces from slow to fast, three launches each, timed with HIP events ON THE CALLER'S STREAM (which this one call
-// therefore synchronises); it keeps the fastest and backs off by one step.  ~30 launches, once per handle.
-constexpr int RENDER_PACE_PROBES[] = {186, 183, 180, 178, 176, 174, 172, 170, 168, 166};       // 1/16 ns per ticket: 11.6 ... 10.4 ns
+// The pace of the render's tickets.  k_render_q at the rate of ONE ticket counter (11.4 ns per 8-env ticket = 6.6 TB/s) beats every
+// unpaced shape because the counter PACES the chip's stores (render_launch); the best pace is a little faster -- just below what
+// the device's store stream sustains.  Measured in the step loop on three boxes (profiles/r04/render_pace_ab_*.jsonl, 1/16 ns per
+// ticket -> k_render ms at 1 048 576 envs): 183 -> 1.500-1.508, 179 -> 1.478-1.488, 177 -> 1.481-1.482, 176 -> 1.466 (one box), 175 -> 1.487-1.502,
+// 173 -> 1.485-1.508, 171 -> 1.500-1.508, unpaced two counters 1.527-1.549, one counter (11.4 ns by hardware) 1.501-1.504.  Slower
+// than the optimum costs 8 us per 1/16 ns; faster falls off a (shallow) cliff back to the one-counter figure.  11.1 ns is 6.8 TB/s:
+// no box of the pool fills memory faster (6.87-6.93 TB/s), so the pace is never set faster than RENDER_PACE_MIN; boxes with a
+// SLOWER store stream exist (round 2 met one at 0.85 of the others), so the handle measures downwards from a slow pace: its first
+// render is repeated (the render is idempotent) at RENDER_PACE_PROBES, three launches each, timed with HIP events ON THE CALLER'S
+// STREAM (which this one call therefore synchronises); it keeps the fastest and backs off by one step.  ~25 launches, once per handle.
+constexpr int RENDER_PACE_PROBES[] = {200, 194, 189, 185, 182, 179, 177};       // 1/16 ns per ticket: 12.5 ... 11.06 ns
+constexpr int RENDER_PACE_MIN = 178;                                            // 11.125 ns per 8-env ticket = 6.77 TB/s
 static int tune_render_pace(bbai_env* e, const uint8_t* input, uint8_t* pixels, hipStream_t s) {
     const int cus = e->n_cus > 0 ? e->n_cus : 256;
     const int64_t tickets = (e->n + 7) / 8;
@@ -1651,7 +1655,7 @@ static int tune_render_pace(bbai_env* e, const uint8_t* input, uint8_t* pixels, 
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     HIP_TRY(hipGetLastError());
     // one step back towards the slow side: the loop's conditions (k_step before, the generator next to it) are not the idle chip's
-    e->pace_tuned = best <= 0 ? RENDER_PACE_PROBES[0] : RENDER_PACE_PROBES[best] + 1;
+    e->pace_tuned = std::max(RENDER_PACE_MIN, (best < 0 ? RENDER_PACE_PROBES[0] : RENDER_PACE_PROBES[best]) + 1);
     return BBAI_OK;
 }
 

@@ -337,13 +337,14 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
     if pixel:
         pace = env.get_option("render_pace_effective")
         probes = []
-        for k in range(10):
+        for k in range(7):
             v = env.get_option("render_pace_probe_us_%d" % k)
             if v & 0xFFFFFFFF:
                 probes.append({"pace_ns": (v >> 32) / 16.0, "us_per_launch": v & 0xFFFFFFFF})
         render_cfg = {"ticket_pace_ns": pace / 16.0 if pace else None, "tuner_probes": probes,
                       "note": "k_render_q admits one 8-env ticket per ticket_pace_ns of wall clock, just below what the device's store stream "
-                              "sustains; tuned once per handle on its first render (idempotent re-renders, slow to fast, fastest + one step back); "
+                              "sustains: 11.125 ns on every box met in round 4; a handle's first render probes slower paces (idempotent re-renders) and keeps one "
+                              "only where the box's store stream is slower; "
                               "null = tickets as fast as the counter serves them"}
     m = {"level": level, "pixel": pixel, "E": E, "total_envs": total_envs, "first": first, "K": K, "W": W, "S1": S1, "S2": S2, "want": want,
          "blocks": blocks, "profiled": profiled, "local_blocks": local_blocks, "barrier_s": barrier_s,

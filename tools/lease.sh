@@ -53,8 +53,8 @@ ab() {               # tools/ab.py presets
     pace)       # ab:pace[:<envs>:<steps>] -- time-paced render tickets: the calibrated default against fixed paces and the counter-paced shape (1/16 ns per ticket)
                 timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs ${2:-1048576} --pixel --steps ${3:-20} --blocks 8 --reps 3 \
                     --base render_queue=-1,render_queue_bpc=0,render_queue_blocks=0,render_pace=-1 --settings render_queue=1,render_pace=0 render_pace=-1 render_queue=3,render_pace=0 \
-                    render_queue=3,render_pace=182 render_queue=3,render_pace=179 render_queue=3,render_pace=177 render_queue=3,render_pace=175 render_queue=3,render_pace=173 \
-                    render_queue=3,render_pace=171 render_queue=1,render_pace=186 render_queue=3,render_pace=176,render_queue_bpc=2 \
+                    render_queue=3,render_pace=182 render_queue=3,render_pace=180 render_queue=3,render_pace=178 render_queue=3,render_pace=176 render_queue=3,render_pace=174 \
+                    render_queue=3,render_pace=172 \
                     > $OUT/render_pace_ab_${2:-1048576}.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_pace_ab_${2:-1048576}.jsonl; grep -o '"setting": "[^"]*"\|"render_pace_effective_x16": [0-9]*' $OUT/render_pace_ab_${2:-1048576}.jsonl | sort | uniq -c ;;
     *)          # ab:<name>:<level>:<envs>:<steps>:<pixel 0|1>:<setting>:<setting>...   (settings use '/' for ',')
                 local name=$1 level=$2 envs=$3 steps=$4 pix=$5; shift 5
