@@ -78,6 +78,7 @@ struct DeviceGuard {
     HIP_TRY((hipError_t)guard_.err)
 
 constexpr int PROF_RING = 256;          // event pairs per profiled kernel (bbai_profile)
+constexpr int PACE_RING = 64;           // event pairs of the render's pace controller in flight
 
 struct bbai_env {
     LevelCfg cfg;
@@ -139,9 +140,16 @@ struct bbai_env {
                           // profiles/r04/render_queue_ab_1M_b.jsonl: k_render 1.50 ms against 1.61 with two)
     int render_queue_blocks;   // option "render_queue_blocks": their total number (0 = by render_queue_bpc)
     int render_pace;      // option "render_pace": 1/16 ns of wall clock per render ticket; 0 = as fast as the counter serves them; -1 (default) = tuned
-                          // on the handle's first render (tune_render_pace)
-    int pace_tuned;       // the tuned pace (1/16 ns per ticket), 0 = not tuned yet
-    float pace_probe_ms[16];   // what the tuner measured: ms per launch at RENDER_PACE_PROBES[k] (0 = not probed)
+                          // controlled on the launches' own durations (pace_next)
+    // the pace controller of the default render (pace_next / pace_harvest): perturb-and-observe on the launches' own durations
+    struct PaceCtl {
+        int p, dir;                 // current pace (1/16 ns per ticket), direction of the last move (-1 = faster)
+        int n; double sum;          // completed launches at the current pace, their summed milliseconds
+        double last_mean; bool have_last;
+        int64_t moves, samples;     // decisions taken / launches measured so far
+        struct Slot { hipEvent_t a, b; int pace; bool busy; } ring[PACE_RING];
+        int head, tail;             // ring of in-flight event pairs: [tail, head)
+    } pace_ctl;
     int n_cus;            // compute units of the device
     int done_action_enum; // option "done_action_enum": done-action mode only -- bbai_step's `done` actions count as the enum member (verifier.py:543-545)
     int consume_fused;    // BBAI_CONSUME_FUSED / option "consume_fused": -1 = by batch size, 0 = k_consume launch, 1 = inside k_step
@@ -1325,6 +1333,7 @@ void bbai_destroy(bbai_env* e) {
     if (e->ev_switch) (void)hipEventDestroy(e->ev_switch);
     for (int k = 0; k < 3; ++k) for (int i = 0; i < PROF_RING; ++i) if (e->prof[k][i].a) { (void)hipEventDestroy(e->prof[k][i].a); (void)hipEventDestroy(e->prof[k][i].b); }
     for (int k = 0; k < 3; ++k) if (e->ev_refill[k]) (void)hipEventDestroy(e->ev_refill[k]);
+    for (int i = 0; i < PACE_RING; ++i) if (e->pace_ctl.ring[i].a) { (void)hipEventDestroy(e->pace_ctl.ring[i].a); (void)hipEventDestroy(e->pace_ctl.ring[i].b); }
     void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
     void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_list, e->win_count, e->reset_list, e->counters,
@@ -1617,46 +1626,49 @@ int bbai_set_atlas(bbai_env* e, const uint8_t* tiles, int n_tiles, const uint8_t
 
 // The pace of the render's tickets.  k_render_q at the rate of ONE ticket counter (11.4 ns per 8-env ticket = 6.6 TB/s) beats every
 // unpaced shape because the counter PACES the chip's stores (render_launch); the best pace is a little faster -- just below what
-// the device's store stream sustains.  Measured in the step loop on three boxes (profiles/r04/render_pace_ab_*.jsonl, 1/16 ns per
-// ticket -> k_render ms at 1 048 576 envs): 183 -> 1.500-1.508, 179 -> 1.478-1.488, 177 -> 1.481-1.482, 176 -> 1.466 (one box), 175 -> 1.487-1.502,
-// 173 -> 1.485-1.508, 171 -> 1.500-1.508, unpaced two counters 1.527-1.549, one counter (11.4 ns by hardware) 1.501-1.504.  Slower
-// than the optimum costs 8 us per 1/16 ns; faster falls off a (shallow) cliff back to the one-counter figure.  11.1 ns is 6.8 TB/s:
-// no box of the pool fills memory faster (6.87-6.93 TB/s), so the pace is never set faster than RENDER_PACE_MIN; boxes with a
-// SLOWER store stream exist (round 2 met one at 0.85 of the others), so the handle measures downwards from a slow pace: its first
-// render is repeated (the render is idempotent) at RENDER_PACE_PROBES, three launches each, timed with HIP events ON THE CALLER'S
-// STREAM (which this one call therefore synchronises); it keeps the fastest and backs off by one step.  ~25 launches, once per handle.
-constexpr int RENDER_PACE_PROBES[] = {200, 194, 189, 185, 182, 179, 177};       // 1/16 ns per ticket: 12.5 ... 11.06 ns
-constexpr int RENDER_PACE_MIN = 178;                                            // 11.125 ns per 8-env ticket = 6.77 TB/s
-static int tune_render_pace(bbai_env* e, const uint8_t* input, uint8_t* pixels, hipStream_t s) {
-    const int cus = e->n_cus > 0 ? e->n_cus : 256;
-    const int64_t tickets = (e->n + 7) / 8;
-    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cus, tickets));
-    hipEvent_t a, b;
-    HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
-    auto run = [&](int pace, float* ms) -> int {
-        HIP_TRY(hipEventRecord(a, s));
-        hipLaunchKernelGGL((k_render_q<8, 1024, 2, 1>), dim3(blocks), dim3(1024), 0, s, e->n, input, pixels, e->atlas, e->lut, e->n_tiles, e->render_tickets, pace);
-        HIP_TRY(hipEventRecord(b, s));
-        HIP_TRY(hipEventSynchronize(b));
-        HIP_TRY(hipEventElapsedTime(ms, a, b));
-        return BBAI_OK;
-    };
-    float warm = 0;
-    { int rc = run(RENDER_PACE_PROBES[0], &warm); if (rc != BBAI_OK) return rc; }
-    int best = -1, worse = 0;
-    float best_ms = 1e30f;
-    constexpr int NP = (int)(sizeof(RENDER_PACE_PROBES) / sizeof(int));
-    for (int k = 0; k < NP && worse < 2; ++k) {
-        float ms = 1e30f;
-        for (int r = 0; r < 3; ++r) { float t = 0; int rc = run(RENDER_PACE_PROBES[k], &t); if (rc != BBAI_OK) return rc; ms = std::min(ms, t); }
-        e->pace_probe_ms[k] = ms;
-        if (ms < best_ms) { best_ms = ms; best = k; worse = 0; } else ++worse;       // (two probes past the minimum: over the cliff, stop)
+// the store stream sustains at that moment.  Measured in the step loop on five boxes (profiles/r04/render_pace_ab_*.jsonl, 1/16 ns per
+// ticket -> k_render ms at 1 048 576 envs): slower than the optimum the launch is pace-bound (131 072 tickets x pace: 8 us per
+// 1/16 ns), faster it falls off a shallow cliff back to -- or a little behind -- the one-counter figure (1.50 ms).  The optimum
+// moved from 10.8 to 11.3 ns between boxes AND between two processes on one box (the physical placement of a 9.9-GB output differs
+// from run to run), and an idle chip puts it elsewhere than the step loop does: a fixed pace wins 1.5 % here and loses 1.5 % there.
+// So the pace is CONTROLLED on the launches' own durations: every default render is bracketed by an event pair (harvested without
+// ever blocking), and every PACE_WINDOW completed launches the controller compares their mean with the previous window's and moves
+// the pace one step (1/16 ns) in the direction that helped -- perturb and observe; it starts at the counter's own rate, reaches the
+// optimum within a few windows and then hovers one step around it (cost: ~4 us of 1.5 ms).  Results never depend on the pace.
+constexpr int RENDER_PACE_START = 183;          // 11.44 ns: the one counter's own rate -- never worse than round 4's first shape
+constexpr int RENDER_PACE_FASTEST = 168, RENDER_PACE_SLOWEST = 224;     // 10.5 ... 14 ns per 8-env ticket (7.2 ... 5.4 TB/s)
+constexpr int PACE_WINDOW = 12;
+static void pace_harvest(bbai_env* e) {
+    bbai_env::PaceCtl& c = e->pace_ctl;
+    while (c.tail != c.head) {
+        bbai_env::PaceCtl::Slot& sl = c.ring[c.tail % PACE_RING];
+        if (hipEventQuery(sl.b) != hipSuccess) { (void)hipGetLastError(); break; }       // launches complete in order: stop at the first pending one
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, sl.a, sl.b) == hipSuccess && sl.pace == c.p) { c.sum += ms; c.n++; c.samples++; }
+        sl.busy = false;
+        c.tail++;
     }
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    HIP_TRY(hipGetLastError());
-    // one step back towards the slow side: the loop's conditions (k_step before, the generator next to it) are not the idle chip's
-    e->pace_tuned = std::max(RENDER_PACE_MIN, (best < 0 ? RENDER_PACE_PROBES[0] : RENDER_PACE_PROBES[best]) + 1);
-    return BBAI_OK;
+    if (c.n >= PACE_WINDOW) {
+        const double mean = c.sum / c.n;
+        if (c.have_last && mean > c.last_mean - 0.0005) c.dir = -c.dir;      // the last move did not help (by at least half a microsecond): turn round
+        c.last_mean = mean; c.have_last = true;
+        int np = c.p + c.dir;
+        if (np < RENDER_PACE_FASTEST || np > RENDER_PACE_SLOWEST) { c.dir = -c.dir; np = c.p + c.dir; }
+        c.p = np; c.n = 0; c.sum = 0; c.moves++;
+    }
+}
+// the pace of the next default launch, and the event pair to bracket it with (NULL: more launches in flight than the ring holds)
+static int pace_next(bbai_env* e, bbai_env::PaceCtl::Slot** slot) {
+    bbai_env::PaceCtl& c = e->pace_ctl;
+    if (c.p == 0) { c.p = RENDER_PACE_START; c.dir = -1; }
+    pace_harvest(e);
+    *slot = nullptr;
+    if (c.head - c.tail < PACE_RING) {
+        bbai_env::PaceCtl::Slot& sl = c.ring[c.head % PACE_RING];
+        if (!sl.a && (hipEventCreate(&sl.a) != hipSuccess || hipEventCreate(&sl.b) != hipSuccess)) { (void)hipGetLastError(); return c.p; }
+        *slot = &sl;
+    }
+    return c.p;
 }
 
 static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, void* stream) {
@@ -1681,15 +1693,17 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
     // encoding is still in the memory-side cache and short-lived (512, 2) blocks win.
     // BBAI_RENDER_QUEUE / option "render_queue": -1 = by batch size (default), 0 = never, m > 0 = queue shape m of the table below.
     const bool big = e->n >= 786432;
+    bbai_env::PaceCtl::Slot* pace_slot = nullptr;
     int qm = e->render_queue;
     int pace = e->render_pace;
     if (qm < 0) {
         qm = e->n >= RENDER_QUEUE_MIN_ENVS ? RENDER_QUEUE_DEFAULT : 0;
         // Time-paced tickets (the default): two interleaved counters serve tickets twice as fast as the chip can store them, and
-        // the wall clock admits one per `pace` -- tuned ONCE per handle, on this first launch itself (tune_render_pace).
+        // the wall clock admits one per `pace`, which the controller above keeps at the optimum of the moment.
         if (qm == RENDER_QUEUE_DEFAULT && pace < 0) {
-            if (!e->pace_tuned) { int rc = tune_render_pace(e, input, pixels, (hipStream_t)stream); if (rc != BBAI_OK) return rc; }
-            if (e->pace_tuned > 0) { qm = RENDER_QUEUE_PACED; pace = e->pace_tuned; }
+            qm = RENDER_QUEUE_PACED;
+            pace = pace_next(e, &pace_slot);
+            if (pace_slot) { pace_slot->pace = pace; (void)hipEventRecord(pace_slot->a, (hipStream_t)stream); }
         }
     }
     if (pace < 0) pace = 0;
@@ -1716,6 +1730,7 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
         case 11: RENDER_Q(10, 1024, 1, 1); break;
         }
 #undef RENDER_Q
+        if (pace_slot) { (void)hipEventRecord(pace_slot->b, (hipStream_t)stream); pace_slot->busy = true; e->pace_ctl.head++; }
         HIP_TRY(hipGetLastError());
         return call.leave();
     }
@@ -2105,7 +2120,6 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     else if (!strcmp(name, "render_queue_bpc")) e->render_queue_bpc = v;
     else if (!strcmp(name, "render_queue_blocks")) e->render_queue_blocks = v;
     else if (!strcmp(name, "render_pace")) e->render_pace = v < 0 ? -1 : v;
-    else if (!strcmp(name, "render_pace_retune")) e->pace_tuned = 0;           // (the next default render tunes again)
     else if (!strcmp(name, "render_group")) e->render_group = v;
     else if (!strcmp(name, "render_tpb")) e->render_tpb = v;
     else if (!strcmp(name, "step_prio")) e->step_prio = v;
@@ -2121,8 +2135,8 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
 }
 
 // Read back a knob or a measured quantity: the names of bbai_set_option, plus "render_pace_effective" (1/16 ns per render ticket in
-// use: the option, or what the handle's first render tuned; 0 = unpaced / not tuned yet), "render_pace_probe_us_<k>" (the tuner's k-th
-// probe: pace << 32 | microseconds per launch) and "lookahead_period".
+// use: the option, or where the pace controller stands; 0 = unpaced), "render_pace_moves" / "render_pace_samples" (its decisions and
+// measured launches so far) and "lookahead_period".
 int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     if (!e || !name || !out) ARG_FAIL("null handle, name or output");
     if (!strcmp(name, "render_queue")) *out = e->render_queue;
@@ -2137,12 +2151,10 @@ int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     else if (!strcmp(name, "consume_fused")) *out = e->consume_fused;
     else if (!strcmp(name, "done_action_enum")) *out = e->done_action_enum;
     else if (!strcmp(name, "lookahead_period")) *out = e->period;
-    else if (!strcmp(name, "render_pace_effective")) *out = e->render_pace >= 0 ? e->render_pace : ((e->render_queue < 0 && e->n >= RENDER_QUEUE_MIN_ENVS) ? e->pace_tuned : 0);
-    else if (!strncmp(name, "render_pace_probe_us_", 21)) {          // what the tuner measured at RENDER_PACE_PROBES[k]: microseconds per launch (0 = not probed)
-        const int k = atoi(name + 21);
-        if (k < 0 || k >= (int)(sizeof(RENDER_PACE_PROBES) / sizeof(int))) ARG_FAIL("probe index out of range");
-        *out = (int64_t)(e->pace_probe_ms[k] * 1000.0f + 0.5f) | ((int64_t)RENDER_PACE_PROBES[k] << 32);
-    } else {
+    else if (!strcmp(name, "render_pace_effective")) *out = e->render_pace >= 0 ? e->render_pace : ((e->render_queue < 0 && e->n >= RENDER_QUEUE_MIN_ENVS) ? e->pace_ctl.p : 0);
+    else if (!strcmp(name, "render_pace_moves")) *out = e->pace_ctl.moves;
+    else if (!strcmp(name, "render_pace_samples")) *out = e->pace_ctl.samples;
+    else {
         snprintf(g_err, sizeof(g_err), "get_option: unknown option '%s'", name);
         return BBAI_ERR_ARG;
     }

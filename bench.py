@@ -336,16 +336,11 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
     render_cfg = None
     if pixel:
         pace = env.get_option("render_pace_effective")
-        probes = []
-        for k in range(7):
-            v = env.get_option("render_pace_probe_us_%d" % k)
-            if v & 0xFFFFFFFF:
-                probes.append({"pace_ns": (v >> 32) / 16.0, "us_per_launch": v & 0xFFFFFFFF})
-        render_cfg = {"ticket_pace_ns": pace / 16.0 if pace else None, "tuner_probes": probes,
-                      "note": "k_render_q admits one 8-env ticket per ticket_pace_ns of wall clock, just below what the device's store stream "
-                              "sustains: 11.125 ns on every box met in round 4; a handle's first render probes slower paces (idempotent re-renders) and keeps one "
-                              "only where the box's store stream is slower; "
-                              "null = tickets as fast as the counter serves them"}
+        render_cfg = {"ticket_pace_ns": pace / 16.0 if pace else None, "controller_moves": env.get_option("render_pace_moves"),
+                      "launches_measured": env.get_option("render_pace_samples"),
+                      "note": "k_render_q admits one 8-env ticket per ticket_pace_ns of wall clock; the pace is controlled on the launches' own "
+                              "durations (perturb and observe, one 1/16-ns step per 12 launches, started at the one ticket counter's 11.44 ns): "
+                              "ticket_pace_ns = where it stood at the end of the run; null = tickets as fast as the counter serves them"}
     m = {"level": level, "pixel": pixel, "E": E, "total_envs": total_envs, "first": first, "K": K, "W": W, "S1": S1, "S2": S2, "want": want,
          "blocks": blocks, "profiled": profiled, "local_blocks": local_blocks, "barrier_s": barrier_s,
          "kernel_ms": {k: v[0] for k, v in prof.items() if v[0] is not None},
