@@ -78,7 +78,6 @@ struct DeviceGuard {
     HIP_TRY((hipError_t)guard_.err)
 
 constexpr int PROF_RING = 256;          // event pairs per profiled kernel (bbai_profile)
-constexpr int PACE_RING = 64;           // event pairs of the render's pace controller in flight
 
 struct bbai_env {
     LevelCfg cfg;
@@ -139,17 +138,8 @@ struct bbai_env {
     int render_queue_bpc; // option "render_queue_bpc": persistent render blocks per CU (0 = 1024 threads' worth: ONE 1024-thread block per CU --
                           // profiles/r04/render_queue_ab_1M_b.jsonl: k_render 1.50 ms against 1.61 with two)
     int render_queue_blocks;   // option "render_queue_blocks": their total number (0 = by render_queue_bpc)
-    int render_pace;      // option "render_pace": 1/16 ns of wall clock per render ticket; 0 = as fast as the counter serves them; -1 (default) = tuned
-                          // controlled on the launches' own durations (pace_next)
-    // the pace controller of the default render (pace_next / pace_harvest): perturb-and-observe on the launches' own durations
-    struct PaceCtl {
-        int p, dir;                 // current pace (1/16 ns per ticket), direction of the last move (-1 = faster)
-        int n; double sum;          // completed launches at the current pace, their summed milliseconds
-        double last_mean; bool have_last;
-        int64_t moves, samples;     // decisions taken / launches measured so far
-        struct Slot { hipEvent_t a, b; int pace; bool busy; } ring[PACE_RING];
-        int head, tail;             // ring of in-flight event pairs: [tail, head)
-    } pace_ctl;
+    int render_pace;      // option "render_pace" (experiment): 1/16 ns of wall clock per render ticket (then with two counters), 0 (default) = as fast as the
+                          // one counter serves them
     int n_cus;            // compute units of the device
     int done_action_enum; // option "done_action_enum": done-action mode only -- bbai_step's `done` actions count as the enum member (verifier.py:543-545)
     int consume_fused;    // BBAI_CONSUME_FUSED / option "consume_fused": -1 = by batch size, 0 = k_consume launch, 1 = inside k_step
@@ -1313,7 +1303,7 @@ static int create_finish(bbai_env* e) {
         const char* qv = getenv("BBAI_RENDER_QUEUE");
         e->render_queue = qv ? atoi(qv) : -1;
         const char* pv2 = getenv("BBAI_RENDER_PACE");
-        e->render_pace = pv2 ? atoi(pv2) : -1;
+        e->render_pace = pv2 ? std::max(0, atoi(pv2)) : 0;
         const char* cf = getenv("BBAI_CONSUME_FUSED");
         e->consume_fused = cf ? atoi(cf) : -1;
         const char* tv = getenv("BBAI_RENDER_TPB");
@@ -1333,7 +1323,6 @@ void bbai_destroy(bbai_env* e) {
     if (e->ev_switch) (void)hipEventDestroy(e->ev_switch);
     for (int k = 0; k < 3; ++k) for (int i = 0; i < PROF_RING; ++i) if (e->prof[k][i].a) { (void)hipEventDestroy(e->prof[k][i].a); (void)hipEventDestroy(e->prof[k][i].b); }
     for (int k = 0; k < 3; ++k) if (e->ev_refill[k]) (void)hipEventDestroy(e->ev_refill[k]);
-    for (int i = 0; i < PACE_RING; ++i) if (e->pace_ctl.ring[i].a) { (void)hipEventDestroy(e->pace_ctl.ring[i].a); (void)hipEventDestroy(e->pace_ctl.ring[i].b); }
     void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
     void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_list, e->win_count, e->reset_list, e->counters,
@@ -1624,53 +1613,14 @@ int bbai_set_atlas(bbai_env* e, const uint8_t* tiles, int n_tiles, const uint8_t
 
 }  // extern "C"
 
-// The pace of the render's tickets.  k_render_q at the rate of ONE ticket counter (11.4 ns per 8-env ticket = 6.6 TB/s) beats every
-// unpaced shape because the counter PACES the chip's stores (render_launch); the best pace is a little faster -- just below what
-// the store stream sustains at that moment.  Measured in the step loop on five boxes (profiles/r04/render_pace_ab_*.jsonl, 1/16 ns per
-// ticket -> k_render ms at 1 048 576 envs): slower than the optimum the launch is pace-bound (131 072 tickets x pace: 8 us per
-// 1/16 ns), faster it falls off a shallow cliff back to -- or a little behind -- the one-counter figure (1.50 ms).  The optimum
-// moved from 10.8 to 11.3 ns between boxes AND between two processes on one box (the physical placement of a 9.9-GB output differs
-// from run to run), and an idle chip puts it elsewhere than the step loop does: a fixed pace wins 1.5 % here and loses 1.5 % there.
-// So the pace is CONTROLLED on the launches' own durations: every default render is bracketed by an event pair (harvested without
-// ever blocking), and every PACE_WINDOW completed launches the controller compares their mean with the previous window's and moves
-// the pace one step (1/16 ns) in the direction that helped -- perturb and observe; it starts at the counter's own rate, reaches the
-// optimum within a few windows and then hovers one step around it (cost: ~4 us of 1.5 ms).  Results never depend on the pace.
-constexpr int RENDER_PACE_START = 183;          // 11.44 ns: the one counter's own rate -- never worse than round 4's first shape
-constexpr int RENDER_PACE_FASTEST = 168, RENDER_PACE_SLOWEST = 224;     // 10.5 ... 14 ns per 8-env ticket (7.2 ... 5.4 TB/s)
-constexpr int PACE_WINDOW = 12;
-static void pace_harvest(bbai_env* e) {
-    bbai_env::PaceCtl& c = e->pace_ctl;
-    while (c.tail != c.head) {
-        bbai_env::PaceCtl::Slot& sl = c.ring[c.tail % PACE_RING];
-        if (hipEventQuery(sl.b) != hipSuccess) { (void)hipGetLastError(); break; }       // launches complete in order: stop at the first pending one
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, sl.a, sl.b) == hipSuccess && sl.pace == c.p) { c.sum += ms; c.n++; c.samples++; }
-        sl.busy = false;
-        c.tail++;
-    }
-    if (c.n >= PACE_WINDOW) {
-        const double mean = c.sum / c.n;
-        if (c.have_last && mean > c.last_mean - 0.0005) c.dir = -c.dir;      // the last move did not help (by at least half a microsecond): turn round
-        c.last_mean = mean; c.have_last = true;
-        int np = c.p + c.dir;
-        if (np < RENDER_PACE_FASTEST || np > RENDER_PACE_SLOWEST) { c.dir = -c.dir; np = c.p + c.dir; }
-        c.p = np; c.n = 0; c.sum = 0; c.moves++;
-    }
-}
-// the pace of the next default launch, and the event pair to bracket it with (NULL: more launches in flight than the ring holds)
-static int pace_next(bbai_env* e, bbai_env::PaceCtl::Slot** slot) {
-    bbai_env::PaceCtl& c = e->pace_ctl;
-    if (c.p == 0) { c.p = RENDER_PACE_START; c.dir = -1; }
-    pace_harvest(e);
-    *slot = nullptr;
-    if (c.head - c.tail < PACE_RING) {
-        bbai_env::PaceCtl::Slot& sl = c.ring[c.head % PACE_RING];
-        if (!sl.a && (hipEventCreate(&sl.a) != hipSuccess || hipEventCreate(&sl.b) != hipSuccess)) { (void)hipGetLastError(); return c.p; }
-        *slot = &sl;
-    }
-    return c.p;
-}
-
+// Time-paced tickets (option "render_pace", off by default).  k_render_q at the rate of ONE ticket counter (11.4 ns per 8-env ticket
+// = 6.6 TB/s) beats every unpaced shape because the counter PACES the chip's stores; a wall-clock gate over two counters can set the
+// pace anywhere.  Measured in the step loop on seven boxes (profiles/r04/render_pace_*.jsonl, NOTES section 1): slower than the optimum
+// the launch is pace-bound (131 072 tickets x pace), faster it falls off a shallow cliff; at the optimum it beat the one counter by
+// 1.5-2.3 % on three boxes (k_render 1.466-1.482 vs 1.50 ms: 0.85 of peak) and LOST 0.5-1.5 % at every pace on two others; the optimum
+// moved from 10.8 to 11.4 ns between boxes and between two processes on one box, an idle chip puts it elsewhere than the loop does
+// (a first-render tuner), and a perturb-and-observe controller on the launches' own durations paid more for its event pairs and its
+// hovering than it gained.  The one counter's 1.50 ms is the same on all of them: it ships; the gate stays as a knob.
 static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, void* stream) {
     CallScope call(e, (hipStream_t)stream);
     if (call.rc != BBAI_OK) return call.rc;
@@ -1693,18 +1643,11 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
     // encoding is still in the memory-side cache and short-lived (512, 2) blocks win.
     // BBAI_RENDER_QUEUE / option "render_queue": -1 = by batch size (default), 0 = never, m > 0 = queue shape m of the table below.
     const bool big = e->n >= 786432;
-    bbai_env::PaceCtl::Slot* pace_slot = nullptr;
     int qm = e->render_queue;
     int pace = e->render_pace;
     if (qm < 0) {
         qm = e->n >= RENDER_QUEUE_MIN_ENVS ? RENDER_QUEUE_DEFAULT : 0;
-        // Time-paced tickets (the default): two interleaved counters serve tickets twice as fast as the chip can store them, and
-        // the wall clock admits one per `pace`, which the controller above keeps at the optimum of the moment.
-        if (qm == RENDER_QUEUE_DEFAULT && pace < 0) {
-            qm = RENDER_QUEUE_PACED;
-            pace = pace_next(e, &pace_slot);
-            if (pace_slot) { pace_slot->pace = pace; (void)hipEventRecord(pace_slot->a, (hipStream_t)stream); }
-        }
+        if (qm == RENDER_QUEUE_DEFAULT && pace > 0) qm = RENDER_QUEUE_PACED;        // (a pace needs tickets served faster than it admits them: two counters)
     }
     if (pace < 0) pace = 0;
     if (qm > 0) {
@@ -1730,7 +1673,6 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
         case 11: RENDER_Q(10, 1024, 1, 1); break;
         }
 #undef RENDER_Q
-        if (pace_slot) { (void)hipEventRecord(pace_slot->b, (hipStream_t)stream); pace_slot->busy = true; e->pace_ctl.head++; }
         HIP_TRY(hipGetLastError());
         return call.leave();
     }
@@ -2119,7 +2061,7 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     if (!strcmp(name, "render_queue")) e->render_queue = v;
     else if (!strcmp(name, "render_queue_bpc")) e->render_queue_bpc = v;
     else if (!strcmp(name, "render_queue_blocks")) e->render_queue_blocks = v;
-    else if (!strcmp(name, "render_pace")) e->render_pace = v < 0 ? -1 : v;
+    else if (!strcmp(name, "render_pace")) e->render_pace = v < 0 ? 0 : v;
     else if (!strcmp(name, "render_group")) e->render_group = v;
     else if (!strcmp(name, "render_tpb")) e->render_tpb = v;
     else if (!strcmp(name, "step_prio")) e->step_prio = v;
@@ -2134,9 +2076,7 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     return BBAI_OK;
 }
 
-// Read back a knob or a measured quantity: the names of bbai_set_option, plus "render_pace_effective" (1/16 ns per render ticket in
-// use: the option, or where the pace controller stands; 0 = unpaced), "render_pace_moves" / "render_pace_samples" (its decisions and
-// measured launches so far) and "lookahead_period".
+// Read back a knob: the names of bbai_set_option, plus "render_pace_effective" and "lookahead_period" (the refill period the handle chose).
 int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     if (!e || !name || !out) ARG_FAIL("null handle, name or output");
     if (!strcmp(name, "render_queue")) *out = e->render_queue;
@@ -2151,9 +2091,7 @@ int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     else if (!strcmp(name, "consume_fused")) *out = e->consume_fused;
     else if (!strcmp(name, "done_action_enum")) *out = e->done_action_enum;
     else if (!strcmp(name, "lookahead_period")) *out = e->period;
-    else if (!strcmp(name, "render_pace_effective")) *out = e->render_pace >= 0 ? e->render_pace : ((e->render_queue < 0 && e->n >= RENDER_QUEUE_MIN_ENVS) ? e->pace_ctl.p : 0);
-    else if (!strcmp(name, "render_pace_moves")) *out = e->pace_ctl.moves;
-    else if (!strcmp(name, "render_pace_samples")) *out = e->pace_ctl.samples;
+    else if (!strcmp(name, "render_pace_effective")) *out = e->render_pace > 0 ? e->render_pace : 0;
     else {
         snprintf(g_err, sizeof(g_err), "get_option: unknown option '%s'", name);
         return BBAI_ERR_ARG;

@@ -333,19 +333,11 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
         torch.cuda.synchronize()
     prof = env.profile_read()
     env.profile(False)
-    render_cfg = None
-    if pixel:
-        pace = env.get_option("render_pace_effective")
-        render_cfg = {"ticket_pace_ns": pace / 16.0 if pace else None, "controller_moves": env.get_option("render_pace_moves"),
-                      "launches_measured": env.get_option("render_pace_samples"),
-                      "note": "k_render_q admits one 8-env ticket per ticket_pace_ns of wall clock; the pace is controlled on the launches' own "
-                              "durations (perturb and observe, one 1/16-ns step per 12 launches, started at the one ticket counter's 11.44 ns): "
-                              "ticket_pace_ns = where it stood at the end of the run; null = tickets as fast as the counter serves them"}
     m = {"level": level, "pixel": pixel, "E": E, "total_envs": total_envs, "first": first, "K": K, "W": W, "S1": S1, "S2": S2, "want": want,
          "blocks": blocks, "profiled": profiled, "local_blocks": local_blocks, "barrier_s": barrier_s,
          "kernel_ms": {k: v[0] for k, v in prof.items() if v[0] is not None},
          "kernel_launches": {k: v[1] for k, v in prof.items() if v[0] is not None},
-         "resets": resets, "setup_ms": setup_ms, "render_cfg": render_cfg,
+         "resets": resets, "setup_ms": setup_ms,
          "log1": log1, "log2": log2, "ids2": ids2, "PP1": PP1, "PP2": PP2, "sel2": sel2, "env": env}
     return m
 
@@ -510,7 +502,7 @@ def main():
             level, "56x56x3 pixel (RGBImgPartialObsWrapper)" if pixel else "7x7x3 encoded", total_envs, E, world),
             "envs_per_gpu": E, "total_envs": total_envs, "resets_in_timed_region": m["resets"],
             "parallelism": "env-shards x%d, no collective" % world,
-            "render_input": "the step's 147-byte encoding" if pixel else None, "render": m["render_cfg"],
+            "render_input": "the step's 147-byte encoding" if pixel else None,
             "actions": "counter-based (action_seed %d, step, global env index), uniform over 7" % args.action_seed},
         "rccl": dict(group, per_rank_ms_per_step=per_rank_ms,
                      per_rank_ms_per_step_min=min(per_rank_ms) if all(v is not None for v in per_rank_ms) else None,

@@ -212,8 +212,7 @@ int bbai_get_done_actions(bbai_env* env);
  * no counterpart: these choose launch shapes and buffers, never results -- every setting but the last yields the same bytes, which
  * tests/test_gpu_parity.py::test_options_do_not_change_results checks).  Synchronises the device.  Names:
  *   "render_queue"      -1 = by batch size (default), 0 = one-shot render blocks, m > 0 = persistent-block queue shape m
- *   "render_pace"       1/16 ns of wall clock per render ticket: -1 = controlled on the launches' own durations (default: every
- *                       bbai_render of a batch >= 262 144 envs is bracketed by an event pair, harvested without blocking), 0 = unpaced
+ *   "render_pace"       experiment: 1/16 ns of wall clock per render ticket (a time gate over two ticket counters); 0 = off (default)
  *   "render_queue_bpc", "render_queue_blocks"   persistent render blocks per CU (0 = 1024 threads' worth) / in total (0 = per CU)
  *   "render_group", "render_tpb"   envs / threads per one-shot render block (0 = by batch size)
  *   "step_prio", "pregen_group", "pregen_blocks", "consume_fused"   as BBAI_STEP_PRIO / BBAI_PREGEN_GROUP / BBAI_PREGEN_BLOCKS /
@@ -221,8 +220,7 @@ int bbai_get_done_actions(bbai_env* env);
  *   "done_action_enum"  the one semantic switch, meaningful in done-action mode only: see bbai_set_done_actions
  * BBAI_ERR_ARG for an unknown name. */
 int bbai_set_option(bbai_env* env, const char* name, int64_t value);
-/* Read a knob back, or a measured quantity: "render_pace_effective" (1/16 ns per render ticket in use), "render_pace_moves" /
- * "render_pace_samples" (the pace controller's decisions / measured launches), "lookahead_period". */
+/* Read a knob back (the names of bbai_set_option), or "lookahead_period" (the refill period the handle chose at bbai_create). */
 int bbai_get_option(bbai_env* env, const char* name, int64_t* out);
 
 /* Number of level generations (resets) performed so far, all envs. */

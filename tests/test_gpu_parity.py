@@ -1388,7 +1388,7 @@ def test_render_queue_equals_one_shot_render(gpu, n):
         b.set_option("render_queue", 1 + t % N_QUEUE_SHAPES)
         b.set_option("render_queue_bpc", (0, 1, 3, 0)[t // N_QUEUE_SHAPES])
         b.set_option("render_queue_blocks", (0, 0, 0, 77)[t // N_QUEUE_SHAPES])
-        b.set_option("render_pace", (0, 170, 0, 183)[t // N_QUEUE_SHAPES])            # (time-paced tickets: same bytes)
+        b.set_option("render_pace", (0, 170, 0, 183)[t // N_QUEUE_SHAPES])            # (time-gated tickets: same bytes)
         act = torch.randint(0, 7, (n,), dtype=torch.uint8, device=gpu, generator=gen)
         oa, _, _, _ = a.step(act)
         ob, _, _, _ = b.step(act)

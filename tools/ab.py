@@ -119,8 +119,6 @@ def main():
                     "ms_per_step": round(median(plain), 5), "ms_per_step_min": round(min(plain), 5),
                     "profiled_ms_per_step": round(median(prof), 5) if prof else None, "kernel_avg_ms": km,
                     "resets_per_step": (env.reset_count() - r0) / (args.blocks * K)}
-            if args.pixel:
-                line["render_pace_effective_x16"] = env.get_option("render_pace_effective")
             print(json.dumps(line), flush=True)
             results.setdefault(name, []).append(line)
     rank = sorted(((median([l["ms_per_step"] for l in ls]), n) for n, ls in results.items()))

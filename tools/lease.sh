@@ -50,11 +50,11 @@ ab() {               # tools/ab.py presets
                     --base render_queue_bpc=0,render_queue_blocks=0 --settings render_queue=0 render_queue=1 render_queue=2 render_queue=3 render_queue=4 render_queue=5 \
                     render_queue=6 render_queue=7 render_queue=8 render_queue=10 render_queue=11 render_queue=1,render_queue_bpc=2 render_queue=1,render_queue_blocks=224 \
                     > $OUT/render_queue_ab_${2:-1048576}.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_queue_ab_${2:-1048576}.jsonl ;;
-    pace)       # ab:pace[:<envs>:<steps>] -- the render's controlled pace (default) against fixed paces, the one-counter shape and no pace at all (1/16 ns per ticket)
-                timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs ${2:-1048576} --pixel --steps ${3:-20} --blocks 10 --reps 4 \
-                    --base render_queue=-1,render_queue_bpc=0,render_queue_blocks=0,render_pace=-1 --settings render_pace=-1 render_queue=1,render_pace=0 render_queue=3,render_pace=0 \
-                    render_queue=3,render_pace=183 render_queue=3,render_pace=180 render_queue=3,render_pace=178 render_queue=3,render_pace=176 render_queue=3,render_pace=174 \
-                    > $OUT/render_pace_ab_${2:-1048576}.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_pace_ab_${2:-1048576}.jsonl; grep '"setting": "render_pace=-1"' $OUT/render_pace_ab_${2:-1048576}.jsonl | grep -o '"rep": [0-9]*\|"ms_per_step": [0-9.]*\|"k_render": [0-9.]*\|"render_pace_effective_x16": [0-9]*' | paste - - - - ;;
+    pace)       # ab:pace[:<envs>:<steps>] -- time-gated render tickets (option render_pace, 1/16 ns per ticket, two counters) against the shipped one-counter shape
+                timeout 600 python $REPO/tools/ab.py --tag $TAG --level BossLevel --envs ${2:-1048576} --pixel --steps ${3:-20} --blocks 8 --reps 3 \
+                    --base render_queue=-1,render_queue_bpc=0,render_queue_blocks=0,render_pace=0 --settings render_pace=0 render_queue=3,render_pace=0 \
+                    render_pace=183 render_pace=180 render_pace=178 render_pace=176 render_pace=174 \
+                    > $OUT/render_pace_ab_${2:-1048576}.jsonl 2>> $OUT/ab.err; tail -1 $OUT/render_pace_ab_${2:-1048576}.jsonl ;;
     *)          # ab:<name>:<level>:<envs>:<steps>:<pixel 0|1>:<setting>:<setting>...   (settings use '/' for ',')
                 local name=$1 level=$2 envs=$3 steps=$4 pix=$5; shift 5
                 local sets=(); for s in "$@"; do sets+=("${s//\//,}"); done
