@@ -97,6 +97,15 @@ print("soak mismatches:", bad)
 PY
     tail -4 $OUT/soak_random.txt
 }
+soakbot() {          # expert-driven soak: scattered envs against the host build incl. the expert, very high reset rates
+    cd $REPO && timeout 900 python tools/gpu_soak.py bot > $OUT/soak_bot.txt 2>&1; tail -7 $OUT/soak_bot.txt
+}
+demobench() {        # generate_demos: device rollout vs the step-by-step host loop, equal digests (tools/demo_bench.py)
+    cd /tmp
+    for cfg in "GoToLocal 65536 65536" "BossLevel 32768 32768" "BossLevel 131072 131072"; do
+        timeout 600 python $REPO/tools/demo_bench.py $cfg 2>> $OUT/demo_bench.err | tail -1 | tee -a $OUT/demo_bench.jsonl
+    done
+}
 ubench() {           # the microbenchmarks DESIGN.md quotes (built here: hipcc is on the box)
     cd $REPO && for u in gather render fetchcal; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/ubench_$u tools/ubench_$u.hip 2>/dev/null; done
     timeout 120 python tools/membw.py > $OUT/membw.json 2> $OUT/membw.err
