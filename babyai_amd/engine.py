@@ -452,7 +452,7 @@ class BatchedBabyAIEnv(object):
         _check(self.lib, self.lib.bbai_set_option(self.handle, name.encode(), int(value)), "bbai_set_option(%s)" % name)
     
     def get_option(self, name):
-        """A knob of the live handle, or a measured quantity ("fill_GBs", "render_pace_effective", "lookahead_period")."""
+        """A knob of the live handle (the names of set_option), or "lookahead_period" (the refill period chosen at create)."""
         v = ctypes.c_int64(0)
         _check(self.lib, self.lib.bbai_get_option(self.handle, name.encode(), ctypes.byref(v)), "bbai_get_option(%s)" % name)
         return int(v.value)
