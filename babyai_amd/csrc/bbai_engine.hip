@@ -154,10 +154,6 @@ struct bbai_env {
     int bot_eager;        // BBAI_BOT_EAGER (default 1): expand the first search tree at the top of every decision
     int64_t bot_threads;
     uint64_t* bot_stats;  // [2] decisions that ended in a dead bot: by the reference's rules / by our capacity limits
-    int bot_sort;         // option "bot_sort" / BBAI_BOT_SORT: 1 = the expert's lanes take the envs bucketed by expected search size (k_bot_key)
-    int32_t* bot_order;   // [n] that order; bot_keys [n] the buckets; bot_hist [2][BOT_BUCKETS] counts / cursors
-    uint8_t* bot_keys;
-    uint32_t* bot_hist;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -830,45 +826,6 @@ __global__ __launch_bounds__(256) void k_sync_view(LevelCfg c, int64_t first, in
     }
 }
 
-// Buckets for k_bot (option "bot_sort"): the lanes of a wave run their searches in lockstep, so a wave lasts as long as its
-// slowest lane; what a decision costs grows with the area the bot has seen (its breadth-first searches cover it).  key = 0 for
-// envs without a decision to take (frozen), 1 for a first decision (fresh Bot), else 2 + seen cells / 32: envs of one bucket
-// form the waves.  Three tiny launches: keys + histogram, exclusive scan of 32 buckets, scatter into `order`.
-constexpr int BOT_BUCKETS = 32;
-__global__ __launch_bounds__(256) void k_bot_key(LevelCfg c, int64_t n, const Hot* __restrict__ hots, const uint8_t* __restrict__ states, int stack_cap,
-                                                 uint8_t* __restrict__ keys, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t s_hist[BOT_BUCKETS];
-    if (threadIdx.x < BOT_BUCKETS) s_hist[threadIdx.x] = 0;
-    __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const Hot h = hots[i];
-        const BotState& st = *(const BotState*)(states + i * (int64_t)bot_state_bytes(stack_cap));
-        int key;
-        if (h.frozen) key = 0;
-        else if (h.step == 0 || st.next_step != h.step) key = 1;
-        else {
-            int seen = 0;
-            for (int y = 0; y < c.H; ++y) seen += __popc(st.vis[y]);
-            key = 2 + (seen >> 5);
-            key = key < BOT_BUCKETS ? key : BOT_BUCKETS - 1;
-        }
-        keys[i] = (uint8_t)key;
-        atomicAdd(&s_hist[key], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < BOT_BUCKETS && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
-}
-__global__ void k_bot_scan(uint32_t* __restrict__ hist /* [BOT_BUCKETS] counts -> cursors; [BOT_BUCKETS..] zeroed for the next round */) {
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int b = 0; b < BOT_BUCKETS; ++b) { const uint32_t cnt = hist[b]; hist[BOT_BUCKETS + b] = run; run += cnt; hist[b] = 0; }
-    }
-}
-__global__ __launch_bounds__(256) void k_bot_scatter(int64_t n, const uint8_t* __restrict__ keys, uint32_t* __restrict__ cursor, int32_t* __restrict__ order) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        order[atomicAdd(&cursor[keys[i]], 1u)] = (int32_t)i;
-}
-
 // The reference's expert for every env (babyai/bot.py Bot.replan): lane = env, grid-stride over the batch with one BFS
 // scratch block per resident thread.  A new episode (step_count == 0) starts a fresh Bot.
 template <int WAVES_PER_SIMD>
@@ -877,8 +834,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_bot(LevelCfg c, int64_t 
                                             uint16_t* __restrict__ works, uint32_t* __restrict__ slow_rows, int eager, const uint8_t* __restrict__ prev_actions,
                                             uint8_t* __restrict__ out, unsigned long long* __restrict__ stats,
                                             int dead_action /* what a bot that gave up emits: BOT_DEAD, or A_RESET_ENV in a rollout */,
-                                            uint8_t* __restrict__ gave_up /* or NULL: [n] 1 where the bot gave up at this decision */,
-                                            const int32_t* __restrict__ order /* or NULL: the envs in the order the lanes take them (k_bot_scatter) */) {
+                                            uint8_t* __restrict__ gave_up /* or NULL: [n] 1 where the bot gave up at this decision */) {
     // the searches' hot row masks (expandable / queued / seen), [row][lane] in LDS: every lane on its own bank
     extern __shared__ uint32_t s_rows[];              // [R_FAST][H][64] row masks, then the queue ring uint16 [BOT_RING][64]
     uint16_t* s_ring = (uint16_t*)(s_rows + R_FAST * c.H * 64);
@@ -894,8 +850,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_bot(LevelCfg c, int64_t 
     w.cells = c.W * c.H;                                    // 64 cells (512 B of scratch) for an 8x8 room, 484 for a 3x3 maze
     w.base = works + tid * (int64_t)(4 * w.cells);
     w.stride = 1;
-    for (int64_t idx = tid; idx < n; idx += nthreads) {
-        const int64_t i = order ? (int64_t)order[idx] : idx;
+    for (int64_t i = tid; i < n; i += nthreads) {
         const Hot h = hots[i];
         if (h.frozen) { out[i] = A_DONE; if (gave_up) gave_up[i] = 0; continue; }
         BotState& st = *(BotState*)(states + i * (int64_t)bot_state_bytes(stack_cap));
@@ -1368,7 +1323,7 @@ void bbai_destroy(bbai_env* e) {
     if (e->ev_switch) (void)hipEventDestroy(e->ev_switch);
     for (int k = 0; k < 3; ++k) for (int i = 0; i < PROF_RING; ++i) if (e->prof[k][i].a) { (void)hipEventDestroy(e->prof[k][i].a); (void)hipEventDestroy(e->prof[k][i].b); }
     for (int k = 0; k < 3; ++k) if (e->ev_refill[k]) (void)hipEventDestroy(e->ev_refill[k]);
-    void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows, e->bot_order, e->bot_keys, e->bot_hist};
+    void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
     void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_list, e->win_count, e->reset_list, e->counters,
                     e->total_resets, e->atlas, e->lut, e->vplane, e->fcache, e->lsm, e->render_tickets, e->reset_slot};
@@ -1947,18 +1902,6 @@ static int bot_alloc(bbai_env* e, int cap) {             // the expert's state: 
     e->bot_state = (uint8_t*)st; e->bot_work = (uint16_t*)wk; e->bot_stats = (uint64_t*)ss; e->bot_threads = threads;
     e->bot_rows = (uint32_t*)rw;
     { const char* ev = getenv("BBAI_BOT_EAGER"); e->bot_eager = ev ? atoi(ev) != 0 : 1; }
-    {   // bucketed lane order (option "bot_sort" / BBAI_BOT_SORT): optional, the expert works without it
-        const char* ev = getenv("BBAI_BOT_SORT");
-        if (ev) e->bot_sort = atoi(ev);
-        void *od = nullptr, *ky = nullptr, *hs = nullptr;
-        if (hipMalloc(&od, (size_t)e->n * 4) == hipSuccess && hipMalloc(&ky, (size_t)e->n) == hipSuccess && hipMalloc(&hs, 2 * BOT_BUCKETS * 4) == hipSuccess &&
-            hipMemset(hs, 0, 2 * BOT_BUCKETS * 4) == hipSuccess) {
-            e->bot_order = (int32_t*)od; e->bot_keys = (uint8_t*)ky; e->bot_hist = (uint32_t*)hs;
-        } else {
-            (void)hipGetLastError();
-            (void)hipFree(od); (void)hipFree(ky); (void)hipFree(hs);
-        }
-    }
     return BBAI_OK;
 }
 
@@ -1979,20 +1922,12 @@ static int bot_launch(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions
     const dim3 grid((unsigned)(e->bot_threads / 64)), block(64);
     unsigned long long* stats = (unsigned long long*)e->bot_stats;
     const size_t lds = (size_t)R_FAST * e->cfg.H * 64 * 4 + (size_t)BOT_RING * 64 * 2;     // BossLevel: 11.3 + 8 KB -> 8 waves per CU
-    const int32_t* order = nullptr;
-    if (e->bot_sort && e->bot_order) {
-        const unsigned kb = (unsigned)std::min<int64_t>((e->n + 255) / 256, 2048);
-        hipLaunchKernelGGL(k_bot_key, dim3(kb), dim3(256), 0, s, e->cfg, e->n, e->hot, e->bot_state, e->bot_stack, e->bot_keys, e->bot_hist);
-        hipLaunchKernelGGL(k_bot_scan, dim3(1), dim3(64), 0, s, e->bot_hist);
-        hipLaunchKernelGGL(k_bot_scatter, dim3(kb), dim3(256), 0, s, e->n, e->bot_keys, e->bot_hist + BOT_BUCKETS, e->bot_order);
-        order = e->bot_order;
-    }
     if (maze)
         hipLaunchKernelGGL(k_bot<2>, grid, block, lds, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
-                           e->bot_rows, e->bot_eager, prev_actions, actions, stats, dead_action, gave_up, order);
+                           e->bot_rows, e->bot_eager, prev_actions, actions, stats, dead_action, gave_up);
     else
         hipLaunchKernelGGL(k_bot<1>, grid, block, lds, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
-                           e->bot_rows, e->bot_eager, prev_actions, actions, stats, dead_action, gave_up, order);
+                           e->bot_rows, e->bot_eager, prev_actions, actions, stats, dead_action, gave_up);
     HIP_TRY(hipGetLastError());
     return BBAI_OK;
 }
@@ -2133,7 +2068,6 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     else if (!strcmp(name, "pregen_group")) e->pregen_group = v;
     else if (!strcmp(name, "pregen_blocks")) e->pregen_cap = std::max(64, v);
     else if (!strcmp(name, "consume_fused")) e->consume_fused = v;
-    else if (!strcmp(name, "bot_sort")) e->bot_sort = v;
     else if (!strcmp(name, "done_action_enum")) e->done_action_enum = v != 0;       // (the one SEMANTIC switch in this list: include/bbai.h bbai_set_done_actions)
     else {
         snprintf(g_err, sizeof(g_err), "set_option: unknown option '%s'", name);
@@ -2155,7 +2089,6 @@ int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     else if (!strcmp(name, "pregen_group")) *out = e->pregen_group;
     else if (!strcmp(name, "pregen_blocks")) *out = e->pregen_cap;
     else if (!strcmp(name, "consume_fused")) *out = e->consume_fused;
-    else if (!strcmp(name, "bot_sort")) *out = e->bot_sort;
     else if (!strcmp(name, "done_action_enum")) *out = e->done_action_enum;
     else if (!strcmp(name, "lookahead_period")) *out = e->period;
     else if (!strcmp(name, "render_pace_effective")) *out = e->render_pace > 0 ? e->render_pace : 0;

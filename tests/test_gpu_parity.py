@@ -1433,30 +1433,3 @@ def test_options_do_not_change_results(gpu):
     assert a.reset_count() == b.reset_count() and a.reset_count() > 2 * n
     a.close()
     b.close()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("level,n", [("BossLevel", 3000), ("GoToLocal", 1000)])
-def test_bucketed_lane_order_does_not_change_the_experts_decisions(gpu, level, n):
-    """Option "bot_sort": k_bot's lanes take the envs bucketed by expected search size (k_bot_key / k_bot_scatter).  Every env's
-    decision is its own business: same actions, same give-ups, same episodes as with the plain order."""
-    import torch
-    from babyai_amd.engine import BatchedBabyAIEnv
-    a = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=77)
-    b = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=77)
-    a.reset()
-    b.reset()
-    a.bot_actions(None)                       # (the expert's buffers exist from the first decision on)
-    b.bot_actions(None)
-    b.set_option("bot_sort", 1)
-    reset_cmd = torch.full((n,), a.RESET_ENV, dtype=torch.uint8, device=gpu)
-    for t in range(150):
-        xa, xb = a.bot_actions(None).clone(), b.bot_actions(None).clone()
-        assert torch.equal(xa, xb), t
-        act = torch.where(xa == a.BOT_GAVE_UP, reset_cmd, xa)
-        a.step(act)
-        b.step(act)
-        assert torch.equal(a.image, b.image) and torch.equal(a.done, b.done), t
-    assert a.bot_stats() == b.bot_stats() and a.reset_count() == b.reset_count() > n
-    a.close()
-    b.close()

@@ -97,12 +97,6 @@ print("soak mismatches:", bad)
 PY
     tail -4 $OUT/soak_random.txt
 }
-botsort() {          # the expert with the plain / the bucketed lane order (BBAI_BOT_SORT), two processes alternated twice
-    cd /tmp
-    for rep in 1 2; do for so in 0 1; do for cfg in "BossLevel 1048576 30" "BossLevel 262144 60" "GoTo 131072 100"; do
-        BBAI_BOT_SORT=$so timeout 300 python $REPO/tools/bot_bench.py $cfg 2>> $OUT/bot_bench.err | tail -1 | sed "s/^{/{\"bot_sort\": $so, /" | tee -a $OUT/bot_sort_ab.jsonl
-    done; done; done
-}
 soakbot() {          # expert-driven soak: scattered envs against the host build incl. the expert, very high reset rates
     cd $REPO && timeout 900 python tools/gpu_soak.py bot > $OUT/soak_bot.txt 2>&1; tail -7 $OUT/soak_bot.txt
 }
