@@ -119,6 +119,32 @@ lib() {              # the same ab spec under two engine builds, alternated twic
         echo "--- $other"; BBAI_ENGINE_LIB=$REPO/$other AB_SUFFIX=_other_$rep ab "$@"
     done
 }
+tracecfg() {         # rocprofv3 kernel trace of one BASELINE config (tracecfg:C2): launch gaps on the small shards
+    cd /tmp && rm -rf $OUT/trace_$1
+    timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_$1 -o t -- python $REPO/bench.py --config $1 --no-extra-configs --no-cpu-baseline --parity-envs 0 --min-seconds 0.2 --steps 256 --warmup 16 > $OUT/trace_$1.json 2> $OUT/trace_$1.log
+    python - <<PY | tee $OUT/trace_$1_gaps.txt
+import csv, glob
+rows = []
+for path in glob.glob("$OUT/trace_$1/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(path)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")))
+rows.sort()
+steady = [r for r in rows if r[2].startswith(("k_step", "k_consume", "k_tap", "k_pregen"))]
+main = [r for r in steady if not r[2].startswith("k_pregen")]
+main = main[len(main) // 2:]                       # the second half of the run: steady state
+import collections
+dur, gap = collections.defaultdict(list), collections.defaultdict(list)
+for a, b in zip(main, main[1:]):
+    dur[a[2]].append((a[1] - a[0]) / 1e3)
+    gap[a[2] + " -> " + b[2]].append((b[0] - a[1]) / 1e3)
+med = lambda v: sorted(v)[len(v) // 2]
+for k, v in dur.items(): print("kernel %-28s n=%5d median %.2f us" % (k, len(v), med(v)))
+for k, v in gap.items(): print("gap    %-44s n=%5d median %.2f us" % (k, len(v), med(v)))
+steps = [r for r in main if r[2].startswith("k_step")]
+if len(steps) > 2: print("step period median %.2f us" % med([(b[0] - a[0]) / 1e3 for a, b in zip(steps, steps[1:])]))
+PY
+    find $OUT -name "*.csv" -size +20M -delete
+}
 run() { cd $REPO && timeout 900 "$@"; }          # run:python:tools/x.py:arg ...
 
 for job in "$@"; do
