@@ -2016,6 +2016,43 @@ int bbai_tap_ids(int64_t count, int64_t pix_count, const int64_t* ids_dev, const
     return tap_launch(count, pix_count, ids_dev, image, dirs, rew64, dones, pixels, image_out, dirs_out, rew64_out, dones_out, pixels_out, stream);
 }
 
+// T steps of the hot path with no host round trip in between (include/bbai.h): what a caller's loop of bbai_step [+ bbai_render]
+// [+ bbai_tap_ids] enqueues, enqueued from here.  On the small shards a step is 30-40 us of GPU work, which an interpreter's
+// per-step call overhead does not reliably stay ahead of (profiles/r04/kernel_trace_gaps_*.txt: 10-us gaps between the kernels
+// of one step).
+int bbai_rollout(bbai_env* e, int T, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64, uint8_t* dones,
+                 int auto_reset, uint8_t* pixels, const bbai_tap_log* tap, void* stream) {
+    if (!e || T < 1 || !actions || !image || !dirs || !rewards || !dones) ARG_FAIL("null handle or buffer, or T < 1");
+    if (!e->live) { snprintf(g_err, sizeof(g_err), "rollout before reset"); return BBAI_ERR_STATE; }
+    if (auto_reset && !e->seeded) { snprintf(g_err, sizeof(g_err), "auto-reset rollout before seed"); return BBAI_ERR_STATE; }
+    if (pixels && e->n_tiles <= 0) { snprintf(g_err, sizeof(g_err), "rollout with pixels before set_atlas"); return BBAI_ERR_STATE; }
+    if (tap && (!rewards64 || tap->count <= 0 || tap->pix_count < 0 || tap->pix_count > tap->count || !tap->ids_dev || !tap->image_out || !tap->dir_out ||
+                !tap->reward64_out || !tap->done_out || (tap->pix_count && (!pixels || !tap->pixels_out))))
+        ARG_FAIL("tap log incomplete (it needs reward64_dev, and pixels_dev for its pixel rows)");
+    ON_DEVICE(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)e->n;
+    for (int t = 0; t < T; ++t) {
+        {
+            CallScope call(e, s);
+            if (call.rc != BBAI_OK) return call.rc;
+            int rc = step_launch(e, actions + (size_t)t * n, image, dirs, rewards, rewards64, dones, auto_reset, s, e->done_action_enum);
+            if (rc != BBAI_OK) return rc;
+            rc = call.leave();
+            if (rc != BBAI_OK) return rc;
+        }
+        if (pixels) { int rc = render_launch(e, image, pixels, stream); if (rc != BBAI_OK) return rc; }
+        if (tap) {
+            const size_t c = (size_t)tap->count, orow = (size_t)(tap->obs_row0 + t), row = (size_t)(tap->row0 + t);
+            int rc = tap_launch(tap->count, tap->pix_count, tap->ids_dev, image, dirs, rewards64, dones, pixels, tap->image_out + orow * c * OBS_BYTES,
+                                tap->dir_out + orow * c, tap->reward64_out + row * c, tap->done_out + row * c,
+                                tap->pix_count ? tap->pixels_out + orow * (size_t)tap->pix_count * PIX_BYTES : nullptr, stream);
+            if (rc != BBAI_OK) return rc;
+        }
+    }
+    return BBAI_OK;
+}
+
 int bbai_gae(int64_t num_envs, int num_frames, const float* rewards, const float* values, const float* masks, const float* last_mask,
              const float* last_value, double discount, double gae_lambda, float* advantage, float* returnn, void* stream) {
     if (num_envs <= 0 || num_frames <= 0 || !rewards || !values || !masks || !last_mask || !last_value || !advantage || !returnn)

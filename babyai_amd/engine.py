@@ -78,6 +78,7 @@ def load_library():
     lib.bbai_bot_stats.argtypes = [P, P, P]
     lib.bbai_bot_rollout.argtypes = [P, I32, P, P, P, P, P, P, P, P, P, P]
     lib.bbai_set_done_actions.argtypes = [P, I32]
+    lib.bbai_rollout.argtypes = [P, I32, P, P, P, P, P, P, I32, P, P, P]
     lib.bbai_set_option.argtypes = [P, ctypes.c_char_p, I64]
     lib.bbai_get_option.argtypes = [P, ctypes.c_char_p, ctypes.POINTER(I64)]
     lib.bbai_get_done_actions.argtypes = [P]
@@ -91,13 +92,20 @@ EXPORTED_SYMBOLS = (
     "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures", "bbai_bot_act", "bbai_bot_stats",
     "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load", "bbai_profile", "bbai_profile_read", "bbai_gae", "bbai_tap",
     "bbai_tap_ids", "bbai_set_call_events", "bbai_bot_rollout", "bbai_set_done_actions", "bbai_get_done_actions",
-    "bbai_set_option", "bbai_get_option",
+    "bbai_set_option", "bbai_get_option", "bbai_rollout",
 )
 
 
 def _check(lib, rc, what):
     if rc != 0:
         raise EngineError("%s failed (%d): %s" % (what, rc, lib.bbai_last_error().decode()))
+
+
+class TapLog(ctypes.Structure):
+    """include/bbai.h bbai_tap_log"""
+    _fields_ = [("count", ctypes.c_int64), ("pix_count", ctypes.c_int64), ("ids_dev", ctypes.c_void_p), ("image_out", ctypes.c_void_p),
+                ("dir_out", ctypes.c_void_p), ("reward64_out", ctypes.c_void_p), ("done_out", ctypes.c_void_p), ("pixels_out", ctypes.c_void_p),
+                ("obs_row0", ctypes.c_int64), ("row0", ctypes.c_int64)]
 
 
 class Missions(object):
@@ -300,6 +308,38 @@ class BatchedBabyAIEnv(object):
                                              1 if self.auto_reset else 0, self._stream()), "bbai_step")
         self._ev_end("step", ev)
         return self._obs(), self.reward, self.done, {}
+
+    def rollout(self, actions, tap=None, obs_row0=0, row0=0):
+        """An open-loop rollout (include/bbai.h bbai_rollout): `actions` uint8[T, N] on the device; T steps (+ the pixel render
+        in pixel mode) are enqueued by ONE call, exactly what T calls of step() enqueue.  `tap`: a log dict as bench.py builds
+        it -- device tensors "image" [rows, P, 7, 7, 3], "direction" [rows, P], "reward64" [rows, P], "done" [rows, P],
+        optionally "pixels" [rows, PP, 56, 56, 3], and "ids" int64[P]: step t logs the listed envs' outputs into obs row
+        obs_row0 + t / result row row0 + t.  Afterwards image / direction / reward / done (/ pixels) hold the last step's
+        outputs; returns the observation dict of that step."""
+        torch = self.torch
+        if actions.dtype != torch.uint8 or actions.device != self.device or not actions.is_contiguous() or actions.dim() != 2 \
+                or actions.shape[1] != self.num_envs:
+            raise ValueError("actions: contiguous uint8[T, %d] on %s" % (self.num_envs, self.device))
+        T = int(actions.shape[0])
+        log = None
+        if tap is not None:
+            P_ = int(tap["done"].shape[1])
+            pix = tap.get("pixels")
+            for k in ("image", "direction", "reward64", "done"):
+                if not tap[k].is_contiguous():
+                    raise ValueError("tap log tensors must be contiguous")
+            log = TapLog(P_, int(pix.shape[1]) if pix is not None else 0, tap["ids"].data_ptr(), tap["image"].data_ptr(), tap["direction"].data_ptr(),
+                         tap["reward64"].data_ptr(), tap["done"].data_ptr(), pix.data_ptr() if pix is not None else None, int(obs_row0), int(row0))
+            if tap["image"].shape[0] < obs_row0 + T or tap["done"].shape[0] < row0 + T:
+                raise ValueError("tap log has too few rows for %d steps" % T)
+        self._actions = actions
+        _check(self.lib, self.lib.bbai_rollout(self.handle, T, actions.data_ptr(), self.image.data_ptr(), self.direction.data_ptr(),
+                                                self.reward.data_ptr(), self.reward64.data_ptr(), self.done.data_ptr(), 1 if self.auto_reset else 0,
+                                                self.pixels.data_ptr() if self.pixel else None, ctypes.byref(log) if log is not None else None,
+                                                self._stream()), "bbai_rollout")
+        self._obs_version += 1
+        self._missions = Missions(self)
+        return {"image": self.pixels if self.pixel else self.image, "direction": self.direction, "mission": self._missions}
 
     # ---- state access -------------------------------------------------------------------
     def programs(self, first=0, count=None):

@@ -170,7 +170,7 @@ def gather_to_rank0(tensor, dist, via_all_gather=False):
 
 
 def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None, after_block=None, before_block=None, local_out=None,
-                 barrier_out=None):
+                 barrier_out=None, run_steps=None):
     """The measured loop.  `actions`: uint8[warmup + blocks*steps, E] resident on the env's device.  `warmup` untimed
     steps, then `blocks` timed blocks of EXACTLY `steps` steps.  Every block is bracketed by ranks.barrier() (device idle,
     barrier, device idle) on both sides; a rank's clock runs from the end of the opening barrier until ITS OWN device is
@@ -179,26 +179,37 @@ def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None, af
     not part of any rank's steps (a block of 20 steps of a 131 072-env shard lasts 4.5 ms).  What the closing barrier
     costs -- waiting for the slowest rank included -- goes to `barrier_out` (max over ranks, seconds per block).
     `after_step(t)` (t = index into `actions`) runs inside the timed region (parity tap, digests), `before_block(i)` /
-    `after_block(i)` between blocks (untimed).  Returns the list of per-block seconds (max over ranks); `local_out`
+    `after_block(i)` between blocks (untimed).  `run_steps(t0, k)`, when given, REPLACES the per-step loop and `after_step`: it
+    enqueues steps t0 .. t0 + k - 1 (tap included) in one call -- the engine's open-loop rollout entry (include/bbai.h
+    bbai_rollout), so that an interpreter's per-step overhead is not what a 40-us step is timed at.  Returns the list of per-block seconds (max over ranks); `local_out`
     (a list) receives this rank's own per-block seconds."""
     import time
     t = 0
-    for _ in range(warmup):
-        env.step(actions[t])
-        if after_step:
-            after_step(t)
-        t += 1
+    if run_steps is not None:
+        if warmup:
+            run_steps(0, warmup)
+        t = warmup
+    else:
+        for _ in range(warmup):
+            env.step(actions[t])
+            if after_step:
+                after_step(t)
+            t += 1
     out = []
     for b in range(blocks):
         if before_block:
             before_block(b)
         ranks.barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            env.step(actions[t])
-            if after_step:
-                after_step(t)
-            t += 1
+        if run_steps is not None:
+            run_steps(t, steps)
+            t += steps
+        else:
+            for _ in range(steps):
+                env.step(actions[t])
+                if after_step:
+                    after_step(t)
+                t += 1
         ranks._sync()
         mine = time.perf_counter() - t0                      # this rank's own device went idle: its clock stops here
         ranks.barrier()

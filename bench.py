@@ -19,6 +19,9 @@ N GPUs (`scaling: "strong"`; 131 072 envs per GPU at N = 8).  `--weak` keeps 1 0
 (`scaling: "weak"`); `--envs` sets the per-GPU count by hand.
 
 What one run proves about itself (all in the one JSON line rank 0 prints):
+  * the loop    a block's K steps are enqueued by ONE call of the engine's open-loop rollout entry (include/bbai.h bbai_rollout: K x
+                (bbai_step [+ bbai_render] + bbai_tap_ids), the same launches a per-step loop makes; --python-loop makes them from
+                Python): a 65 536-env step is 30-40 us of GPU work, which an interpreter's per-call overhead does not stay ahead of.
   * timing      W warmup steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both sides; a rank's
                 clock stops when its own device is idle, the block is the max over ranks (the closing barrier itself is
                 reported as timing.barrier_ms, not timed); repeated until >= --min-seconds of timed work.  Blocks alternate between PLAIN (nothing but
@@ -147,6 +150,7 @@ def parse_args(argv=None):
     ap.add_argument("--extra-seconds", type=float, default=0.3, help="timed work per extra config")
     ap.add_argument("--extra-parity-envs", type=int, default=256)
     ap.add_argument("--extra-parity-budget", type=int, default=300000, help="oracle env-steps per extra config")
+    ap.add_argument("--python-loop", action="store_true", help="one bbai_step / bbai_render / bbai_tap_ids call per step from Python instead of one bbai_rollout call per block")
     ap.add_argument("--dump-digest", default=None, help="write per-env output digests of this rank to <prefix>.rank<r>.npy")
     args = ap.parse_args(argv)
     if args.gpus < 1:
@@ -278,8 +282,15 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
         if digest is not None:
             digest.update(env.image, env.direction, env.reward64, env.done)
 
+    # one call per block (include/bbai.h bbai_rollout: K x (step [+ render] + tap) enqueued by the engine) unless a per-step hook is
+    # needed (--dump-digest) or --python-loop asks for the per-step calls
+    fast = digest is None and not args.python_loop
+
+    def run1(t0, k):
+        env.rollout(actions1[t0:t0 + k], tap=log1, obs_row0=t0 + 1, row0=t0)
+
     torch.cuda.synchronize()
-    blocks = shard.timed_blocks(env, actions1, W, K, 1, ranks, after1)
+    blocks = shard.timed_blocks(env, actions1, W, K, 1, ranks, after1, run_steps=run1 if fast else None)
     want = int(min(max_blocks, max(0, -(-min_seconds // blocks[0]))))
     want = int(ranks.max(want))
     if want == 1:
@@ -317,9 +328,12 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
             else:
                 env.profile_pause()
 
+        def run2(t0, k):
+            env.rollout(actions2[t0:t0 + k], tap=log2, obs_row0=t0, row0=t0)
+
         torch.cuda.synchronize()
         all_blocks = shard.timed_blocks(env, actions2, 0, K, want, ranks, after2, before_block=before_block, local_out=local_blocks,
-                                        barrier_out=barrier_s)
+                                        barrier_out=barrier_s, run_steps=run2 if fast else None)
         env.profile_pause()
         blocks = all_blocks[0::2]
         profiled = all_blocks[1::2]
@@ -511,6 +525,8 @@ def main():
         "timing": {"blocks": len(blocks), "steps_per_block": K, "block_ms": {"min": bs[0] * 1e3, "median": med * 1e3, "max": bs[-1] * 1e3},
                    "timed_seconds": sum(blocks) + sum(profiled), "value_from": "median plain block", "value_at_min": K * E * world / bs[0],
                    "value_at_max": K * E * world / bs[-1],
+                   "loop": "per-step calls from Python (--python-loop / --dump-digest)" if (args.python_loop or args.dump_digest) else
+                           "one bbai_rollout call per block: the engine enqueues K x (step [+ render] + tap)",
                    "clock": "per block: opening barrier -> K steps -> this rank's device idle; the block = max over ranks; the closing barrier "
                             "and the max-reduce run after every rank's clock has stopped (barrier_ms)",
                    "barrier_ms": {"median": median(m["barrier_s"]) * 1e3, "max": max(m["barrier_s"]) * 1e3} if m["barrier_s"] else None,

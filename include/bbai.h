@@ -170,6 +170,26 @@ int bbai_tap_ids(int64_t count, int64_t pix_count, const int64_t* ids_dev, const
                  const double* reward64_dev, const uint8_t* done_dev, const uint8_t* pixels_dev, uint8_t* image_out, uint8_t* dir_out,
                  double* reward64_out, uint8_t* done_out, uint8_t* pixels_out, void* stream);
 
+/* An open-loop rollout: T steps with NO host round trip in between.  actions_dev[T][n_envs] are resident on the device -- the
+ * random-action rollouts the reference's own level test plays (babyai/levels/levelgen.py:522-527), a replayed demonstration, a
+ * benchmark's pre-drawn action stream.  For t = 0 .. T-1 exactly what a caller's loop would enqueue:
+ *     bbai_step(actions_dev + t * n_envs, ...)                       (auto_reset as in bbai_step)
+ *     bbai_render(image_dev -> pixels_dev)                           when pixels_dev != NULL
+ *     bbai_tap_ids(...) into log rows obs_row0 + t / row0 + t        when tap != NULL
+ * image / dir / reward / reward64 / done (/ pixels) hold the LAST step's outputs on return; the tap log keeps every step of the listed
+ * envs: image_out [rows][count][147], dir_out [rows][count], pixels_out [rows][pix_count][9408] indexed by obs_row0 + t (a caller
+ * that stored the reset()'s observation in row 0 passes obs_row0 = 1), reward64_out / done_out [rows][count] indexed by row0 + t.
+ * On small shards a step is 30-40 us of GPU work: an interpreter's per-call overhead does not stay ahead of that (bench.py times
+ * its blocks through this entry; the per-step calls give the same bytes: tests/test_gpu_parity.py::test_rollout_entry_*). */
+typedef struct bbai_tap_log {
+    int64_t count, pix_count;           /* envs listed / how many of the first listed ones also log pixels */
+    const int64_t* ids_dev;             /* int64[count] env indices */
+    uint8_t* image_out; uint8_t* dir_out; double* reward64_out; uint8_t* done_out; uint8_t* pixels_out;
+    int64_t obs_row0, row0;
+} bbai_tap_log;
+int bbai_rollout(bbai_env* env, int T, const uint8_t* actions_dev, uint8_t* image_dev, uint8_t* dir_dev, float* reward_dev,
+                 double* reward64_dev, uint8_t* done_dev, int auto_reset, uint8_t* pixels_dev, const bbai_tap_log* tap, void* stream);
+
 /* Generalised advantage estimation of a rollout on the current device (the loop of babyai/rl/algos/base.py:196-202 as
  * one reverse scan per env).  All buffers float32, env-major [num_envs][num_frames] (the order base.py:207-232 flattens
  * experiences to); masks[p][i] = 1 - done before frame i, last_mask / last_value [num_envs] = the mask and the critic's

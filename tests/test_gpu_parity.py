@@ -1433,3 +1433,44 @@ def test_options_do_not_change_results(gpu):
     assert a.reset_count() == b.reset_count() and a.reset_count() > 2 * n
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level,n,pixel", [("GoToLocal", 3000, False), ("BossLevel", 1500, True), ("PickupLoc", 700, True)])
+def test_rollout_entry_equals_per_step_calls(gpu, level, n, pixel):
+    """bbai_rollout (T steps [+ render] [+ tap] enqueued by ONE call: what bench.py times) against the same T steps as per-step
+    calls: every logged output of the tapped envs at every step, and the final outputs of every env."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from babyai_amd.action_stream import actions_torch
+    from babyai_amd.shard import scattered_ids
+    T, P, PP = 70, 96, (8 if pixel else 0)
+    a = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, pixel=pixel, seeds=21)
+    b = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, pixel=pixel, seeds=21)
+    a.reset()
+    b.reset()
+    acts = actions_torch(5, 0, T, 0, n, gpu)
+    ids = torch.as_tensor(scattered_ids(n, P), dtype=torch.int64, device=gpu)
+
+    def mklog():
+        lg = {"image": torch.zeros((T + 1, P, 7, 7, 3), dtype=torch.uint8, device=gpu), "direction": torch.zeros((T + 1, P), dtype=torch.uint8, device=gpu),
+              "reward64": torch.zeros((T, P), dtype=torch.float64, device=gpu), "done": torch.zeros((T, P), dtype=torch.uint8, device=gpu), "ids": ids}
+        if PP:
+            lg["pixels"] = torch.zeros((T + 1, PP, 56, 56, 3), dtype=torch.uint8, device=gpu)
+        return lg
+
+    la, lb = mklog(), mklog()
+    for t in range(T):
+        a.step(acts[t])
+        a.tap(la["image"][t + 1], la["direction"][t + 1], la["reward64"][t], la["done"][t], la["pixels"][t + 1] if PP else None, ids=ids)
+    obs = b.rollout(acts[:40], tap=lb, obs_row0=1, row0=0)             # two calls: the second continues where the first stopped
+    obs = b.rollout(acts[40:], tap=lb, obs_row0=41, row0=40)
+    for k in la:
+        assert torch.equal(la[k], lb[k]), k
+    assert torch.equal(a.image, b.image) and torch.equal(a.direction, b.direction) and torch.equal(a.reward64, b.reward64)
+    assert torch.equal(a.done, b.done) and torch.equal(a.reward, b.reward)
+    if pixel:
+        assert torch.equal(a.pixels, b.pixels) and obs["image"] is b.pixels
+    assert a.reset_count() == b.reset_count() and obs["mission"][0] == a.missions()[0]
+    a.close()
+    b.close()
