@@ -2017,9 +2017,9 @@ int bbai_tap_ids(int64_t count, int64_t pix_count, const int64_t* ids_dev, const
 }
 
 // T steps of the hot path with no host round trip in between (include/bbai.h): what a caller's loop of bbai_step [+ bbai_render]
-// [+ bbai_tap_ids] enqueues, enqueued from here.  On the small shards a step is 30-40 us of GPU work, which an interpreter's
-// per-step call overhead does not reliably stay ahead of (profiles/r04/kernel_trace_gaps_*.txt: 10-us gaps between the kernels
-// of one step).
+// [+ bbai_tap_ids] enqueues, enqueued from here.  (Built on the suspicion that an interpreter's per-step overhead does not stay
+// ahead of a 40-us step -- a rocprofv3 trace shows 10-us gaps between the kernels of one step, profiles/r04/kernel_trace_gaps_*.txt --
+// and measured equal to the Python loop on every config: the gaps are the tracer's.  Kept as the open-loop entry it is.)
 int bbai_rollout(bbai_env* e, int T, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64, uint8_t* dones,
                  int auto_reset, uint8_t* pixels, const bbai_tap_log* tap, void* stream) {
     if (!e || T < 1 || !actions || !image || !dirs || !rewards || !dones) ARG_FAIL("null handle or buffer, or T < 1");

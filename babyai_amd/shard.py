@@ -181,7 +181,7 @@ def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None, af
     `after_step(t)` (t = index into `actions`) runs inside the timed region (parity tap, digests), `before_block(i)` /
     `after_block(i)` between blocks (untimed).  `run_steps(t0, k)`, when given, REPLACES the per-step loop and `after_step`: it
     enqueues steps t0 .. t0 + k - 1 (tap included) in one call -- the engine's open-loop rollout entry (include/bbai.h
-    bbai_rollout), so that an interpreter's per-step overhead is not what a 40-us step is timed at.  Returns the list of per-block seconds (max over ranks); `local_out`
+    bbai_rollout; bench.py --rollout-entry).  Returns the list of per-block seconds (max over ranks); `local_out`
     (a list) receives this rank's own per-block seconds."""
     import time
     t = 0

@@ -19,9 +19,9 @@ N GPUs (`scaling: "strong"`; 131 072 envs per GPU at N = 8).  `--weak` keeps 1 0
 (`scaling: "weak"`); `--envs` sets the per-GPU count by hand.
 
 What one run proves about itself (all in the one JSON line rank 0 prints):
-  * the loop    a block's K steps are enqueued by ONE call of the engine's open-loop rollout entry (include/bbai.h bbai_rollout: K x
-                (bbai_step [+ bbai_render] + bbai_tap_ids), the same launches a per-step loop makes; --python-loop makes them from
-                Python): a 65 536-env step is 30-40 us of GPU work, which an interpreter's per-call overhead does not stay ahead of.
+  * the loop    per step one bbai_step [+ bbai_render] + bbai_tap_ids call from Python, like any caller's loop; --rollout-entry
+                enqueues a block's K steps with ONE call of the engine's open-loop rollout entry instead (include/bbai.h bbai_rollout,
+                the same launches) -- measured equal on every config, 65 536-env steps included: the GPU sets the pace.
   * timing      W warmup steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both sides; a rank's
                 clock stops when its own device is idle, the block is the max over ranks (the closing barrier itself is
                 reported as timing.barrier_ms, not timed); repeated until >= --min-seconds of timed work.  Blocks alternate between PLAIN (nothing but
@@ -150,7 +150,7 @@ def parse_args(argv=None):
     ap.add_argument("--extra-seconds", type=float, default=0.3, help="timed work per extra config")
     ap.add_argument("--extra-parity-envs", type=int, default=256)
     ap.add_argument("--extra-parity-budget", type=int, default=300000, help="oracle env-steps per extra config")
-    ap.add_argument("--python-loop", action="store_true", help="one bbai_step / bbai_render / bbai_tap_ids call per step from Python instead of one bbai_rollout call per block")
+    ap.add_argument("--rollout-entry", action="store_true", help="one bbai_rollout call per block instead of one bbai_step / bbai_render / bbai_tap_ids call per step from Python (the same launches)")
     ap.add_argument("--dump-digest", default=None, help="write per-env output digests of this rank to <prefix>.rank<r>.npy")
     args = ap.parse_args(argv)
     if args.gpus < 1:
@@ -282,9 +282,10 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
         if digest is not None:
             digest.update(env.image, env.direction, env.reward64, env.done)
 
-    # one call per block (include/bbai.h bbai_rollout: K x (step [+ render] + tap) enqueued by the engine) unless a per-step hook is
-    # needed (--dump-digest) or --python-loop asks for the per-step calls
-    fast = digest is None and not args.python_loop
+    # --rollout-entry: one call per block (include/bbai.h bbai_rollout: K x (step [+ render] + tap) enqueued by the engine) instead of
+    # the per-step calls -- the same launches; measured equal on every config (profiles/r04/bench_loop_rollout_entry_vs_python_ab.jsonl:
+    # the GPU, not the interpreter, sets the pace even of a 40-us step), so the default stays what a caller's loop looks like
+    fast = digest is None and args.rollout_entry
 
     def run1(t0, k):
         env.rollout(actions1[t0:t0 + k], tap=log1, obs_row0=t0 + 1, row0=t0)
@@ -525,8 +526,8 @@ def main():
         "timing": {"blocks": len(blocks), "steps_per_block": K, "block_ms": {"min": bs[0] * 1e3, "median": med * 1e3, "max": bs[-1] * 1e3},
                    "timed_seconds": sum(blocks) + sum(profiled), "value_from": "median plain block", "value_at_min": K * E * world / bs[0],
                    "value_at_max": K * E * world / bs[-1],
-                   "loop": "per-step calls from Python (--python-loop / --dump-digest)" if (args.python_loop or args.dump_digest) else
-                           "one bbai_rollout call per block: the engine enqueues K x (step [+ render] + tap)",
+                   "loop": "one bbai_rollout call per block: the engine enqueues K x (step [+ render] + tap)" if (args.rollout_entry and not args.dump_digest) else
+                           "per-step calls from Python: bbai_step [+ bbai_render] + bbai_tap_ids",
                    "clock": "per block: opening barrier -> K steps -> this rank's device idle; the block = max over ranks; the closing barrier "
                             "and the max-reduce run after every rank's clock has stopped (barrier_ms)",
                    "barrier_ms": {"median": median(m["barrier_s"]) * 1e3, "max": max(m["barrier_s"]) * 1e3} if m["barrier_s"] else None,

@@ -179,8 +179,8 @@ int bbai_tap_ids(int64_t count, int64_t pix_count, const int64_t* ids_dev, const
  * image / dir / reward / reward64 / done (/ pixels) hold the LAST step's outputs on return; the tap log keeps every step of the listed
  * envs: image_out [rows][count][147], dir_out [rows][count], pixels_out [rows][pix_count][9408] indexed by obs_row0 + t (a caller
  * that stored the reset()'s observation in row 0 passes obs_row0 = 1), reward64_out / done_out [rows][count] indexed by row0 + t.
- * On small shards a step is 30-40 us of GPU work: an interpreter's per-call overhead does not stay ahead of that (bench.py times
- * its blocks through this entry; the per-step calls give the same bytes: tests/test_gpu_parity.py::test_rollout_entry_*). */
+ * The per-step calls give the same bytes (tests/test_gpu_parity.py::test_rollout_entry_*) and, measured, the same speed even on 65 536-env
+ * shards (bench.py --rollout-entry; profiles/r04/bench_loop_rollout_entry_vs_python_ab.jsonl): the entry is a convenience, not a fast path. */
 typedef struct bbai_tap_log {
     int64_t count, pix_count;           /* envs listed / how many of the first listed ones also log pixels */
     const int64_t* ids_dev;             /* int64[count] env indices */

@@ -121,11 +121,11 @@ lib() {              # the same ab spec under two engine builds, alternated twic
 }
 loopab() {           # bench.py's block loop: one bbai_rollout call per block against per-step calls from Python, per config, alternated twice
     cd /tmp
-    for rep in 1 2; do for cfg in C2 C3 C4-shard C4 C5; do for mode in "" "--python-loop"; do
+    for rep in 1 2; do for cfg in C2 C3 C4-shard C4 C5; do for mode in "" "--rollout-entry"; do
         timeout 300 python $REPO/bench.py --config $cfg --no-extra-configs --no-cpu-baseline --parity-envs 64 --min-seconds 0.4 $mode 2>> $OUT/loopab.err | python -c "
 import json, sys
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(json.dumps({'config': '$cfg', 'loop': 'python' if '$mode' else 'bbai_rollout', 'ms_per_step': round(d['ms_per_step'], 5), 'value': d['value'], 'kernels': d['roofline']['kernel_avg_ms'], 'parity': (d['parity'] or {}).get('mismatches_all_ranks')}))" | tee -a $OUT/loop_ab.jsonl
+print(json.dumps({'config': '$cfg', 'loop': 'bbai_rollout' if '$mode' else 'python', 'ms_per_step': round(d['ms_per_step'], 5), 'value': d['value'], 'kernels': d['roofline']['kernel_avg_ms'], 'parity': (d['parity'] or {}).get('mismatches_all_ranks')}))" | tee -a $OUT/loop_ab.jsonl
     done; done; done
 }
 tracecfg() {         # rocprofv3 kernel trace of one BASELINE config (tracecfg:C2): launch gaps on the small shards
