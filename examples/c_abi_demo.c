@@ -51,6 +51,11 @@ int main(void) {
         if (hipMemcpy(host_done, done, n, hipMemcpyDeviceToHost)) return 2;
         for (int64_t i = 0; i < n; ++i) { reward_sum += host_reward[i]; episodes += host_done[i]; }
     }
+    /* performance knobs never change results (include/bbai.h bbai_set_option): consume finished envs inside the step kernel from here on */
+    int64_t period = 0;
+    CHECK(bbai_get_option(env, "lookahead_period", &period));
+    CHECK(bbai_set_option(env, "consume_fused", 1));
+    printf("look-ahead: one generator launch per %lld steps, ring of %lld levels per env\n", (long long)period, (long long)(2 * period));
     /* second phase: the reference's expert (babyai/bot.py) chooses the actions, on the device */
     long expert_episodes = 0, expert_solved = 0;
     for (int t = 0; t < 100; ++t) {
