@@ -120,6 +120,7 @@ struct bbai_env {
     int render_tpb;       // BBAI_RENDER_TPB: 256 / 512 / 1024 threads per render block; anything else = by batch size
     int render_group;     // BBAI_RENDER_GROUP: 2, 4 or 8 envs per one-shot render block; anything else = by batch size (bbai_render)
     int pregen_cap;       // BBAI_PREGEN_BLOCKS: upper bound on look-ahead lane groups per launch (experiments)
+    int pregen_min;       // BBAI_PREGEN_MIN / option "pregen_min": lane groups that work on a refill at least (k_pregen: entries / 32 otherwise); 0 = the whole grid
     int pregen_group;     // BBAI_PREGEN_GROUP: lanes per env in k_pregen: 32 (default: two envs per wave), 16 or 64
     int step_prio;        // BBAI_STEP_PRIO: s_setprio level of the step-path kernels' waves (they share CUs with k_pregen)
     // optional per-kernel timing (bbai_profile): HIP event pairs on the launch stream around k_step / k_consume / k_render
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
                                                   int32_t* __restrict__ mtis, const int32_t* __restrict__ win_list,
                                                   const uint32_t* __restrict__ win_count, int all, int depth,
                                                   uint8_t* __restrict__ pending, const uint8_t* __restrict__ first_slot,
-                                                  unsigned long long* __restrict__ gen_failures) {
+                                                  unsigned long long* __restrict__ gen_failures, int min_groups) {
     constexpr int NG = 64 / G;
     __shared__ GenWork ws[NG];
     typedef GroupCtx<G> Ctx;
@@ -654,8 +655,22 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
     const int lane = ctx.lane();
     int64_t count = n;
     if (!all) count = win_prefix(win_count, MAX_PERIOD);     // window list = concatenated per-tick lists
+    // How many lane groups WORK on a window's refill: the grid is sized for the worst case (every env finished on every tick), the
+    // list usually holds a fraction of that, and every resident generator wave holds registers and LDS that the step kernels'
+    // workgroups queue for.  A refill has a whole window (B ticks) to land, so ~B list entries per group keep pace with the
+    // consumption: active = entries / 32, at least `min_groups` (the launch must not become its slowest level x a long queue),
+    // at most the grid.  Measured (profiles/r04/pregen_cap_priority_group_ab.jsonl, groups in flight 32 768 -> 4 096 / 2 048):
+    // PickupLoc 262 144 envs 0.0870 -> 0.0811 ms per step, GoToLocal 65 536 0.0371 -> 0.0342; 1 024 / 512 groups: 0.209 / 0.092 --
+    // the generator no longer keeps up and the step stream waits.  Surplus blocks leave at once.
+    int64_t stride = (int64_t)gridDim.x * NG;
+    if (!all && min_groups > 0) {
+        int64_t active = count / MAX_PERIOD;
+        active = active < min_groups ? min_groups : active;
+        active = (active + NG - 1) / NG * NG;                   // whole blocks: every group of a block that stays has its own residue
+        stride = active < stride ? active : stride;
+    }
     int64_t it = (int64_t)blockIdx.x * NG + threadIdx.x / G;
-    const int64_t stride = (int64_t)gridDim.x * NG;
+    if ((int64_t)blockIdx.x * NG >= stride) return;             // (whole blocks only: the groups of a wave stay together)
     // the group's current env
     bool have = false;
     int64_t env = 0;
@@ -1294,6 +1309,8 @@ static int create_finish(bbai_env* e) {
         e->call_events = cv && atoi(cv) != 0;
         const char* ev = getenv("BBAI_PREGEN_BLOCKS");
         e->pregen_cap = ev ? std::max(64, atoi(ev)) : 256 * 32 * 4;
+        const char* mv = getenv("BBAI_PREGEN_MIN");
+        e->pregen_min = mv ? std::max(0, atoi(mv)) : 2048;
         const char* pg = getenv("BBAI_PREGEN_GROUP");
         e->pregen_group = pg ? atoi(pg) : 32;
         const char* sp = getenv("BBAI_STEP_PRIO");
@@ -1342,13 +1359,13 @@ static void launch_pregen_g(const bbai_env* e, unsigned groups, const int32_t* w
     const dim3 g((groups + 64 / G - 1) / (64 / G)), b(64);
     if (e->cfg.kind == K_LEVELGEN)
         hipLaunchKernelGGL((k_pregen<K_LEVELGEN, G>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
-                           win_count, all, e->depth, pending, first_slot, fails);
+                           win_count, all, e->depth, pending, first_slot, fails, e->pregen_min);
     else if (e->cfg.kind == K_BONUS)
         hipLaunchKernelGGL((k_pregen<K_BONUS, G>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
-                           win_count, all, e->depth, pending, first_slot, fails);
+                           win_count, all, e->depth, pending, first_slot, fails, e->pregen_min);
     else
         hipLaunchKernelGGL((k_pregen<K_GOTO, G>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
-                           win_count, all, e->depth, pending, first_slot, fails);
+                           win_count, all, e->depth, pending, first_slot, fails, e->pregen_min);
 }
 static void launch_pregen(const bbai_env* e, unsigned groups, const int32_t* win_list, const uint32_t* win_count, int all,
                           uint8_t* pending, const uint8_t* first_slot) {
@@ -2104,6 +2121,7 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     else if (!strcmp(name, "step_prio")) e->step_prio = v;
     else if (!strcmp(name, "pregen_group")) e->pregen_group = v;
     else if (!strcmp(name, "pregen_blocks")) e->pregen_cap = std::max(64, v);
+    else if (!strcmp(name, "pregen_min")) e->pregen_min = std::max(0, v);
     else if (!strcmp(name, "consume_fused")) e->consume_fused = v;
     else if (!strcmp(name, "done_action_enum")) e->done_action_enum = v != 0;       // (the one SEMANTIC switch in this list: include/bbai.h bbai_set_done_actions)
     else {
@@ -2125,6 +2143,7 @@ int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     else if (!strcmp(name, "step_prio")) *out = e->step_prio;
     else if (!strcmp(name, "pregen_group")) *out = e->pregen_group;
     else if (!strcmp(name, "pregen_blocks")) *out = e->pregen_cap;
+    else if (!strcmp(name, "pregen_min")) *out = e->pregen_min;
     else if (!strcmp(name, "consume_fused")) *out = e->consume_fused;
     else if (!strcmp(name, "done_action_enum")) *out = e->done_action_enum;
     else if (!strcmp(name, "lookahead_period")) *out = e->period;

@@ -235,8 +235,8 @@ int bbai_get_done_actions(bbai_env* env);
  *   "render_pace"       experiment: 1/16 ns of wall clock per render ticket (a time gate over two ticket counters); 0 = off (default)
  *   "render_queue_bpc", "render_queue_blocks"   persistent render blocks per CU (0 = 1024 threads' worth) / in total (0 = per CU)
  *   "render_group", "render_tpb"   envs / threads per one-shot render block (0 = by batch size)
- *   "step_prio", "pregen_group", "pregen_blocks", "consume_fused"   as BBAI_STEP_PRIO / BBAI_PREGEN_GROUP / BBAI_PREGEN_BLOCKS /
- *                       BBAI_CONSUME_FUSED
+ *   "step_prio", "pregen_group", "pregen_blocks", "pregen_min", "consume_fused"   as BBAI_STEP_PRIO / BBAI_PREGEN_GROUP /
+ *                       BBAI_PREGEN_BLOCKS / BBAI_PREGEN_MIN / BBAI_CONSUME_FUSED
  *   "done_action_enum"  the one semantic switch, meaningful in done-action mode only: see bbai_set_done_actions
  * BBAI_ERR_ARG for an unknown name. */
 int bbai_set_option(bbai_env* env, const char* name, int64_t value);

@@ -1421,7 +1421,8 @@ def test_options_do_not_change_results(gpu):
     gen.manual_seed(3)
     settings = [("step_prio", 0), ("pregen_group", 64), ("pregen_blocks", 64), ("render_group", 4), ("render_tpb", 256),
                 ("consume_fused", 1), ("pregen_group", 16), ("render_queue", 1), ("consume_fused", 0),
-                ("render_queue", 6), ("pregen_group", 32), ("step_prio", 1), ("consume_fused", 1), ("consume_fused", -1)]
+                ("render_queue", 6), ("pregen_group", 32), ("step_prio", 1), ("consume_fused", 1), ("consume_fused", -1), ("pregen_min", 0),
+                ("pregen_min", 7), ("pregen_group", 64), ("pregen_min", 2048)]
     for t in range(20 * len(settings)):
         assert torch.equal(oa["image"], ob["image"]) and torch.equal(a.image, b.image) and torch.equal(a.direction, b.direction), t
         if t % 20 == 0:
