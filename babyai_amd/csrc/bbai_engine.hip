@@ -120,7 +120,7 @@ struct bbai_env {
     int render_tpb;       // BBAI_RENDER_TPB: 256 / 512 / 1024 threads per render block; anything else = by batch size
     int render_group;     // BBAI_RENDER_GROUP: 2, 4 or 8 envs per one-shot render block; anything else = by batch size (bbai_render)
     int pregen_cap;       // BBAI_PREGEN_BLOCKS: upper bound on look-ahead lane groups per launch (experiments)
-    int pregen_min;       // BBAI_PREGEN_MIN / option "pregen_min": lane groups that work on a refill at least (k_pregen: entries / 32 otherwise); 0 = the whole grid
+    int pregen_min;       // BBAI_PREGEN_MIN / option "pregen_min": single-room levels: lane groups that work on a refill at least (k_pregen: entries / 32 otherwise); 0 = the whole grid, as mazes always get
     int pregen_group;     // BBAI_PREGEN_GROUP: lanes per env in k_pregen: 32 (default: two envs per wave), 16 or 64
     int step_prio;        // BBAI_STEP_PRIO: s_setprio level of the step-path kernels' waves (they share CUs with k_pregen)
     // optional per-kernel timing (bbai_profile): HIP event pairs on the launch stream around k_step / k_consume / k_render
@@ -1357,15 +1357,19 @@ static void launch_pregen_g(const bbai_env* e, unsigned groups, const int32_t* w
                             uint8_t* pending, const uint8_t* first_slot) {
     unsigned long long* fails = (unsigned long long*)(e->total_resets + 1);
     const dim3 g((groups + 64 / G - 1) / (64 / G)), b(64);
+    // Demand-sized groups only where a level is cheap (single rooms, <= 60 us per group): a maze level costs a group ~300 us,
+    // and GoTo at 131 072 envs stalls the step stream with 4 entries per group (0.0534 vs 0.0385 ms per step,
+    // profiles/r04/pregen_min_ab.jsonl) -- mazes keep one entry per group.
+    const int min_groups = e->cfg.num_rows * e->cfg.num_cols > 1 ? 0 : e->pregen_min;
     if (e->cfg.kind == K_LEVELGEN)
         hipLaunchKernelGGL((k_pregen<K_LEVELGEN, G>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
-                           win_count, all, e->depth, pending, first_slot, fails, e->pregen_min);
+                           win_count, all, e->depth, pending, first_slot, fails, min_groups);
     else if (e->cfg.kind == K_BONUS)
         hipLaunchKernelGGL((k_pregen<K_BONUS, G>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
-                           win_count, all, e->depth, pending, first_slot, fails, e->pregen_min);
+                           win_count, all, e->depth, pending, first_slot, fails, min_groups);
     else
         hipLaunchKernelGGL((k_pregen<K_GOTO, G>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
-                           win_count, all, e->depth, pending, first_slot, fails, e->pregen_min);
+                           win_count, all, e->depth, pending, first_slot, fails, min_groups);
 }
 static void launch_pregen(const bbai_env* e, unsigned groups, const int32_t* win_list, const uint32_t* win_count, int all,
                           uint8_t* pending, const uint8_t* first_slot) {
