@@ -1364,6 +1364,41 @@ def test_record_path_equals_window_plane_path(gpu, level, fused, monkeypatch):
     b.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("vplane", ["1", "0"])
+@pytest.mark.parametrize("level", ["GoToLocal", "PutNextS6N3Carrying", "BossLevel", "KeyInBox"])
+def test_fused_consume_equals_k_consume_under_reset_storms(gpu, level, vplane, monkeypatch):
+    """The finished envs consumed inside k_step (consume_fused = 1) against the k_consume launch when waves carry anything from none
+    to sixty-four finished envs: a reset command on a tenth of the envs, for a stretch on most of them.  Every output byte and pixel at
+    every step; afterwards the missions, the reset counts and the exported records / hot state (ring slot included) / stale sets."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    n, steps = 2500, 140
+    monkeypatch.setenv("BBAI_VPLANE", vplane)
+    monkeypatch.setenv("BBAI_CONSUME_FUSED", "0")
+    a = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=77, pixel=True)
+    monkeypatch.setenv("BBAI_CONSUME_FUSED", "1")
+    b = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=77, pixel=True)
+    oa, ob = a.reset(), b.reset()
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(5)
+    weights = torch.tensor([1.0, 1.0, 2.0, 1.5, 1.5, 1.5, 0.3, 0.9], device=gpu)      # 7 = "reset this env now"
+    heavy = torch.tensor([1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 21.0], device=gpu)
+    for t in range(steps):
+        assert torch.equal(a.image, b.image) and torch.equal(oa["image"], ob["image"]) and torch.equal(a.direction, b.direction), t
+        w = heavy if 60 <= t < 70 else weights
+        act = torch.multinomial(w, n, replacement=True, generator=gen).to(torch.uint8)
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(a.reward64, b.reward64) and torch.equal(da, db), t
+    assert a.reset_count() == b.reset_count() and a.reset_count() > 8 * n
+    assert a.missions() == b.missions()
+    (ra_, ha_, sa_), (rb_, hb_, sb_) = a.export_state(), b.export_state()
+    assert np.array_equal(ra_, rb_) and np.array_equal(ha_, hb_) and np.array_equal(sa_, sb_)
+    a.close()
+    b.close()
+
+
 N_QUEUE_SHAPES = 11
 
 
