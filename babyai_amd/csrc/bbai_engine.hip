@@ -97,6 +97,7 @@ struct bbai_env {
     int depth, period;    // D, B
     uint8_t* next_rec;    // [D][n][rec_bytes]
     Hot* next_hot;        // [D][n]
+    uint8_t* next_obs;    // [D][n][OBS_SLOT] in-place layout only: the first observation of every look-ahead level, written by the generator
     uint8_t* pending;     // [3][n]  per window buffer: slots consumed by env in the window (0 = not in the window)
     uint8_t* first_slot;  // [3][n]  first slot the env consumed in the window
     int32_t* win_list;    // [3][B*n] envs consumed in the window, one entry per (tick, finished env); an env that
@@ -144,6 +145,7 @@ struct bbai_env {
     int n_cus;            // compute units of the device
     int done_action_enum; // option "done_action_enum": done-action mode only -- bbai_step's `done` actions count as the enum member (verifier.py:543-545)
     int consume_fused;    // BBAI_CONSUME_FUSED / option "consume_fused": -1 = by batch size, 0 = k_consume launch, 1 = inside k_step
+    int inplace;          // BBAI_INPLACE: the in-place layout (live_slot below): an env's live record IS the look-ahead slot its episode was generated into
     uint8_t* atlas;       // [n_tiles][192]
     uint8_t* lut;         // [2][256]
     int n_tiles;
@@ -339,6 +341,28 @@ __device__ __forceinline__ u32x4 v_segment(const LevelCfg& c, const uint8_t* __r
     return out;
 }
 
+// ---- the in-place layout (bbai_env::inplace, chosen at bbai_create) ------------------------------------------------------------
+// Classic layout: every env has a live record of its own (rec[env]); a finished env's next level is COPIED out of its look-ahead
+// slot (1.3 - 1.7 KB + the window plane), by a k_consume launch behind every step or by the stepping wave.  On reset-heavy small
+// shards (single rooms: 2 % of the envs finish on every step) that second dependent launch is 40 % of a step (profiles/r04/NOTES.md
+// section 2), and doing its work inside the stepping waves costs more than the launch.  In-place layout: the live record of an env
+// IS the ring slot its episode was generated into -- the slot BEFORE hot.slot -- and a finished env just moves on to the next
+// slot: nothing is copied, the stepping LANE loads the new pose and program (one round trip), emits the first observation with the
+// step's own window pipeline and swaps the SoA state.  The ring is one slot deeper (2B + 1: the live one + the 2B look-ahead
+// levels of the classic ring); the slot an episode leaves is the one the window's refill regenerates.  rec[] stays allocated as the
+// staging area of export / import / checkpoints.  No window plane in this layout (the window comes out of the record's appearance
+// plane: measures equal on the shards this is for).
+// The look-ahead ring is ENV-MAJOR: entry (slot, env) of next_rec / next_hot / next_obs is number env * depth + slot -- an env's D levels
+// lie together.  (Slot-major, rounds 1-4a, put the 64 envs of a stepping wave into up to 64 regions n * rec_bytes apart as soon as
+// the live records are ring slots: profiles/r04/inplace_ring_depth_ab.jsonl, k_step 0.029 -> 0.035 ms from D = 5 to D = 65.)
+__device__ __forceinline__ int64_t ring_at(int slot, int64_t env, int depth) { return env * depth + slot; }
+constexpr int OBS_SLOT = 160;           // bytes per first observation in next_obs (147 used; sixteen-byte loads)
+__device__ __forceinline__ int live_slot(int next_slot, int depth) { return (next_slot ? next_slot : depth) - 1; }
+__device__ __forceinline__ uint8_t* live_rec(const LevelCfg& c, int64_t n, int64_t env, uint8_t* recs, uint8_t* ring, int depth, int next_slot) {
+    (void)n;
+    return ring ? ring + ring_at(live_slot(next_slot, depth), env, depth) * (int64_t)c.rec_bytes : recs + env * (int64_t)c.rec_bytes;
+}
+
 // look-ahead slot -> live state of ONE env by ONE wave (k_consume: wave = env over the reset list; k_step<.., FUSE>: the wave that
 // stepped the env): coalesced record copy, SoA verifier view, first observation of the new episode (to `obs_dst`: the caller's
 // image row, or the block's LDS row in k_step), window plane + front cache, window bookkeeping for the batched refill.
@@ -348,16 +372,17 @@ __device__ __forceinline__ u32x4 v_segment(const LevelCfg& c, const uint8_t* __r
 // flight together (pose, program, the record's 16-byte vectors, the window plane's row segments), the one load that needs the
 // new pose (the view cell) goes out as soon as the pose is there, and the stores follow.  Round 3's form (load - store pairs
 // in loops) was ten round trips long.
-__device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_t env, int slot, int lane, uint8_t* __restrict__ recs,
-                                            Hot* __restrict__ hots, uint64_t* __restrict__ stales, const uint8_t* __restrict__ next_recs,
+__device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_t env, int slot, int lane, uint8_t* recs,
+                                            Hot* __restrict__ hots, uint64_t* __restrict__ stales, uint8_t* next_recs /* in-place: the start-carry patch goes into the slot */,
                                             const Hot* __restrict__ next_hots, uint32_t* __restrict__ vheads, uint64_t* __restrict__ vsets,
                                             int depth, uint8_t* __restrict__ pending, uint8_t* __restrict__ first_slot,
                                             int32_t* __restrict__ win_entry, uint8_t* __restrict__ obs_dst, uint8_t* __restrict__ dirs,
                                             uint8_t* __restrict__ vplane /* or NULL */,
-                                            uint16_t* __restrict__ fcache, uint8_t* __restrict__ lsm_arr /* or NULL */) {
+                                            uint16_t* __restrict__ fcache, uint8_t* __restrict__ lsm_arr /* or NULL */,
+                                            bool inplace = false /* the slot BECOMES the live record: no copy; the slot the episode leaves is what gets refilled */) {
     const int nvec = c.rec_bytes >> 4;
-    const uint8_t* nrec = next_recs + ((int64_t)slot * n + env) * (int64_t)c.rec_bytes;
-    Hot h = next_hots[(int64_t)slot * n + env];
+    uint8_t* nrec = next_recs + ring_at(slot, env, depth) * (int64_t)c.rec_bytes;
+    Hot h = next_hots[ring_at(slot, env, depth)];
     const Prog* p = (const Prog*)(nrec + c.off_prog);
     const int start_carry = p->start_carry;
     const uint64_t pset = lane < 8 ? p->set[lane >> 1][lane & 1] : 0ull;
@@ -368,7 +393,7 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
     const int e_view = observe_fetch(c, nrec, h, lane);
     uint32_t fe0 = nrec[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];       // (the front cell for the cache: with the view cells, not behind everything)
     // record: slot -> live copy
-    {
+    if (!inplace) {
         const u32x4* src = (const u32x4*)nrec;
         u32x4* dst = (u32x4*)(recs + env * (int64_t)c.rec_bytes);
         constexpr int CPB = 2;
@@ -414,7 +439,7 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
             }
             if (e_index(c, sx, sy) == e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))) fe0 = E_EMPTY;
             ce0 = nrec[c.off_app + start_carry];
-            apply_start_carry(c, recs + env * (int64_t)c.rec_bytes, h, stale0, start_carry);
+            apply_start_carry(c, inplace ? nrec : recs + env * (int64_t)c.rec_bytes, h, stale0, start_carry);
         }
         if (vplane) fcache[env] = (uint16_t)(fe0 | (ce0 << 8));
         hots[env] = h;
@@ -422,10 +447,70 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
         if (lsm_arr) lsm_arr[env] = 0;                  // fresh instruction objects: lastStepMatch = False (verifier.py:213-214)
         dirs[env] = h.dir;
         // window bookkeeping for the batched refill: first consumption in this window registers the env
-        if (pend == 0) first_slot[env] = (uint8_t)slot;
+        if (pend == 0) first_slot[env] = (uint8_t)(inplace ? live_slot(slot, depth) : slot);
         if (win_entry) *win_entry = pend == 0 ? (int32_t)env : -1;
         pending[env] = (uint8_t)(pend + 1);
     }
+}
+
+// In-place layout: a finished env moves on to its next look-ahead slot, done by the env's OWN lane inside k_step (all the finished
+// lanes of a wave side by side: no per-env loop, no tail).  Everything it needs depends on the slot alone -- pose, program, window
+// bookkeeping and the new episode's first observation, which the generator wrote next to the level (computing it here, with the
+// step's own window pipeline, doubled the vector work of every wave that carries a finished env: measured, profiles/r04/
+// inplace_own_lane_observation_ab.jsonl) -- so it is ONE round trip, and it is issued the moment the lane knows its episode is over
+// (advance_load, right behind the step's own stores), in flight together with the wave's list atomic; advance_finish swaps the SoA
+// state of the env and puts the observation into the lane's LDS row.
+struct AdvanceRegs {
+    u32x4 hv, tail /* Prog bytes 96..111: kind[4], root, n_a, n_b, strict, start_carry */, o[OBS_SLOT / 16];
+    uint64_t ps[8];
+    uint32_t pend;
+};
+__device__ __forceinline__ void advance_load(const LevelCfg& c, int64_t env, int next /* hot.slot: the slot that becomes live */, int depth,
+                                             const uint8_t* ring, const Hot* __restrict__ next_hots, const uint8_t* __restrict__ next_obs,
+                                             const uint8_t* __restrict__ pending, AdvanceRegs& r) {
+    const int64_t at = ring_at(next, env, depth);
+    const uint8_t* nrec = ring + at * (int64_t)c.rec_bytes;
+    r.hv = *(const u32x4*)(next_hots + at);
+    const Prog* p = (const Prog*)(nrec + c.off_prog);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r.ps[k] = p->set[k >> 1][k & 1];
+    r.tail = *(const u32x4*)((const uint8_t*)p + 96);
+    r.pend = pending[env];
+    const u32x4* ob = (const u32x4*)(next_obs + at * OBS_SLOT);
+#pragma unroll
+    for (int k = 0; k < OBS_SLOT / 16; ++k) r.o[k] = ob[k];
+}
+__device__ __forceinline__ void advance_finish(const LevelCfg& c, int64_t n, int64_t env, int lane, int next, int depth, uint8_t* ring, const AdvanceRegs& r,
+                                               Hot* __restrict__ hots, uint64_t* __restrict__ stales, uint32_t* __restrict__ vheads, uint64_t* __restrict__ vsets,
+                                               uint8_t* __restrict__ pending, uint8_t* __restrict__ first_slot, int32_t* __restrict__ win_entry,
+                                               uint8_t* __restrict__ s_rows, uint8_t* __restrict__ dirs, uint8_t* __restrict__ lsm_arr) {
+    static_assert(sizeof(Prog) == 112 && offsetof(Prog, kind) == 96 && offsetof(Prog, start_carry) == 104, "Prog tail");
+    Hot h;
+    __builtin_memcpy(&h, &r.hv, sizeof(h));
+    h.slot = (uint8_t)(next + 1 == depth ? 0 : next + 1);
+    Prog pt;                                    // (only the tail fields are read below)
+    __builtin_memcpy((uint8_t*)&pt + 96, &r.tail, 16);
+    const uint32_t vh = vhead_pack(pt);
+    const int start_carry = pt.start_carry;
+    {
+        RowPacker rp(s_rows, lane);
+#pragma unroll
+        for (int j = 0; j < 37; ++j) rp.put(j, r.o[j >> 2][j & 3]);
+        rp.finish();
+    }
+    uint64_t stale0 = 0;
+    // PutNext*Carrying (consume_env): the first observation shows the object on the grid; now it is in the agent's hands
+    if (start_carry != NONE8) apply_start_carry(c, ring + ring_at(next, env, depth) * (int64_t)c.rec_bytes, h, stale0, start_carry);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) vsets[(int64_t)k * n + env] = r.ps[k];
+    vheads[env] = vh;
+    hots[env] = h;
+    stales[env] = stale0;
+    if (lsm_arr) lsm_arr[env] = 0;
+    dirs[env] = h.dir;
+    if (r.pend == 0) first_slot[env] = (uint8_t)live_slot(next, depth);      // the slot this env's finished episode lived in: free for the refill
+    *win_entry = r.pend == 0 ? (int32_t)env : -1;
+    pending[env] = (uint8_t)(r.pend + 1);
 }
 
 // VP: the window comes from the env's V-plane line (ONE 128-byte line per step) and the transition's inputs -- the
@@ -436,10 +521,10 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
 // the new episode's first observation straight into the block's LDS rows), instead of listing them for a k_consume launch.
 // `fuse` carries what k_consume's arguments carried.
 struct FuseArgs {
-    const uint8_t* next_recs; const Hot* next_hots; uint32_t* vheads_w; uint64_t* vsets_w; int depth, pos;
+    uint8_t* next_recs; const Hot* next_hots; const uint8_t* next_obs; uint32_t* vheads_w; uint64_t* vsets_w; int depth, pos;
     uint8_t* pending; uint8_t* first_slot; int32_t* win_list; uint32_t* win_count; unsigned long long* total_resets;
 };
-template <bool VP, bool FUSE>
+template <bool VP, int FUSE /* 0: finished envs listed for k_consume; 1: consumed by the stepping wave (consume_env); 3: in-place layout (advance_load / advance_finish) */>
 __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c, int64_t n, uint8_t* __restrict__ recs,
                                                      Hot* __restrict__ hots, uint64_t* __restrict__ stales,
                                                      const uint32_t* __restrict__ vheads, const uint64_t* __restrict__ vsets,
@@ -461,6 +546,11 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
     const bool active = env < n;
     bool want_reset = false;
     int my_slot = 0;
+    // (in-place layout: this tick's place in the window list -- the counts of the window's earlier ticks are final -- fetched with the
+    // step's first loads instead of behind the list atomic; the finished lanes' next-slot loads wait in `adv`)
+    int64_t wbase3 = 0;
+    AdvanceRegs adv;
+    if constexpr (FUSE == 3) wbase3 = win_prefix(fuse.win_count, fuse.pos);
     if (active) {
         // everything the step needs from the SoA arrays in ONE memory round trip, before the frozen test (the loads the
         // branch would otherwise delay are a second round trip on every step's critical path)
@@ -475,7 +565,7 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
         Hot h;
         __builtin_memcpy(&h, &hv, sizeof(h));
         my_slot = h.slot;
-        uint8_t* rec = recs + env * (int64_t)c.rec_bytes;
+        uint8_t* rec = FUSE == 3 ? fuse.next_recs + ring_at(live_slot(h.slot, fuse.depth), env, fuse.depth) * (int64_t)c.rec_bytes : recs + env * (int64_t)c.rec_bytes;
         if (!h.frozen) {
             double reward = 0.0;
             const EnvRef r = env_ref(c, rec, vp);
@@ -542,6 +632,7 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
             const uint8_t* src = image + env * OBS_BYTES;
             for (int b = 0; b < OBS_BYTES; ++b) s_rows[lane * OBS_BYTES + b] = src[b];
         }
+        if constexpr (FUSE == 3) { if (want_reset) advance_load(c, env, my_slot, fuse.depth, fuse.next_recs, fuse.next_hots, fuse.next_obs, fuse.pending, adv); }
     }
     // compact finished envs into the reset list: one atomic per wave
     {
@@ -557,7 +648,13 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
                 reset_list[at] = (int32_t)env;
                 if (!FUSE) reset_slot[at] = (uint8_t)my_slot;
             }
-            if (FUSE) {
+            if constexpr (FUSE == 3) {
+                // in-place layout: every finished lane moves its own env on (its stores to its own SoA entries stay in program order)
+                if (lane == leader) atomicAdd(fuse.total_resets, (unsigned long long)__popcll(bal));
+                if (want_reset)
+                    advance_finish(c, n, env, lane, my_slot, fuse.depth, fuse.next_recs, adv, hots, stales, fuse.vheads_w, fuse.vsets_w, fuse.pending, fuse.first_slot,
+                                   fuse.win_list + wbase3 + basei + __popcll(bal & ((1ull << lane) - 1ull)), s_rows, dirs, lsm_arr);
+            } else if constexpr (FUSE != 0) {
                 // Everything this wave stored to the records, window planes and SoA entries of these envs must have landed
                 // before other lanes overwrite them (a terminal pickup patches the record the consume is about to replace).
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -640,13 +737,14 @@ struct GroupCtx {
 #ifndef BBAI_PREGEN_WAVES
 #define BBAI_PREGEN_WAVES 4
 #endif
-template <int KIND, int G>
+template <int KIND, int G, bool OBS /* in-place layout: the level's first observation is written next to it */>
 __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_WAVES) void k_pregen(LevelCfg c, int64_t n, uint8_t* __restrict__ next_recs,
                                                   Hot* __restrict__ next_hots, uint32_t* __restrict__ mts,
                                                   int32_t* __restrict__ mtis, const int32_t* __restrict__ win_list,
                                                   const uint32_t* __restrict__ win_count, int all, int depth,
                                                   uint8_t* __restrict__ pending, const uint8_t* __restrict__ first_slot,
-                                                  unsigned long long* __restrict__ gen_failures, int min_groups) {
+                                                  unsigned long long* __restrict__ gen_failures, int min_groups,
+                                                  uint8_t* __restrict__ next_obs /* in-place layout: [D][n][OBS_SLOT], else NULL */) {
     constexpr int NG = 64 / G;
     __shared__ GenWork ws[NG];
     typedef GroupCtx<G> Ctx;
@@ -701,7 +799,7 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
                 for (int q = 0; q < MTQ; ++q) { const int k = lane + q * G; if (k < MT_N) w.mt[k] = mtw[q]; }
                 ctx.sync();
                 const int prev = slot == 0 ? depth - 1 : slot - 1;          // holds the level generated just before
-                last_locked = next_hots[(int64_t)prev * n + env].last_locked;   // LevelGen.locked_room survives episodes
+                last_locked = next_hots[ring_at(prev, env, depth)].last_locked;   // LevelGen.locked_room survives episodes
                 last_locked = last_locked == NONE8 ? -1 : last_locked;
                 done_levels = 0; attempts = 0;
             }
@@ -717,7 +815,7 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
         if (!ok && !gave_up) continue;
         const int max_steps = g.finish();
         // write-out: record planes, tables, program
-        uint8_t* rec = next_recs + ((int64_t)slot * n + env) * (int64_t)c.rec_bytes;
+        uint8_t* rec = next_recs + ring_at(slot, env, depth) * (int64_t)c.rec_bytes;
         {
             const uint32_t* src = (const uint32_t*)w.E;
             uint32_t* dst = (uint32_t*)rec;
@@ -746,6 +844,49 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
             uint32_t* dst = (uint32_t*)(rec + c.off_prog);
             for (int k = lane; k < (int)(sizeof(Prog) / 4); k += G) dst[k] = src[k];
         }
+        if constexpr (OBS) {
+            // In-place layout: the level's first observation (gen_obs at the start pose: MiniGridEnv.reset), from the appearance plane
+            // in LDS.  Lane l of the group takes view cells l, l + G, ...: cell = vi + 7 vj; the opacity mask of the view is the
+            // group's share of a ballot per round; every lane runs the 7-row visibility sweep and writes its cells' three bytes
+            // (the layout observe_emit writes: cell (vi, vj) at byte (7 vi + vj) * 3; the agent's own cell shows what it carries: nothing yet).
+            constexpr int R = (VIEW * VIEW + G - 1) / G;
+            constexpr unsigned long long GM = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
+            uint8_t* ob = next_obs + ring_at(slot, env, depth) * OBS_SLOT;
+            int ec[R];
+            unsigned long long opaque = 0;
+            ctx.sync();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int cell = r * G + lane;
+                int e = E_EMPTY;
+                if (cell < VIEW * VIEW) {
+                    int x, y;
+                    view_to_world(g.ax, g.ay, g.adir, cell % VIEW, cell / VIEW, x, y);
+                    e = w.E[(y + MARGIN) * c.ES + (x + MARGIN)];
+                }
+                ec[r] = e;
+                const unsigned long long bal = __ballot(cell < VIEW * VIEW && e_opaque(e));
+                opaque |= ((bal >> ((int)threadIdx.x & ~(G - 1) & 63)) & GM) << (r * G);
+            }
+            uint32_t opq[VIEW], vis[VIEW];
+#pragma unroll
+            for (int r = 0; r < VIEW; ++r) opq[r] = (uint32_t)(opaque >> (VIEW * r)) & 0x7Fu;
+            process_vis_rows(opq, vis);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int cell = r * G + lane;
+                if (cell < VIEW * VIEW) {
+                    const int vi = cell % VIEW, vj = cell / VIEW;
+                    const int e = (vi == 3 && vj == 6) ? (int)E_EMPTY : ec[r];
+                    uint32_t row = 0;
+#pragma unroll
+                    for (int q = 0; q < VIEW; ++q) row = (vj == q) ? vis[q] : row;
+                    const bool v = row >> vi & 1;
+                    uint8_t* o = ob + (vi * VIEW + vj) * 3;
+                    o[0] = v ? e_type(e) : 0; o[1] = v ? e_color(e) : 0; o[2] = v ? e_state(e) : 0;
+                }
+            }
+        }
         if (lane == 0) {
             Hot h;
             h.ax = (uint8_t)g.ax; h.ay = (uint8_t)g.ay; h.dir = (uint8_t)g.adir; h.carry = NONE8;
@@ -758,7 +899,7 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
             }
             h.last_locked = last_locked < 0 ? NONE8 : (uint8_t)last_locked;
             h.slot = 0;
-            next_hots[(int64_t)slot * n + env] = h;
+            next_hots[ring_at(slot, env, depth)] = h;
         }
         slot = slot + 1 == depth ? 0 : slot + 1;
         attempts = 0;
@@ -776,8 +917,8 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
 }
 
 // look-ahead slot -> live state for the envs that finished (or all, on reset()): one wave copies one record
-__global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t* __restrict__ recs, Hot* __restrict__ hots,
-                                                 uint64_t* __restrict__ stales, const uint8_t* __restrict__ next_recs,
+__global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t* recs, Hot* __restrict__ hots,
+                                                 uint64_t* __restrict__ stales, uint8_t* next_recs,
                                                  const Hot* __restrict__ next_hots, uint32_t* __restrict__ vheads,
                                                  uint64_t* __restrict__ vsets, const int32_t* __restrict__ reset_list,
                                                  const uint8_t* __restrict__ reset_slot, const uint32_t* __restrict__ counter, int all,
@@ -787,7 +928,7 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
                                                  uint8_t* __restrict__ image, uint8_t* __restrict__ dirs,
                                                  uint32_t* __restrict__ other_counter, int prio,
                                                  uint8_t* __restrict__ vplane /* or NULL */, uint16_t* __restrict__ fcache,
-                                                 uint8_t* __restrict__ lsm_arr /* or NULL */) {
+                                                 uint8_t* __restrict__ lsm_arr /* or NULL */, int inplace) {
     if (prio) __builtin_amdgcn_s_setprio(3);
     const int64_t count = all ? n : (int64_t)counter[0];
     // this tick's entries go behind those of the window's earlier ticks (their counts were written by earlier
@@ -800,13 +941,36 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
         const int slot = all ? (int)hots[env].slot : (int)reset_slot[it];       // (k_step listed it next to the env: no round trip through the env's state)
         consume_env(c, n, env, slot, lane, recs, hots, stales, next_recs, next_hots, vheads, vsets, depth, pending, first_slot,
                     all ? nullptr : win_list + base + it, image + env * OBS_BYTES, dirs, vplane, fcache,
-                    lsm_arr);
+                    lsm_arr, inplace != 0);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(total_resets, (unsigned long long)count);
         win_count[1 + pos] = all ? 0u : (uint32_t)count;
         other_counter[0] = 0;       // the next step's k_step appends to the other ping-pong counter from zero
     }
+}
+
+// In-place layout: rec[] is the staging area of export / import / checkpoints.  dir 0: live slots -> rec[first ..], dir 1: rec[first ..] -> live
+// slots; one wave per env.
+__global__ __launch_bounds__(256) void k_live_copy(LevelCfg c, int64_t n, int64_t first, int64_t count, uint8_t* __restrict__ recs,
+                                                   uint8_t* __restrict__ ring, const Hot* __restrict__ hots, int depth, int dir) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const int nvec = c.rec_bytes >> 4;
+    for (int64_t it = wave; it < count; it += nwaves) {
+        const int64_t env = first + it;
+        u32x4* stage = (u32x4*)(recs + env * (int64_t)c.rec_bytes);
+        u32x4* live = (u32x4*)(ring + ring_at(live_slot(hots[env].slot, depth), env, depth) * (int64_t)c.rec_bytes);
+        for (int k = lane; k < nvec; k += 64) { if (dir) live[k] = stage[k]; else stage[k] = live[k]; }
+    }
+}
+// ... and an imported hot state keeps the env's place in its ring (hot.slot): the slot says where the live record IS
+__global__ void k_import_hot(int64_t first, int64_t count, const Hot* __restrict__ staged, Hot* __restrict__ hots) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Hot h = staged[i];
+    h.slot = hots[first + i].slot;
+    hots[first + i] = h;
 }
 
 // rebuild the SoA verifier view from the records (after bbai_import_state)
@@ -844,7 +1008,8 @@ __global__ __launch_bounds__(256) void k_sync_view(LevelCfg c, int64_t first, in
 // The reference's expert for every env (babyai/bot.py Bot.replan): lane = env, grid-stride over the batch with one BFS
 // scratch block per resident thread.  A new episode (step_count == 0) starts a fresh Bot.
 template <int WAVES_PER_SIMD>
-__global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_bot(LevelCfg c, int64_t n, const uint8_t* __restrict__ recs, const Hot* __restrict__ hots,
+__global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_bot(LevelCfg c, int64_t n, const uint8_t* __restrict__ recs, const uint8_t* __restrict__ ring /* in-place layout: the live records are ring slots; else NULL */,
+                                            int depth, const Hot* __restrict__ hots,
                                             const uint64_t* __restrict__ stales, uint8_t* __restrict__ states, int stack_cap,
                                             uint16_t* __restrict__ works, uint32_t* __restrict__ slow_rows, int eager, const uint8_t* __restrict__ prev_actions,
                                             uint8_t* __restrict__ out, unsigned long long* __restrict__ stats,
@@ -872,7 +1037,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_bot(LevelCfg c, int64_t 
         const bool first = h.step == 0 || st.next_step != h.step;       // (bot_decide applies the same rule)
         const int taken = (prev_actions && !first) ? prev_actions[i] : -1;
         const bool was_dead = !first && st.dead;
-        const int a = bot_decide(c, recs + i * (int64_t)c.rec_bytes, h, stales[i], st, stack_cap, w, first, taken);
+        const int a = bot_decide(c, live_rec(c, n, i, (uint8_t*)recs, (uint8_t*)ring, depth, h.slot), h, stales[i], st, stack_cap, w, first, taken);
         out[i] = (uint8_t)(a == BOT_DEAD ? dead_action : a);
         if (gave_up) gave_up[i] = a == BOT_DEAD ? 1 : 0;
         if (a == BOT_DEAD && !was_dead) atomicAdd(&stats[st.dead == DEAD_CAPACITY ? 1 : 0], 1ull);
@@ -1070,12 +1235,13 @@ __device__ __forceinline__ void tok_side(TokOut& o, const Prog* p, int base, int
         if (kind == L_PUTNEXT) { o.put(7); o.put(2); tok_desc(o, p->desc[base + q][1]); }   // next to
     }
 }
-__global__ __launch_bounds__(64) void k_tokens(LevelCfg c, int64_t n, const uint8_t* __restrict__ recs, uint8_t* __restrict__ tokens,
+__global__ __launch_bounds__(64) void k_tokens(LevelCfg c, int64_t n, const uint8_t* __restrict__ recs, const uint8_t* __restrict__ ring /* in-place layout, else NULL */, int depth,
+                                               const Hot* __restrict__ hots, uint8_t* __restrict__ tokens,
                                                const int32_t* __restrict__ reset_list, const uint32_t* __restrict__ counter, int all) {
     const int64_t count = all ? n : (int64_t)counter[0];
     for (int64_t it = (int64_t)blockIdx.x * 64 + threadIdx.x; it < count; it += (int64_t)gridDim.x * 64) {
         const int64_t env = all ? it : (int64_t)reset_list[it];
-        const Prog* p = (const Prog*)(recs + env * (int64_t)c.rec_bytes + c.off_prog);
+        const Prog* p = (const Prog*)(live_rec(c, n, env, (uint8_t*)recs, (uint8_t*)ring, depth, ring ? hots[env].slot : 0) + c.off_prog);
         TokOut o; o.p = tokens + env * TOK_MAX; o.n = 0;
         tok_side(o, p, 0, p->n_a);
         if (p->root == R_BEFORE) { o.put(31); tok_side(o, p, 2, p->n_b); }                   // , then
@@ -1176,6 +1342,16 @@ static int validate_cfg(const LevelCfg& c) {
     return 0;
 }
 
+static int inplace_by_default(const LevelCfg& c, int64_t n_envs) {
+    // Measured (profiles/r04/inplace_*.jsonl, ms per step classic -> in-place): GoToLocal 32 768 envs 0.0253 -> 0.0183, 65 536 0.0341 -> 0.0322
+    // (bench loop with its tap: 0.0443 -> 0.0398); PickupLoc 131 072 0.0568 -> 0.0576, 196 608 0.0700 -> 0.0851, 262 144 0.0799 -> 0.1091; mazes
+    // lose at every size (no window plane: BossLevel 1 048 576 0.111 -> 0.133).  What turns it is the address range the live records are spread
+    // over -- the whole ring (2.5 GiB at 65 536 single-room envs, 10 GiB at 262 144) instead of n records side by side: in-place for the
+    // single rooms while a full-depth ring stays under 3 GiB, i.e. for the reset-heavy small shards the second launch costs most.
+    if (c.num_rows * c.num_cols > 1) return 0;
+    return (size_t)n_envs * c.rec_bytes * (2 * MAX_PERIOD + 1) <= ((size_t)3 << 30) ? 1 : 0;
+}
+
 int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env** out) {
     if (!cfg || !out || n_envs <= 0 || n_envs > (1ll << 30)) { snprintf(g_err, sizeof(g_err), "bad argument"); return BBAI_ERR_ARG; }
     LevelCfg c;
@@ -1202,8 +1378,13 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->first_slot, 3 * (size_t)n_envs);
     alloc((void**)&e->win_count, 3 * WIN_STRIDE * 4);
     {
+        // BBAI_INPLACE: 1 / 0 force the in-place layout (live_slot above) on / off; default: by level family and batch size
+        const char* iv = getenv("BBAI_INPLACE");
+        e->inplace = iv ? (atoi(iv) != 0) : inplace_by_default(c, n_envs);
+    }
+    {
         const char* vv = getenv("BBAI_VPLANE");              // 0: round 2's record-only step path (A/B runs)
-        if (!(vv && atoi(vv) == 0)) {
+        if (!(vv && atoi(vv) == 0) && !e->inplace) {
             alloc((void**)&e->vplane, (size_t)n_envs * v_bytes(c));
             alloc((void**)&e->fcache, (size_t)n_envs * 2);
         }
@@ -1225,20 +1406,22 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
         const size_t cap = std::min((size_t)(gv ? std::max(1, atoi(gv)) : 64) << 30, free_b / 4);
         int b = 2;
         if (ev) b = atoi(ev);
-        else for (int cand = MAX_PERIOD; cand >= 2; cand >>= 1) if (slot_bytes * 2 * (size_t)cand <= cap) { b = cand; break; }
+        else for (int cand = MAX_PERIOD; cand >= 2; cand >>= 1) if (slot_bytes * (2 * (size_t)cand + (size_t)e->inplace) <= cap) { b = cand; break; }
         b = b < 1 ? 1 : (b > MAX_PERIOD ? MAX_PERIOD : b);
         for (; err == hipSuccess; b >>= 1) {
             e->period = b;
-            e->depth = 2 * b;
+            e->depth = 2 * b + e->inplace;         // (in-place: the live slot + the 2B look-ahead levels)
             const size_t D = (size_t)e->depth;
             hipError_t r1 = hipMalloc((void**)&e->next_rec, D * slot_bytes);
             hipError_t r2 = r1 == hipSuccess ? hipMalloc((void**)&e->next_hot, D * (size_t)n_envs * sizeof(Hot)) : r1;
             hipError_t r3 = r2 == hipSuccess ? hipMalloc((void**)&e->win_list, 3 * (size_t)b * (size_t)n_envs * 4) : r2;
+            if (r3 == hipSuccess && e->inplace) r3 = hipMalloc((void**)&e->next_obs, D * (size_t)n_envs * OBS_SLOT);
             if (r3 == hipSuccess) break;
             (void)hipGetLastError();                       // clear the sticky out-of-memory error before retrying
             if (e->next_rec) { (void)hipFree(e->next_rec); e->next_rec = nullptr; }
             if (e->next_hot) { (void)hipFree(e->next_hot); e->next_hot = nullptr; }
             if (e->win_list) { (void)hipFree(e->win_list); e->win_list = nullptr; }
+            if (e->next_obs) { (void)hipFree(e->next_obs); e->next_obs = nullptr; }
             if (b == 1 || ev) err = r3;                    // an explicit BBAI_LOOKAHEAD is a request, not a hint
         }
     }
@@ -1272,7 +1455,9 @@ static int create_finish(bbai_env* e) {
     const int64_t n_envs = e->n;
     const size_t D = (size_t)e->depth;
     HIP_TRY(hipMemset(e->rec, 0, (size_t)n_envs * c.rec_bytes));
+    HIP_TRY(hipMemset(e->hot, 0, (size_t)n_envs * sizeof(Hot)));       // (slot 0 before any seed: an in-place handle that is only imported into keeps its live records in slot depth - 1)
     HIP_TRY(hipMemset(e->next_rec, 0, D * (size_t)n_envs * c.rec_bytes));
+    if (e->next_obs) HIP_TRY(hipMemset(e->next_obs, 0, D * (size_t)n_envs * OBS_SLOT));
     HIP_TRY(hipMemset(e->pending, 0, 3 * (size_t)n_envs));
     HIP_TRY(hipMemset(e->first_slot, 0, 3 * (size_t)n_envs));
     HIP_TRY(hipMemset(e->win_count, 0, 3 * WIN_STRIDE * 4));
@@ -1343,7 +1528,7 @@ void bbai_destroy(bbai_env* e) {
     void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
     void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_list, e->win_count, e->reset_list, e->counters,
-                    e->total_resets, e->atlas, e->lut, e->vplane, e->fcache, e->lsm, e->render_tickets, e->reset_slot};
+                    e->total_resets, e->atlas, e->lut, e->vplane, e->fcache, e->lsm, e->render_tickets, e->reset_slot, e->next_obs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete e;
 }
@@ -1361,15 +1546,12 @@ static void launch_pregen_g(const bbai_env* e, unsigned groups, const int32_t* w
     // and GoTo at 131 072 envs stalls the step stream with 4 entries per group (0.0534 vs 0.0385 ms per step,
     // profiles/r04/pregen_min_ab.jsonl) -- mazes keep one entry per group.
     const int min_groups = e->cfg.num_rows * e->cfg.num_cols > 1 ? 0 : e->pregen_min;
-    if (e->cfg.kind == K_LEVELGEN)
-        hipLaunchKernelGGL((k_pregen<K_LEVELGEN, G>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
-                           win_count, all, e->depth, pending, first_slot, fails, min_groups);
-    else if (e->cfg.kind == K_BONUS)
-        hipLaunchKernelGGL((k_pregen<K_BONUS, G>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
-                           win_count, all, e->depth, pending, first_slot, fails, min_groups);
-    else
-        hipLaunchKernelGGL((k_pregen<K_GOTO, G>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list,
-                           win_count, all, e->depth, pending, first_slot, fails, min_groups);
+#define PREGEN_LAUNCH(KK, OO) hipLaunchKernelGGL((k_pregen<KK, G, OO>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list, \
+                                                win_count, all, e->depth, pending, first_slot, fails, min_groups, e->next_obs)
+    if (e->cfg.kind == K_LEVELGEN) { if (e->next_obs) PREGEN_LAUNCH(K_LEVELGEN, true); else PREGEN_LAUNCH(K_LEVELGEN, false); }
+    else if (e->cfg.kind == K_BONUS) { if (e->next_obs) PREGEN_LAUNCH(K_BONUS, true); else PREGEN_LAUNCH(K_BONUS, false); }
+    else { if (e->next_obs) PREGEN_LAUNCH(K_GOTO, true); else PREGEN_LAUNCH(K_GOTO, false); }
+#undef PREGEN_LAUNCH
 }
 static void launch_pregen(const bbai_env* e, unsigned groups, const int32_t* win_list, const uint32_t* win_count, int all,
                           uint8_t* pending, const uint8_t* first_slot) {
@@ -1480,7 +1662,7 @@ static int window_end(bbai_env* e, hipStream_t s, int all, bool fused) {
     const int wb = tp.wb, pos = tp.pos;
     const int64_t hint = all ? e->n : std::max<int64_t>(e->n / 64, 64);
     if (e->tokens)     // (fused: the tick's count is the window's count entry, which k_step's waves added up)
-        hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n, e->rec,
+        hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n, e->rec, e->inplace ? e->next_rec : nullptr, e->depth, e->hot,
                            e->tokens, e->reset_list, fused ? e->win_count + WIN_STRIDE * wb + 1 + pos : e->counters + 16 * e->step_parity, all);
     if (!fused) {
         e->step_parity ^= 1;
@@ -1514,7 +1696,7 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
                        e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, e->reset_list, e->reset_slot, e->counters + 16 * e->step_parity, all,
                        e->total_resets, e->depth, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n,
                        e->win_list + (size_t)wb * e->period * e->n, e->win_count + WIN_STRIDE * wb, pos, image, dirs,
-                       e->counters + 16 * (e->step_parity ^ 1), e->step_prio, e->vplane, e->fcache, e->lsm);
+                       e->counters + 16 * (e->step_parity ^ 1), e->step_prio, e->vplane, e->fcache, e->lsm, e->inplace);
     }
     return window_end(e, s, all, false);
 }
@@ -1533,7 +1715,7 @@ int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
     // window buffers start clean: a re-seed may land in the middle of a window that was using buffer 1 or 2.
     HIP_TRY(hipMemsetAsync(e->pending, 0, 3 * (size_t)n, e->side));
     HIP_TRY(hipMemsetAsync(e->first_slot, 0, 3 * (size_t)n, e->side));
-    HIP_TRY(hipMemsetAsync(e->pending, e->depth, (size_t)n, e->side));
+    HIP_TRY(hipMemsetAsync(e->pending, e->depth - e->inplace, (size_t)n, e->side));      // (in-place: slot depth - 1 is the live one -- empty until the first reset)
     launch_pregen(e, pregen_grid(e, n), e->win_list, e->win_count, 1, e->pending, e->first_slot);
     HIP_TRY(hipGetLastError());
     for (int k = 0; k < 3; ++k) HIP_TRY(hipEventRecord(e->ev_refill[k], e->side));
@@ -1576,7 +1758,7 @@ static bool use_fused_consume(const bbai_env* e) {
 }
 static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64,
                        uint8_t* dones, int auto_reset, hipStream_t s, int enum_done) {
-    const bool fused = auto_reset && use_fused_consume(e);
+    const bool fused = auto_reset && (e->inplace || use_fused_consume(e));
     int32_t* list = e->reset_list;
     uint32_t* counter = e->counters + 16 * e->step_parity;
     FuseArgs fa;
@@ -1584,11 +1766,15 @@ static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint
     if (fused) {
         { int rc = window_begin(e, s); if (rc != BBAI_OK) return rc; }        // the slots this step's waves consume have landed
         const TickPos tp = tick_pos(e);
-        fa.next_recs = e->next_rec; fa.next_hots = e->next_hot; fa.vheads_w = e->vhead; fa.vsets_w = e->vset; fa.depth = e->depth; fa.pos = tp.pos;
+        fa.next_recs = e->next_rec; fa.next_hots = e->next_hot; fa.next_obs = e->next_obs; fa.vheads_w = e->vhead; fa.vsets_w = e->vset; fa.depth = e->depth; fa.pos = tp.pos;
         fa.pending = e->pending + (size_t)tp.wb * e->n; fa.first_slot = e->first_slot + (size_t)tp.wb * e->n;
         fa.win_list = e->win_list + (size_t)tp.wb * e->period * e->n; fa.win_count = e->win_count + WIN_STRIDE * tp.wb;
         fa.total_resets = e->total_resets;
         e->next_counter_clean = false;      // (a later unfused step clears its ping-pong counter itself)
+    } else if (e->inplace) {                // (no auto-reset: the kernel still finds the live records through the ring)
+        fa.next_recs = e->next_rec; fa.depth = e->depth; fa.win_count = e->win_count; fa.pos = 0;      // (the kernel's early count-prefix load needs a valid address)
+        if (!e->next_counter_clean) HIP_TRY(hipMemsetAsync(counter, 0, 4, s));
+        e->next_counter_clean = false;
     } else {
         if (!e->next_counter_clean) HIP_TRY(hipMemsetAsync(counter, 0, 4, s));   // (k_consume of the previous step zeroes it)
         e->next_counter_clean = false;
@@ -1597,8 +1783,9 @@ static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint
         ProfScope prof_(e, 0, s);
 #define STEP_LAUNCH(VV, FF) hipLaunchKernelGGL((k_step<VV, FF>), dim3((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), dim3(STEP_BLOCK), 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, \
                                            image, dirs, rewards, rewards64, dones, auto_reset, list, e->reset_slot, counter, e->step_prio, e->vplane, e->fcache, e->lsm, enum_done, fa)
-        if (fused) { if (e->vplane) STEP_LAUNCH(true, true); else STEP_LAUNCH(false, true); }
-        else { if (e->vplane) STEP_LAUNCH(true, false); else STEP_LAUNCH(false, false); }
+        if (e->inplace) STEP_LAUNCH(false, 3);
+        else if (fused) { if (e->vplane) STEP_LAUNCH(true, 1); else STEP_LAUNCH(false, 1); }
+        else { if (e->vplane) STEP_LAUNCH(true, 0); else STEP_LAUNCH(false, 0); }
 #undef STEP_LAUNCH
     }
     HIP_TRY(hipGetLastError());
@@ -1730,7 +1917,7 @@ int bbai_set_token_buffer(bbai_env* e, uint8_t* tokens_dev) {
     if (tokens_dev && e->live) {        // episodes already running: fill every row now
         ON_DEVICE(e->device);
         HIP_TRY(hipDeviceSynchronize());
-        hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((e->n + 63) / 64, 4096)), dim3(64), 0, 0, e->cfg, e->n, e->rec,
+        hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((e->n + 63) / 64, 4096)), dim3(64), 0, 0, e->cfg, e->n, e->rec, e->inplace ? e->next_rec : nullptr, e->depth, e->hot,
                            tokens_dev, e->reset_list, e->counters, 1);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
@@ -1738,10 +1925,21 @@ int bbai_set_token_buffer(bbai_env* e, uint8_t* tokens_dev) {
     return BBAI_OK;
 }
 
+// in-place layout: rec[first ..] <- the live slots (dir 0) or the live slots <- rec[first ..] (dir 1); classic layout: nothing to do
+static int live_copy(bbai_env* e, int64_t first, int64_t count, int dir) {
+    if (!e->inplace || count <= 0) return BBAI_OK;
+    hipLaunchKernelGGL(k_live_copy, dim3((unsigned)std::min<int64_t>((count + 3) / 4, 16384)), dim3(256), 0, 0, e->cfg, e->n, first, count, e->rec,
+                       e->next_rec, e->hot, e->depth, dir);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return BBAI_OK;
+}
+
 int bbai_export_state(bbai_env* e, int64_t first, int64_t count, uint8_t* rec, uint8_t* hot, uint64_t* stale) {
     if (!e || first < 0 || count < 0 || first + count > e->n) ARG_FAIL("null handle or env range out of bounds");
     ON_DEVICE(e->device);
     HIP_TRY(hipDeviceSynchronize());
+    if (rec && count > 0) { int rc = live_copy(e, first, count, 0); if (rc != BBAI_OK) return rc; }
     if (rec) HIP_TRY(hipMemcpy(rec, e->rec + first * e->cfg.rec_bytes, (size_t)count * e->cfg.rec_bytes, hipMemcpyDeviceToHost));
     if (hot) HIP_TRY(hipMemcpy(hot, e->hot + first, (size_t)count * sizeof(Hot), hipMemcpyDeviceToHost));
     if (stale) HIP_TRY(hipMemcpy(stale, e->stale + first, (size_t)count * 8, hipMemcpyDeviceToHost));
@@ -1763,8 +1961,18 @@ int bbai_import_state(bbai_env* e, int64_t first, int64_t count, const uint8_t* 
     ON_DEVICE(e->device);
     HIP_TRY(hipDeviceSynchronize());
     if (rec) HIP_TRY(hipMemcpy(e->rec + first * e->cfg.rec_bytes, rec, (size_t)count * e->cfg.rec_bytes, hipMemcpyHostToDevice));
-    if (hot) HIP_TRY(hipMemcpy(e->hot + first, hot, (size_t)count * sizeof(Hot), hipMemcpyHostToDevice));
+    if (hot && e->inplace && count > 0) {
+        // (the imported hot state keeps this env's place in its ring: hot.slot says where the live record is)
+        Hot* staged = nullptr;
+        HIP_TRY(hipMalloc((void**)&staged, (size_t)count * sizeof(Hot)));
+        hipError_t r = hipMemcpy(staged, hot, (size_t)count * sizeof(Hot), hipMemcpyHostToDevice);
+        if (r == hipSuccess) { hipLaunchKernelGGL(k_import_hot, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, first, count, staged, e->hot); r = hipGetLastError(); }
+        if (r == hipSuccess) r = hipDeviceSynchronize();
+        (void)hipFree(staged);
+        HIP_TRY(r);
+    } else if (hot) HIP_TRY(hipMemcpy(e->hot + first, hot, (size_t)count * sizeof(Hot), hipMemcpyHostToDevice));
     if (stale) HIP_TRY(hipMemcpy(e->stale + first, stale, (size_t)count * 8, hipMemcpyHostToDevice));
+    if (rec && count > 0) { int rc = live_copy(e, first, count, 1); if (rc != BBAI_OK) return rc; }
     if (e->lsm && count > 0) HIP_TRY(hipMemset(e->lsm + first, 0, (size_t)count));     // (not part of the exported state: lastStepMatch = False)
     if (rec && count > 0) {
         hipLaunchKernelGGL(k_sync_prog, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, e->cfg, e->n, first, count, e->rec,
@@ -1796,6 +2004,7 @@ static int ckpt_segments(const bbai_env* e, Seg* out) {
     out[k++] = {e->total_resets, 16};
     if (e->bot_state) { out[k++] = {e->bot_state, n * bot_state_bytes(e->bot_stack)}; out[k++] = {e->bot_stats, 16}; }
     if (e->lsm) out[k++] = {e->lsm, n};
+    if (e->next_obs) out[k++] = {e->next_obs, D * n * OBS_SLOT};
     return k;
 }
 
@@ -1812,9 +2021,10 @@ int bbai_checkpoint_save(bbai_env* e, void* host_buf, int64_t bytes) {
     if (!e || !host_buf || bytes != bbai_checkpoint_bytes(e)) ARG_FAIL("null pointer or buffer size != bbai_checkpoint_bytes()");
     ON_DEVICE(e->device);
     HIP_TRY(hipDeviceSynchronize());             // both streams idle: the ring and the window lists are at rest
+    { int rc = live_copy(e, 0, e->n, 0); if (rc != BBAI_OK) return rc; }       // (in-place layout: the blob's record segment = the live slots)
     CkptHeader h;
     memset(&h, 0, sizeof(h));
-    h.magic = 0x42424149434b5054ull; h.version = 1; h.period = e->period; h.n = e->n; h.cfg = e->cfg; h.depth = e->depth;
+    h.magic = 0x42424149434b5054ull; h.version = 2;        /* 2: env-major look-ahead ring */ h.period = e->period; h.n = e->n; h.cfg = e->cfg; h.depth = e->depth;
     h.step_parity = e->step_parity; h.next_counter_clean = e->next_counter_clean; h.seeded = e->seeded; h.live = e->live;
     for (int i = 0; i < 3; ++i) h.win_all[i] = e->win_all[i];
     h.bot_stack = e->bot_state ? e->bot_stack : 0; h.tick = e->tick; h.bot_threads = e->bot_threads;
@@ -1832,9 +2042,9 @@ int bbai_checkpoint_load(bbai_env* e, const void* host_buf, int64_t bytes) {
     if (!e || !host_buf || bytes < (int64_t)sizeof(CkptHeader)) ARG_FAIL("null pointer or short buffer");
     CkptHeader h;
     memcpy(&h, host_buf, sizeof(h));
-    if (h.magic != 0x42424149434b5054ull || h.version != 1) ARG_FAIL("not a bbai checkpoint");
-    if (h.n != e->n || memcmp(&h.cfg, &e->cfg, sizeof(LevelCfg)) != 0 || h.period < 1 || h.period > MAX_PERIOD || h.depth != 2 * h.period)
-        ARG_FAIL("checkpoint was taken from a different level / batch size");
+    if (h.magic != 0x42424149434b5054ull || h.version != 2) ARG_FAIL("not a bbai checkpoint");
+    if (h.n != e->n || memcmp(&h.cfg, &e->cfg, sizeof(LevelCfg)) != 0 || h.period < 1 || h.period > MAX_PERIOD || h.depth != 2 * h.period + e->inplace)
+        ARG_FAIL("checkpoint was taken from a different level / batch size / state layout (BBAI_INPLACE)");
     ON_DEVICE(e->device);
     HIP_TRY(hipDeviceSynchronize());
     if (h.period != e->period) {
@@ -1842,19 +2052,23 @@ int bbai_checkpoint_load(bbai_env* e, const void* host_buf, int64_t bytes) {
         // ring has the saving handle's.  The ring is part of the state: take the blob's shape.
         const size_t D = (size_t)h.depth, slot_bytes = (size_t)e->n * e->cfg.rec_bytes;
         (void)hipFree(e->next_rec); (void)hipFree(e->next_hot); (void)hipFree(e->win_list);
-        e->next_rec = nullptr; e->next_hot = nullptr; e->win_list = nullptr;
+        if (e->next_obs) (void)hipFree(e->next_obs);
+        e->next_rec = nullptr; e->next_hot = nullptr; e->win_list = nullptr; e->next_obs = nullptr;
         hipError_t r1 = hipMalloc((void**)&e->next_rec, D * slot_bytes);
         hipError_t r2 = r1 == hipSuccess ? hipMalloc((void**)&e->next_hot, D * (size_t)e->n * sizeof(Hot)) : r1;
         hipError_t r3 = r2 == hipSuccess ? hipMalloc((void**)&e->win_list, 3 * (size_t)h.period * (size_t)e->n * 4) : r2;
+        if (r3 == hipSuccess && e->inplace) r3 = hipMalloc((void**)&e->next_obs, D * (size_t)e->n * OBS_SLOT);
         if (r3 != hipSuccess) {
             // leave a consistent (unseeded) handle behind: the old shape again
             (void)hipGetLastError();
             if (e->next_rec) (void)hipFree(e->next_rec);
             if (e->next_hot) (void)hipFree(e->next_hot);
-            e->next_rec = nullptr; e->next_hot = nullptr;
+            if (e->win_list) (void)hipFree(e->win_list);
+            e->next_rec = nullptr; e->next_hot = nullptr; e->win_list = nullptr;
             const size_t D0 = (size_t)e->depth;
             if (hipMalloc((void**)&e->next_rec, D0 * slot_bytes) != hipSuccess || hipMalloc((void**)&e->next_hot, D0 * (size_t)e->n * sizeof(Hot)) != hipSuccess ||
-                hipMalloc((void**)&e->win_list, 3 * (size_t)e->period * (size_t)e->n * 4) != hipSuccess) {
+                hipMalloc((void**)&e->win_list, 3 * (size_t)e->period * (size_t)e->n * 4) != hipSuccess ||
+                (e->inplace && hipMalloc((void**)&e->next_obs, D0 * (size_t)e->n * OBS_SLOT) != hipSuccess)) {
                 snprintf(g_err, sizeof(g_err), "checkpoint_load: out of memory re-shaping the look-ahead ring; the handle is unusable");
                 e->seeded = e->live = false;
                 return BBAI_ERR_NOMEM;
@@ -1899,6 +2113,7 @@ int bbai_get_programs(bbai_env* e, int64_t first, int64_t count, uint8_t* prog) 
     if (!e || !prog || first < 0 || count < 0 || first + count > e->n) ARG_FAIL("null pointer or env range out of bounds");
     ON_DEVICE(e->device);
     HIP_TRY(hipDeviceSynchronize());
+    { int rc = live_copy(e, first, count, 0); if (rc != BBAI_OK) return rc; }
     HIP_TRY(hipMemcpy2D(prog, sizeof(Prog), e->rec + first * e->cfg.rec_bytes + e->cfg.off_prog, (size_t)e->cfg.rec_bytes,
                         sizeof(Prog), (size_t)count, hipMemcpyDeviceToHost));
     return BBAI_OK;
@@ -1944,10 +2159,10 @@ static int bot_launch(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions
     unsigned long long* stats = (unsigned long long*)e->bot_stats;
     const size_t lds = (size_t)R_FAST * e->cfg.H * 64 * 4 + (size_t)BOT_RING * 64 * 2;     // BossLevel: 11.3 + 8 KB -> 8 waves per CU
     if (maze)
-        hipLaunchKernelGGL(k_bot<2>, grid, block, lds, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
+        hipLaunchKernelGGL(k_bot<2>, grid, block, lds, s, e->cfg, e->n, e->rec, e->inplace ? e->next_rec : nullptr, e->depth, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
                            e->bot_rows, e->bot_eager, prev_actions, actions, stats, dead_action, gave_up);
     else
-        hipLaunchKernelGGL(k_bot<1>, grid, block, lds, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
+        hipLaunchKernelGGL(k_bot<1>, grid, block, lds, s, e->cfg, e->n, e->rec, e->inplace ? e->next_rec : nullptr, e->depth, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
                            e->bot_rows, e->bot_eager, prev_actions, actions, stats, dead_action, gave_up);
     HIP_TRY(hipGetLastError());
     return BBAI_OK;
@@ -2149,6 +2364,7 @@ int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     else if (!strcmp(name, "pregen_blocks")) *out = e->pregen_cap;
     else if (!strcmp(name, "pregen_min")) *out = e->pregen_min;
     else if (!strcmp(name, "consume_fused")) *out = e->consume_fused;
+    else if (!strcmp(name, "inplace")) *out = e->inplace;
     else if (!strcmp(name, "done_action_enum")) *out = e->done_action_enum;
     else if (!strcmp(name, "lookahead_period")) *out = e->period;
     else if (!strcmp(name, "render_pace_effective")) *out = e->render_pace > 0 ? e->render_pace : 0;

@@ -353,6 +353,8 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
          "kernel_ms": {k: v[0] for k, v in prof.items() if v[0] is not None},
          "kernel_launches": {k: v[1] for k, v in prof.items() if v[0] is not None},
          "resets": resets, "setup_ms": setup_ms,
+         "state_layout": "in-place (the look-ahead slot is the live record)" if env.get_option("inplace") else "classic (live record per env, k_consume / in-wave copy on reset)",
+         "lookahead_period": env.get_option("lookahead_period"),
          "log1": log1, "log2": log2, "ids2": ids2, "PP1": PP1, "PP2": PP2, "sel2": sel2, "env": env}
     return m
 
@@ -538,6 +540,7 @@ def main():
                    "note": "plain and profiled blocks alternate; kernel_avg_ms are the profiled blocks' launches and add up to (at most) "
                            "profiled_ms_per_step"},
         "setup_ms": m["setup_ms"],
+        "state_layout": m["state_layout"], "lookahead_period": m["lookahead_period"],
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic["bytes"] if traffic else None, "traffic_provenance": traffic,
@@ -631,7 +634,7 @@ def main():
                 "reference": c["ref"], "value": Kc * Ec * world / cmed, "unit": "env-steps/s", "ms_per_step": cmed / Kc * 1e3,
                 "steps_per_block": Kc, "blocks": len(mc["blocks"]), "timed_seconds": sum(mc["blocks"]) + sum(mc["profiled"]),
                 "block_ms": {"min": min(mc["blocks"]) * 1e3, "median": cmed * 1e3, "max": max(mc["blocks"]) * 1e3},
-                "kernel_avg_ms": mc["kernel_ms"],
+                "kernel_avg_ms": mc["kernel_ms"], "state_layout": mc["state_layout"], "lookahead_period": mc["lookahead_period"],
                 "roofline": {"kernel": cdom, "alg_bytes_per_launch": calg, "avg_launch_ms": cdom_ms, "achieved": cach, "unit": "GB/s",
                              "frac": cach / HBM_PEAK_GBS, "whole_step_alg_GBs": Kc * Ec / cmed * cbps / 1e9},
                 "resets": mc["resets"], "resets_per_step": mc["resets"] / float(mc["S2"] or 1), "setup_ms": {k: v for k, v in mc["setup_ms"].items() if k != "note"},

@@ -446,8 +446,18 @@ def test_evaluate_policy_tensor_path(gpu):
     assert a == b and len(a["return_per_episode"]) == 300 and min(a["num_frames_per_episode"]) >= 1
 
 
+def _consume_mode(monkeypatch, mode):
+    """How finished envs get their next level: "0" = k_consume launch, "1" = inside k_step by the stepping wave, "inplace" = the in-place
+    state layout (the look-ahead slot IS the live record; bbai_engine.hip live_slot)."""
+    if mode == "inplace":
+        monkeypatch.setenv("BBAI_INPLACE", "1")
+    else:
+        monkeypatch.setenv("BBAI_INPLACE", "0")
+        monkeypatch.setenv("BBAI_CONSUME_FUSED", mode)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", ["0", "1"])
+@pytest.mark.parametrize("fused", ["0", "1", "inplace"])
 @pytest.mark.parametrize("period", ["1", "2", "8"])
 def test_autoreset_with_interleaved_resets(gpu, period, fused, monkeypatch):
     """Auto-reset stepping with explicit reset() calls thrown in, for several refill periods (BBAI_LOOKAHEAD):
@@ -456,7 +466,7 @@ def test_autoreset_with_interleaved_resets(gpu, period, fused, monkeypatch):
     import torch
     from babyai_amd.engine import BatchedBabyAIEnv
     monkeypatch.setenv("BBAI_LOOKAHEAD", period)
-    monkeypatch.setenv("BBAI_CONSUME_FUSED", fused)
+    _consume_mode(monkeypatch, fused)
     n = 64
     env = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=9)     # tiny level: episodes of a few steps
     refs = _oracle_envs("GoToObjS4", [9 + i for i in range(n)])
@@ -800,7 +810,7 @@ def test_bot_device_equals_host_build(gpu, level, n, steps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", ["0", "1"])
+@pytest.mark.parametrize("fused", ["0", "1", "inplace"])
 @pytest.mark.parametrize("lookahead", [None, "2"])
 def test_very_short_episodes_every_window_tick(gpu, lookahead, fused, monkeypatch):
     """Expert-driven GoToObjS4: episodes of 1-4 steps, so roughly a third of the batch finishes on EVERY step and an env
@@ -812,7 +822,7 @@ def test_very_short_episodes_every_window_tick(gpu, lookahead, fused, monkeypatc
     from hostsim_util import HostBot, HostEnv
     if lookahead:
         monkeypatch.setenv("BBAI_LOOKAHEAD", lookahead)
-    monkeypatch.setenv("BBAI_CONSUME_FUSED", fused)       # k_consume launch / consumed inside k_step
+    _consume_mode(monkeypatch, fused)
     level, n, base = "GoToObjS4", 768, 52000
     env = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=base)
     env.reset()
@@ -940,15 +950,17 @@ def test_bot_device_equals_host_build_on_every_level(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["0", "1"])
 @pytest.mark.parametrize("level,lookahead,use_bot", [("GoToObjS4", "2", False), ("PickupLoc", None, False), ("GoToObjS4", None, True),
                                                      ("MiniBossLevel", "4", True)])
-def test_checkpoint_resume_is_bit_identical(gpu, level, lookahead, use_bot, monkeypatch):
+def test_checkpoint_resume_is_bit_identical(gpu, level, lookahead, use_bot, layout, monkeypatch):
     """bbai_checkpoint_save mid-rollout (at a tick that is not a window boundary), bbai_checkpoint_load into a FRESH
     handle, and both continue through many auto-resets: every output of every later step is identical, the expert's
     decisions included -- i.e. the blob carries the RNG streams, the look-ahead ring, the window bookkeeping and the
-    expert's plans, not just the live grids."""
+    expert's plans, not just the live grids.  Both state layouts (BBAI_INPLACE)."""
     import torch
     from babyai_amd.engine import BatchedBabyAIEnv
+    monkeypatch.setenv("BBAI_INPLACE", layout)
     if lookahead:
         monkeypatch.setenv("BBAI_LOOKAHEAD", lookahead)
     n = 512
@@ -990,14 +1002,16 @@ def test_checkpoint_resume_is_bit_identical(gpu, level, lookahead, use_bot, monk
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["0", "1"])
 @pytest.mark.parametrize("save_period,load_period", [("8", "2"), ("2", None), (None, "4")])
-def test_checkpoint_loads_into_a_handle_with_another_lookahead_period(gpu, save_period, load_period, monkeypatch):
+def test_checkpoint_loads_into_a_handle_with_another_lookahead_period(gpu, save_period, load_period, layout, monkeypatch):
     """The look-ahead period is chosen from the memory that is free at bbai_create (or pinned by BBAI_LOOKAHEAD): two
     identically configured handles may differ in it.  The ring travels in the blob, so the loading handle takes the
-    blob's shape and continues bit-identically."""
+    blob's shape and continues bit-identically.  Both state layouts; a blob of the other layout is refused."""
     import torch
-    from babyai_amd.engine import BatchedBabyAIEnv
+    from babyai_amd.engine import BatchedBabyAIEnv, EngineError
     n = 300
+    monkeypatch.setenv("BBAI_INPLACE", layout)
     if save_period:
         monkeypatch.setenv("BBAI_LOOKAHEAD", save_period)
     a = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=77)
@@ -1020,6 +1034,11 @@ def test_checkpoint_loads_into_a_handle_with_another_lookahead_period(gpu, save_
         assert torch.equal(a.image, b.image) and torch.equal(a.reward64, b.reward64) and torch.equal(a.done, b.done), t
     assert a.reset_count() == b.reset_count() and a.reset_count() > 5 * n
     assert len(b.save_checkpoint()) == len(blob)
+    monkeypatch.setenv("BBAI_INPLACE", "1" if layout == "0" else "0")
+    c = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=1)
+    with pytest.raises(EngineError, match="state layout"):
+        c.load_checkpoint(blob)
+    c.close()
     a.close()
     b.close()
 
@@ -1334,7 +1353,7 @@ def test_step_writes_observations_into_unaligned_caller_buffers(gpu, offset):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", ["0", "1"])
+@pytest.mark.parametrize("fused", ["0", "1", "inplace"])
 @pytest.mark.parametrize("level", ["BossLevel", "PutNextS6N3Carrying", "KeyInBox"])
 def test_record_path_equals_window_plane_path(gpu, level, fused, monkeypatch):
     """BBAI_VPLANE=0 (the step's window and front cell come out of the record's appearance plane: round 2's path, kept for
@@ -1344,7 +1363,7 @@ def test_record_path_equals_window_plane_path(gpu, level, fused, monkeypatch):
     import torch
     from babyai_amd.engine import BatchedBabyAIEnv
     n, steps = 1500, 120
-    monkeypatch.setenv("BBAI_CONSUME_FUSED", fused)
+    _consume_mode(monkeypatch, fused)
     a = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=31, pixel=True)
     monkeypatch.setenv("BBAI_VPLANE", "0")
     b = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=31, pixel=True)
@@ -1365,20 +1384,23 @@ def test_record_path_equals_window_plane_path(gpu, level, fused, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["1", "inplace"])
 @pytest.mark.parametrize("vplane", ["1", "0"])
 @pytest.mark.parametrize("level", ["GoToLocal", "PutNextS6N3Carrying", "BossLevel", "KeyInBox"])
-def test_fused_consume_equals_k_consume_under_reset_storms(gpu, level, vplane, monkeypatch):
-    """The finished envs consumed inside k_step (consume_fused = 1) against the k_consume launch when waves carry anything from none
-    to sixty-four finished envs: a reset command on a tenth of the envs, for a stretch on most of them.  Every output byte and pixel at
-    every step; afterwards the missions, the reset counts and the exported records / hot state (ring slot included) / stale sets."""
+def test_fused_consume_equals_k_consume_under_reset_storms(gpu, level, vplane, mode, monkeypatch):
+    """The finished envs consumed inside k_step (consume_fused = 1), and moved on in place by their own lanes (the in-place layout),
+    against the k_consume launch when waves carry anything from none to sixty-four finished envs: a reset command on a tenth of the
+    envs, for a stretch on most of them, explicit reset() calls in between.  Every output byte and pixel at every step; afterwards the
+    missions, the reset counts and the exported records / hot state / stale sets."""
     import torch
     from babyai_amd.engine import BatchedBabyAIEnv
     n, steps = 2500, 140
     monkeypatch.setenv("BBAI_VPLANE", vplane)
-    monkeypatch.setenv("BBAI_CONSUME_FUSED", "0")
+    _consume_mode(monkeypatch, "0")
     a = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=77, pixel=True)
-    monkeypatch.setenv("BBAI_CONSUME_FUSED", "1")
+    _consume_mode(monkeypatch, mode)
     b = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=77, pixel=True)
+    assert b.get_option("inplace") == (1 if mode == "inplace" else 0) and a.get_option("inplace") == 0
     oa, ob = a.reset(), b.reset()
     gen = torch.Generator(device=gpu)
     gen.manual_seed(5)
@@ -1386,6 +1408,9 @@ def test_fused_consume_equals_k_consume_under_reset_storms(gpu, level, vplane, m
     heavy = torch.tensor([1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 21.0], device=gpu)
     for t in range(steps):
         assert torch.equal(a.image, b.image) and torch.equal(oa["image"], ob["image"]) and torch.equal(a.direction, b.direction), t
+        if t in (33, 34, 101):
+            oa, ob = a.reset(), b.reset()
+            continue
         w = heavy if 60 <= t < 70 else weights
         act = torch.multinomial(w, n, replacement=True, generator=gen).to(torch.uint8)
         oa, ra, da, _ = a.step(act)
@@ -1394,6 +1419,7 @@ def test_fused_consume_equals_k_consume_under_reset_storms(gpu, level, vplane, m
     assert a.reset_count() == b.reset_count() and a.reset_count() > 8 * n
     assert a.missions() == b.missions()
     (ra_, ha_, sa_), (rb_, hb_, sb_) = a.export_state(), b.export_state()
+    ha_[:, 15] = hb_[:, 15] = 0          # the ring slot: the in-place ring is one slot deeper
     assert np.array_equal(ra_, rb_) and np.array_equal(ha_, hb_) and np.array_equal(sa_, sb_)
     a.close()
     b.close()

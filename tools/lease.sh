@@ -21,6 +21,13 @@ suite() {            # the GPU test suite (optionally: -k expression)
     echo "pytest rc=$?" >> $OUT/gpu_tests.log
     tail -4 $OUT/gpu_tests.log
 }
+suiteenv() {         # the GPU suite under an environment setting, all failures listed (no -x): suiteenv:BBAI_INPLACE=1[:-k expression]
+    cd $REPO
+    env "$1" timeout 1500 python -m pytest tests -m gpu -q ${2:+-k "$2"} > $OUT/gpu_tests_$1.log 2>&1
+    echo "pytest rc=$?" >> $OUT/gpu_tests_$1.log
+    grep -E "^FAILED|^ERROR" $OUT/gpu_tests_$1.log | head -40
+    tail -3 $OUT/gpu_tests_$1.log
+}
 build() { cd $REPO && python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -3; }
 judged() {           # the driver's command
     cd /tmp && timeout 600 $B > $OUT/bench_boss_pixel_1M.json 2> $OUT/bench_boss_pixel_1M.err
