@@ -58,7 +58,12 @@ const char* bbai_last_error(void);
 int bbai_fill_layout(bbai_level_cfg* cfg);
 
 /* gym.make(id) x n_envs (babyai/levels/levelgen.py:467-493 registration; scripts/train_rl.py:53-60
- * builds the env list).  Allocates all per-env state in HBM on `device`. */
+ * builds the env list).  Allocates all per-env state in HBM on `device`.
+ * State layout (an internal choice, never visible in results; bbai_get_option "inplace" reports it, BBAI_INPLACE=1 / 0 forces it): every
+ * env owns a ring of pre-generated levels (its RNG stream, generated ahead of need).  Classic: a live record per env, a finished env's
+ * next level is copied out of its ring slot.  In-place: the live record IS the ring slot the episode was generated into and a
+ * finished env just moves on to the next slot -- no copy and no second launch behind a step; chosen for single-room levels while the
+ * ring stays under 3 GiB (the reset-heavy small shards: 2 % of the envs finish on every step there), see DESIGN.md section 5. */
 int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env** out);
 void bbai_destroy(bbai_env* env);
 
@@ -106,7 +111,9 @@ int bbai_render(bbai_env* env, const uint8_t* image_dev, uint8_t* pixels_dev, vo
 #define BBAI_TOK_MAX 72
 int bbai_set_token_buffer(bbai_env* env, uint8_t* tokens_dev);
 
-/* State access (host buffers; synchronous): parity tests, checkpoints, mission strings. */
+/* State access (host buffers; synchronous): parity tests, checkpoints, mission strings.  hot_host[15] is the env's place in its
+ * look-ahead ring: engine bookkeeping, imported as given by a classic-layout handle and left alone by an in-place one (there it says
+ * where the live record is). */
 int bbai_export_state(bbai_env* env, int64_t first, int64_t count, uint8_t* rec_host,
                       uint8_t* hot_host /* 16 B each */, uint64_t* stale_host);
 int bbai_import_state(bbai_env* env, int64_t first, int64_t count, const uint8_t* rec_host,
@@ -118,7 +125,8 @@ int bbai_get_programs(bbai_env* env, int64_t first, int64_t count, uint8_t* prog
  * stream, the look-ahead ring with its window bookkeeping, the counters and -- when bbai_bot_act has been used -- the
  * expert's plans.  Loading it into a fresh handle of the same level and batch size continues the run
  * bit-identically, auto-resets included (tests/test_gpu_parity.py::test_checkpoint_resume_*); a handle whose look-ahead
- * period differs (it is chosen from the free memory at bbai_create unless BBAI_LOOKAHEAD pins it) takes the blob's ring shape.  Synchronous, host buffers.
+ * period differs (it is chosen from the free memory at bbai_create unless BBAI_LOOKAHEAD pins it) takes the blob's ring shape; a blob of the
+ * other state layout (bbai_create) is refused.  Synchronous, host buffers.
  * Caller-owned buffers are not part of the blob: keep the last observation next to it if it is needed before the next
  * step, and register the token buffer again after a load (bbai_set_token_buffer refills every row of a live handle). */
 int64_t bbai_checkpoint_bytes(bbai_env* env);
@@ -240,7 +248,8 @@ int bbai_get_done_actions(bbai_env* env);
  *   "done_action_enum"  the one semantic switch, meaningful in done-action mode only: see bbai_set_done_actions
  * BBAI_ERR_ARG for an unknown name. */
 int bbai_set_option(bbai_env* env, const char* name, int64_t value);
-/* Read a knob back (the names of bbai_set_option), or "lookahead_period" (the refill period the handle chose at bbai_create). */
+/* Read a knob back (the names of bbai_set_option), or "lookahead_period" (the refill period the handle chose at bbai_create), or
+ * "inplace" (1: the in-place state layout, bbai_create). */
 int bbai_get_option(bbai_env* env, const char* name, int64_t* out);
 
 /* Number of level generations (resets) performed so far, all envs. */
