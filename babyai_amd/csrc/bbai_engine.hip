@@ -102,7 +102,7 @@ struct bbai_env {
     uint8_t* first_slot;  // [3][n]  first slot the env consumed in the window
     int32_t* win_list;    // [3][B*n] envs consumed in the window, one entry per (tick, finished env); an env that
                           //          finishes again within the window is marked -1 (every env may finish on every tick)
-    uint32_t* win_count;  // [3][WIN_STRIDE]: [1 + pos] = finished envs of tick `pos` of the window
+    uint32_t* win_count;  // [3][WIN_STRIDE]: [WIN_ENTRY * (1 + pos)] = finished envs of tick `pos` of the window
     int win_all[3];       // window contained a reset() of every env: refill iterates all envs
     int32_t* reset_list;  // [n]     envs finished by the current step (k_step -> k_consume / k_tokens)
     uint8_t* reset_slot;  // [n]     ... and the look-ahead slot each of them consumes (spares k_consume one dependent round trip)
@@ -163,12 +163,17 @@ struct bbai_env {
 // k_step
 // ------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int MAX_PERIOD = 32;          // refill period B (ticks per look-ahead refill); ring depth D = 2B
+constexpr int WIN_ENTRY = 32;           // uint32 per tick entry of a window-count block: every tick's count in a 128-byte line of its OWN -- the
+                                        // current tick's entry takes one atomic per stepping wave (fused / in-place consume), and every wave also
+                                        // READS the earlier ticks' entries (win_prefix): sharing lines queues those reads behind the atomics
+constexpr int WIN_STRIDE = (1 + MAX_PERIOD) * WIN_ENTRY;   // uint32 per window-count block; entry of tick t at WIN_ENTRY * (1 + t)
 // Sum of the first `upto` (<= 64) per-tick counts of a window's count block (entries [1 ..]): ONE load per lane and a wave
 // reduction.  (As a scalar loop this was `upto` dependent memory round trips -- up to 31 of them, ~15 us, at the top of every
 // k_consume / k_pregen wave: most of what a small shard's k_consume launch cost in rounds 1-3.)  Call with the full wave active.
 __device__ __forceinline__ int64_t win_prefix(const uint32_t* __restrict__ win_count, int upto) {
     const int lane = (int)threadIdx.x & 63;
-    uint32_t lo = lane < upto ? win_count[1 + lane] : 0u, hi = 0u;
+    uint32_t lo = lane < upto ? win_count[WIN_ENTRY * (1 + lane)] : 0u, hi = 0u;
 #pragma unroll
     for (int o = 32; o; o >>= 1) {
         const uint32_t l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
@@ -178,8 +183,6 @@ __device__ __forceinline__ int64_t win_prefix(const uint32_t* __restrict__ win_c
     }
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
-constexpr int MAX_PERIOD = 32;          // refill period B (ticks per look-ahead refill); ring depth D = 2B
-constexpr int WIN_STRIDE = 64;          // uint32 per window-count block (1 + MAX_PERIOD used)
 // envs (= threads) per k_step block.  The kernel is bound by its chain of dependent memory round trips, not by bytes or
 // instructions, and a block is what waits at its barriers for its slowest wave: ONE wave per block (64) measured against
 // 128 / 256 in round 3 (profiles/r03/step_variants_ab.jsonl: BossLevel encoded 1 048 576 envs k_step 0.130 -> 0.124 -> 0.111 ms,
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
             int leader = __ffsll((long long)bal) - 1;
             uint32_t basei = 0;
             // (FUSE: the tick's count lives in the window's count block -- what k_consume would have written there at the end)
-            if (lane == leader) basei = atomicAdd(FUSE ? &fuse.win_count[1 + fuse.pos] : &counters[0], (uint32_t)__popcll(bal));
+            if (lane == leader) basei = atomicAdd(FUSE ? &fuse.win_count[WIN_ENTRY * (1 + fuse.pos)] : &counters[0], (uint32_t)__popcll(bal));
             basei = __shfl(basei, leader);
             if (want_reset) {
                 const uint32_t at = basei + __popcll(bal & ((1ull << lane) - 1));
@@ -945,7 +948,7 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(total_resets, (unsigned long long)count);
-        win_count[1 + pos] = all ? 0u : (uint32_t)count;
+        win_count[WIN_ENTRY * (1 + pos)] = all ? 0u : (uint32_t)count;
         other_counter[0] = 0;       // the next step's k_step appends to the other ping-pong counter from zero
     }
 }
@@ -1344,12 +1347,12 @@ static int validate_cfg(const LevelCfg& c) {
 
 static int inplace_by_default(const LevelCfg& c, int64_t n_envs) {
     // Measured (profiles/r04/inplace_*.jsonl, ms per step classic -> in-place): GoToLocal 32 768 envs 0.0253 -> 0.0183, 65 536 0.0341 -> 0.0322
-    // (bench loop with its tap: 0.0443 -> 0.0398); PickupLoc 131 072 0.0568 -> 0.0576, 196 608 0.0700 -> 0.0851, 262 144 0.0799 -> 0.1091; mazes
-    // lose at every size (no window plane: BossLevel 1 048 576 0.111 -> 0.133).  What turns it is the address range the live records are spread
-    // over -- the whole ring (2.5 GiB at 65 536 single-room envs, 10 GiB at 262 144) instead of n records side by side: in-place for the
-    // single rooms while a full-depth ring stays under 3 GiB, i.e. for the reset-heavy small shards the second launch costs most.
+    // (bench loop with its tap: 0.0443 -> 0.0398), PickupLoc 262 144 0.0780 -> 0.0733 (once the window's count entries had lines of their own:
+    // WIN_ENTRY); mazes lose at every size (no window plane in this layout: BossLevel 1 048 576 0.111 -> 0.133).  Single rooms up to a
+    // 12-GiB ring (~ 310 k envs): beyond that nothing was measured with the final kernel, and the window plane the classic layout has
+    // starts to matter with the batch size.
     if (c.num_rows * c.num_cols > 1) return 0;
-    return (size_t)n_envs * c.rec_bytes * (2 * MAX_PERIOD + 1) <= ((size_t)3 << 30) ? 1 : 0;
+    return (size_t)n_envs * c.rec_bytes * (2 * MAX_PERIOD + 1) <= ((size_t)12 << 30) ? 1 : 0;
 }
 
 int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env** out) {
@@ -1663,7 +1666,7 @@ static int window_end(bbai_env* e, hipStream_t s, int all, bool fused) {
     const int64_t hint = all ? e->n : std::max<int64_t>(e->n / 64, 64);
     if (e->tokens)     // (fused: the tick's count is the window's count entry, which k_step's waves added up)
         hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n, e->rec, e->inplace ? e->next_rec : nullptr, e->depth, e->hot,
-                           e->tokens, e->reset_list, fused ? e->win_count + WIN_STRIDE * wb + 1 + pos : e->counters + 16 * e->step_parity, all);
+                           e->tokens, e->reset_list, fused ? e->win_count + WIN_STRIDE * wb + WIN_ENTRY * (1 + pos) : e->counters + 16 * e->step_parity, all);
     if (!fused) {
         e->step_parity ^= 1;
         e->next_counter_clean = true;

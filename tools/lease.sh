@@ -33,6 +33,12 @@ judged() {           # the driver's command
     cd /tmp && timeout 600 $B > $OUT/bench_boss_pixel_1M.json 2> $OUT/bench_boss_pixel_1M.err
     python $REPO/tools/summarize_profile.py --line $OUT/bench_boss_pixel_1M.json
 }
+rejudged() {         # after trace + pmc: condense them ON THE BOX (profiles/pmc_latest.json of this copy) and run the driver's command once
+                     # more, so that the line quotes the counter passes of its own sources
+    cd $REPO && python tools/summarize_profile.py $TAG > $OUT/summarize.log 2>&1
+    cd /tmp && timeout 600 $B > $OUT/bench_boss_pixel_1M_with_traffic.json 2> $OUT/bench_boss_pixel_1M_with_traffic.err
+    python $REPO/tools/summarize_profile.py --line $OUT/bench_boss_pixel_1M_with_traffic.json | head -1
+}
 trace() {            # rocprofv3 --kernel-trace --stats of the same command
     cd /tmp && rm -rf $OUT/stats
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o boss -- $B --no-cpu-baseline --parity-envs 0 --no-extra-configs \
