@@ -63,7 +63,7 @@ int bbai_fill_layout(bbai_level_cfg* cfg);
  * env owns a ring of pre-generated levels (its RNG stream, generated ahead of need).  Classic: a live record per env, a finished env's
  * next level is copied out of its ring slot.  In-place: the live record IS the ring slot the episode was generated into and a
  * finished env just moves on to the next slot -- no copy and no second launch behind a step; chosen for single-room levels while the
- * ring stays under 3 GiB (the reset-heavy small shards: 2 % of the envs finish on every step there), see DESIGN.md section 5. */
+ * ring stays under 12 GiB (the reset-heavy single-room batches: 2 % of the envs finish on every step there), see DESIGN.md section 5. */
 int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env** out);
 void bbai_destroy(bbai_env* env);
 
