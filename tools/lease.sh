@@ -119,6 +119,10 @@ demobench() {        # generate_demos: device rollout vs the step-by-step host l
         timeout 600 python $REPO/tools/demo_bench.py $cfg 2>> $OUT/demo_bench.err | tail -1 | tee -a $OUT/demo_bench.jsonl
     done
 }
+listatomic() {       # one list atomic per stepping wave, sub-lists, and a reader next to it (tools/ubench_listatomic.hip): listatomic[:waves]
+    cd $REPO && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/ubench_listatomic tools/ubench_listatomic.hip 2>/dev/null
+    timeout 200 /tmp/ubench_listatomic ${1:-4096} | tee $OUT/ubench_listatomic_${1:-4096}.jsonl | tail -40
+}
 ubench() {           # the microbenchmarks DESIGN.md quotes (built here: hipcc is on the box)
     cd $REPO && for u in gather render fetchcal; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/ubench_$u tools/ubench_$u.hip 2>/dev/null; done
     timeout 120 python tools/membw.py > $OUT/membw.json 2> $OUT/membw.err
