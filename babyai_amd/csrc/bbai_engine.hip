@@ -98,22 +98,20 @@ struct bbai_env {
     uint8_t* next_rec;    // [D][n][rec_bytes]
     Hot* next_hot;        // [D][n]
     uint8_t* next_obs;    // [D][n][OBS_SLOT] in-place layout only: the first observation of every look-ahead level, written by the generator
-    uint8_t* pending;     // [3][n]  per window buffer: slots consumed by env in the window (0 = not in the window)
-    uint8_t* first_slot;  // [3][n]  first slot the env consumed in the window
-    int32_t* win_list;    // [3][B*n] envs consumed in the window, one entry per (tick, finished env); an env that
-                          //          finishes again within the window is marked -1 (every env may finish on every tick)
-    uint32_t* win_count;  // [3][WIN_STRIDE]: [WIN_ENTRY * (1 + pos)] = finished envs of tick `pos` of the window
-    int win_all[3];       // window contained a reset() of every env: refill iterates all envs
-    int32_t* reset_list;  // [n]     envs finished by the current step (k_step -> k_consume / k_tokens)
+    uint8_t* pending;     // [NWIN][n]  per window buffer: slots consumed by env in the window (0 = not in the window)
+    uint8_t* first_slot;  // [NWIN][n]  first slot the env freed in the window
+    uint32_t* win_meta;   // [NWIN][META_U32] one 128-byte line per window buffer (k_gate / k_window_close / k_pregen)
+    unsigned long long* totals;   // [SHARDS][SHARD_U64] resets so far, sharded over cache lines (sum = bbai_reset_count)
+    unsigned long long* flow;     // [FLOW_WORDS] refilled windows, gate time-outs, total at the last window close, generator give-ups
+    int32_t* reset_list;  // [n]     unfused consume only: envs finished by the current step (k_step<.., 0> -> k_consume / k_tokens)
     uint8_t* reset_slot;  // [n]     ... and the look-ahead slot each of them consumes (spares k_consume one dependent round trip)
     uint32_t* counters;   // [2][16] [p][0] = reset list length; ping-pong by step parity so that k_consume can zero the
                           //         other one for the next step (no memset launch on the step path)
     int step_parity;
     bool next_counter_clean;
-    unsigned long long* total_resets;   // [0] resets so far, [1] generator give-ups (last-resort guard)
     uint8_t* tokens;      // optional caller-owned [n][72] mission token buffer kept current on resets
     hipStream_t side;     // look-ahead generation stream
-    hipEvent_t ev_consumed, ev_refill[3];
+    hipEvent_t ev_consumed;
     hipStream_t last_stream;   // the caller's stream of the previous call (compared, never used): a handle follows ONE stream
     bool have_stream;          // at a time; a call on another stream waits for ev_switch = end of the previous call
     hipEvent_t ev_switch;      // (enter_call / leave_call)
@@ -164,24 +162,28 @@ struct bbai_env {
 // ------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int MAX_PERIOD = 32;          // refill period B (ticks per look-ahead refill); ring depth D = 2B
-constexpr int WIN_ENTRY = 32;           // uint32 per tick entry of a window-count block: every tick's count in a 128-byte line of its OWN -- the
-                                        // current tick's entry takes one atomic per stepping wave (fused / in-place consume), and every wave also
-                                        // READS the earlier ticks' entries (win_prefix): sharing lines queues those reads behind the atomics
-constexpr int WIN_STRIDE = (1 + MAX_PERIOD) * WIN_ENTRY;   // uint32 per window-count block; entry of tick t at WIN_ENTRY * (1 + t)
-// Sum of the first `upto` (<= 64) per-tick counts of a window's count block (entries [1 ..]): ONE load per lane and a wave
-// reduction.  (As a scalar loop this was `upto` dependent memory round trips -- up to 31 of them, ~15 us, at the top of every
-// k_consume / k_pregen wave: most of what a small shard's k_consume launch cost in rounds 1-3.)  Call with the full wave active.
-__device__ __forceinline__ int64_t win_prefix(const uint32_t* __restrict__ win_count, int upto) {
-    const int lane = (int)threadIdx.x & 63;
-    uint32_t lo = lane < upto ? win_count[WIN_ENTRY * (1 + lane)] : 0u, hi = 0u;
-#pragma unroll
-    for (int o = 32; o; o >>= 1) {
-        const uint32_t l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
-        const uint32_t sum = lo + l2;
-        hi += h2 + (sum < lo ? 1u : 0u);
-        lo = sum;
-    }
-    return (int64_t)(((uint64_t)hi << 32) | lo);
+// ---- the windows' bookkeeping: no lists, no same-address atomics on the step path -----------------------------------------------
+// Rounds 1-4 compacted the finished envs of every tick into a window list for the refill (one RETURNING atomic per stepping wave
+// on ONE address: ~2 700 of them per step at 262 144 reset-heavy envs, served at ~11 ns each -- half of that k_step's time) and made
+// the step stream wait, at the start of window w + 2, for the refill of window w (an env MIGHT finish on every tick).  Now:
+//   * a window's refill SCANS the window's `pending` bytes (n bytes per B ticks) instead of walking a list; what a stepping wave
+//     leaves behind is one fire-and-forget add to a sharded total (SHARDS cache lines) and per-env bytes;
+//   * every window records M = the most often ONE env finished in it (1 unless short episodes repeat inside a window: the
+//     rare atomicMax in the consume paths); an env's unrefilled slots are <= the sum of M over the windows whose refill has not
+//     landed, so window x may start as soon as that sum is <= B (every env then still has B ready levels, and a window consumes
+//     at most B) -- k_gate, one wave on the step stream at every window start, waits for exactly that instead of for "refill
+//     w - 2 has landed".  A reset storm (a million maze envs timing out on the same tick: 37 ms of generator time) then runs
+//     UNDER the following windows instead of stopping the step stream, as long as no env finishes B more times meanwhile.
+//   * NWIN window buffers (pending / first_slot / meta) so that up to B + 1 refills can be outstanding.
+// tests/test_ring_protocol.py models the rule (sufficient, and the ring depths stay tight).
+constexpr int NWIN = MAX_PERIOD + 2;    // window buffers
+constexpr int META_U32 = 32;            // uint32 per window buffer's meta line: [0] = M when > 1 (atomicMax), [1] = finished envs (written at its close)
+constexpr int SHARDS = 64;              // cache lines the reset total is spread over (k_step: shard = block & 63)
+constexpr int SHARD_U64 = 16;           // uint64 per shard: one 128-byte line each
+enum : int { FLOW_REFILLED = 0 /* windows whose refill has landed */, FLOW_GATE_TIMEOUTS = 1, FLOW_CLOSE_TOTAL = 2 /* reset total at the last window close */,
+             FLOW_GEN_FAILURES = 3 /* levels the generator gave up on */, FLOW_WORDS = 16 };
+__device__ __forceinline__ void count_resets(unsigned long long* __restrict__ totals, unsigned int k) {
+    atomicAdd(&totals[(blockIdx.x & (SHARDS - 1)) * SHARD_U64], (unsigned long long)k);        // (result unused: a no-return atomic)
 }
 // envs (= threads) per k_step block.  The kernel is bound by its chain of dependent memory round trips, not by bytes or
 // instructions, and a block is what waits at its barriers for its slowest wave: ONE wave per block (64) measured against
@@ -369,7 +371,7 @@ __device__ __forceinline__ uint8_t* live_rec(const LevelCfg& c, int64_t n, int64
 // look-ahead slot -> live state of ONE env by ONE wave (k_consume: wave = env over the reset list; k_step<.., FUSE>: the wave that
 // stepped the env): coalesced record copy, SoA verifier view, first observation of the new episode (to `obs_dst`: the caller's
 // image row, or the block's LDS row in k_step), window plane + front cache, window bookkeeping for the batched refill.
-// `win_entry` = where this consumption is listed for k_pregen (NULL on reset(): the refill walks all envs).
+// `win_meta` = the meta line of the tick's window (its M is raised when an env finishes for the second time inside one window).
 // The job is a handful of kilobytes per env, so what it costs is its chain of dependent memory round trips (a reset-heavy small
 // shard pays it on every step): everything that depends on nothing but the slot is LOADED FIRST, in batches that are all in
 // flight together (pose, program, the record's 16-byte vectors, the window plane's row segments), the one load that needs the
@@ -379,7 +381,7 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
                                             Hot* __restrict__ hots, uint64_t* __restrict__ stales, uint8_t* next_recs /* in-place: the start-carry patch goes into the slot */,
                                             const Hot* __restrict__ next_hots, uint32_t* __restrict__ vheads, uint64_t* __restrict__ vsets,
                                             int depth, uint8_t* __restrict__ pending, uint8_t* __restrict__ first_slot,
-                                            int32_t* __restrict__ win_entry, uint8_t* __restrict__ obs_dst, uint8_t* __restrict__ dirs,
+                                            uint32_t* __restrict__ win_meta, uint8_t* __restrict__ obs_dst, uint8_t* __restrict__ dirs,
                                             uint8_t* __restrict__ vplane /* or NULL */,
                                             uint16_t* __restrict__ fcache, uint8_t* __restrict__ lsm_arr /* or NULL */,
                                             bool inplace = false /* the slot BECOMES the live record: no copy; the slot the episode leaves is what gets refilled */) {
@@ -451,7 +453,7 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
         dirs[env] = h.dir;
         // window bookkeeping for the batched refill: first consumption in this window registers the env
         if (pend == 0) first_slot[env] = (uint8_t)(inplace ? live_slot(slot, depth) : slot);
-        if (win_entry) *win_entry = pend == 0 ? (int32_t)env : -1;
+        else atomicMax(win_meta, (uint32_t)(pend + 1));       // (rare: the env finished before in this window)
         pending[env] = (uint8_t)(pend + 1);
     }
 }
@@ -461,8 +463,8 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
 // bookkeeping and the new episode's first observation, which the generator wrote next to the level (computing it here, with the
 // step's own window pipeline, doubled the vector work of every wave that carries a finished env: measured, profiles/r04/
 // inplace_own_lane_observation_ab.jsonl) -- so it is ONE round trip, and it is issued the moment the lane knows its episode is over
-// (advance_load, right behind the step's own stores), in flight together with the wave's list atomic; advance_finish swaps the SoA
-// state of the env and puts the observation into the lane's LDS row.
+// (advance_load, right behind the step's own stores); advance_finish swaps the SoA state of the env and puts the observation into
+// the lane's LDS row.  Nothing here waits for another wave: the window keeps no list (see NWIN above).
 struct AdvanceRegs {
     u32x4 hv, tail /* Prog bytes 96..111: kind[4], root, n_a, n_b, strict, start_carry */, o[OBS_SLOT / 16];
     uint64_t ps[8];
@@ -485,7 +487,7 @@ __device__ __forceinline__ void advance_load(const LevelCfg& c, int64_t env, int
 }
 __device__ __forceinline__ void advance_finish(const LevelCfg& c, int64_t n, int64_t env, int lane, int next, int depth, uint8_t* ring, const AdvanceRegs& r,
                                                Hot* __restrict__ hots, uint64_t* __restrict__ stales, uint32_t* __restrict__ vheads, uint64_t* __restrict__ vsets,
-                                               uint8_t* __restrict__ pending, uint8_t* __restrict__ first_slot, int32_t* __restrict__ win_entry,
+                                               uint8_t* __restrict__ pending, uint8_t* __restrict__ first_slot, uint32_t* __restrict__ win_meta,
                                                uint8_t* __restrict__ s_rows, uint8_t* __restrict__ dirs, uint8_t* __restrict__ lsm_arr) {
     static_assert(sizeof(Prog) == 112 && offsetof(Prog, kind) == 96 && offsetof(Prog, start_carry) == 104, "Prog tail");
     Hot h;
@@ -512,7 +514,7 @@ __device__ __forceinline__ void advance_finish(const LevelCfg& c, int64_t n, int
     if (lsm_arr) lsm_arr[env] = 0;
     dirs[env] = h.dir;
     if (r.pend == 0) first_slot[env] = (uint8_t)live_slot(next, depth);      // the slot this env's finished episode lived in: free for the refill
-    *win_entry = r.pend == 0 ? (int32_t)env : -1;
+    else atomicMax(win_meta, r.pend + 1u);
     pending[env] = (uint8_t)(r.pend + 1);
 }
 
@@ -524,13 +526,13 @@ __device__ __forceinline__ void advance_finish(const LevelCfg& c, int64_t n, int
 // the new episode's first observation straight into the block's LDS rows), instead of listing them for a k_consume launch.
 // `fuse` carries what k_consume's arguments carried.
 struct FuseArgs {
-    uint8_t* next_recs; const Hot* next_hots; const uint8_t* next_obs; uint32_t* vheads_w; uint64_t* vsets_w; int depth, pos;
-    uint8_t* pending; uint8_t* first_slot; int32_t* win_list; uint32_t* win_count; unsigned long long* total_resets;
+    uint8_t* next_recs; const Hot* next_hots; const uint8_t* next_obs; int depth;
+    uint8_t* pending; uint8_t* first_slot; uint32_t* win_meta; unsigned long long* totals;
 };
 template <bool VP, int FUSE /* 0: finished envs listed for k_consume; 1: consumed by the stepping wave (consume_env); 3: in-place layout (advance_load / advance_finish) */>
 __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c, int64_t n, uint8_t* __restrict__ recs,
                                                      Hot* __restrict__ hots, uint64_t* __restrict__ stales,
-                                                     const uint32_t* __restrict__ vheads, const uint64_t* __restrict__ vsets,
+                                                     uint32_t* vheads, uint64_t* vsets /* read by every lane, WRITTEN for the envs the wave moves on (FUSE): no restrict */,
                                                      const uint8_t* __restrict__ actions, uint8_t* image /* read (frozen envs re-emit) AND written: no restrict */,
                                                      uint8_t* __restrict__ dirs, float* __restrict__ rewards,
                                                      double* __restrict__ rewards64, uint8_t* __restrict__ dones, int auto_reset,
@@ -549,11 +551,7 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
     const bool active = env < n;
     bool want_reset = false;
     int my_slot = 0;
-    // (in-place layout: this tick's place in the window list -- the counts of the window's earlier ticks are final -- fetched with the
-    // step's first loads instead of behind the list atomic; the finished lanes' next-slot loads wait in `adv`)
-    int64_t wbase3 = 0;
-    AdvanceRegs adv;
-    if constexpr (FUSE == 3) wbase3 = win_prefix(fuse.win_count, fuse.pos);
+    AdvanceRegs adv;          // (in-place layout: the finished lanes' next-slot loads)
     if (active) {
         // everything the step needs from the SoA arrays in ONE memory round trip, before the frozen test (the loads the
         // branch would otherwise delay are a second round trip on every step's critical path)
@@ -562,7 +560,7 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
         VProg vp; vp.bind(vheads[env], vsets + env, n);
         int action = actions[env];
         uint32_t fc = VP ? (uint32_t)fcache[env] : 0u;
-        uint32_t lsm = lsm_arr ? (uint32_t)lsm_arr[env] : 0u;
+        Lsm lsm = {lsm_arr ? (uint32_t)lsm_arr[env] : 0u, lsm_arr != nullptr};
         // (the empty asm pins the loaded values here: the compiler would otherwise sink the loads into the branch)
         asm volatile("" : "+v"(hv), "+v"(stale), "+v"(vp.head), "+v"(vp.set00), "+v"(action), "+v"(fc));
         Hot h;
@@ -611,8 +609,8 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
             uint32_t cp[13], vis[VIEW];
             view_cells(wd, txm & 3, dir, (uint32_t)ce, nfe, s_rows + row_scratch(lane), cp, vis, fe2);
             // "env.reset() for THIS env, now" (A_RESET_ENV, bbai_step.hpp): the episode ends with done = 1, reward = 0
-            const bool done = action == A_RESET_ENV ? true : finish_step(c, r, h, stale, action, fe2, reward, lsm_arr ? &lsm : nullptr, idf, enum_done != 0);
-            if (lsm_arr) lsm_arr[env] = (uint8_t)lsm;
+            const bool done = action == A_RESET_ENV ? true : finish_step(c, r, h, stale, action, fe2, reward, lsm, idf, enum_done != 0);
+            if (lsm_arr) lsm_arr[env] = (uint8_t)lsm.bits;
             if (done && !auto_reset) h.frozen = 1;
             want_reset = done && auto_reset;
             hots[env] = h;
@@ -637,42 +635,40 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
         }
         if constexpr (FUSE == 3) { if (want_reset) advance_load(c, env, my_slot, fuse.depth, fuse.next_recs, fuse.next_hots, fuse.next_obs, fuse.pending, adv); }
     }
-    // compact finished envs into the reset list: one atomic per wave
+    // finished envs.  Unfused: compacted into the reset list for k_consume (one returning atomic per wave).  Fused / in-place: counted
+    // (one fire-and-forget add to this block's shard of the total) and moved on by this wave itself.
     {
         unsigned long long bal = __ballot(want_reset);
         if (bal) {
-            int leader = __ffsll((long long)bal) - 1;
-            uint32_t basei = 0;
-            // (FUSE: the tick's count lives in the window's count block -- what k_consume would have written there at the end)
-            if (lane == leader) basei = atomicAdd(FUSE ? &fuse.win_count[WIN_ENTRY * (1 + fuse.pos)] : &counters[0], (uint32_t)__popcll(bal));
-            basei = __shfl(basei, leader);
-            if (want_reset) {
-                const uint32_t at = basei + __popcll(bal & ((1ull << lane) - 1));
-                reset_list[at] = (int32_t)env;
-                if (!FUSE) reset_slot[at] = (uint8_t)my_slot;
-            }
-            if constexpr (FUSE == 3) {
+            const int leader = __ffsll((long long)bal) - 1;
+            if constexpr (FUSE == 0) {
+                uint32_t basei = 0;
+                if (lane == leader) basei = atomicAdd(&counters[0], (uint32_t)__popcll(bal));
+                basei = __shfl(basei, leader);
+                if (want_reset) {
+                    const uint32_t at = basei + __popcll(bal & ((1ull << lane) - 1));
+                    reset_list[at] = (int32_t)env;
+                    reset_slot[at] = (uint8_t)my_slot;
+                }
+            } else if constexpr (FUSE == 3) {
                 // in-place layout: every finished lane moves its own env on (its stores to its own SoA entries stay in program order)
-                if (lane == leader) atomicAdd(fuse.total_resets, (unsigned long long)__popcll(bal));
+                if (lane == leader) count_resets(fuse.totals, (unsigned int)__popcll(bal));
                 if (want_reset)
-                    advance_finish(c, n, env, lane, my_slot, fuse.depth, fuse.next_recs, adv, hots, stales, fuse.vheads_w, fuse.vsets_w, fuse.pending, fuse.first_slot,
-                                   fuse.win_list + wbase3 + basei + __popcll(bal & ((1ull << lane) - 1ull)), s_rows, dirs, lsm_arr);
-            } else if constexpr (FUSE != 0) {
+                    advance_finish(c, n, env, lane, my_slot, fuse.depth, fuse.next_recs, adv, hots, stales, vheads, vsets, fuse.pending, fuse.first_slot,
+                                   fuse.win_meta, s_rows, dirs, lsm_arr);
+            } else {
                 // Everything this wave stored to the records, window planes and SoA entries of these envs must have landed
                 // before other lanes overwrite them (a terminal pickup patches the record the consume is about to replace).
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == leader) atomicAdd(fuse.total_resets, (unsigned long long)__popcll(bal));
-                const int64_t wbase = win_prefix(fuse.win_count, fuse.pos);          // this tick's entries go behind those of the window's earlier ticks
-                uint32_t k = 0;
+                if (lane == leader) count_resets(fuse.totals, (unsigned int)__popcll(bal));
                 while (bal) {
                     const int src = __ffsll((long long)bal) - 1;
                     bal &= bal - 1;
                     const int slot = __shfl(my_slot, src);
                     // (the new episode's first observation goes over the finished env's row; LDS traffic of the one wave stays in program order)
-                    consume_env(c, n, env0 + src, slot, lane, recs, hots, stales, fuse.next_recs, fuse.next_hots, fuse.vheads_w, fuse.vsets_w,
-                                fuse.depth, fuse.pending, fuse.first_slot, fuse.win_list + wbase + basei + k, s_rows + src * OBS_BYTES, dirs,
+                    consume_env(c, n, env0 + src, slot, lane, recs, hots, stales, fuse.next_recs, fuse.next_hots, vheads, vsets,
+                                fuse.depth, fuse.pending, fuse.first_slot, fuse.win_meta, s_rows + src * OBS_BYTES, dirs,
                                 VP ? vplane : nullptr, fcache, lsm_arr);
-                    ++k;
                 }
             }
         }
@@ -721,6 +717,11 @@ struct GroupCtx {
     __device__ __forceinline__ uint32_t shfl(uint32_t v, int src) const { return __shfl(v, src, G); }
     __device__ __forceinline__ uint32_t shfl_up1(uint32_t v) const { uint32_t t = __shfl_up(v, 1, G); return lane() == 0 ? 0u : t; }
     __device__ __forceinline__ uint32_t shfl_down1(uint32_t v) const { uint32_t t = __shfl_down(v, 1, G); return lane() == G - 1 ? 0u : t; }
+    __device__ __forceinline__ unsigned long long ballot(bool p) const {     // the group's share of the wave's ballot: bit k = lane k of the group
+        const unsigned long long b = __ballot(p);
+        constexpr unsigned long long m = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
+        return (b >> ((int)threadIdx.x & ~(G - 1) & 63)) & m;
+    }
     __device__ __forceinline__ bool any(bool p) const {
         const unsigned long long b = __ballot(p);
         constexpr unsigned long long m = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
@@ -728,11 +729,15 @@ struct GroupCtx {
     }
 };
 
-// The look-ahead generator.  A workgroup is ONE wave carrying 64 / G envs; every group walks its share of the work list
-// (window list entries, or all envs) on its own: fetch an env that has levels pending, load its MT19937 state into the
+// The look-ahead generator.  A workgroup is ONE wave carrying 64 / G envs; every group walks its share of the window's `pending`
+// bytes on its own: fetch an env that has levels pending, load its MT19937 state into the
 // group's LDS block, then one ATTEMPT of the generator's rejection loop per trip of the main loop (Gen::attempt) -- a
 // group whose attempt was accepted writes the level out and goes on to its next level / env while its neighbours retry,
 // so the wave only idles lanes inside an attempt, never across attempts.
+// Work items: the pending bytes are read G at a time (one per lane: a CHUNK of G consecutive envs); a chunk is PREGEN_SPLIT items --
+// item (chunk, sub) = the chunk's pending envs at lanes == sub (mod PREGEN_SPLIT): a fixed partition, so that the byte a group
+// clears when it is done with an env changes no other group's share -- and a storm (every env pending) still spreads over
+// n * PREGEN_SPLIT / G groups, while a quiet window costs a group a few G-byte loads.
 // Minimum waves per SIMD the generator's register allocation has to allow.  4 (<= 128 VGPRs) instead of the 3 the compiler
 // settles on by itself (131-135 VGPRs at two envs per wave): PickupLoc 262 144 envs 0.0939 -> 0.0877 ms per step, the GoTo family
 // already fits (profiles/r04/pregen_waves_per_simd_ab.jsonl).  The bonus family would spill (167 VGPRs) and four envs per wave
@@ -740,11 +745,13 @@ struct GroupCtx {
 #ifndef BBAI_PREGEN_WAVES
 #define BBAI_PREGEN_WAVES 4
 #endif
+constexpr int PREGEN_SPLIT = 4;
 template <int KIND, int G, bool OBS /* in-place layout: the level's first observation is written next to it */>
 __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_WAVES) void k_pregen(LevelCfg c, int64_t n, uint8_t* __restrict__ next_recs,
                                                   Hot* __restrict__ next_hots, uint32_t* __restrict__ mts,
-                                                  int32_t* __restrict__ mtis, const int32_t* __restrict__ win_list,
-                                                  const uint32_t* __restrict__ win_count, int all, int depth,
+                                                  int32_t* __restrict__ mtis,
+                                                  const uint32_t* __restrict__ win_meta /* the window's meta line ([1] = its finished envs), or NULL: the whole grid works */,
+                                                  int depth,
                                                   uint8_t* __restrict__ pending, const uint8_t* __restrict__ first_slot,
                                                   unsigned long long* __restrict__ gen_failures, int min_groups,
                                                   uint8_t* __restrict__ next_obs /* in-place layout: [D][n][OBS_SLOT], else NULL */) {
@@ -754,38 +761,47 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
     const Ctx ctx;
     GenWork& w = ws[threadIdx.x / G];
     const int lane = ctx.lane();
-    int64_t count = n;
-    if (!all) count = win_prefix(win_count, MAX_PERIOD);     // window list = concatenated per-tick lists
     // How many lane groups WORK on a window's refill: the grid is sized for the worst case (every env finished on every tick), the
-    // list usually holds a fraction of that, and every resident generator wave holds registers and LDS that the step kernels'
-    // workgroups queue for.  A refill has a whole window (B ticks) to land, so ~B list entries per group keep pace with the
+    // window usually holds a fraction of that, and every resident generator wave holds registers and LDS that the step kernels'
+    // workgroups queue for.  A refill has a whole window (B ticks) to land, so ~B levels per group keep pace with the
     // consumption: active = entries / 32, at least `min_groups` (the launch must not become its slowest level x a long queue),
     // at most the grid.  Measured (profiles/r04/pregen_cap_priority_group_ab.jsonl, groups in flight 32 768 -> 4 096 / 2 048):
     // PickupLoc 262 144 envs 0.0870 -> 0.0811 ms per step, GoToLocal 65 536 0.0371 -> 0.0342; 1 024 / 512 groups: 0.209 / 0.092 --
     // the generator no longer keeps up and the step stream waits.  Surplus blocks leave at once.
     int64_t stride = (int64_t)gridDim.x * NG;
-    if (!all && min_groups > 0) {
-        int64_t active = count / MAX_PERIOD;
+    if (win_meta && min_groups > 0) {
+        int64_t active = (int64_t)win_meta[1] / MAX_PERIOD;
         active = active < min_groups ? min_groups : active;
         active = (active + NG - 1) / NG * NG;                   // whole blocks: every group of a block that stays has its own residue
         stride = active < stride ? active : stride;
     }
+    const int64_t nitems = (n + G - 1) / G * PREGEN_SPLIT;
     int64_t it = (int64_t)blockIdx.x * NG + threadIdx.x / G;
     if ((int64_t)blockIdx.x * NG >= stride) return;             // (whole blocks only: the groups of a wave stay together)
-    // the group's current env
+    // the group's current item (the envs of its chunk that are still to do) and env
+    unsigned long long todo = 0;
+    int64_t chunk_base = 0;
+    int pc_mine = 0;
     bool have = false;
     int64_t env = 0;
     int cnt = 0, done_levels = 0, slot = 0, mti = 0, last_locked = -1, attempts = 0;
     for (;;) {
         if (!have) {
-            while (it < count) {
-                const int64_t cand = all ? it : (int64_t)win_list[it];
+            for (;;) {
+                if (todo) {
+                    const int b = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    env = chunk_base + b;
+                    cnt = (int)ctx.shfl((uint32_t)pc_mine, b);      // levels to generate for this env (consecutive ring slots)
+                    have = true;
+                    break;
+                }
+                if (it >= nitems) break;
+                const int sub = (int)(it % PREGEN_SPLIT);
+                chunk_base = it / PREGEN_SPLIT * G;
                 it += stride;
-                if (cand < 0) continue;                   // repeat consumption of an env already listed in this window
-                const int pc = pending[cand];            // levels to generate for this env (consecutive ring slots)
-                if (pc == 0) continue;                   // (all-mode: env was not consumed in this window)
-                env = cand; cnt = pc; have = true;
-                break;
+                pc_mine = chunk_base + lane < n ? (int)pending[chunk_base + lane] : 0;
+                todo = ctx.ballot(pc_mine != 0 && lane % PREGEN_SPLIT == sub);
             }
             if (have) {
                 // the env's generator state: all of its loads in flight together (MT19937 words, position, first slot) -- as a
@@ -925,32 +941,76 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
                                                  const Hot* __restrict__ next_hots, uint32_t* __restrict__ vheads,
                                                  uint64_t* __restrict__ vsets, const int32_t* __restrict__ reset_list,
                                                  const uint8_t* __restrict__ reset_slot, const uint32_t* __restrict__ counter, int all,
-                                                 unsigned long long* __restrict__ total_resets, int depth,
+                                                 unsigned long long* __restrict__ totals, int depth,
                                                  uint8_t* __restrict__ pending, uint8_t* __restrict__ first_slot,
-                                                 int32_t* __restrict__ win_list, uint32_t* __restrict__ win_count, int pos,
+                                                 uint32_t* __restrict__ win_meta,
                                                  uint8_t* __restrict__ image, uint8_t* __restrict__ dirs,
                                                  uint32_t* __restrict__ other_counter, int prio,
                                                  uint8_t* __restrict__ vplane /* or NULL */, uint16_t* __restrict__ fcache,
                                                  uint8_t* __restrict__ lsm_arr /* or NULL */, int inplace) {
     if (prio) __builtin_amdgcn_s_setprio(3);
     const int64_t count = all ? n : (int64_t)counter[0];
-    // this tick's entries go behind those of the window's earlier ticks (their counts were written by earlier
-    // launches); no atomics: an env appears at most once per tick, repeats within the window are marked -1
-    const int64_t base = win_prefix(win_count, pos);
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
     for (int64_t it = wave; it < count; it += nwaves) {
         const int64_t env = all ? it : (int64_t)reset_list[it];
         const int slot = all ? (int)hots[env].slot : (int)reset_slot[it];       // (k_step listed it next to the env: no round trip through the env's state)
         consume_env(c, n, env, slot, lane, recs, hots, stales, next_recs, next_hots, vheads, vsets, depth, pending, first_slot,
-                    all ? nullptr : win_list + base + it, image + env * OBS_BYTES, dirs, vplane, fcache,
-                    lsm_arr, inplace != 0);
+                    win_meta, image + env * OBS_BYTES, dirs, vplane, fcache, lsm_arr, inplace != 0);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        atomicAdd(total_resets, (unsigned long long)count);
-        win_count[WIN_ENTRY * (1 + pos)] = all ? 0u : (uint32_t)count;
+        atomicAdd(&totals[0], (unsigned long long)count);
         other_counter[0] = 0;       // the next step's k_step appends to the other ping-pong counter from zero
     }
+}
+
+// ---- window turnover (NWIN above): three one-wave kernels per window of B ticks --------------------------------------------------
+// k_window_close, step stream, behind the window's last tick: the window's number of finished envs (what its refill is sized by) =
+// the sharded reset total now - the total at the previous close.
+__global__ __launch_bounds__(64) void k_window_close(const unsigned long long* __restrict__ totals, uint32_t* __restrict__ meta, unsigned long long* __restrict__ flow) {
+    unsigned long long t = totals[threadIdx.x * SHARD_U64];          // (SHARDS == 64: one shard per lane)
+#pragma unroll
+    for (int o = 32; o; o >>= 1) t += __shfl_xor(t, o);
+    if (threadIdx.x == 0) {
+        const unsigned long long before = flow[FLOW_CLOSE_TOTAL];
+        meta[1] = (uint32_t)(t - before < 0xFFFFFFFFull ? t - before : 0xFFFFFFFFull);
+        flow[FLOW_CLOSE_TOTAL] = t;
+    }
+}
+// k_mark, look-ahead stream, behind the refill of window w: `refilled` = w + 1.  (A kernel of its own: the refill's stores are visible to
+// whoever sees this value because that kernel has ENDED -- no fence inside the generator's waves.)
+__global__ void k_mark(unsigned long long* __restrict__ flow, unsigned long long refilled) {
+    __hip_atomic_store(&flow[FLOW_REFILLED], refilled, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// k_gate, step stream, in front of the first tick of window x (which uses buffer x % NWIN): waits until
+//   (a) the windows r .. x - 1 whose refill has not landed (r = `refilled`) are at most NWIN - 1 (buffer x % NWIN is free again), and
+//   (b) the sum of their M (meta[0]; 1 unless an env finished repeatedly inside one window) is <= B: every env then has at least
+//       2B - B = B ready levels, and window x consumes at most B per env;
+// then clears the meta line of window x.  With r = x - 1 (rounds 1-4 waited for exactly that) both hold trivially, so the wait ends at the
+// latest when refill x - 2 lands; every refill it can wait for was enqueued before it.  One wave; polls with s_sleep.  A wait beyond
+// ~20 s of the constant 100-MHz clock gives up (counted in flow[FLOW_GATE_TIMEOUTS], read back as option "gate_timeouts": the handle's
+// results are void then -- it means a lost refill, never seen) instead of hanging the device.
+__global__ __launch_bounds__(64) void k_gate(unsigned long long* __restrict__ flow, uint32_t* __restrict__ metas, unsigned long long x, int period) {
+    const int lane = (int)threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const unsigned long long r = __hip_atomic_load(&flow[FLOW_REFILLED], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long open = x > r ? x - r : 0ull;          // windows r .. x - 1
+        uint32_t m = 0;
+        if ((unsigned long long)lane < open && open < (unsigned long long)NWIN) {
+            m = metas[(size_t)((r + lane) % NWIN) * META_U32];
+            m = m < 1u ? 1u : m;
+        }
+#pragma unroll
+        for (int o = 32; o; o >>= 1) m += __shfl_xor(m, o);
+        if (open < (unsigned long long)NWIN && m <= (uint32_t)period) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {
+            if (lane == 0) atomicAdd(&flow[FLOW_GATE_TIMEOUTS], 1ull);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (lane == 0) metas[(size_t)(x % NWIN) * META_U32] = 0;
 }
 
 // In-place layout: rec[] is the staging area of export / import / checkpoints.  dir 0: live slots -> rec[first ..], dir 1: rec[first ..] -> live
@@ -1064,7 +1124,7 @@ __global__ void k_init_hot(int64_t n, Hot* __restrict__ hots, Hot* __restrict__ 
         h.carry = NONE8; h.frozen = 1; h.last_locked = NONE8;
         h.pre4 = 0xFFFFFFFFu;
         hots[i] = h;
-        for (int d = 0; d < depth; ++d) next_hots[(int64_t)d * n + i] = h;
+        for (int d = 0; d < depth; ++d) next_hots[ring_at(d, i, depth)] = h;
         stales[i] = 0;
     }
 }
@@ -1240,10 +1300,14 @@ __device__ __forceinline__ void tok_side(TokOut& o, const Prog* p, int base, int
 }
 __global__ __launch_bounds__(64) void k_tokens(LevelCfg c, int64_t n, const uint8_t* __restrict__ recs, const uint8_t* __restrict__ ring /* in-place layout, else NULL */, int depth,
                                                const Hot* __restrict__ hots, uint8_t* __restrict__ tokens,
-                                               const int32_t* __restrict__ reset_list, const uint32_t* __restrict__ counter, int all) {
-    const int64_t count = all ? n : (int64_t)counter[0];
+                                               const int32_t* __restrict__ reset_list, const uint32_t* __restrict__ counter,
+                                               int mode /* 0: the reset list (unfused consume); 1: every env; 2: the envs whose `dones` byte is set -- a fused / in-place
+                                                           auto-reset step keeps no list, and there done == "a new episode started" */,
+                                               const uint8_t* __restrict__ dones) {
+    const int64_t count = mode ? n : (int64_t)counter[0];
     for (int64_t it = (int64_t)blockIdx.x * 64 + threadIdx.x; it < count; it += (int64_t)gridDim.x * 64) {
-        const int64_t env = all ? it : (int64_t)reset_list[it];
+        const int64_t env = mode ? it : (int64_t)reset_list[it];
+        if (mode == 2 && !dones[env]) continue;
         const Prog* p = (const Prog*)(live_rec(c, n, env, (uint8_t*)recs, (uint8_t*)ring, depth, ring ? hots[env].slot : 0) + c.off_prog);
         TokOut o; o.p = tokens + env * TOK_MAX; o.n = 0;
         tok_side(o, p, 0, p->n_a);
@@ -1377,9 +1441,11 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->mti, (size_t)n_envs * 4);
     alloc((void**)&e->vhead, (size_t)n_envs * 4);
     alloc((void**)&e->vset, (size_t)n_envs * 8 * 8);
-    alloc((void**)&e->pending, 3 * (size_t)n_envs);
-    alloc((void**)&e->first_slot, 3 * (size_t)n_envs);
-    alloc((void**)&e->win_count, 3 * WIN_STRIDE * 4);
+    alloc((void**)&e->pending, NWIN * (size_t)n_envs);
+    alloc((void**)&e->first_slot, NWIN * (size_t)n_envs);
+    alloc((void**)&e->win_meta, NWIN * META_U32 * 4);
+    alloc((void**)&e->totals, SHARDS * SHARD_U64 * 8);
+    alloc((void**)&e->flow, FLOW_WORDS * 8);
     {
         // BBAI_INPLACE: 1 / 0 force the in-place layout (live_slot above) on / off; default: by level family and batch size
         const char* iv = getenv("BBAI_INPLACE");
@@ -1417,13 +1483,12 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
             const size_t D = (size_t)e->depth;
             hipError_t r1 = hipMalloc((void**)&e->next_rec, D * slot_bytes);
             hipError_t r2 = r1 == hipSuccess ? hipMalloc((void**)&e->next_hot, D * (size_t)n_envs * sizeof(Hot)) : r1;
-            hipError_t r3 = r2 == hipSuccess ? hipMalloc((void**)&e->win_list, 3 * (size_t)b * (size_t)n_envs * 4) : r2;
+            hipError_t r3 = r2;
             if (r3 == hipSuccess && e->inplace) r3 = hipMalloc((void**)&e->next_obs, D * (size_t)n_envs * OBS_SLOT);
             if (r3 == hipSuccess) break;
             (void)hipGetLastError();                       // clear the sticky out-of-memory error before retrying
             if (e->next_rec) { (void)hipFree(e->next_rec); e->next_rec = nullptr; }
             if (e->next_hot) { (void)hipFree(e->next_hot); e->next_hot = nullptr; }
-            if (e->win_list) { (void)hipFree(e->win_list); e->win_list = nullptr; }
             if (e->next_obs) { (void)hipFree(e->next_obs); e->next_obs = nullptr; }
             if (b == 1 || ev) err = r3;                    // an explicit BBAI_LOOKAHEAD is a request, not a hint
         }
@@ -1436,7 +1501,6 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->reset_list, (size_t)n_envs * 4);
     alloc((void**)&e->reset_slot, (size_t)n_envs);
     alloc((void**)&e->counters, 128);
-    alloc((void**)&e->total_resets, 16);
     alloc((void**)&e->atlas, MAX_TILES * TILE_BYTES);
     alloc((void**)&e->render_tickets, 64 * 64 * 4);
     alloc((void**)&e->lut, 512);
@@ -1461,13 +1525,14 @@ static int create_finish(bbai_env* e) {
     HIP_TRY(hipMemset(e->hot, 0, (size_t)n_envs * sizeof(Hot)));       // (slot 0 before any seed: an in-place handle that is only imported into keeps its live records in slot depth - 1)
     HIP_TRY(hipMemset(e->next_rec, 0, D * (size_t)n_envs * c.rec_bytes));
     if (e->next_obs) HIP_TRY(hipMemset(e->next_obs, 0, D * (size_t)n_envs * OBS_SLOT));
-    HIP_TRY(hipMemset(e->pending, 0, 3 * (size_t)n_envs));
-    HIP_TRY(hipMemset(e->first_slot, 0, 3 * (size_t)n_envs));
-    HIP_TRY(hipMemset(e->win_count, 0, 3 * WIN_STRIDE * 4));
+    HIP_TRY(hipMemset(e->pending, 0, NWIN * (size_t)n_envs));
+    HIP_TRY(hipMemset(e->first_slot, 0, NWIN * (size_t)n_envs));
+    HIP_TRY(hipMemset(e->win_meta, 0, NWIN * META_U32 * 4));
+    HIP_TRY(hipMemset(e->totals, 0, SHARDS * SHARD_U64 * 8));
+    HIP_TRY(hipMemset(e->flow, 0, FLOW_WORDS * 8));
     HIP_TRY(hipMemset(e->vhead, 0, (size_t)n_envs * 4));
     HIP_TRY(hipMemset(e->vset, 0, (size_t)n_envs * 64));
     HIP_TRY(hipMemset(e->counters, 0, 128));
-    HIP_TRY(hipMemset(e->total_resets, 0, 16));
     HIP_TRY(hipMemset(e->render_tickets, 0, 64 * 64 * 4));
     {
         int cus = 0;
@@ -1489,7 +1554,6 @@ static int create_finish(bbai_env* e) {
         const char* pv = getenv("BBAI_PREGEN_PRIORITY");     // 1 (default): highest priority, 0: default priority
         HIP_TRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, (pv && atoi(pv) == 0) ? lo : hi));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_consumed, hipEventDisableTiming));
-        for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreateWithFlags(&e->ev_refill[k], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_switch, hipEventDisableTiming));
     }
     {
@@ -1527,11 +1591,10 @@ void bbai_destroy(bbai_env* e) {
     if (e->ev_consumed) (void)hipEventDestroy(e->ev_consumed);
     if (e->ev_switch) (void)hipEventDestroy(e->ev_switch);
     for (int k = 0; k < 3; ++k) for (int i = 0; i < PROF_RING; ++i) if (e->prof[k][i].a) { (void)hipEventDestroy(e->prof[k][i].a); (void)hipEventDestroy(e->prof[k][i].b); }
-    for (int k = 0; k < 3; ++k) if (e->ev_refill[k]) (void)hipEventDestroy(e->ev_refill[k]);
     void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
-    void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_list, e->win_count, e->reset_list, e->counters,
-                    e->total_resets, e->atlas, e->lut, e->vplane, e->fcache, e->lsm, e->render_tickets, e->reset_slot, e->next_obs};
+    void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_meta, e->totals, e->flow, e->reset_list, e->counters,
+                    e->atlas, e->lut, e->vplane, e->fcache, e->lsm, e->render_tickets, e->reset_slot, e->next_obs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete e;
 }
@@ -1541,31 +1604,29 @@ void bbai_destroy(bbai_env* e) {
 // k_pregen is instantiated per level family so that a launch carries only that family's mission code, and per group
 // width G (envs per wave = 64 / G; BBAI_PREGEN_GROUP, default 32: two envs per wave)
 template <int G>
-static void launch_pregen_g(const bbai_env* e, unsigned groups, const int32_t* win_list, const uint32_t* win_count, int all,
-                            uint8_t* pending, const uint8_t* first_slot) {
-    unsigned long long* fails = (unsigned long long*)(e->total_resets + 1);
+static void launch_pregen_g(const bbai_env* e, unsigned groups, const uint32_t* win_meta /* NULL: the whole grid works */, uint8_t* pending, const uint8_t* first_slot) {
+    unsigned long long* fails = e->flow + FLOW_GEN_FAILURES;
     const dim3 g((groups + 64 / G - 1) / (64 / G)), b(64);
     // Demand-sized groups only where a level is cheap (single rooms, <= 60 us per group): a maze level costs a group ~300 us,
     // and GoTo at 131 072 envs stalls the step stream with 4 entries per group (0.0534 vs 0.0385 ms per step,
-    // profiles/r04/pregen_min_ab.jsonl) -- mazes keep one entry per group.
+    // profiles/r04/pregen_min_ab.jsonl) -- mazes keep the whole grid.
     const int min_groups = e->cfg.num_rows * e->cfg.num_cols > 1 ? 0 : e->pregen_min;
-#define PREGEN_LAUNCH(KK, OO) hipLaunchKernelGGL((k_pregen<KK, G, OO>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_list, \
-                                                win_count, all, e->depth, pending, first_slot, fails, min_groups, e->next_obs)
+#define PREGEN_LAUNCH(KK, OO) hipLaunchKernelGGL((k_pregen<KK, G, OO>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_meta, \
+                                                e->depth, pending, first_slot, fails, min_groups, e->next_obs)
     if (e->cfg.kind == K_LEVELGEN) { if (e->next_obs) PREGEN_LAUNCH(K_LEVELGEN, true); else PREGEN_LAUNCH(K_LEVELGEN, false); }
     else if (e->cfg.kind == K_BONUS) { if (e->next_obs) PREGEN_LAUNCH(K_BONUS, true); else PREGEN_LAUNCH(K_BONUS, false); }
     else { if (e->next_obs) PREGEN_LAUNCH(K_GOTO, true); else PREGEN_LAUNCH(K_GOTO, false); }
 #undef PREGEN_LAUNCH
 }
-static void launch_pregen(const bbai_env* e, unsigned groups, const int32_t* win_list, const uint32_t* win_count, int all,
-                          uint8_t* pending, const uint8_t* first_slot) {
+static void launch_pregen(const bbai_env* e, unsigned groups, const uint32_t* win_meta, uint8_t* pending, const uint8_t* first_slot) {
     // Measured (profiles/r03/gen_rate_by_group_width.jsonl, pregen_group_width_in_bench.jsonl): levels per second of a bulk
     // fill 64 -> 32 -> 16 lanes per env: BossLevel 1 : 1.16 : 1.18, GoTo 1 : 1.13 : 1.17, PickupLoc 1 : 1.20 : 1.27,
     // GoToLocal 1 : 1.25 : 1.36; inside the step loop 32 is never behind 64 (GoToLocal 65 536 envs -3 %, PickupLoc 262 144
     // -6 %, GoTo 131 072 +-0) while 16 costs the step kernels of GoTo 131 072 9 % (fewer, fatter generator waves next to
     // them: 200 VGPRs and 20 KB of LDS each).
-    if (e->pregen_group == 64) launch_pregen_g<64>(e, groups, win_list, win_count, all, pending, first_slot);
-    else if (e->pregen_group == 16) launch_pregen_g<16>(e, groups, win_list, win_count, all, pending, first_slot);
-    else launch_pregen_g<32>(e, groups, win_list, win_count, all, pending, first_slot);
+    if (e->pregen_group == 64) launch_pregen_g<64>(e, groups, win_meta, pending, first_slot);
+    else if (e->pregen_group == 16) launch_pregen_g<16>(e, groups, win_meta, pending, first_slot);
+    else launch_pregen_g<32>(e, groups, win_meta, pending, first_slot);
 }
 
 extern "C" {
@@ -1637,50 +1698,46 @@ struct ProfScope {
     }
 };
 
-// A consume-tick (one reset() or one auto-resetting step) in three parts: window_begin -- at the first tick of a window the
-// stream waits for the refill that filled the slots consumed from now on; the consume itself -- k_consume over the reset list,
+// A consume-tick (one reset() or one auto-resetting step) in three parts: window_begin -- at the first tick of a window k_gate holds
+// the stream until every env is sure to find B ready levels (NWIN above); the consume itself -- k_consume over the reset list,
 // or, fused, inside k_step (which therefore has to be launched AFTER window_begin); window_end -- the mission tokens of the new
-// episodes and, at the last tick of a window, ONE refill launch on the look-ahead stream for everything the window consumed.
+// episodes and, at the last tick of a window, the window's close and ONE refill launch on the look-ahead stream for everything it consumed.
 struct TickPos { int wb, pos; };
 static TickPos tick_pos(const bbai_env* e) {
     const int64_t w = e->tick / e->period;           // window of this consume-tick
-    return {(int)(w % 3), (int)(e->tick % e->period)};      // its buffer (pending / first_slot / list / count / event), its place in the window
+    return {(int)(w % NWIN), (int)(e->tick % e->period)};      // its buffer (pending / first_slot / meta), its place in the window
 }
 static int window_begin(bbai_env* e, hipStream_t s) {
-    const int B = e->period;
-    const int64_t w = e->tick / B;
-    if (e->tick % B == 0) {
-        // Window start: the slots consumed from now on were refilled by window w-2 at the latest (buffer (w+1)%3):
-        // wait for that refill; its buffer becomes the one window w+1 will use, so clear its count.
-        const int ob = (int)((w + 1) % 3);
-        HIP_TRY(hipStreamWaitEvent(s, e->ev_refill[ob], 0));
-        HIP_TRY(hipMemsetAsync(e->win_count + WIN_STRIDE * ob, 0, WIN_STRIDE * 4, s));
-        e->win_all[ob] = 0;
+    if (e->tick % e->period == 0) {
+        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, e->flow, e->win_meta, (unsigned long long)(e->tick / e->period), e->period);
+        HIP_TRY(hipGetLastError());
     }
     return BBAI_OK;
 }
-static int window_end(bbai_env* e, hipStream_t s, int all, bool fused) {
+static int window_end(bbai_env* e, hipStream_t s, int tokens_mode /* k_tokens: 0 list, 1 every env, 2 by `dones` */, const uint8_t* dones) {
     const int B = e->period;
     const TickPos tp = tick_pos(e);
     const int wb = tp.wb, pos = tp.pos;
-    const int64_t hint = all ? e->n : std::max<int64_t>(e->n / 64, 64);
-    if (e->tokens)     // (fused: the tick's count is the window's count entry, which k_step's waves added up)
+    if (e->tokens) {
+        const int64_t hint = tokens_mode ? e->n : std::max<int64_t>(e->n / 64, 64);
         hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n, e->rec, e->inplace ? e->next_rec : nullptr, e->depth, e->hot,
-                           e->tokens, e->reset_list, fused ? e->win_count + WIN_STRIDE * wb + WIN_ENTRY * (1 + pos) : e->counters + 16 * e->step_parity, all);
-    if (!fused) {
+                           e->tokens, e->reset_list, e->counters + 16 * e->step_parity, tokens_mode, dones);
+    }
+    if (tokens_mode == 0) {                  // (unfused: the ping-pong list counters)
         e->step_parity ^= 1;
         e->next_counter_clean = true;
     }
     HIP_TRY(hipGetLastError());
     if (pos == B - 1) {
-        // Window end: one refill launch for everything consumed in the window, on the look-ahead stream.
-        const int wall = e->win_all[wb];
-        const int64_t rh = wall ? e->n : std::max<int64_t>((int64_t)B * (e->n / 64), 64);
+        // Window end: its count, then one refill launch for everything consumed in it, on the look-ahead stream, and the mark behind it.
+        const int64_t w = e->tick / B;
+        uint32_t* meta = e->win_meta + (size_t)wb * META_U32;
+        hipLaunchKernelGGL(k_window_close, dim3(1), dim3(64), 0, s, e->totals, meta, e->flow);
         HIP_TRY(hipEventRecord(e->ev_consumed, s));
         HIP_TRY(hipStreamWaitEvent(e->side, e->ev_consumed, 0));
-        launch_pregen(e, pregen_grid(e, rh), e->win_list + (size_t)wb * e->period * e->n, e->win_count + WIN_STRIDE * wb, wall,
-                      e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n);
-        HIP_TRY(hipEventRecord(e->ev_refill[wb], e->side));
+        const int64_t rh = std::max<int64_t>((int64_t)B * (e->n / 64), 64);
+        launch_pregen(e, pregen_grid(e, rh), meta, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n);
+        hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, e->side, e->flow, (unsigned long long)(w + 1));
         HIP_TRY(hipGetLastError());
     }
     e->tick++;
@@ -1690,41 +1747,50 @@ static int window_end(bbai_env* e, hipStream_t s, int all, bool fused) {
 static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_t* dirs, int all) {
     { int rc = window_begin(e, s); if (rc != BBAI_OK) return rc; }
     const TickPos tp = tick_pos(e);
-    const int wb = tp.wb, pos = tp.pos;
-    if (all) e->win_all[wb] = 1;
+    const int wb = tp.wb;
     const int64_t hint = all ? e->n : std::max<int64_t>(e->n / 64, 64);
     {
     ProfScope prof_(e, 1, s);
     hipLaunchKernelGGL(k_consume, dim3((unsigned)std::min<int64_t>((hint + 3) / 4, 8192)), dim3(256), 0, s, e->cfg, e->n, e->rec,
                        e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, e->reset_list, e->reset_slot, e->counters + 16 * e->step_parity, all,
-                       e->total_resets, e->depth, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n,
-                       e->win_list + (size_t)wb * e->period * e->n, e->win_count + WIN_STRIDE * wb, pos, image, dirs,
+                       e->totals, e->depth, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n,
+                       e->win_meta + (size_t)wb * META_U32, image, dirs,
                        e->counters + 16 * (e->step_parity ^ 1), e->step_prio, e->vplane, e->fcache, e->lsm, e->inplace);
     }
-    return window_end(e, s, all, false);
+    return window_end(e, s, all ? 1 : 0, nullptr);
 }
 
 int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
     if (!e || !seeds || n != e->n) { snprintf(g_err, sizeof(g_err), "seed: need exactly n_envs seeds"); return BBAI_ERR_ARG; }
     ON_DEVICE(e->device);
     HIP_TRY(hipDeviceSynchronize());             // nothing of an earlier run may still be in flight on either stream
-    // 8 bytes per env cross PCIe; sha512 + init_by_array run per lane (k_seed).  The seeds are parked in the reset list +
-    // window list area (n * 4 * (1 + 3B) bytes >= 8 n), which nothing reads before the first reset.
-    uint64_t* seeds_dev = (uint64_t*)e->win_list;
+    // 8 bytes per env cross PCIe; sha512 + init_by_array run per lane (k_seed).  The seeds are parked in the verifier's obj_set area
+    // (n * 64 bytes), which nothing reads before the first reset rewrites it.
+    uint64_t* seeds_dev = e->vset;
     HIP_TRY(hipMemcpy(seeds_dev, seeds, (size_t)n * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_seed, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, e->side, n, seeds_dev, e->mt, e->mti);
     hipLaunchKernelGGL(k_init_hot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->side, n, e->hot, e->next_hot, e->stale, e->depth);
-    // fill every env's look-ahead ring with the first D levels of its stream (slot order == stream order).  ALL THREE
-    // window buffers start clean: a re-seed may land in the middle of a window that was using buffer 1 or 2.
-    HIP_TRY(hipMemsetAsync(e->pending, 0, 3 * (size_t)n, e->side));
-    HIP_TRY(hipMemsetAsync(e->first_slot, 0, 3 * (size_t)n, e->side));
+    // fill every env's look-ahead ring with the first D levels of its stream (slot order == stream order).  EVERY
+    // window buffer starts clean: a re-seed may land in the middle of a window that was using any of them.
+    HIP_TRY(hipMemsetAsync(e->pending, 0, NWIN * (size_t)n, e->side));
+    HIP_TRY(hipMemsetAsync(e->first_slot, 0, NWIN * (size_t)n, e->side));
     HIP_TRY(hipMemsetAsync(e->pending, e->depth - e->inplace, (size_t)n, e->side));      // (in-place: slot depth - 1 is the live one -- empty until the first reset)
-    launch_pregen(e, pregen_grid(e, n), e->win_list, e->win_count, 1, e->pending, e->first_slot);
+    launch_pregen(e, pregen_grid(e, n), nullptr, e->pending, e->first_slot);
     HIP_TRY(hipGetLastError());
-    for (int k = 0; k < 3; ++k) HIP_TRY(hipEventRecord(e->ev_refill[k], e->side));
-    HIP_TRY(hipMemsetAsync(e->win_count, 0, 3 * WIN_STRIDE * 4, e->side));
+    HIP_TRY(hipMemsetAsync(e->win_meta, 0, NWIN * META_U32 * 4, e->side));
+    HIP_TRY(hipMemsetAsync(e->vset, 0, (size_t)n * 64, e->side));
     HIP_TRY(hipMemsetAsync(e->counters, 0, 128, e->side));
-    e->win_all[0] = e->win_all[1] = e->win_all[2] = 0;
+    {   // the flow words start over (window numbering restarts with tick 0); the reset total and the give-up count keep running
+        unsigned long long total = 0;
+        HIP_TRY(hipDeviceSynchronize());
+        unsigned long long shards[SHARDS * SHARD_U64];
+        HIP_TRY(hipMemcpy(shards, e->totals, sizeof(shards), hipMemcpyDeviceToHost));
+        for (int k = 0; k < SHARDS; ++k) total += shards[k * SHARD_U64];
+        unsigned long long fl[FLOW_WORDS];
+        HIP_TRY(hipMemcpy(fl, e->flow, sizeof(fl), hipMemcpyDeviceToHost));
+        fl[FLOW_REFILLED] = 0; fl[FLOW_CLOSE_TOTAL] = total;
+        HIP_TRY(hipMemcpy(e->flow, fl, sizeof(fl), hipMemcpyHostToDevice));
+    }
     e->tick = 0;
     e->step_parity = 0;
     e->next_counter_clean = true;
@@ -1769,13 +1835,13 @@ static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint
     if (fused) {
         { int rc = window_begin(e, s); if (rc != BBAI_OK) return rc; }        // the slots this step's waves consume have landed
         const TickPos tp = tick_pos(e);
-        fa.next_recs = e->next_rec; fa.next_hots = e->next_hot; fa.next_obs = e->next_obs; fa.vheads_w = e->vhead; fa.vsets_w = e->vset; fa.depth = e->depth; fa.pos = tp.pos;
+        fa.next_recs = e->next_rec; fa.next_hots = e->next_hot; fa.next_obs = e->next_obs; fa.depth = e->depth;
         fa.pending = e->pending + (size_t)tp.wb * e->n; fa.first_slot = e->first_slot + (size_t)tp.wb * e->n;
-        fa.win_list = e->win_list + (size_t)tp.wb * e->period * e->n; fa.win_count = e->win_count + WIN_STRIDE * tp.wb;
-        fa.total_resets = e->total_resets;
+        fa.win_meta = e->win_meta + (size_t)tp.wb * META_U32;
+        fa.totals = e->totals;
         e->next_counter_clean = false;      // (a later unfused step clears its ping-pong counter itself)
     } else if (e->inplace) {                // (no auto-reset: the kernel still finds the live records through the ring)
-        fa.next_recs = e->next_rec; fa.depth = e->depth; fa.win_count = e->win_count; fa.pos = 0;      // (the kernel's early count-prefix load needs a valid address)
+        fa.next_recs = e->next_rec; fa.depth = e->depth;
         if (!e->next_counter_clean) HIP_TRY(hipMemsetAsync(counter, 0, 4, s));
         e->next_counter_clean = false;
     } else {
@@ -1793,7 +1859,7 @@ static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint
     }
     HIP_TRY(hipGetLastError());
     // the number of finished envs is only known on the device: fixed grids, device-side count
-    if (auto_reset) { int rc = fused ? window_end(e, s, 0, true) : consume_and_refill(e, s, image, dirs, 0); if (rc != BBAI_OK) return rc; }
+    if (auto_reset) { int rc = fused ? window_end(e, s, 2, dones) : consume_and_refill(e, s, image, dirs, 0); if (rc != BBAI_OK) return rc; }
     return BBAI_OK;
 }
 
@@ -1921,7 +1987,7 @@ int bbai_set_token_buffer(bbai_env* e, uint8_t* tokens_dev) {
         ON_DEVICE(e->device);
         HIP_TRY(hipDeviceSynchronize());
         hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((e->n + 63) / 64, 4096)), dim3(64), 0, 0, e->cfg, e->n, e->rec, e->inplace ? e->next_rec : nullptr, e->depth, e->hot,
-                           tokens_dev, e->reset_list, e->counters, 1);
+                           tokens_dev, e->reset_list, e->counters, 1, nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
     }
@@ -1964,8 +2030,9 @@ int bbai_import_state(bbai_env* e, int64_t first, int64_t count, const uint8_t* 
     ON_DEVICE(e->device);
     HIP_TRY(hipDeviceSynchronize());
     if (rec) HIP_TRY(hipMemcpy(e->rec + first * e->cfg.rec_bytes, rec, (size_t)count * e->cfg.rec_bytes, hipMemcpyHostToDevice));
-    if (hot && e->inplace && count > 0) {
-        // (the imported hot state keeps this env's place in its ring: hot.slot says where the live record is)
+    if (hot && count > 0) {
+        // (the imported hot state keeps this env's place in ITS ring in both layouts: the ring belongs to the handle -- in-place, hot.slot
+        // says where the live record is; classic, an exporter's slot may not even exist here: it comes from another ring depth)
         Hot* staged = nullptr;
         HIP_TRY(hipMalloc((void**)&staged, (size_t)count * sizeof(Hot)));
         hipError_t r = hipMemcpy(staged, hot, (size_t)count * sizeof(Hot), hipMemcpyHostToDevice);
@@ -1973,7 +2040,7 @@ int bbai_import_state(bbai_env* e, int64_t first, int64_t count, const uint8_t* 
         if (r == hipSuccess) r = hipDeviceSynchronize();
         (void)hipFree(staged);
         HIP_TRY(r);
-    } else if (hot) HIP_TRY(hipMemcpy(e->hot + first, hot, (size_t)count * sizeof(Hot), hipMemcpyHostToDevice));
+    }
     if (stale) HIP_TRY(hipMemcpy(e->stale + first, stale, (size_t)count * 8, hipMemcpyHostToDevice));
     if (rec && count > 0) { int rc = live_copy(e, first, count, 1); if (rc != BBAI_OK) return rc; }
     if (e->lsm && count > 0) HIP_TRY(hipMemset(e->lsm + first, 0, (size_t)count));     // (not part of the exported state: lastStepMatch = False)
@@ -1993,28 +2060,30 @@ int bbai_import_state(bbai_env* e, int64_t first, int64_t count, const uint8_t* 
 // expert's plans when the expert has been used.  Blob = header + the device arrays in a fixed order.
 struct CkptHeader {
     uint64_t magic; int32_t version, period; int64_t n; LevelCfg cfg; int32_t depth, step_parity, next_counter_clean, seeded, live;
-    int32_t win_all[3]; int32_t bot_stack; int64_t tick; int64_t bot_threads;
+    int32_t has_lsm, pad0, pad1; int32_t bot_stack; int64_t tick; int64_t bot_threads;
 };
+constexpr int CKPT_VERSION = 3;        // 3: listless windows (NWIN buffers, meta lines, sharded totals, flow words); 2: env-major look-ahead ring
 struct Seg { void* p; size_t bytes; };
-static int ckpt_segments(const bbai_env* e, Seg* out) {
-    const size_t n = (size_t)e->n, D = (size_t)e->depth, B = (size_t)e->period, rb = (size_t)e->cfg.rec_bytes;
+// the blob's segments for a handle shaped (period, depth) with / without expert state and done-action bits
+static int ckpt_segments(const bbai_env* e, int depth, bool with_bot, int bot_stack, bool with_lsm, Seg* out) {
+    const size_t n = (size_t)e->n, D = (size_t)depth, rb = (size_t)e->cfg.rec_bytes;
     int k = 0;
     out[k++] = {e->rec, n * rb}; out[k++] = {e->hot, n * sizeof(Hot)}; out[k++] = {e->stale, n * 8};
     out[k++] = {e->mt, n * MT_N * 4}; out[k++] = {e->mti, n * 4}; out[k++] = {e->vhead, n * 4}; out[k++] = {e->vset, n * 64};
     out[k++] = {e->next_rec, D * n * rb}; out[k++] = {e->next_hot, D * n * sizeof(Hot)};
-    out[k++] = {e->pending, 3 * n}; out[k++] = {e->first_slot, 3 * n}; out[k++] = {e->win_list, 3 * B * n * 4};
-    out[k++] = {e->win_count, 3 * WIN_STRIDE * 4}; out[k++] = {e->reset_list, n * 4}; out[k++] = {e->counters, 128};
-    out[k++] = {e->total_resets, 16};
-    if (e->bot_state) { out[k++] = {e->bot_state, n * bot_state_bytes(e->bot_stack)}; out[k++] = {e->bot_stats, 16}; }
-    if (e->lsm) out[k++] = {e->lsm, n};
-    if (e->next_obs) out[k++] = {e->next_obs, D * n * OBS_SLOT};
+    out[k++] = {e->pending, NWIN * n}; out[k++] = {e->first_slot, NWIN * n};
+    out[k++] = {e->win_meta, NWIN * META_U32 * 4}; out[k++] = {e->totals, SHARDS * SHARD_U64 * 8}; out[k++] = {e->flow, FLOW_WORDS * 8};
+    out[k++] = {e->reset_list, n * 4}; out[k++] = {e->counters, 128};
+    if (with_bot) { out[k++] = {e->bot_state, n * bot_state_bytes(bot_stack)}; out[k++] = {e->bot_stats, 16}; }
+    if (with_lsm) out[k++] = {e->lsm, n};
+    if (e->inplace) out[k++] = {e->next_obs, D * n * OBS_SLOT};
     return k;
 }
 
 int64_t bbai_checkpoint_bytes(bbai_env* e) {
     if (!e) return -1;
     Seg seg[24];
-    const int k = ckpt_segments(e, seg);
+    const int k = ckpt_segments(e, e->depth, e->bot_state != nullptr, e->bot_stack, e->lsm != nullptr, seg);
     size_t total = sizeof(CkptHeader);
     for (int i = 0; i < k; ++i) total += seg[i].bytes;
     return (int64_t)total;
@@ -2023,18 +2092,18 @@ int64_t bbai_checkpoint_bytes(bbai_env* e) {
 int bbai_checkpoint_save(bbai_env* e, void* host_buf, int64_t bytes) {
     if (!e || !host_buf || bytes != bbai_checkpoint_bytes(e)) ARG_FAIL("null pointer or buffer size != bbai_checkpoint_bytes()");
     ON_DEVICE(e->device);
-    HIP_TRY(hipDeviceSynchronize());             // both streams idle: the ring and the window lists are at rest
+    HIP_TRY(hipDeviceSynchronize());             // both streams idle: the ring and the windows' bookkeeping are at rest, every refill has landed
     { int rc = live_copy(e, 0, e->n, 0); if (rc != BBAI_OK) return rc; }       // (in-place layout: the blob's record segment = the live slots)
     CkptHeader h;
     memset(&h, 0, sizeof(h));
-    h.magic = 0x42424149434b5054ull; h.version = 2;        /* 2: env-major look-ahead ring */ h.period = e->period; h.n = e->n; h.cfg = e->cfg; h.depth = e->depth;
+    h.magic = 0x42424149434b5054ull; h.version = CKPT_VERSION; h.period = e->period; h.n = e->n; h.cfg = e->cfg; h.depth = e->depth;
     h.step_parity = e->step_parity; h.next_counter_clean = e->next_counter_clean; h.seeded = e->seeded; h.live = e->live;
-    for (int i = 0; i < 3; ++i) h.win_all[i] = e->win_all[i];
+    h.has_lsm = e->lsm ? 1 : 0;
     h.bot_stack = e->bot_state ? e->bot_stack : 0; h.tick = e->tick; h.bot_threads = e->bot_threads;
     uint8_t* dst = (uint8_t*)host_buf;
     memcpy(dst, &h, sizeof(h)); dst += sizeof(h);
     Seg seg[24];
-    const int k = ckpt_segments(e, seg);
+    const int k = ckpt_segments(e, e->depth, e->bot_state != nullptr, e->bot_stack, e->lsm != nullptr, seg);
     for (int i = 0; i < k; ++i) { HIP_TRY(hipMemcpy(dst, seg[i].p, seg[i].bytes, hipMemcpyDeviceToHost)); dst += seg[i].bytes; }
     return BBAI_OK;
 }
@@ -2045,69 +2114,68 @@ int bbai_checkpoint_load(bbai_env* e, const void* host_buf, int64_t bytes) {
     if (!e || !host_buf || bytes < (int64_t)sizeof(CkptHeader)) ARG_FAIL("null pointer or short buffer");
     CkptHeader h;
     memcpy(&h, host_buf, sizeof(h));
-    if (h.magic != 0x42424149434b5054ull || h.version != 2) ARG_FAIL("not a bbai checkpoint");
+    if (h.magic != 0x42424149434b5054ull) ARG_FAIL("not a bbai checkpoint");
+    if (h.version != CKPT_VERSION) {
+        snprintf(g_err, sizeof(g_err), "bbai_checkpoint_load: unsupported checkpoint version %d (this library reads version %d)", h.version, CKPT_VERSION);
+        return BBAI_ERR_ARG;
+    }
     if (h.n != e->n || memcmp(&h.cfg, &e->cfg, sizeof(LevelCfg)) != 0 || h.period < 1 || h.period > MAX_PERIOD || h.depth != 2 * h.period + e->inplace)
         ARG_FAIL("checkpoint was taken from a different level / batch size / state layout (BBAI_INPLACE)");
+    // EVERYTHING is validated before the handle is touched (a refused blob leaves the handle exactly as it was): the expert's stack
+    // capacity, the done-action mode, and the blob's size for the shape its header announces.
+    if (h.bot_stack && e->bot_state && e->bot_stack != h.bot_stack) ARG_FAIL("the handle's expert uses a different stack capacity (BBAI_BOT_STACK)");
+    if ((h.has_lsm != 0) != (e->lsm != nullptr)) ARG_FAIL("checkpoint and handle differ in the done-action mode (bbai_set_done_actions)");
+    {
+        Seg seg[24];
+        const int k = ckpt_segments(e, h.depth, h.bot_stack != 0, h.bot_stack, h.has_lsm != 0, seg);
+        size_t total = sizeof(CkptHeader);
+        for (int i = 0; i < k; ++i) total += seg[i].bytes;
+        if ((int64_t)total != bytes) ARG_FAIL("checkpoint size does not match its header (truncated blob?)");
+    }
     ON_DEVICE(e->device);
     HIP_TRY(hipDeviceSynchronize());
-    if (h.period != e->period) {
-        // The handle chose its look-ahead period from the memory that was free when it was created (bbai_create); the blob's
-        // ring has the saving handle's.  The ring is part of the state: take the blob's shape.
-        const size_t D = (size_t)h.depth, slot_bytes = (size_t)e->n * e->cfg.rec_bytes;
-        (void)hipFree(e->next_rec); (void)hipFree(e->next_hot); (void)hipFree(e->win_list);
-        if (e->next_obs) (void)hipFree(e->next_obs);
-        e->next_rec = nullptr; e->next_hot = nullptr; e->win_list = nullptr; e->next_obs = nullptr;
-        hipError_t r1 = hipMalloc((void**)&e->next_rec, D * slot_bytes);
-        hipError_t r2 = r1 == hipSuccess ? hipMalloc((void**)&e->next_hot, D * (size_t)e->n * sizeof(Hot)) : r1;
-        hipError_t r3 = r2 == hipSuccess ? hipMalloc((void**)&e->win_list, 3 * (size_t)h.period * (size_t)e->n * 4) : r2;
-        if (r3 == hipSuccess && e->inplace) r3 = hipMalloc((void**)&e->next_obs, D * (size_t)e->n * OBS_SLOT);
-        if (r3 != hipSuccess) {
-            // leave a consistent (unseeded) handle behind: the old shape again
-            (void)hipGetLastError();
-            if (e->next_rec) (void)hipFree(e->next_rec);
-            if (e->next_hot) (void)hipFree(e->next_hot);
-            if (e->win_list) (void)hipFree(e->win_list);
-            e->next_rec = nullptr; e->next_hot = nullptr; e->win_list = nullptr;
-            const size_t D0 = (size_t)e->depth;
-            if (hipMalloc((void**)&e->next_rec, D0 * slot_bytes) != hipSuccess || hipMalloc((void**)&e->next_hot, D0 * (size_t)e->n * sizeof(Hot)) != hipSuccess ||
-                hipMalloc((void**)&e->win_list, 3 * (size_t)e->period * (size_t)e->n * 4) != hipSuccess ||
-                (e->inplace && hipMalloc((void**)&e->next_obs, D0 * (size_t)e->n * OBS_SLOT) != hipSuccess)) {
-                snprintf(g_err, sizeof(g_err), "checkpoint_load: out of memory re-shaping the look-ahead ring; the handle is unusable");
-                e->seeded = e->live = false;
-                return BBAI_ERR_NOMEM;
-            }
-            e->seeded = e->live = false;
-            snprintf(g_err, sizeof(g_err), "checkpoint_load: no memory for the checkpoint's look-ahead ring (period %d); seed the handle again", h.period);
-            return BBAI_ERR_NOMEM;
-        }
-        e->period = h.period;
-        e->depth = h.depth;
-    }
-    if (h.bot_stack && (!e->bot_state || e->bot_stack != h.bot_stack)) {
-        if (e->bot_state) ARG_FAIL("the handle's expert uses a different stack capacity (BBAI_BOT_STACK)");
+    if (h.bot_stack && !e->bot_state) {          // (allocates only; on failure the handle is unchanged)
         int rc = bot_alloc(e, h.bot_stack);
         if (rc != BBAI_OK) return rc;
+    }
+    if (h.period != e->period) {
+        // The handle chose its look-ahead period from the memory that was free when it was created (bbai_create); the blob's
+        // ring has the saving handle's.  The ring is part of the state: take the blob's shape.  The new ring is allocated BEFORE the
+        // old one is let go, so that a failure leaves the handle as it was.
+        const size_t D = (size_t)h.depth, slot_bytes = (size_t)e->n * e->cfg.rec_bytes;
+        uint8_t* nrec = nullptr; Hot* nhot = nullptr; uint8_t* nobs = nullptr;
+        hipError_t r1 = hipMalloc((void**)&nrec, D * slot_bytes);
+        hipError_t r2 = r1 == hipSuccess ? hipMalloc((void**)&nhot, D * (size_t)e->n * sizeof(Hot)) : r1;
+        hipError_t r3 = r2;
+        if (r3 == hipSuccess && e->inplace) r3 = hipMalloc((void**)&nobs, D * (size_t)e->n * OBS_SLOT);
+        if (r3 != hipSuccess) {
+            (void)hipGetLastError();
+            if (nrec) (void)hipFree(nrec);
+            if (nhot) (void)hipFree(nhot);
+            if (nobs) (void)hipFree(nobs);
+            snprintf(g_err, sizeof(g_err), "checkpoint_load: no memory for the checkpoint's look-ahead ring (period %d); the handle is unchanged", h.period);
+            return BBAI_ERR_NOMEM;
+        }
+        (void)hipFree(e->next_rec); (void)hipFree(e->next_hot);
+        if (e->next_obs) (void)hipFree(e->next_obs);
+        e->next_rec = nrec; e->next_hot = nhot; e->next_obs = nobs;
+        e->period = h.period;
+        e->depth = h.depth;
     }
     const bool had_bot = e->bot_state != nullptr;
     if (!h.bot_stack && had_bot) {               // checkpoint without expert state: every env gets a fresh Bot
         HIP_TRY(hipMemset(e->bot_state, 0, (size_t)e->n * bot_state_bytes(e->bot_stack)));
         HIP_TRY(hipMemset(e->bot_stats, 0, 16));
     }
-    uint8_t* keep_state = e->bot_state;
-    if (!h.bot_stack) e->bot_state = nullptr;    // (segment list follows the checkpoint's contents)
     Seg seg[24];
-    const int k = ckpt_segments(e, seg);
-    e->bot_state = keep_state;
-    size_t total = sizeof(CkptHeader);
-    for (int i = 0; i < k; ++i) total += seg[i].bytes;
-    if ((int64_t)total != bytes) ARG_FAIL("checkpoint size does not match this handle (different done-action mode, bbai_set_done_actions?)");
+    const int k = ckpt_segments(e, e->depth, h.bot_stack != 0, h.bot_stack, h.has_lsm != 0, seg);
     const uint8_t* src = (const uint8_t*)host_buf + sizeof(CkptHeader);
+    // (from here on a failing copy leaves a half-loaded handle: it must not be stepped)
+    e->seeded = e->live = false;
     for (int i = 0; i < k; ++i) { HIP_TRY(hipMemcpy(seg[i].p, src, seg[i].bytes, hipMemcpyHostToDevice)); src += seg[i].bytes; }
     e->step_parity = h.step_parity; e->next_counter_clean = h.next_counter_clean != 0; e->seeded = h.seeded != 0; e->live = h.live != 0;
-    for (int i = 0; i < 3; ++i) e->win_all[i] = h.win_all[i];
     e->tick = h.tick;
-    // the refill events of the saved run completed before the save: re-record them on the (idle) look-ahead stream
-    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventRecord(e->ev_refill[i], e->side));
+    // (the saved run was idle: every refill it had launched has landed, and flow[FLOW_REFILLED] in the blob says so)
     HIP_TRY(hipDeviceSynchronize());
     return sync_view(e, 0, e->n);
 }
@@ -2353,6 +2421,12 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     return BBAI_OK;
 }
 
+static int read_flow(bbai_env* e, int word, unsigned long long* out) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, e->flow + word, 8, hipMemcpyDeviceToHost));
+    return BBAI_OK;
+}
+
 // Read back a knob: the names of bbai_set_option, plus "render_pace_effective" and "lookahead_period" (the refill period the handle chose).
 int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     if (!e || !name || !out) ARG_FAIL("null handle, name or output");
@@ -2370,6 +2444,13 @@ int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     else if (!strcmp(name, "inplace")) *out = e->inplace;
     else if (!strcmp(name, "done_action_enum")) *out = e->done_action_enum;
     else if (!strcmp(name, "lookahead_period")) *out = e->period;
+    else if (!strcmp(name, "gate_timeouts")) {      // (synchronises) window gates that gave up waiting for a refill: must be 0 (k_gate)
+        ON_DEVICE(e->device);
+        unsigned long long v = 0;
+        int rc = read_flow(e, FLOW_GATE_TIMEOUTS, &v);
+        if (rc != BBAI_OK) return rc;
+        *out = (int64_t)v;
+    }
     else if (!strcmp(name, "render_pace_effective")) *out = e->render_pace > 0 ? e->render_pace : 0;
     else {
         snprintf(g_err, sizeof(g_err), "get_option: unknown option '%s'", name);
@@ -2399,9 +2480,8 @@ int bbai_profile_read(bbai_env* e, double* ms_total /* [3] */, int64_t* launches
 int bbai_generator_failures(bbai_env* e, uint64_t* out) {
     if (!e || !out) ARG_FAIL("null pointer");
     ON_DEVICE(e->device);
-    HIP_TRY(hipDeviceSynchronize());
     unsigned long long v = 0;
-    HIP_TRY(hipMemcpy(&v, e->total_resets + 1, 8, hipMemcpyDeviceToHost));
+    { int rc = read_flow(e, FLOW_GEN_FAILURES, &v); if (rc != BBAI_OK) return rc; }
     *out = (uint64_t)v;
     return BBAI_OK;
 }
@@ -2410,8 +2490,9 @@ int bbai_reset_count(bbai_env* e, uint64_t* out) {
     if (!e || !out) ARG_FAIL("null pointer");
     ON_DEVICE(e->device);
     HIP_TRY(hipDeviceSynchronize());
-    unsigned long long v = 0;
-    HIP_TRY(hipMemcpy(&v, e->total_resets, 8, hipMemcpyDeviceToHost));
+    unsigned long long shards[SHARDS * SHARD_U64], v = 0;
+    HIP_TRY(hipMemcpy(shards, e->totals, sizeof(shards), hipMemcpyDeviceToHost));
+    for (int k = 0; k < SHARDS; ++k) v += shards[k * SHARD_U64];
     *out = (uint64_t)v;
     return BBAI_OK;
 }

@@ -102,11 +102,14 @@ BB_HD int verify_leaf_action(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_
 // by include/bbai.h's definition, every byte above 7) succeeds iff the previous evaluated action completed the instruction
 // and FAILS otherwise; any other action only records whether it did and returns None (V_NONE: neither success nor
 // failure for the callers, exactly as the reference's missing `return` behaves).
-BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int leaf, int action, int fe2, uint32_t* lsm, int idf) {
-    if (!lsm) return verify_leaf_action(c, r, h, stale, leaf, action, fe2, idf);
-    if (action >= A_DONE) return (*lsm >> leaf & 1u) ? V_SUCCESS : V_FAILURE;
+// (The bits travel as a value + a mode flag, by reference: a NULLABLE POINTER to them kept the kernel's copy in scratch memory --
+// a select between an address and NULL cannot be promoted to a register -- 8 bytes of scratch per lane in every k_step.)
+struct Lsm { uint32_t bits; bool on; };
+BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int leaf, int action, int fe2, Lsm& lsm, int idf) {
+    if (!lsm.on) return verify_leaf_action(c, r, h, stale, leaf, action, fe2, idf);
+    if (action >= A_DONE) return (lsm.bits >> leaf & 1u) ? V_SUCCESS : V_FAILURE;
     const int res = verify_leaf_action(c, r, h, stale, leaf, action, fe2, idf);
-    *lsm = (*lsm & ~(1u << leaf)) | ((res == V_SUCCESS ? 1u : 0u) << leaf);
+    lsm.bits = (lsm.bits & ~(1u << leaf)) | ((res == V_SUCCESS ? 1u : 0u) << leaf);
     return V_NONE;
 }
 
@@ -117,7 +120,7 @@ BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale
 // reference's own bot returns the member (bot.py:593, fed to env.step by scripts/make_agent_demos.py:93-107).  `enum_done`
 // says which kind this step's `done` actions are: bbai_bot_rollout (the expert's own actions) and the "done_action_enum"
 // option set it.  A lone ActionInstr passes its failure through.
-BB_HD int verify_side(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int base, int n, int bit_a, int action, int fe2, uint32_t* lsm, int idf,
+BB_HD int verify_side(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int base, int n, int bit_a, int action, int fe2, Lsm& lsm, int idf,
                       bool enum_done = false) {
     if (n == 1) return verify_leaf(c, r, h, stale, base, action, fe2, lsm, idf);
     int sa = V_SUCCESS, sb = V_SUCCESS;              // (a side that succeeded earlier is not verified again: a_done stays 'success')
@@ -129,11 +132,11 @@ BB_HD int verify_side(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale
         sb = verify_leaf(c, r, h, stale, base + 1, action, fe2, lsm, idf);
         if (sb == V_SUCCESS) h.vstate |= 1 << (bit_a + 1);
     }
-    if (lsm && enum_done && action == A_DONE && sa == V_FAILURE && sb == V_FAILURE) return V_FAILURE;
+    if (lsm.on && enum_done && action == A_DONE && sa == V_FAILURE && sb == V_FAILURE) return V_FAILURE;
     return (h.vstate >> bit_a & 3) == 3 ? V_SUCCESS : V_CONTINUE;
 }
 
-BB_HD int verify_root(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2, uint32_t* lsm, int idf, bool enum_done = false) {
+BB_HD int verify_root(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2, Lsm& lsm, int idf, bool enum_done = false) {
     const VProg* p = &r.prog;
     if (p->root() == R_ACTION || p->root() == R_AND) return verify_side(c, r, h, stale, 0, p->n_a(), 1, action, fe2, lsm, idf, enum_done);
     // Before: a then b; After: b then a.  The second part is verified with the SAME action in
@@ -238,7 +241,7 @@ BB_HD int apply_action(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t& sta
 
 // Second half: the instruction verifier and the episode end (RoomGridLevel.step, levelgen.py:56-66).  `fe2` = appearance
 // byte of the front cell of the pose AFTER the action.  Returns done; reward by reference.
-BB_HD bool finish_step(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2, double& reward, uint32_t* lsm = nullptr, int idf = -1,
+BB_HD bool finish_step(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2, double& reward, Lsm& lsm, int idf = -1,
                        bool enum_done = false) {
     const int status = verify_root(c, r, h, stale, action, fe2, lsm, idf, enum_done);
     bool done = h.step >= h.max_steps;
@@ -257,7 +260,10 @@ BB_HD bool step_env(const LevelCfg& c, uint8_t* rec, const VProg& vp, Hot& h, ui
     int ce = h.carry != NONE8 ? r.app[h.carry] : (int)E_EMPTY;
     apply_action(c, r, h, stale, action, fe, ce);
     const int fe2 = r.E[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];
-    return finish_step(c, r, h, stale, action, fe2, reward, lsm, -1, enum_done);
+    Lsm l = {lsm ? *lsm : 0u, lsm != nullptr};
+    const bool done = finish_step(c, r, h, stale, action, fe2, reward, l, -1, enum_done);
+    if (lsm) *lsm = l.bits;
+    return done;
 }
 
 // The same step in k_step's order of operations: pose, then the front cell's id fetched BEFORE the object actions (with the
@@ -276,7 +282,10 @@ BB_HD bool step_env_prefetch(const LevelCfg& c, uint8_t* rec, const VProg& vp, H
     const int nfe = apply_objects(c, r, h, stale, action, fe, ce, idf, &nid);
     if (nfe >= 0) fe2 = nfe;
     if (nid >= 0) idf = nid;
-    return finish_step(c, r, h, stale, action, fe2, reward, lsm, idf, enum_done);
+    Lsm l = {lsm ? *lsm : 0u, lsm != nullptr};
+    const bool done = finish_step(c, r, h, stale, action, fe2, reward, l, idf, enum_done);
+    if (lsm) *lsm = l.bits;
+    return done;
 }
 
 // Not a MiniGrid action: "env.reset() for THIS env, now" -- what a ParallelEnv worker does on a `reset` command

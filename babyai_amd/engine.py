@@ -295,7 +295,10 @@ class BatchedBabyAIEnv(object):
             # everything outside 0..255 becomes 255, which include/bbai.h defines -- like every unknown action -- as `done`
             if actions.dtype.is_floating_point or actions.dtype == torch.bool:
                 raise TypeError("actions must be an integer tensor, got %s" % actions.dtype)
-            actions = torch.where((actions < 0) | (actions > 255), torch.full_like(actions, 255), actions)
+            # (ONE extra elementwise launch, then the cast: RL callers step with int64 samples on 30-us steps)
+            if actions.dtype == torch.int8:
+                actions = actions.to(torch.int16)
+            actions = torch.where((actions & -256) != 0, 255, actions)
         if actions.dtype != torch.uint8 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
         if actions.numel() != self.num_envs:
@@ -531,10 +534,23 @@ class BatchedBabyAIEnv(object):
         _, hot, _ = self.export_state()
         return hot[:, 6].astype(np.int32) | (hot[:, 7].astype(np.int32) << 8)
 
+    def gate_timeouts(self):
+        """Window gates that gave up waiting for a look-ahead refill (bbai_engine.hip k_gate): must be 0 -- anything else means a
+        refill was lost and the batch's results are void.  Synchronises."""
+        return self.get_option("gate_timeouts")
+
     def close(self):
+        """Destroy the handle.  Raises EngineError if a window gate ever timed out on this batch (a lost refill is never silent)."""
         if getattr(self, "handle", None) is not None and self.handle:
+            timeouts = 0
+            try:
+                timeouts = self.gate_timeouts()
+            except Exception:
+                pass
             self.lib.bbai_destroy(self.handle)
             self.handle = ctypes.c_void_p()
+            if timeouts:
+                raise EngineError("%d window gate(s) of this batch timed out waiting for a look-ahead refill: its results are void" % timeouts)
 
     def __del__(self):
         try:

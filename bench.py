@@ -26,7 +26,9 @@ What one run proves about itself (all in the one JSON line rank 0 prints):
                 clock stops when its own device is idle, the block is the max over ranks (the closing barrier itself is
                 reported as timing.barrier_ms, not timed); repeated until >= --min-seconds of timed work.  Blocks alternate between PLAIN (nothing but
                 the steps and the parity tap) and PROFILED (every kernel launch bracketed by a HIP event pair on its
-                launch stream).  `value` / `ms_per_step` = median plain block; `roofline` = the profiled blocks, whose own
+                launch stream).  `value` / `ms_per_step` = the MEAN over the plain blocks (all their steps / all their seconds:
+                what a long rollout sustains -- reset storms, when a million envs time out on the same tick, are in it); the
+                median, p90, max and every block's time are next to it (`timing`).  `roofline` = the profiled blocks, whose own
                 median step time is reported next to it (`timing.profiled_block_ms`), so that the kernel times add up to
                 a step that was really measured and the cost of the event pairs is visible.
   * rccl        the live process group: world size, backend, every rank's device, an all-reduce of ones, and every
@@ -41,9 +43,11 @@ What one run proves about itself (all in the one JSON line rank 0 prints):
                 stream: `parity.mismatches_all_ranks` must be 0 (exit code 3 otherwise; 4 when the checker itself broke).
   * configs     after the headline's timed region, the default single-GPU run puts every other BASELINE.json config through
                 the SAME loop on the same GPU -- C2 GoToLocal 65 536, C3 PickupLoc 262 144, C4 GoTo 1 048 576 (and its 131 072-env
-                8-GPU shard), encoded BossLevel 1 048 576: >= --extra-seconds of timed work each, alternating plain / profiled
-                blocks, 256 scattered envs tapped at every step and re-derived by the oracle.  `configs` in the line;
-                a mismatch there exits 3 like one in the headline.  --no-extra-configs skips them.
+                8-GPU shard), encoded BossLevel 1 048 576, and the headline's own per-GPU shards of the 8- / 4- / 2-GPU job
+                (BossLevel pixels, 131 072 / 262 144 / 524 288 envs: `C5-shard-*`, with the strong-scaling efficiency they imply
+                under `scaling_implied`): >= --extra-seconds of timed work each, alternating plain / profiled blocks, 256 scattered
+                envs tapped at every step of the first ~1000 steps (a spread of them at every step of the rest) and re-derived by
+                the oracle.  `configs` in the line; a mismatch there exits 3 like one in the headline.  --no-extra-configs skips them.
   * setup_ms    what is outside the metric: bbai_create, bbai_seed (incl. the first fill of the look-ahead rings), first reset.
   * cpu_baseline  the oracle on the usable host cores over the same seeds and action stream (rank 0; a reported
                 baseline), with the measured reference/port ratio of the build container when it is on file.
@@ -149,7 +153,8 @@ def parse_args(argv=None):
     ap.add_argument("--extra-configs", action="store_true", help="measure the other configs with --gpus N > 1 too (sharded over the N ranks)")
     ap.add_argument("--extra-seconds", type=float, default=0.3, help="timed work per extra config")
     ap.add_argument("--extra-parity-envs", type=int, default=256)
-    ap.add_argument("--extra-parity-budget", type=int, default=300000, help="oracle env-steps per extra config")
+    ap.add_argument("--extra-parity-budget", type=int, default=400000, help="oracle env-steps per extra config")
+    ap.add_argument("--extra-parity-horizon", type=int, default=1024, help="steps over which ALL --extra-parity-envs are followed (then a spread of them)")
     ap.add_argument("--rollout-entry", action="store_true", help="one bbai_rollout call per block instead of one bbai_step / bbai_render / bbai_tap_ids call per step from Python (the same launches)")
     ap.add_argument("--dump-digest", default=None, help="write per-env output digests of this rank to <prefix>.rank<r>.npy")
     args = ap.parse_args(argv)
@@ -197,6 +202,42 @@ def self_launch(args):
 def median(xs):
     xs = sorted(xs)
     return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
+
+
+def block_stats(blocks, K, E, world):
+    """What the plain blocks say: sustained (mean) throughput first, the spread next to it."""
+    bs = sorted(blocks)
+    med = median(blocks)
+    mean = sum(blocks) / len(blocks)
+    p90 = bs[min(len(bs) - 1, int(0.9 * len(bs)))]
+    return {"mean": mean, "median": med, "p90": p90, "min": bs[0], "max": bs[-1],
+            "value_mean": K * E * world / mean, "value_median": K * E * world / med,
+            "mean_over_median": mean / med, "max_over_median": bs[-1] / med}
+
+
+def traffic_of(level, E, pixel, dom):
+    """HBM bytes per launch of kernel `dom` on this workload from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate
+    runs; tools/lease.sh pmccfg -> tools/summarize_profile.py -> profiles/pmc_latest.json: one entry per workload).  Counters
+    cannot be collected inside this process: the committed summary is quoted with its provenance, and only while the kernel
+    sources still hash to what was profiled on this exact workload."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        wl = pmc["workloads"]["%s:%d:%s" % (level, E, "pixel" if pixel else "encoded")]
+        cands = [k for k in wl["kernels"] if k == dom or k.startswith(dom + "<") or k.startswith(dom + "_q<")]      # k_render / k_render_q are templates
+        if not cands:
+            return None
+        key = max(cands, key=lambda k: wl["kernels"][k].get("launches", 0))        # (the instantiation the step loop runs)
+        kk = wl["kernels"][key]
+        fetch = kk.get("FETCH_SIZE_corrected", 2 * kk["FETCH_SIZE"])      # gfx950: FETCH_SIZE tallies 128-B requests as 64 B
+        t = {"bytes": fetch + kk["WRITE_SIZE"], "fetch_corrected": fetch, "fetch_raw": kk["FETCH_SIZE"], "write": kk["WRITE_SIZE"],
+             "kernel": key, "correction": "FETCH_SIZE x 2 (MI355X_MICROARCH.md, calibrated on k_render's known byte counts)",
+             "source": "profiles/pmc_latest.json", "commit": pmc.get("commit"), "csrc_sha": pmc.get("csrc_sha"),
+             "current": pmc.get("csrc_sha") == csrc_sha()}
+        if not t["current"]:
+            t["bytes"] = None         # kernels changed since the counters were taken
+        return t
+    except Exception:
+        return None
 
 
 class Ctx(object):
@@ -300,8 +341,9 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
     # phase-1 block was only the probe
     S2 = want * K
     ids2, PP2, sel2 = ids1, PP1, None
-    if P and (S1 + S2) * P > parity_budget:      # long run: every step of FEWER envs in phase 2 -- a spread of phase 1's
-        P2 = max(min(16, P), parity_budget // (S1 + S2))
+    if P and (S1 + S2) * P > parity_budget:      # long run: every step of FEWER envs in phase 2 -- a spread of phase 1's (ALL P are checked over phase 1)
+        P2 = max(min(16, P), (parity_budget - S1 * P) // max(1, S2))
+        P2 = min(P, P2)
         PP2 = min(PP1, P2)
         pix_rows = sorted(set((PP1 - 1) * k // max(1, PP2 - 1) for k in range(PP2))) if PP2 else []
         n_rest = len(ids1) - PP1
@@ -360,7 +402,8 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
 
 
 def replay(ctx, m):
-    """Outside the timed region: the oracle re-derives what the tap recorded (oracle/cpu_baseline.py parity_replay)."""
+    """Outside the timed region: the oracle re-derives what the tap recorded (oracle/cpu_baseline.py parity_replay).  When phase 2
+    followed a subset of the tapped envs (long runs), the subset is checked over ALL steps and the other envs over phase 1."""
     torch, np = ctx.torch, ctx.np
     log1, log2, sel2, PP1, PP2, ids2 = m["log1"], m["log2"], m["sel2"], m["PP1"], m["PP2"], m["ids2"]
     if log1 is None:
@@ -371,12 +414,33 @@ def replay(ctx, m):
             if k == "ids" or (k == "pixels" and not PP2):
                 continue
             a = log1[k]
-            if sel2 is not None:                    # phase 2 followed a subset: the checked envs are that subset, all steps
+            if sel2 is not None:                    # phase 2 followed a subset: those envs, all steps
                 rows = [r for r in sel2 if r < PP1] if k == "pixels" else sel2
                 a = a[:, torch.as_tensor(rows, dtype=torch.int64, device=ctx.dev)]
             host[k] = np.concatenate([a.cpu().numpy()] + ([log2[k].cpu().numpy()] if log2 is not None else []))
         par = ctx.cpu_baseline.parity_replay(m["level"], host, ctx.args.seed, ctx.args.action_seed, m["first"], PP2,
                                              env_ids=[m["first"] + i for i in ids2], pool=ctx.pool)
+        par["envs_all_steps"] = par["envs"]
+        if sel2 is not None:                        # ... and the rest of phase 1's envs over phase 1
+            ids1 = [int(i) for i in log1["ids"].cpu().tolist()]
+            keep = set(sel2)
+            rows = [r for r in range(len(ids1)) if r not in keep]
+            if rows:
+                pix_rows = [r for r in rows if r < PP1]
+                hostA = {}
+                for k in log1:
+                    if k == "ids" or (k == "pixels" and not pix_rows):
+                        continue
+                    rr = pix_rows if k == "pixels" else rows
+                    hostA[k] = log1[k][:, torch.as_tensor(rr, dtype=torch.int64, device=ctx.dev)].cpu().numpy()
+                parA = ctx.cpu_baseline.parity_replay(m["level"], hostA, ctx.args.seed, ctx.args.action_seed, m["first"], len(pix_rows),
+                                                      env_ids=[m["first"] + ids1[r] for r in rows], pool=ctx.pool)
+                par["mismatches"] += parA["mismatches"]
+                par["first_mismatch"] = par["first_mismatch"] or parA["first_mismatch"]
+                par["seconds"] += parA["seconds"]
+                par["envs"] += parA["envs"]
+                par["pixel_envs"] += parA["pixel_envs"]
+                par["envs_first_steps_only"] = {"envs": parA["envs"], "steps": parA["steps"], "pixel_envs": parA["pixel_envs"]}
     except Exception as exc:
         par = {"error": repr(exc), "mismatches": None}          # the CHECKER broke: reported, not a parity verdict
     return par
@@ -402,6 +466,11 @@ EXTRA_CONFIGS = [
     ("C4", dict(level="GoTo", total=1048576, pixel=False, steps=32, ref="BASELINE.json configs[3] (1 048 576 envs, here on ONE GPU); iclr19_levels.py:224-257")),
     ("C4-shard", dict(level="GoTo", total=131072, pixel=False, steps=128, ref="one GPU's share of configs[3] on 8 GPUs")),
     ("C5-encoded", dict(level="BossLevel", total=1048576, pixel=False, steps=32, ref="the headline's level with 7x7x3 encoded observations (k_step's own roofline)")),
+    # the headline's own per-GPU workloads on 8 / 4 / 2 GPUs (`scaling: "strong"`: 1 048 576 envs in total), on this ONE GPU: the only
+    # driver-timed evidence a scaling claim can have while no multi-GPU node runs the bench (`scaling_implied` in the line)
+    ("C5-shard-131072", dict(level="BossLevel", total=131072, pixel=True, steps=64, horizon=384, of_gpus=8, ref="one GPU's share of configs[4] (the headline) on 8 GPUs")),
+    ("C5-shard-262144", dict(level="BossLevel", total=262144, pixel=True, steps=32, horizon=256, of_gpus=4, ref="one GPU's share of the headline on 4 GPUs")),
+    ("C5-shard-524288", dict(level="BossLevel", total=524288, pixel=True, steps=20, horizon=160, of_gpus=2, ref="one GPU's share of the headline on 2 GPUs")),
 ]
 
 
@@ -487,33 +556,16 @@ def main():
     S, want = m["S1"] + m["S2"], m["want"]
 
     bs = sorted(blocks)
-    med = median(blocks)
-    value = K * E * world / med
+    st = block_stats(blocks, K, E, world)
+    med = st["median"]
+    value = st["value_mean"]
     per_rank_ms = ranks.gather_objects(median(local_blocks) / K * 1e3 if local_blocks else None)
     dom, alg_bytes, bytes_per_step, dom_ms, achieved, ceiling_key = roofline_of(m)
-    # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate
-    # runs; tools/lease.sh pmc -> tools/summarize_profile.py -> profiles/pmc_latest.json).  Counters cannot be
-    # collected inside this process: the committed summary is quoted with its provenance, and only while the kernel
-    # sources still hash to what was profiled on this exact workload.
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        key = next((k for k in pmc["kernels"] if k == dom or k.startswith(dom + "<") or k.startswith(dom + "_q<")), None)      # k_render / k_render_q are templates
-        if pmc.get("level") == level and pmc.get("envs") == E and key:
-            kk = pmc["kernels"][key]
-            fetch = kk.get("FETCH_SIZE_corrected", 2 * kk["FETCH_SIZE"])      # gfx950: FETCH_SIZE tallies 128-B requests as 64 B
-            traffic = {"bytes": fetch + kk["WRITE_SIZE"], "fetch_corrected": fetch, "fetch_raw": kk["FETCH_SIZE"], "write": kk["WRITE_SIZE"],
-                       "kernel": key, "correction": "FETCH_SIZE x 2 (MI355X_MICROARCH.md, calibrated on k_render's known byte counts)",
-                       "source": "profiles/pmc_latest.json", "commit": pmc.get("commit"), "csrc_sha": pmc.get("csrc_sha"),
-                       "current": pmc.get("csrc_sha") == csrc_sha()}
-            if not traffic["current"]:
-                traffic["bytes"] = None         # kernels changed since the counters were taken
-    except Exception:
-        traffic = None
+    traffic = traffic_of(level, E, pixel, dom)
     prof_med = median(profiled) if profiled else None
     out = {
         "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": med / K * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "ms_per_step": st["mean"] / K * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": "BabyAI-%s-v0 %s obs, %d envs in total = %d per GPU x %d, random actions, auto-reset" % (
             level, "56x56x3 pixel (RGBImgPartialObsWrapper)" if pixel else "7x7x3 encoded", total_envs, E, world),
@@ -525,8 +577,13 @@ def main():
                      per_rank_ms_per_step_min=min(per_rank_ms) if all(v is not None for v in per_rank_ms) else None,
                      per_rank_ms_per_step_max=max(per_rank_ms) if all(v is not None for v in per_rank_ms) else None,
                      launched_by="bench.py itself" if os.environ.get("BBAI_BENCH_SELF_LAUNCHED") else ("external launcher" if world > 1 else "single process")),
-        "timing": {"blocks": len(blocks), "steps_per_block": K, "block_ms": {"min": bs[0] * 1e3, "median": med * 1e3, "max": bs[-1] * 1e3},
-                   "timed_seconds": sum(blocks) + sum(profiled), "value_from": "median plain block", "value_at_min": K * E * world / bs[0],
+        "timing": {"blocks": len(blocks), "steps_per_block": K,
+                   "block_ms": {"min": bs[0] * 1e3, "median": med * 1e3, "mean": st["mean"] * 1e3, "p90": st["p90"] * 1e3, "max": bs[-1] * 1e3},
+                   "block_ms_list": [round(b * 1e3, 4) for b in blocks],
+                   "timed_seconds": sum(blocks) + sum(profiled),
+                   "value_from": "MEAN over the plain blocks: all their steps / all their seconds (sustained throughput)",
+                   "value_mean": st["value_mean"], "value_median": st["value_median"], "mean_over_median": st["mean_over_median"],
+                   "max_over_median": st["max_over_median"], "value_at_min": K * E * world / bs[0],
                    "value_at_max": K * E * world / bs[-1],
                    "loop": "one bbai_rollout call per block: the engine enqueues K x (step [+ render] + tap)" if (args.rollout_entry and not args.dump_digest) else
                            "per-step calls from Python: bbai_step [+ bbai_render] + bbai_tap_ids",
@@ -584,8 +641,9 @@ def main():
             if c["total"] % world:
                 continue
             try:
-                mc = measure(ctx, c["level"], c["pixel"], c["total"] // world, c["total"], c["steps"], 16, args.extra_seconds, 64,
-                             args.extra_parity_envs, 0, args.extra_parity_budget)
+                horizon = min(args.extra_parity_horizon, c.get("horizon", args.extra_parity_horizon))
+                mc = measure(ctx, c["level"], c["pixel"], c["total"] // world, c["total"], c["steps"], max(16, horizon - c["steps"]), args.extra_seconds, 64,
+                             args.extra_parity_envs, 16 if c["pixel"] else 0, args.extra_parity_budget)
                 mc["env"].close()
                 mc["env"] = None
                 extras.append((name, c, mc))
@@ -626,23 +684,47 @@ def main():
                 exit_code = exit_code or 4
             elif bad:
                 exit_code = 3
-            cdom, calg, cbps, cdom_ms, cach, _ = roofline_of(mc)
-            cmed = median(mc["blocks"])
+            cdom, calg, cbps, cdom_ms, cach, ckey = roofline_of(mc)
             Kc, Ec = mc["K"], mc["E"]
+            cst = block_stats(mc["blocks"], Kc, Ec, world)
+            ctraffic = traffic_of(c["level"], Ec, c["pixel"], cdom)
             cfgs[name] = {
-                "workload": "BabyAI-%s-v0 7x7x3 encoded obs, %d envs in total = %d per GPU x %d, random actions, auto-reset" % (c["level"], c["total"], Ec, world),
-                "reference": c["ref"], "value": Kc * Ec * world / cmed, "unit": "env-steps/s", "ms_per_step": cmed / Kc * 1e3,
+                "workload": "BabyAI-%s-v0 %s obs, %d envs in total = %d per GPU x %d, random actions, auto-reset" % (
+                    c["level"], "56x56x3 pixel (RGBImgPartialObsWrapper)" if c["pixel"] else "7x7x3 encoded", c["total"], Ec, world),
+                "reference": c["ref"], "value": cst["value_mean"], "unit": "env-steps/s", "ms_per_step": cst["mean"] / Kc * 1e3,
+                "value_from": "MEAN over the plain blocks (sustained)", "value_median": cst["value_median"], "ms_per_step_median": cst["median"] / Kc * 1e3,
+                "mean_over_median": cst["mean_over_median"], "max_over_median": cst["max_over_median"],
                 "steps_per_block": Kc, "blocks": len(mc["blocks"]), "timed_seconds": sum(mc["blocks"]) + sum(mc["profiled"]),
-                "block_ms": {"min": min(mc["blocks"]) * 1e3, "median": cmed * 1e3, "max": max(mc["blocks"]) * 1e3},
+                "block_ms": {"min": cst["min"] * 1e3, "median": cst["median"] * 1e3, "mean": cst["mean"] * 1e3, "p90": cst["p90"] * 1e3, "max": cst["max"] * 1e3},
+                "block_ms_list": [round(b * 1e3, 4) for b in mc["blocks"]],
                 "kernel_avg_ms": mc["kernel_ms"], "state_layout": mc["state_layout"], "lookahead_period": mc["lookahead_period"],
-                "roofline": {"kernel": cdom, "alg_bytes_per_launch": calg, "avg_launch_ms": cdom_ms, "achieved": cach, "unit": "GB/s",
-                             "frac": cach / HBM_PEAK_GBS, "whole_step_alg_GBs": Kc * Ec / cmed * cbps / 1e9},
+                "roofline": {"bound": "hbm", "kernel": cdom, "alg_bytes_per_launch": calg, "avg_launch_ms": cdom_ms, "achieved": cach, "unit": "GB/s",
+                             "peak": HBM_PEAK_GBS, "frac": cach / HBM_PEAK_GBS,
+                             "frac_of_achievable": (cach / achievable[ckey]) if achievable else None, "achievable_ceiling": ckey,
+                             "traffic": ctraffic["bytes"] if ctraffic else None, "traffic_provenance": ctraffic,
+                             "whole_step_alg_GBs": cst["value_mean"] / world * cbps / 1e9},
                 "resets": mc["resets"], "resets_per_step": mc["resets"] / float(mc["S2"] or 1), "setup_ms": {k: v for k, v in mc["setup_ms"].items() if k != "note"},
-                "parity": None if pc is None else {"envs": pc.get("envs"), "steps": pc.get("steps"), "mismatches": None if broken else bad,
+                "parity": None if pc is None else {"envs": pc.get("envs"), "envs_all_steps": pc.get("envs_all_steps"), "steps": pc.get("steps"),
+                                                   "envs_first_steps_only": pc.get("envs_first_steps_only"), "pixel_envs": pc.get("pixel_envs"),
+                                                   "mismatches": None if broken else bad,
                                                    "first_mismatch": pc.get("first_mismatch"), "seconds": pc.get("seconds"), "error": pc.get("error"),
                                                    "env_selection": "scattered over the shard (shard.scattered_ids), every step"},
             }
         out["configs"] = cfgs
+        # what the per-GPU shards of the headline imply for the N-GPU job (envs never interact and there is no collective on the step
+        # path, so an N-GPU step lasts as long as its slowest shard): efficiency = t(1 048 576 envs on 1 GPU) / (N x t(1 048 576 / N envs on 1 GPU)).
+        # IMPLIED from single-GPU runs of the shard sizes on this box -- not a measurement of N GPUs.
+        if world == 1 and level == "BossLevel" and pixel and E == HEADLINE_ENVS:
+            imp = {}
+            for name, c, mc in extras:
+                if c.get("of_gpus") and name in cfgs and "error" not in cfgs[name]:
+                    n_g = c["of_gpus"]
+                    t_shard = cfgs[name]["ms_per_step"]
+                    imp[str(n_g)] = {"config": name, "envs_per_gpu": c["total"], "ms_per_step_shard": t_shard,
+                                     "implied_value": HEADLINE_ENVS / (t_shard * 1e-3),
+                                     "implied_efficiency": out["ms_per_step"] / (n_g * t_shard)}
+            out["scaling_implied"] = {"basis": "single-GPU runs of each per-GPU shard size, same process, same box; no collective on the step path",
+                                      "one_gpu_ms_per_step": out["ms_per_step"], "gpus": imp}
     ranks.barrier()
     if rank == 0 and not args.no_cpu_baseline:
         try:
