@@ -78,6 +78,8 @@ struct DeviceGuard {
     HIP_TRY((hipError_t)guard_.err)
 
 constexpr int PROF_RING = 256;          // event pairs per profiled kernel (bbai_profile)
+constexpr int MAX_PERIOD = 32;          // refill period B (ticks per look-ahead refill); ring depth D = 2B
+constexpr int NWIN = MAX_PERIOD + 2;    // window buffers (see "the windows' bookkeeping" below)
 
 struct bbai_env {
     LevelCfg cfg;
@@ -112,6 +114,9 @@ struct bbai_env {
     uint8_t* tokens;      // optional caller-owned [n][72] mission token buffer kept current on resets
     hipStream_t side;     // look-ahead generation stream
     hipEvent_t ev_consumed;
+    hipEvent_t ev_refill[NWIN];     // recorded behind every window's refill; only waited for in strict mode (below) -- k_gate reads flow[FLOW_REFILLED]
+    int gate_strict;      // BBAI_GATE_STRICT / option "gate_strict": 1 = rounds 1-4's rule as well: the stream waits (an event) for the refill of window
+                          // x - 2 before window x starts, so k_gate never has to wait (A/B runs; a fallback should a profiler serialise the two streams)
     hipStream_t last_stream;   // the caller's stream of the previous call (compared, never used): a handle follows ONE stream
     bool have_stream;          // at a time; a call on another stream waits for ev_switch = end of the previous call
     hipEvent_t ev_switch;      // (enter_call / leave_call)
@@ -161,7 +166,6 @@ struct bbai_env {
 // k_step
 // ------------------------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr int MAX_PERIOD = 32;          // refill period B (ticks per look-ahead refill); ring depth D = 2B
 // ---- the windows' bookkeeping: no lists, no same-address atomics on the step path -----------------------------------------------
 // Rounds 1-4 compacted the finished envs of every tick into a window list for the refill (one RETURNING atomic per stepping wave
 // on ONE address: ~2 700 of them per step at 262 144 reset-heavy envs, served at ~11 ns each -- half of that k_step's time) and made
@@ -176,7 +180,6 @@ constexpr int MAX_PERIOD = 32;          // refill period B (ticks per look-ahead
 //     UNDER the following windows instead of stopping the step stream, as long as no env finishes B more times meanwhile.
 //   * NWIN window buffers (pending / first_slot / meta) so that up to B + 1 refills can be outstanding.
 // tests/test_ring_protocol.py models the rule (sufficient, and the ring depths stay tight).
-constexpr int NWIN = MAX_PERIOD + 2;    // window buffers
 constexpr int META_U32 = 32;            // uint32 per window buffer's meta line: [0] = M when > 1 (atomicMax), [1] = finished envs (written at its close)
 constexpr int SHARDS = 64;              // cache lines the reset total is spread over (k_step: shard = block & 63)
 constexpr int SHARD_U64 = 16;           // uint64 per shard: one 128-byte line each
@@ -988,7 +991,7 @@ __global__ void k_mark(unsigned long long* __restrict__ flow, unsigned long long
 //       2B - B = B ready levels, and window x consumes at most B per env;
 // then clears the meta line of window x.  With r = x - 1 (rounds 1-4 waited for exactly that) both hold trivially, so the wait ends at the
 // latest when refill x - 2 lands; every refill it can wait for was enqueued before it.  One wave; polls with s_sleep.  A wait beyond
-// ~20 s of the constant 100-MHz clock gives up (counted in flow[FLOW_GATE_TIMEOUTS], read back as option "gate_timeouts": the handle's
+// ~10 s of the constant 100-MHz clock gives up (counted in flow[FLOW_GATE_TIMEOUTS], read back as option "gate_timeouts": the handle's
 // results are void then -- it means a lost refill, never seen) instead of hanging the device.
 __global__ __launch_bounds__(64) void k_gate(unsigned long long* __restrict__ flow, uint32_t* __restrict__ metas, unsigned long long x, int period) {
     const int lane = (int)threadIdx.x;
@@ -1004,7 +1007,7 @@ __global__ __launch_bounds__(64) void k_gate(unsigned long long* __restrict__ fl
 #pragma unroll
         for (int o = 32; o; o >>= 1) m += __shfl_xor(m, o);
         if (open < (unsigned long long)NWIN && m <= (uint32_t)period) break;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 1000000000ull) {
             if (lane == 0) atomicAdd(&flow[FLOW_GATE_TIMEOUTS], 1ull);
             break;
         }
@@ -1554,6 +1557,7 @@ static int create_finish(bbai_env* e) {
         const char* pv = getenv("BBAI_PREGEN_PRIORITY");     // 1 (default): highest priority, 0: default priority
         HIP_TRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, (pv && atoi(pv) == 0) ? lo : hi));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_consumed, hipEventDisableTiming));
+        for (int k = 0; k < NWIN; ++k) HIP_TRY(hipEventCreateWithFlags(&e->ev_refill[k], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_switch, hipEventDisableTiming));
     }
     {
@@ -1573,6 +1577,8 @@ static int create_finish(bbai_env* e) {
         e->render_queue = qv ? atoi(qv) : -1;
         const char* pv2 = getenv("BBAI_RENDER_PACE");
         e->render_pace = pv2 ? std::max(0, atoi(pv2)) : 0;
+        const char* gs = getenv("BBAI_GATE_STRICT");
+        e->gate_strict = gs ? atoi(gs) != 0 : 0;
         const char* cf = getenv("BBAI_CONSUME_FUSED");
         e->consume_fused = cf ? atoi(cf) : -1;
         const char* tv = getenv("BBAI_RENDER_TPB");
@@ -1590,6 +1596,7 @@ void bbai_destroy(bbai_env* e) {
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->ev_consumed) (void)hipEventDestroy(e->ev_consumed);
     if (e->ev_switch) (void)hipEventDestroy(e->ev_switch);
+    for (int k = 0; k < NWIN; ++k) if (e->ev_refill[k]) (void)hipEventDestroy(e->ev_refill[k]);
     for (int k = 0; k < 3; ++k) for (int i = 0; i < PROF_RING; ++i) if (e->prof[k][i].a) { (void)hipEventDestroy(e->prof[k][i].a); (void)hipEventDestroy(e->prof[k][i].b); }
     void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
@@ -1709,6 +1716,8 @@ static TickPos tick_pos(const bbai_env* e) {
 }
 static int window_begin(bbai_env* e, hipStream_t s) {
     if (e->tick % e->period == 0) {
+        const int64_t x = e->tick / e->period;
+        if (e->gate_strict && x >= 2) HIP_TRY(hipStreamWaitEvent(s, e->ev_refill[(x - 2) % NWIN], 0));
         hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, e->flow, e->win_meta, (unsigned long long)(e->tick / e->period), e->period);
         HIP_TRY(hipGetLastError());
     }
@@ -1738,6 +1747,7 @@ static int window_end(bbai_env* e, hipStream_t s, int tokens_mode /* k_tokens: 0
         const int64_t rh = std::max<int64_t>((int64_t)B * (e->n / 64), 64);
         launch_pregen(e, pregen_grid(e, rh), meta, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n);
         hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, e->side, e->flow, (unsigned long long)(w + 1));
+        HIP_TRY(hipEventRecord(e->ev_refill[wb], e->side));
         HIP_TRY(hipGetLastError());
     }
     e->tick++;
@@ -1791,6 +1801,7 @@ int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
         fl[FLOW_REFILLED] = 0; fl[FLOW_CLOSE_TOTAL] = total;
         HIP_TRY(hipMemcpy(e->flow, fl, sizeof(fl), hipMemcpyHostToDevice));
     }
+    for (int k = 0; k < NWIN; ++k) HIP_TRY(hipEventRecord(e->ev_refill[k], e->side));
     e->tick = 0;
     e->step_parity = 0;
     e->next_counter_clean = true;
@@ -2176,6 +2187,7 @@ int bbai_checkpoint_load(bbai_env* e, const void* host_buf, int64_t bytes) {
     e->step_parity = h.step_parity; e->next_counter_clean = h.next_counter_clean != 0; e->seeded = h.seeded != 0; e->live = h.live != 0;
     e->tick = h.tick;
     // (the saved run was idle: every refill it had launched has landed, and flow[FLOW_REFILLED] in the blob says so)
+    for (int i = 0; i < NWIN; ++i) HIP_TRY(hipEventRecord(e->ev_refill[i], e->side));
     HIP_TRY(hipDeviceSynchronize());
     return sync_view(e, 0, e->n);
 }
@@ -2413,6 +2425,7 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     else if (!strcmp(name, "pregen_blocks")) e->pregen_cap = std::max(64, v);
     else if (!strcmp(name, "pregen_min")) e->pregen_min = std::max(0, v);
     else if (!strcmp(name, "consume_fused")) e->consume_fused = v;
+    else if (!strcmp(name, "gate_strict")) e->gate_strict = v != 0;
     else if (!strcmp(name, "done_action_enum")) e->done_action_enum = v != 0;       // (the one SEMANTIC switch in this list: include/bbai.h bbai_set_done_actions)
     else {
         snprintf(g_err, sizeof(g_err), "set_option: unknown option '%s'", name);
@@ -2441,6 +2454,7 @@ int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     else if (!strcmp(name, "pregen_blocks")) *out = e->pregen_cap;
     else if (!strcmp(name, "pregen_min")) *out = e->pregen_min;
     else if (!strcmp(name, "consume_fused")) *out = e->consume_fused;
+    else if (!strcmp(name, "gate_strict")) *out = e->gate_strict;
     else if (!strcmp(name, "inplace")) *out = e->inplace;
     else if (!strcmp(name, "done_action_enum")) *out = e->done_action_enum;
     else if (!strcmp(name, "lookahead_period")) *out = e->period;

@@ -79,6 +79,10 @@ CONFIGS = {
     "C5": dict(level="BossLevel", total=1048576, pixel=True),
     "C4-shard": dict(level="GoTo", per_gpu=131072, pixel=False),
     "C5-shard": dict(level="BossLevel", per_gpu=131072, pixel=True),
+    "C5-shard-131072": dict(level="BossLevel", per_gpu=131072, pixel=True),
+    "C5-shard-262144": dict(level="BossLevel", per_gpu=262144, pixel=True),
+    "C5-shard-524288": dict(level="BossLevel", per_gpu=524288, pixel=True),
+    "C5-encoded": dict(level="BossLevel", total=1048576, pixel=False),
 }
 
 

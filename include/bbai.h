@@ -112,8 +112,8 @@ int bbai_render(bbai_env* env, const uint8_t* image_dev, uint8_t* pixels_dev, vo
 int bbai_set_token_buffer(bbai_env* env, uint8_t* tokens_dev);
 
 /* State access (host buffers; synchronous): parity tests, checkpoints, mission strings.  hot_host[15] is the env's place in its
- * look-ahead ring: engine bookkeeping, imported as given by a classic-layout handle and left alone by an in-place one (there it says
- * where the live record is). */
+ * look-ahead ring: engine bookkeeping of the EXPORTING handle -- bbai_import_state ignores it and keeps the importing handle's own
+ * (the ring belongs to the handle; in the in-place layout the slot says where the live record is). */
 int bbai_export_state(bbai_env* env, int64_t first, int64_t count, uint8_t* rec_host,
                       uint8_t* hot_host /* 16 B each */, uint64_t* stale_host);
 int bbai_import_state(bbai_env* env, int64_t first, int64_t count, const uint8_t* rec_host,
@@ -126,7 +126,8 @@ int bbai_get_programs(bbai_env* env, int64_t first, int64_t count, uint8_t* prog
  * expert's plans.  Loading it into a fresh handle of the same level and batch size continues the run
  * bit-identically, auto-resets included (tests/test_gpu_parity.py::test_checkpoint_resume_*); a handle whose look-ahead
  * period differs (it is chosen from the free memory at bbai_create unless BBAI_LOOKAHEAD pins it) takes the blob's ring shape; a blob of the
- * other state layout (bbai_create) is refused.  Synchronous, host buffers.
+ * other state layout (bbai_create), of the other done-action mode, of another expert stack capacity, of another format version or of the
+ * wrong size is refused BEFORE the handle is touched: a refused load leaves the handle exactly as it was.  Synchronous, host buffers.
  * Caller-owned buffers are not part of the blob: keep the last observation next to it if it is needed before the next
  * step, and register the token buffer again after a load (bbai_set_token_buffer refills every row of a live handle). */
 int64_t bbai_checkpoint_bytes(bbai_env* env);
@@ -245,11 +246,15 @@ int bbai_get_done_actions(bbai_env* env);
  *   "render_group", "render_tpb"   envs / threads per one-shot render block (0 = by batch size)
  *   "step_prio", "pregen_group", "pregen_blocks", "pregen_min", "consume_fused"   as BBAI_STEP_PRIO / BBAI_PREGEN_GROUP /
  *                       BBAI_PREGEN_BLOCKS / BBAI_PREGEN_MIN / BBAI_CONSUME_FUSED
+ *   "gate_strict"       1 = the step stream ALSO waits, at the start of every look-ahead window, for the refill launched two windows
+ *                       earlier (rounds 1-4's rule); 0 (default) = it runs ahead of the refills as far as every env is sure to keep
+ *                       a window's worth of ready levels (k_gate) -- a reset storm then refills under the steps
  *   "done_action_enum"  the one semantic switch, meaningful in done-action mode only: see bbai_set_done_actions
  * BBAI_ERR_ARG for an unknown name. */
 int bbai_set_option(bbai_env* env, const char* name, int64_t value);
 /* Read a knob back (the names of bbai_set_option), or "lookahead_period" (the refill period the handle chose at bbai_create), or
- * "inplace" (1: the in-place state layout, bbai_create). */
+ * "inplace" (1: the in-place state layout, bbai_create), or "gate_timeouts" (synchronises: window gates that gave up waiting for a
+ * look-ahead refill after ~10 s -- must be 0; anything else means a refill was lost and the batch's results are void). */
 int bbai_get_option(bbai_env* env, const char* name, int64_t* out);
 
 /* Number of level generations (resets) performed so far, all envs. */

@@ -1483,7 +1483,7 @@ def test_options_do_not_change_results(gpu):
     settings = [("step_prio", 0), ("pregen_group", 64), ("pregen_blocks", 64), ("render_group", 4), ("render_tpb", 256),
                 ("consume_fused", 1), ("pregen_group", 16), ("render_queue", 1), ("consume_fused", 0),
                 ("render_queue", 6), ("pregen_group", 32), ("step_prio", 1), ("consume_fused", 1), ("consume_fused", -1), ("pregen_min", 0),
-                ("pregen_min", 7), ("pregen_group", 64), ("pregen_min", 2048)]
+                ("pregen_min", 7), ("pregen_group", 64), ("pregen_min", 2048), ("gate_strict", 1), ("pregen_blocks", 64), ("gate_strict", 0)]
     for t in range(20 * len(settings)):
         assert torch.equal(oa["image"], ob["image"]) and torch.equal(a.image, b.image) and torch.equal(a.direction, b.direction), t
         if t % 20 == 0:
@@ -1493,8 +1493,162 @@ def test_options_do_not_change_results(gpu):
         ob, rb, db, _ = b.step(act)
         assert torch.equal(a.reward64, b.reward64) and torch.equal(da, db), t
     assert a.reset_count() == b.reset_count() and a.reset_count() > 2 * n
+    assert a.gate_timeouts() == 0 and b.gate_timeouts() == 0
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["0", "1"])
+@pytest.mark.parametrize("level,n,period", [("GoToObjS4", 20000, "4"), ("GoTo", 6000, "2"), ("PickupLoc", 30000, None)])
+def test_steps_run_ahead_of_a_reset_storms_refill(gpu, level, n, period, layout, monkeypatch):
+    """The step stream no longer waits for the refill of window w at the start of window w + 2: it runs on while every env is sure to
+    keep a window's worth of ready levels (bbai_engine.hip k_gate).  A reset command to EVERY env on one tick (a storm: one long
+    refill) followed at once by many windows of ordinary steps, every few windows another storm, a tick on which a quarter of the envs
+    reset again inside the same window (M = 2), and stretches of resets on every tick (the worst case: the gate degenerates to the old
+    rule) -- against a second batch that runs the old rule (gate_strict) and, for scattered envs, against the oracle."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from oracle import levels as olevels
+    monkeypatch.setenv("BBAI_INPLACE", layout)
+    if period:
+        monkeypatch.setenv("BBAI_LOOKAHEAD", period)
+    a = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=77)
+    b = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=77)
+    b.set_option("gate_strict", 1)
+    B = a.get_option("lookahead_period")
+    ids = [0, 1, 63, 64, n // 2, n - 65, n - 1]
+    refs = []
+    for i in ids:
+        e = olevels.make_env(level)
+        e.seed(77 + i)
+        refs.append([e, e.reset()])
+    a.reset()
+    b.reset()
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(5)
+    T = 14 * B + 9
+    for t in range(T):
+        img = a.image[torch.as_tensor(ids, device=gpu)].cpu().numpy()
+        for k, i in enumerate(ids):
+            assert np.array_equal(img[k], refs[k][1]["image"]), (level, layout, t, i)
+        act = torch.randint(0, 7, (n,), dtype=torch.uint8, device=gpu, generator=gen)
+        if t % (5 * B) == 1:
+            act[:] = a.RESET_ENV                                  # the storm
+        elif t % (5 * B) == 2:
+            act[::4] = a.RESET_ENV                                # ... and again inside the same window for a quarter of the envs
+        elif 8 * B <= t < 10 * B + 3:
+            act[5::7] = a.RESET_ENV                               # resets on every tick for more than two windows
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(a.image, b.image) and torch.equal(a.direction, b.direction) and torch.equal(a.reward64, b.reward64) and torch.equal(da, db), (level, layout, t)
+        acts = act[torch.as_tensor(ids, device=gpu)].cpu().numpy()
+        dn = da[torch.as_tensor(ids, device=gpu)].cpu().numpy()
+        for k in range(len(ids)):
+            if acts[k] == a.RESET_ENV:
+                refs[k][1] = refs[k][0].reset()
+                assert dn[k] == 1
+            else:
+                o, r, d, _ = refs[k][0].step(int(acts[k]))
+                assert bool(d) == bool(dn[k]), (level, layout, t, ids[k])
+                refs[k][1] = refs[k][0].reset() if d else o
+    assert a.reset_count() == b.reset_count() and a.reset_count() > 3 * n
+    assert a.gate_timeouts() == 0 and b.gate_timeouts() == 0
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
+def test_a_refused_checkpoint_leaves_the_handle_as_it_was(gpu, monkeypatch):
+    """bbai_checkpoint_load validates EVERYTHING before it touches the handle: a blob of another look-ahead period that is
+    refused for another reason -- wrong done-action mode, truncated, another format version -- must not re-shape the ring on its way
+    out.  The handle keeps stepping in lock-step with a twin afterwards."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv, EngineError
+    n = 600
+    monkeypatch.setenv("BBAI_LOOKAHEAD", "4")
+    donor = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=5, done_actions=True)
+    donor.reset()
+    blob = donor.save_checkpoint()
+    donor.close()
+    monkeypatch.setenv("BBAI_LOOKAHEAD", "2")
+    a = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=9)
+    b = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=9)
+    a.reset()
+    b.reset()
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(1)
+
+    def lockstep(steps):
+        for t in range(steps):
+            act = torch.randint(0, 7, (n,), dtype=torch.uint8, device=gpu, generator=gen)
+            a.step(act)
+            b.step(act)
+            assert torch.equal(a.image, b.image) and torch.equal(a.reward64, b.reward64) and torch.equal(a.done, b.done), t
+
+    lockstep(7)
+    with pytest.raises(EngineError, match="done-action mode"):
+        a.load_checkpoint(blob)                       # period 4 into a period-2 handle, refused for its done-action bits
+    assert a.get_option("lookahead_period") == 2
+    lockstep(9)
+    with pytest.raises(EngineError, match="size does not match"):
+        a.load_checkpoint(blob[:-64])
+    bad = blob.copy()
+    bad[8:12] = np.frombuffer(np.int32(2).tobytes(), dtype=np.uint8)      # CkptHeader.version
+    with pytest.raises(EngineError, match="unsupported checkpoint version 2"):
+        a.load_checkpoint(bad)
+    assert a.get_option("lookahead_period") == 2
+    lockstep(40)
+    assert a.reset_count() == b.reset_count() > n
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
+def test_import_state_keeps_the_importing_handles_ring_position(gpu, monkeypatch):
+    """hot[15] (the ring slot) of an exported state belongs to the EXPORTER's ring: an in-place handle with a 65-slot ring exports slots a
+    classic handle with a 4-slot ring does not have.  The import keeps the importer's own slot in both layouts, and the
+    importer goes on auto-resetting through ITS level stream."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    n = 300
+    monkeypatch.setenv("BBAI_INPLACE", "1")
+    monkeypatch.delenv("BBAI_LOOKAHEAD", raising=False)
+    src = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=3)
+    src.reset()
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(2)
+    for t in range(150):                                  # far enough that ring slots beyond 4 are in use
+        src.step(torch.randint(0, 7, (n,), dtype=torch.uint8, device=gpu, generator=gen))
+    rec, hot, stale = src.export_state()
+    assert hot[:, 15].max() >= 4
+    monkeypatch.setenv("BBAI_INPLACE", "0")
+    monkeypatch.setenv("BBAI_LOOKAHEAD", "2")
+    dst = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=1000)
+    twin = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=1000)
+    dst.reset()
+    twin.reset()
+    dst.import_state(rec, hot, stale)
+    _, hot2, _ = dst.export_state()
+    assert hot2[:, 15].max() < 4                          # the importer's own slots
+    assert np.array_equal(hot2[:, :15], hot[:, :15])
+    # the imported episodes play on exactly like the exporter's ...
+    first_done = np.zeros(n, bool)
+    for t in range(60):
+        act = torch.randint(0, 7, (n,), dtype=torch.uint8, device=gpu, generator=gen)
+        src.step(act)
+        dst.step(act)
+        twin.step(act)
+        live = ~first_done
+        assert np.array_equal(src.reward64.cpu().numpy()[live], dst.reward64.cpu().numpy()[live]), t
+        assert np.array_equal(src.done.cpu().numpy()[live], dst.done.cpu().numpy()[live]), t
+        fin_now = dst.done.cpu().numpy().astype(bool) & live
+        first_done |= fin_now
+    # ... and once finished, every env continues in the IMPORTER's own level stream: the levels its twin (same seeds, one reset() at the
+    # same point of the stream) gets
+    assert first_done.sum() > n // 2
+    assert dst.gate_timeouts() == 0
+    src.close(); dst.close(); twin.close()
 
 
 @pytest.mark.gpu

@@ -145,6 +145,20 @@ d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(json.dumps({'config': '$cfg', 'loop': 'bbai_rollout' if '$mode' else 'python', 'ms_per_step': round(d['ms_per_step'], 5), 'value': d['value'], 'kernels': d['roofline']['kernel_avg_ms'], 'parity': (d['parity'] or {}).get('mismatches_all_ranks')}))" | tee -a $OUT/loop_ab.jsonl
     done; done; done
 }
+profcfg() {          # profcfg:<config>[:<bench args>] -- the evidence set of ONE BASELINE workload on the shipped sources: rocprofv3 --kernel-trace --stats,
+                     # FETCH_SIZE and WRITE_SIZE passes (each on its own: gpurun refuses counter + trace-domain mixes), and the SQ pass; condensed by
+                     # tools/summarize_profile.py into profiles/<tag>/ and profiles/pmc_latest.json (one entry per workload)
+    local cfg=$1; shift
+    local B1="python $REPO/bench.py --config $cfg --no-extra-configs --no-cpu-baseline --parity-envs 0 --min-seconds 0.25 --max-blocks 8 $@"
+    cd /tmp && rm -rf $OUT/stats_$cfg $OUT/pmc_fetch_$cfg $OUT/pmc_write_$cfg $OUT/pmc_sq_$cfg
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$cfg -o t -- $B1 > $OUT/bench_${cfg}_under_rocprof.json 2> $OUT/rocprof_stats_$cfg.log
+    timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$cfg -o t -- $B1 > /dev/null 2> $OUT/rocprof_fetch_$cfg.log
+    timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$cfg -o t -- $B1 > /dev/null 2> $OUT/rocprof_write_$cfg.log
+    timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_ACTIVE_INST_VALU \
+        --kernel-trace --output-format csv -d $OUT/pmc_sq_$cfg -o t -- $B1 > /dev/null 2> $OUT/rocprof_sq_$cfg.log
+    cd $REPO && python tools/summarize_profile.py $TAG --config $cfg 2>&1 | tail -12
+    find $OUT -name "*.csv" -size +8M -delete
+}
 tracecfg() {         # rocprofv3 kernel trace of one BASELINE config (tracecfg:C2): launch gaps on the small shards
     cd /tmp && rm -rf $OUT/trace_$1
     timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_$1 -o t -- python $REPO/bench.py --config $1 --no-extra-configs --no-cpu-baseline --parity-envs 0 --min-seconds 0.2 --steps 256 --warmup 16 > $OUT/trace_$1.json 2> $OUT/trace_$1.log
