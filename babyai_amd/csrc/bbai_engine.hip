@@ -102,9 +102,11 @@ struct bbai_env {
     uint8_t* next_obs;    // [D][n][OBS_SLOT] in-place layout only: the first observation of every look-ahead level, written by the generator
     uint8_t* pending;     // [NWIN][n]  per window buffer: slots consumed by env in the window (0 = not in the window)
     uint8_t* first_slot;  // [NWIN][n]  first slot the env freed in the window
-    uint32_t* win_meta;   // [NWIN][META_U32] one 128-byte line per window buffer (k_gate / k_window_close / k_pregen)
+    uint32_t* win_meta;   // [NWIN][META_U32] one 128-byte line per window buffer (k_gate; the consume paths' atomicMax)
     unsigned long long* totals;   // [SHARDS][SHARD_U64] resets so far, sharded over cache lines (sum = bbai_reset_count)
-    unsigned long long* flow;     // [FLOW_WORDS] refilled windows, gate time-outs, total at the last window close, generator give-ups
+    unsigned long long* flow;     // [FLOW_WORDS] refilled windows, gate time-outs, generator give-ups
+    int32_t* gen_list;    // [SHARDS][gen_sublist_cap(n)] the refill's work list (look-ahead stream only): k_compact -> k_pregen
+    uint32_t* gen_count;  // [SHARDS][GEN_COUNT_U32] its sub-list lengths
     int32_t* reset_list;  // [n]     unfused consume only: envs finished by the current step (k_step<.., 0> -> k_consume / k_tokens)
     uint8_t* reset_slot;  // [n]     ... and the look-ahead slot each of them consumes (spares k_consume one dependent round trip)
     uint32_t* counters;   // [2][16] [p][0] = reset list length; ping-pong by step parity so that k_consume can zero the
@@ -113,6 +115,9 @@ struct bbai_env {
     bool next_counter_clean;
     uint8_t* tokens;      // optional caller-owned [n][72] mission token buffer kept current on resets
     hipStream_t side;     // look-ahead generation stream
+    hipStream_t split;    // bbai_step_render: the second half-batch's k_step runs here, under the first half's render
+    hipEvent_t ev_split0, ev_splitB;
+    int step_render_split;   // BBAI_STEP_RENDER_SPLIT / option "step_render_split": 1 = split (from STEP_RENDER_SPLIT_MIN envs), 0 = never, -1 = default
     hipEvent_t ev_consumed;
     hipEvent_t ev_refill[NWIN];     // recorded behind every window's refill; only waited for in strict mode (below) -- k_gate reads flow[FLOW_REFILLED]
     int gate_strict;      // BBAI_GATE_STRICT / option "gate_strict": 1 = rounds 1-4's rule as well: the stream waits (an event) for the refill of window
@@ -125,7 +130,8 @@ struct bbai_env {
     int render_group;     // BBAI_RENDER_GROUP: 2, 4 or 8 envs per one-shot render block; anything else = by batch size (bbai_render)
     int pregen_cap;       // BBAI_PREGEN_BLOCKS: upper bound on look-ahead lane groups per launch (experiments)
     int pregen_min;       // BBAI_PREGEN_MIN / option "pregen_min": single-room levels: lane groups that work on a refill at least (k_pregen: entries / 32 otherwise); 0 = the whole grid, as mazes always get
-    int pregen_group;     // BBAI_PREGEN_GROUP: lanes per env in k_pregen: 32 (default: two envs per wave), 16 or 64
+    int pregen_group;     // BBAI_PREGEN_GROUP: lanes per env in k_pregen: 32 (two envs per wave), 16, 64, or 1 = lane per env (GroupCtx<1>)
+    uint8_t* lane_scratch;   // pregen_group == 1: one GenWork per thread of the largest k_pregen grid (LANE_CAP threads); allocated on first use
     int step_prio;        // BBAI_STEP_PRIO: s_setprio level of the step-path kernels' waves (they share CUs with k_pregen)
     // optional per-kernel timing (bbai_profile): HIP event pairs on the launch stream around k_step / k_consume / k_render
     bool prof_on;
@@ -170,8 +176,13 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // Rounds 1-4 compacted the finished envs of every tick into a window list for the refill (one RETURNING atomic per stepping wave
 // on ONE address: ~2 700 of them per step at 262 144 reset-heavy envs, served at ~11 ns each -- half of that k_step's time) and made
 // the step stream wait, at the start of window w + 2, for the refill of window w (an env MIGHT finish on every tick).  Now:
-//   * a window's refill SCANS the window's `pending` bytes (n bytes per B ticks) instead of walking a list; what a stepping wave
-//     leaves behind is one fire-and-forget add to a sharded total (SHARDS cache lines) and per-env bytes;
+//   * what a stepping wave leaves behind is one fire-and-forget add to a sharded total (SHARDS cache lines) and per-env bytes; the
+//     refill's work list is built where it costs nothing: k_compact, on the look-ahead stream in front of k_pregen, turns the window's
+//     `pending` bytes (n bytes per B ticks) into SHARDS dense sub-lists (one returning atomic per 64 envs that hold a finished one,
+//     spread over SHARDS counters), which k_pregen walks as ONE list through a prefix of the sub-counts -- the same perfectly
+//     balanced entry-per-group distribution as before.  (Letting the generator's groups scan the bytes themselves was measured
+//     first -- lease r05a: a group then finds 0 to 4 envs where its neighbour finds one, a wave lives as long as its unluckiest
+//     group, and the mazes' steps slowed by 10-30 % under the generator's idle lanes.)
 //   * every window records M = the most often ONE env finished in it (1 unless short episodes repeat inside a window: the
 //     rare atomicMax in the consume paths); an env's unrefilled slots are <= the sum of M over the windows whose refill has not
 //     landed, so window x may start as soon as that sum is <= B (every env then still has B ready levels, and a window consumes
@@ -180,11 +191,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 //     UNDER the following windows instead of stopping the step stream, as long as no env finishes B more times meanwhile.
 //   * NWIN window buffers (pending / first_slot / meta) so that up to B + 1 refills can be outstanding.
 // tests/test_ring_protocol.py models the rule (sufficient, and the ring depths stay tight).
-constexpr int META_U32 = 32;            // uint32 per window buffer's meta line: [0] = M when > 1 (atomicMax), [1] = finished envs (written at its close)
+constexpr int META_U32 = 32;            // uint32 per window buffer's meta line: [0] = M when > 1 (atomicMax)
 constexpr int SHARDS = 64;              // cache lines the reset total is spread over (k_step: shard = block & 63)
 constexpr int SHARD_U64 = 16;           // uint64 per shard: one 128-byte line each
-enum : int { FLOW_REFILLED = 0 /* windows whose refill has landed */, FLOW_GATE_TIMEOUTS = 1, FLOW_CLOSE_TOTAL = 2 /* reset total at the last window close */,
-             FLOW_GEN_FAILURES = 3 /* levels the generator gave up on */, FLOW_WORDS = 16 };
+enum : int { FLOW_REFILLED = 0 /* windows whose refill has landed */, FLOW_GATE_TIMEOUTS = 1, FLOW_GEN_FAILURES = 3 /* levels the generator gave up on */, FLOW_WORDS = 16 };
+constexpr int GEN_COUNT_U32 = 32;       // uint32 per sub-list counter of the refill list: one 128-byte line each
+__host__ __device__ __forceinline__ int64_t gen_sublist_cap(int64_t n) { return ((n + 63) / 64 + SHARDS - 1) / SHARDS * 64; }      // entries a sub-list can get: its waves x 64
 __device__ __forceinline__ void count_resets(unsigned long long* __restrict__ totals, unsigned int k) {
     atomicAdd(&totals[(blockIdx.x & (SHARDS - 1)) * SHARD_U64], (unsigned long long)k);        // (result unused: a no-return atomic)
 }
@@ -543,13 +555,13 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
                                                      int prio, uint8_t* __restrict__ vplane, uint16_t* __restrict__ fcache,
                                                      uint8_t* __restrict__ lsm_arr /* NULL, or the done-action mode's per-env bits */,
                                                      int enum_done /* done-action mode: this step's `done` actions are the enum member (bbai_step.hpp verify_side) */,
-                                                     FuseArgs fuse) {
+                                                     FuseArgs fuse, int64_t block0 /* first 64-env block of this launch (bbai_step_render steps the batch in two halves) */) {
     // the block's observation rows at the OUTPUT pitch of 147 bytes (bbai_step.hpp RowPacker), 16 bytes of front padding
     __shared__ __attribute__((aligned(16))) uint8_t s_obs[ROWS_FRONT + STEP_BLOCK * OBS_BYTES + 16];
     uint8_t* const s_rows = s_obs + ROWS_FRONT;
     if (prio) __builtin_amdgcn_s_setprio(3);            // the look-ahead generator's waves share the CUs: issue ours first
     const int lane = (int)threadIdx.x;
-    const int64_t env0 = (int64_t)blockIdx.x * STEP_BLOCK;
+    const int64_t env0 = ((int64_t)blockIdx.x + block0) * STEP_BLOCK;
     const int64_t env = env0 + lane;
     const bool active = env < n;
     bool want_reset = false;
@@ -732,15 +744,33 @@ struct GroupCtx {
     }
 };
 
+// G = 1: lane = level.  The generator's program is one SCALAR program per env (draw, test, branch, draw ...): with a lane group per env
+// every instruction of it is issued for ONE or two envs, whatever the group's width (two envs of a wave diverge almost all the time) --
+// the generator is bound by instruction issue.  With one lane per env an instruction serves every lane of the wave that
+// is at the same place of the program; the working set moves from LDS to a per-lane block of global memory (lane-private lines: L2 hits
+// for as long as the level lasts) and the MT19937 state is advanced in place.  Same templates, same draws: the host build (tests/hostsim)
+// is this very instantiation (kLanes == 1).
+template <>
+struct GroupCtx<1> {
+    static constexpr int kLanes = 1;
+    __device__ __forceinline__ int lane() const { return 0; }
+    __device__ __forceinline__ int nlanes() const { return 1; }
+    __device__ __forceinline__ void sync() const {}
+    __device__ __forceinline__ uint32_t shfl(uint32_t v, int) const { return v; }
+    __device__ __forceinline__ uint32_t shfl_up1(uint32_t) const { return 0u; }
+    __device__ __forceinline__ uint32_t shfl_down1(uint32_t) const { return 0u; }
+    __device__ __forceinline__ unsigned long long ballot(bool p) const { return p ? 1ull : 0ull; }
+    __device__ __forceinline__ bool any(bool p) const { return p; }
+};
+
 // The look-ahead generator.  A workgroup is ONE wave carrying 64 / G envs; every group walks its share of the window's `pending`
 // bytes on its own: fetch an env that has levels pending, load its MT19937 state into the
 // group's LDS block, then one ATTEMPT of the generator's rejection loop per trip of the main loop (Gen::attempt) -- a
 // group whose attempt was accepted writes the level out and goes on to its next level / env while its neighbours retry,
 // so the wave only idles lanes inside an attempt, never across attempts.
-// Work items: the pending bytes are read G at a time (one per lane: a CHUNK of G consecutive envs); a chunk is PREGEN_SPLIT items --
-// item (chunk, sub) = the chunk's pending envs at lanes == sub (mod PREGEN_SPLIT): a fixed partition, so that the byte a group
-// clears when it is done with an env changes no other group's share -- and a storm (every env pending) still spreads over
-// n * PREGEN_SPLIT / G groups, while a quiet window costs a group a few G-byte loads.
+// Work list: the window's finished envs as SHARDS dense sub-lists (k_compact); entry k of their concatenation is found through the
+// prefix of the sub-counts (64 words in LDS, a six-step search per entry: once per level, i.e. per ~50-300 us of work); groups stride
+// over the entries, so every group gets the same number of envs to within one.  `dense` (bbai_seed's first fill): every env, no list.
 // Minimum waves per SIMD the generator's register allocation has to allow.  4 (<= 128 VGPRs) instead of the 3 the compiler
 // settles on by itself (131-135 VGPRs at two envs per wave): PickupLoc 262 144 envs 0.0939 -> 0.0877 ms per step, the GoTo family
 // already fits (profiles/r04/pregen_waves_per_simd_ab.jsonl).  The bonus family would spill (167 VGPRs) and four envs per wave
@@ -748,78 +778,100 @@ struct GroupCtx {
 #ifndef BBAI_PREGEN_WAVES
 #define BBAI_PREGEN_WAVES 4
 #endif
-constexpr int PREGEN_SPLIT = 4;
 template <int KIND, int G, bool OBS /* in-place layout: the level's first observation is written next to it */>
-__global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_WAVES) void k_pregen(LevelCfg c, int64_t n, uint8_t* __restrict__ next_recs,
+__global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16 || G == 1) ? 2 : BBAI_PREGEN_WAVES) void k_pregen(LevelCfg c, int64_t n, uint8_t* __restrict__ next_recs,
                                                   Hot* __restrict__ next_hots, uint32_t* __restrict__ mts,
                                                   int32_t* __restrict__ mtis,
-                                                  const uint32_t* __restrict__ win_meta /* the window's meta line ([1] = its finished envs), or NULL: the whole grid works */,
+                                                  const int32_t* __restrict__ gen_list, const uint32_t* __restrict__ gen_count /* NULL: dense -- every env, the whole grid works */,
                                                   int depth,
                                                   uint8_t* __restrict__ pending, const uint8_t* __restrict__ first_slot,
                                                   unsigned long long* __restrict__ gen_failures, int min_groups,
-                                                  uint8_t* __restrict__ next_obs /* in-place layout: [D][n][OBS_SLOT], else NULL */) {
+                                                  uint8_t* __restrict__ next_obs /* in-place layout: [D][n][OBS_SLOT], else NULL */,
+                                                  uint8_t* __restrict__ lane_scratch /* G == 1: one GenWork per thread of the grid */) {
     constexpr int NG = 64 / G;
-    __shared__ GenWork ws[NG];
     typedef GroupCtx<G> Ctx;
     const Ctx ctx;
-    GenWork& w = ws[threadIdx.x / G];
+    GenWork* wp;
+    if constexpr (G == 1) {
+        wp = (GenWork*)lane_scratch + ((size_t)blockIdx.x * 64 + threadIdx.x);
+    } else {
+        __shared__ GenWork ws[NG];
+        __shared__ uint32_t s_mt[NG][MT_N];
+        wp = &ws[threadIdx.x / G];
+        wp->mt = s_mt[threadIdx.x / G];
+    }
+    GenWork& w = *wp;
     const int lane = ctx.lane();
+    // the refill list: prefix of the sub-list lengths (one word per lane, a wave scan, parked in LDS for the groups' searches)
+    __shared__ uint32_t s_start[SHARDS + 1];
+    int64_t count = n;
+    const int64_t cap = gen_sublist_cap(n);
+    if (gen_count) {
+        uint32_t c = gen_count[threadIdx.x * GEN_COUNT_U32], incl = c;            // (SHARDS == 64 == the block)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if ((int)threadIdx.x >= o) incl += t; }
+        s_start[threadIdx.x + 1] = incl;
+        if (threadIdx.x == 0) s_start[0] = 0;
+        __syncthreads();
+        count = (int64_t)s_start[SHARDS];
+    }
     // How many lane groups WORK on a window's refill: the grid is sized for the worst case (every env finished on every tick), the
-    // window usually holds a fraction of that, and every resident generator wave holds registers and LDS that the step kernels'
-    // workgroups queue for.  A refill has a whole window (B ticks) to land, so ~B levels per group keep pace with the
+    // list usually holds a fraction of that, and every resident generator wave holds registers and LDS that the step kernels'
+    // workgroups queue for.  A refill has a whole window (B ticks) to land, so ~B list entries per group keep pace with the
     // consumption: active = entries / 32, at least `min_groups` (the launch must not become its slowest level x a long queue),
     // at most the grid.  Measured (profiles/r04/pregen_cap_priority_group_ab.jsonl, groups in flight 32 768 -> 4 096 / 2 048):
     // PickupLoc 262 144 envs 0.0870 -> 0.0811 ms per step, GoToLocal 65 536 0.0371 -> 0.0342; 1 024 / 512 groups: 0.209 / 0.092 --
     // the generator no longer keeps up and the step stream waits.  Surplus blocks leave at once.
     int64_t stride = (int64_t)gridDim.x * NG;
-    if (win_meta && min_groups > 0) {
-        int64_t active = (int64_t)win_meta[1] / MAX_PERIOD;
+    if (gen_count && min_groups > 0) {
+        int64_t active = count / MAX_PERIOD;
         active = active < min_groups ? min_groups : active;
         active = (active + NG - 1) / NG * NG;                   // whole blocks: every group of a block that stays has its own residue
         stride = active < stride ? active : stride;
     }
-    const int64_t nitems = (n + G - 1) / G * PREGEN_SPLIT;
     int64_t it = (int64_t)blockIdx.x * NG + threadIdx.x / G;
     if ((int64_t)blockIdx.x * NG >= stride) return;             // (whole blocks only: the groups of a wave stay together)
-    // the group's current item (the envs of its chunk that are still to do) and env
-    unsigned long long todo = 0;
-    int64_t chunk_base = 0;
-    int pc_mine = 0;
+    // the group's current env
     bool have = false;
     int64_t env = 0;
     int cnt = 0, done_levels = 0, slot = 0, mti = 0, last_locked = -1, attempts = 0;
     for (;;) {
         if (!have) {
-            for (;;) {
-                if (todo) {
-                    const int b = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1;
-                    env = chunk_base + b;
-                    cnt = (int)ctx.shfl((uint32_t)pc_mine, b);      // levels to generate for this env (consecutive ring slots)
-                    have = true;
-                    break;
+            while (it < count) {
+                int64_t cand = it;
+                if (gen_count) {
+                    // entry `it` of the concatenated sub-lists: the sub-list j with s_start[j] <= it < s_start[j + 1]
+                    int j = 0;
+#pragma unroll
+                    for (int o = SHARDS / 2; o; o >>= 1) if ((int64_t)s_start[j + o] <= it) j += o;
+                    cand = (int64_t)gen_list[(int64_t)j * cap + (it - (int64_t)s_start[j])];
                 }
-                if (it >= nitems) break;
-                const int sub = (int)(it % PREGEN_SPLIT);
-                chunk_base = it / PREGEN_SPLIT * G;
                 it += stride;
-                pc_mine = chunk_base + lane < n ? (int)pending[chunk_base + lane] : 0;
-                todo = ctx.ballot(pc_mine != 0 && lane % PREGEN_SPLIT == sub);
+                const int pc = pending[cand];            // levels to generate for this env (consecutive ring slots)
+                if (pc == 0) continue;                   // (dense: env was not consumed in this window)
+                env = cand; cnt = pc; have = true;
+                break;
             }
             if (have) {
                 // the env's generator state: all of its loads in flight together (MT19937 words, position, first slot) -- as a
                 // load - store loop this was five dependent round trips before the first draw
-                const uint32_t* mt = mts + env * MT_N;
-                constexpr int MTQ = (MT_N + G - 1) / G;
-                uint32_t mtw[MTQ];
+                if constexpr (G == 1) {
+                    w.mt = mts + env * MT_N;                  // advanced in place
+                    mti = mtis[env];
+                    slot = first_slot[env];
+                } else {
+                    const uint32_t* mt = mts + env * MT_N;
+                    constexpr int MTQ = (MT_N + G - 1) / G;
+                    uint32_t mtw[MTQ];
 #pragma unroll
-                for (int q = 0; q < MTQ; ++q) { const int k = lane + q * G; mtw[q] = mt[k < MT_N ? k : MT_N - 1]; }
-                mti = mtis[env];
-                slot = first_slot[env];
-                ctx.sync();
+                    for (int q = 0; q < MTQ; ++q) { const int k = lane + q * G; mtw[q] = mt[k < MT_N ? k : MT_N - 1]; }
+                    mti = mtis[env];
+                    slot = first_slot[env];
+                    ctx.sync();
 #pragma unroll
-                for (int q = 0; q < MTQ; ++q) { const int k = lane + q * G; if (k < MT_N) w.mt[k] = mtw[q]; }
-                ctx.sync();
+                    for (int q = 0; q < MTQ; ++q) { const int k = lane + q * G; if (k < MT_N) w.mt[k] = mtw[q]; }
+                    ctx.sync();
+                }
                 const int prev = slot == 0 ? depth - 1 : slot - 1;          // holds the level generated just before
                 last_locked = next_hots[ring_at(prev, env, depth)].last_locked;   // LevelGen.locked_room survives episodes
                 last_locked = last_locked == NONE8 ? -1 : last_locked;
@@ -871,9 +923,36 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
             // in LDS.  Lane l of the group takes view cells l, l + G, ...: cell = vi + 7 vj; the opacity mask of the view is the
             // group's share of a ballot per round; every lane runs the 7-row visibility sweep and writes its cells' three bytes
             // (the layout observe_emit writes: cell (vi, vj) at byte (7 vi + vj) * 3; the agent's own cell shows what it carries: nothing yet).
+            uint8_t* ob = next_obs + ring_at(slot, env, depth) * OBS_SLOT;
+            if constexpr (G == 1) {
+                // lane = level: the 49 cells one after the other, twice (opacity mask, then the bytes) -- rolled loops, a handful of registers
+                unsigned long long opaque = 0;
+#pragma unroll 1
+                for (int cell = 0; cell < VIEW * VIEW; ++cell) {
+                    int x, y;
+                    view_to_world(g.ax, g.ay, g.adir, cell % VIEW, cell / VIEW, x, y);
+                    if (e_opaque(w.E[(y + MARGIN) * c.ES + (x + MARGIN)])) opaque |= 1ull << cell;
+                }
+                uint32_t opq[VIEW], vis[VIEW];
+#pragma unroll
+                for (int r = 0; r < VIEW; ++r) opq[r] = (uint32_t)(opaque >> (VIEW * r)) & 0x7Fu;
+                process_vis_rows(opq, vis);
+                unsigned long long visible = 0;
+#pragma unroll
+                for (int r = 0; r < VIEW; ++r) visible |= (unsigned long long)(vis[r] & 0x7Fu) << (VIEW * r);
+#pragma unroll 1
+                for (int cell = 0; cell < VIEW * VIEW; ++cell) {
+                    const int vi = cell % VIEW, vj = cell / VIEW;
+                    int x, y;
+                    view_to_world(g.ax, g.ay, g.adir, vi, vj, x, y);
+                    const int e = (vi == 3 && vj == 6) ? (int)E_EMPTY : (int)w.E[(y + MARGIN) * c.ES + (x + MARGIN)];
+                    const bool v = visible >> cell & 1;
+                    uint8_t* o = ob + (vi * VIEW + vj) * 3;
+                    o[0] = v ? e_type(e) : 0; o[1] = v ? e_color(e) : 0; o[2] = v ? e_state(e) : 0;
+                }
+            } else {
             constexpr int R = (VIEW * VIEW + G - 1) / G;
             constexpr unsigned long long GM = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
-            uint8_t* ob = next_obs + ring_at(slot, env, depth) * OBS_SLOT;
             int ec[R];
             unsigned long long opaque = 0;
             ctx.sync();
@@ -908,6 +987,7 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
                     o[0] = v ? e_type(e) : 0; o[1] = v ? e_color(e) : 0; o[2] = v ? e_state(e) : 0;
                 }
             }
+            }
         }
         if (lane == 0) {
             Hot h;
@@ -926,9 +1006,11 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
         slot = slot + 1 == depth ? 0 : slot + 1;
         attempts = 0;
         if (++done_levels == cnt) {                      // this env's levels are done: MT state back, buffer entry free
-            uint32_t* mt = mts + env * MT_N;
-            ctx.sync();
-            for (int k = lane; k < MT_N; k += G) mt[k] = w.mt[k];
+            if constexpr (G != 1) {
+                uint32_t* mt = mts + env * MT_N;
+                ctx.sync();
+                for (int k = lane; k < MT_N; k += G) mt[k] = w.mt[k];
+            }
             if (lane == 0) {
                 mtis[env] = mti;
                 pending[env] = 0;                        // buffer entry is free for a later window
@@ -967,18 +1049,23 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
     }
 }
 
-// ---- window turnover (NWIN above): three one-wave kernels per window of B ticks --------------------------------------------------
-// k_window_close, step stream, behind the window's last tick: the window's number of finished envs (what its refill is sized by) =
-// the sharded reset total now - the total at the previous close.
-__global__ __launch_bounds__(64) void k_window_close(const unsigned long long* __restrict__ totals, uint32_t* __restrict__ meta, unsigned long long* __restrict__ flow) {
-    unsigned long long t = totals[threadIdx.x * SHARD_U64];          // (SHARDS == 64: one shard per lane)
-#pragma unroll
-    for (int o = 32; o; o >>= 1) t += __shfl_xor(t, o);
-    if (threadIdx.x == 0) {
-        const unsigned long long before = flow[FLOW_CLOSE_TOTAL];
-        meta[1] = (uint32_t)(t - before < 0xFFFFFFFFull ? t - before : 0xFFFFFFFFull);
-        flow[FLOW_CLOSE_TOTAL] = t;
-    }
+// ---- window turnover (NWIN above) ------------------------------------------------------------------------------------------------
+// k_compact, look-ahead stream, in front of the window's k_pregen: the envs whose `pending` byte is set, as SHARDS dense sub-lists.  Wave
+// w covers envs [64 w, 64 w + 64) and appends to sub-list w % SHARDS: one returning atomic per wave that found any, spread over SHARDS
+// counters (1 048 576 envs, every one pending: 256 per counter) -- off the step path, a few microseconds per window.
+__global__ __launch_bounds__(256) void k_compact(int64_t n, const uint8_t* __restrict__ pending, int32_t* __restrict__ gen_list, uint32_t* __restrict__ gen_count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t env = wave * 64 + lane;
+    const bool mine = env < n && pending[env] != 0;
+    const unsigned long long bal = __ballot(mine);
+    if (!bal) return;
+    const int j = (int)(wave % SHARDS);
+    const int leader = __ffsll((long long)bal) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&gen_count[j * GEN_COUNT_U32], (uint32_t)__popcll(bal));
+    base = __shfl(base, leader);
+    if (mine) gen_list[(int64_t)j * gen_sublist_cap(n) + base + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)env;
 }
 // k_mark, look-ahead stream, behind the refill of window w: `refilled` = w + 1.  (A kernel of its own: the refill's stores are visible to
 // whoever sees this value because that kernel has ENDED -- no fence inside the generator's waves.)
@@ -1449,6 +1536,8 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->win_meta, NWIN * META_U32 * 4);
     alloc((void**)&e->totals, SHARDS * SHARD_U64 * 8);
     alloc((void**)&e->flow, FLOW_WORDS * 8);
+    alloc((void**)&e->gen_list, (size_t)SHARDS * (size_t)gen_sublist_cap(n_envs) * 4);
+    alloc((void**)&e->gen_count, SHARDS * GEN_COUNT_U32 * 4);
     {
         // BBAI_INPLACE: 1 / 0 force the in-place layout (live_slot above) on / off; default: by level family and batch size
         const char* iv = getenv("BBAI_INPLACE");
@@ -1557,6 +1646,9 @@ static int create_finish(bbai_env* e) {
         const char* pv = getenv("BBAI_PREGEN_PRIORITY");     // 1 (default): highest priority, 0: default priority
         HIP_TRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, (pv && atoi(pv) == 0) ? lo : hi));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_consumed, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&e->split, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_split0, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_splitB, hipEventDisableTiming));
         for (int k = 0; k < NWIN; ++k) HIP_TRY(hipEventCreateWithFlags(&e->ev_refill[k], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_switch, hipEventDisableTiming));
     }
@@ -1577,6 +1669,8 @@ static int create_finish(bbai_env* e) {
         e->render_queue = qv ? atoi(qv) : -1;
         const char* pv2 = getenv("BBAI_RENDER_PACE");
         e->render_pace = pv2 ? std::max(0, atoi(pv2)) : 0;
+        const char* ss = getenv("BBAI_STEP_RENDER_SPLIT");
+        e->step_render_split = ss ? atoi(ss) : -1;
         const char* gs = getenv("BBAI_GATE_STRICT");
         e->gate_strict = gs ? atoi(gs) != 0 : 0;
         const char* cf = getenv("BBAI_CONSUME_FUSED");
@@ -1594,13 +1688,16 @@ void bbai_destroy(bbai_env* e) {
     DeviceGuard guard_(e->device);
     (void)hipDeviceSynchronize();
     if (e->side) (void)hipStreamDestroy(e->side);
+    if (e->split) (void)hipStreamDestroy(e->split);
+    if (e->ev_split0) (void)hipEventDestroy(e->ev_split0);
+    if (e->ev_splitB) (void)hipEventDestroy(e->ev_splitB);
     if (e->ev_consumed) (void)hipEventDestroy(e->ev_consumed);
     if (e->ev_switch) (void)hipEventDestroy(e->ev_switch);
     for (int k = 0; k < NWIN; ++k) if (e->ev_refill[k]) (void)hipEventDestroy(e->ev_refill[k]);
     for (int k = 0; k < 3; ++k) for (int i = 0; i < PROF_RING; ++i) if (e->prof[k][i].a) { (void)hipEventDestroy(e->prof[k][i].a); (void)hipEventDestroy(e->prof[k][i].b); }
-    void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
+    void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows, e->lane_scratch};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
-    void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_meta, e->totals, e->flow, e->reset_list, e->counters,
+    void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_meta, e->totals, e->flow, e->gen_list, e->gen_count, e->reset_list, e->counters,
                     e->atlas, e->lut, e->vplane, e->fcache, e->lsm, e->render_tickets, e->reset_slot, e->next_obs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete e;
@@ -1610,38 +1707,45 @@ void bbai_destroy(bbai_env* e) {
 
 // k_pregen is instantiated per level family so that a launch carries only that family's mission code, and per group
 // width G (envs per wave = 64 / G; BBAI_PREGEN_GROUP, default 32: two envs per wave)
+constexpr int64_t LANE_CAP = 262144;       // lane = level: threads of the largest generator grid (4 096 waves: four per SIMD of the part)
 template <int G>
-static void launch_pregen_g(const bbai_env* e, unsigned groups, const uint32_t* win_meta /* NULL: the whole grid works */, uint8_t* pending, const uint8_t* first_slot) {
+static void launch_pregen_g(const bbai_env* e, unsigned groups, bool listed /* false: dense -- every env, the whole grid works */, uint8_t* pending, const uint8_t* first_slot) {
     unsigned long long* fails = e->flow + FLOW_GEN_FAILURES;
     const dim3 g((groups + 64 / G - 1) / (64 / G)), b(64);
     // Demand-sized groups only where a level is cheap (single rooms, <= 60 us per group): a maze level costs a group ~300 us,
     // and GoTo at 131 072 envs stalls the step stream with 4 entries per group (0.0534 vs 0.0385 ms per step,
     // profiles/r04/pregen_min_ab.jsonl) -- mazes keep the whole grid.
-    const int min_groups = e->cfg.num_rows * e->cfg.num_cols > 1 ? 0 : e->pregen_min;
-#define PREGEN_LAUNCH(KK, OO) hipLaunchKernelGGL((k_pregen<KK, G, OO>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, win_meta, \
-                                                e->depth, pending, first_slot, fails, min_groups, e->next_obs)
+    const int min_groups = (G == 1 || e->cfg.num_rows * e->cfg.num_cols > 1) ? 0 : e->pregen_min;      // (lane = level: one entry per lane, all at once)
+#define PREGEN_LAUNCH(KK, OO) hipLaunchKernelGGL((k_pregen<KK, G, OO>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, e->gen_list, \
+                                                listed ? e->gen_count : nullptr, e->depth, pending, first_slot, fails, min_groups, e->next_obs, e->lane_scratch)
     if (e->cfg.kind == K_LEVELGEN) { if (e->next_obs) PREGEN_LAUNCH(K_LEVELGEN, true); else PREGEN_LAUNCH(K_LEVELGEN, false); }
     else if (e->cfg.kind == K_BONUS) { if (e->next_obs) PREGEN_LAUNCH(K_BONUS, true); else PREGEN_LAUNCH(K_BONUS, false); }
     else { if (e->next_obs) PREGEN_LAUNCH(K_GOTO, true); else PREGEN_LAUNCH(K_GOTO, false); }
 #undef PREGEN_LAUNCH
 }
-static void launch_pregen(const bbai_env* e, unsigned groups, const uint32_t* win_meta, uint8_t* pending, const uint8_t* first_slot) {
+static void launch_pregen(const bbai_env* e, unsigned groups, bool listed, uint8_t* pending, const uint8_t* first_slot) {
     // Measured (profiles/r03/gen_rate_by_group_width.jsonl, pregen_group_width_in_bench.jsonl): levels per second of a bulk
     // fill 64 -> 32 -> 16 lanes per env: BossLevel 1 : 1.16 : 1.18, GoTo 1 : 1.13 : 1.17, PickupLoc 1 : 1.20 : 1.27,
     // GoToLocal 1 : 1.25 : 1.36; inside the step loop 32 is never behind 64 (GoToLocal 65 536 envs -3 %, PickupLoc 262 144
     // -6 %, GoTo 131 072 +-0) while 16 costs the step kernels of GoTo 131 072 9 % (fewer, fatter generator waves next to
     // them: 200 VGPRs and 20 KB of LDS each).
-    if (e->pregen_group == 64) launch_pregen_g<64>(e, groups, win_meta, pending, first_slot);
-    else if (e->pregen_group == 16) launch_pregen_g<16>(e, groups, win_meta, pending, first_slot);
-    else launch_pregen_g<32>(e, groups, win_meta, pending, first_slot);
+    if (e->pregen_group == 1) launch_pregen_g<1>(e, groups, listed, pending, first_slot);
+    else if (e->pregen_group == 64) launch_pregen_g<64>(e, groups, listed, pending, first_slot);
+    else if (e->pregen_group == 16) launch_pregen_g<16>(e, groups, listed, pending, first_slot);
+    else launch_pregen_g<32>(e, groups, listed, pending, first_slot);
 }
 
 extern "C" {
 
 static unsigned pregen_grid(const bbai_env* e, int64_t count_hint) {
-    // one lane group per env, capped at pregen_cap groups in flight (the rest is reached by the groups' strides)
-    int64_t g = std::min<int64_t>(count_hint, e->pregen_cap);
+    // one lane group per env, capped at pregen_cap groups in flight (the rest is reached by the groups' strides); lane = level: LANE_CAP lanes
+    int64_t g = std::min<int64_t>(count_hint, e->pregen_group == 1 ? LANE_CAP : (int64_t)e->pregen_cap);
     return (unsigned)std::max<int64_t>(g, 1);
+}
+static int ensure_lane_scratch(bbai_env* e) {
+    if (e->pregen_group != 1 || e->lane_scratch) return BBAI_OK;
+    HIP_TRY(hipMalloc((void**)&e->lane_scratch, (size_t)LANE_CAP * sizeof(GenWork)));
+    return BBAI_OK;
 }
 
 // A handle's launches are ordered by ONE caller stream at a time (plus the private look-ahead stream, which is tied to
@@ -1738,14 +1842,15 @@ static int window_end(bbai_env* e, hipStream_t s, int tokens_mode /* k_tokens: 0
     }
     HIP_TRY(hipGetLastError());
     if (pos == B - 1) {
-        // Window end: its count, then one refill launch for everything consumed in it, on the look-ahead stream, and the mark behind it.
+        // Window end, on the look-ahead stream: the window's work list (k_compact), one refill launch for everything consumed in it, the mark behind it.
         const int64_t w = e->tick / B;
-        uint32_t* meta = e->win_meta + (size_t)wb * META_U32;
-        hipLaunchKernelGGL(k_window_close, dim3(1), dim3(64), 0, s, e->totals, meta, e->flow);
         HIP_TRY(hipEventRecord(e->ev_consumed, s));
         HIP_TRY(hipStreamWaitEvent(e->side, e->ev_consumed, 0));
+        { int rc = ensure_lane_scratch(e); if (rc != BBAI_OK) return rc; }
+        HIP_TRY(hipMemsetAsync(e->gen_count, 0, SHARDS * GEN_COUNT_U32 * 4, e->side));
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->side, e->n, e->pending + (size_t)wb * e->n, e->gen_list, e->gen_count);
         const int64_t rh = std::max<int64_t>((int64_t)B * (e->n / 64), 64);
-        launch_pregen(e, pregen_grid(e, rh), meta, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n);
+        launch_pregen(e, pregen_grid(e, rh), true, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n);
         hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, e->side, e->flow, (unsigned long long)(w + 1));
         HIP_TRY(hipEventRecord(e->ev_refill[wb], e->side));
         HIP_TRY(hipGetLastError());
@@ -1785,21 +1890,16 @@ int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
     HIP_TRY(hipMemsetAsync(e->pending, 0, NWIN * (size_t)n, e->side));
     HIP_TRY(hipMemsetAsync(e->first_slot, 0, NWIN * (size_t)n, e->side));
     HIP_TRY(hipMemsetAsync(e->pending, e->depth - e->inplace, (size_t)n, e->side));      // (in-place: slot depth - 1 is the live one -- empty until the first reset)
-    launch_pregen(e, pregen_grid(e, n), nullptr, e->pending, e->first_slot);
+    { int rc = ensure_lane_scratch(e); if (rc != BBAI_OK) return rc; }
+    launch_pregen(e, pregen_grid(e, n), false, e->pending, e->first_slot);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(e->win_meta, 0, NWIN * META_U32 * 4, e->side));
     HIP_TRY(hipMemsetAsync(e->vset, 0, (size_t)n * 64, e->side));
     HIP_TRY(hipMemsetAsync(e->counters, 0, 128, e->side));
-    {   // the flow words start over (window numbering restarts with tick 0); the reset total and the give-up count keep running
-        unsigned long long total = 0;
+    {   // the refill count starts over (window numbering restarts with tick 0); the reset total, the give-up and the time-out counts keep running
         HIP_TRY(hipDeviceSynchronize());
-        unsigned long long shards[SHARDS * SHARD_U64];
-        HIP_TRY(hipMemcpy(shards, e->totals, sizeof(shards), hipMemcpyDeviceToHost));
-        for (int k = 0; k < SHARDS; ++k) total += shards[k * SHARD_U64];
-        unsigned long long fl[FLOW_WORDS];
-        HIP_TRY(hipMemcpy(fl, e->flow, sizeof(fl), hipMemcpyDeviceToHost));
-        fl[FLOW_REFILLED] = 0; fl[FLOW_CLOSE_TOTAL] = total;
-        HIP_TRY(hipMemcpy(e->flow, fl, sizeof(fl), hipMemcpyHostToDevice));
+        const unsigned long long zero = 0;
+        HIP_TRY(hipMemcpy(e->flow + FLOW_REFILLED, &zero, 8, hipMemcpyHostToDevice));
     }
     for (int k = 0; k < NWIN; ++k) HIP_TRY(hipEventRecord(e->ev_refill[k], e->side));
     e->tick = 0;
@@ -1836,14 +1936,17 @@ static bool use_fused_consume(const bbai_env* e) {
     // other behind their own step, where k_consume's waves do them all at once.
     return e->cfg.num_rows * e->cfg.num_cols > 1;
 }
-static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64,
-                       uint8_t* dones, int auto_reset, hipStream_t s, int enum_done) {
-    const bool fused = auto_reset && (e->inplace || use_fused_consume(e));
-    int32_t* list = e->reset_list;
-    uint32_t* counter = e->counters + 16 * e->step_parity;
-    FuseArgs fa;
-    memset(&fa, 0, sizeof(fa));
-    if (fused) {
+// One step in three parts, so that bbai_step_render can put the kernel of the batch's second half on another stream:
+//   step_prepare  the window gate (fused: the slots this step's waves consume must be there) + what the kernel needs to know about the window
+//   step_kernel   k_step over the 64-env blocks [block0, block0 + nblocks) on stream `ks`
+//   step_finish   k_consume (unfused) / mission tokens / the window's close + refill -- on the caller's stream, behind EVERY k_step of the step
+struct StepPlan { FuseArgs fa; bool fused; uint32_t* counter; };
+static int step_prepare(bbai_env* e, int auto_reset, hipStream_t s, StepPlan& p) {
+    p.fused = auto_reset && (e->inplace || use_fused_consume(e));
+    p.counter = e->counters + 16 * e->step_parity;
+    memset(&p.fa, 0, sizeof(p.fa));
+    FuseArgs& fa = p.fa;
+    if (p.fused) {
         { int rc = window_begin(e, s); if (rc != BBAI_OK) return rc; }        // the slots this step's waves consume have landed
         const TickPos tp = tick_pos(e);
         fa.next_recs = e->next_rec; fa.next_hots = e->next_hot; fa.next_obs = e->next_obs; fa.depth = e->depth;
@@ -1853,25 +1956,38 @@ static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint
         e->next_counter_clean = false;      // (a later unfused step clears its ping-pong counter itself)
     } else if (e->inplace) {                // (no auto-reset: the kernel still finds the live records through the ring)
         fa.next_recs = e->next_rec; fa.depth = e->depth;
-        if (!e->next_counter_clean) HIP_TRY(hipMemsetAsync(counter, 0, 4, s));
+        if (!e->next_counter_clean) HIP_TRY(hipMemsetAsync(p.counter, 0, 4, s));
         e->next_counter_clean = false;
     } else {
-        if (!e->next_counter_clean) HIP_TRY(hipMemsetAsync(counter, 0, 4, s));   // (k_consume of the previous step zeroes it)
+        if (!e->next_counter_clean) HIP_TRY(hipMemsetAsync(p.counter, 0, 4, s));   // (k_consume of the previous step zeroes it)
         e->next_counter_clean = false;
     }
-    {
-        ProfScope prof_(e, 0, s);
-#define STEP_LAUNCH(VV, FF) hipLaunchKernelGGL((k_step<VV, FF>), dim3((unsigned)((e->n + STEP_BLOCK - 1) / STEP_BLOCK)), dim3(STEP_BLOCK), 0, s, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, \
-                                           image, dirs, rewards, rewards64, dones, auto_reset, list, e->reset_slot, counter, e->step_prio, e->vplane, e->fcache, e->lsm, enum_done, fa)
-        if (e->inplace) STEP_LAUNCH(false, 3);
-        else if (fused) { if (e->vplane) STEP_LAUNCH(true, 1); else STEP_LAUNCH(false, 1); }
-        else { if (e->vplane) STEP_LAUNCH(true, 0); else STEP_LAUNCH(false, 0); }
-#undef STEP_LAUNCH
-    }
-    HIP_TRY(hipGetLastError());
-    // the number of finished envs is only known on the device: fixed grids, device-side count
-    if (auto_reset) { int rc = fused ? window_end(e, s, 2, dones) : consume_and_refill(e, s, image, dirs, 0); if (rc != BBAI_OK) return rc; }
     return BBAI_OK;
+}
+static int step_kernel(bbai_env* e, const StepPlan& p, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64,
+                       uint8_t* dones, int auto_reset, hipStream_t ks, int enum_done, int64_t block0, int64_t nblocks) {
+    ProfScope prof_(e, 0, ks);
+#define STEP_LAUNCH(VV, FF) hipLaunchKernelGGL((k_step<VV, FF>), dim3((unsigned)nblocks), dim3(STEP_BLOCK), 0, ks, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, \
+                                           image, dirs, rewards, rewards64, dones, auto_reset, e->reset_list, e->reset_slot, p.counter, e->step_prio, e->vplane, e->fcache, e->lsm, enum_done, p.fa, block0)
+    if (e->inplace) STEP_LAUNCH(false, 3);
+    else if (p.fused) { if (e->vplane) STEP_LAUNCH(true, 1); else STEP_LAUNCH(false, 1); }
+    else { if (e->vplane) STEP_LAUNCH(true, 0); else STEP_LAUNCH(false, 0); }
+#undef STEP_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return BBAI_OK;
+}
+static int step_finish(bbai_env* e, const StepPlan& p, uint8_t* image, uint8_t* dirs, const uint8_t* dones, int auto_reset, hipStream_t s) {
+    // the number of finished envs is only known on the device: fixed grids, device-side count
+    if (auto_reset) return p.fused ? window_end(e, s, 2, dones) : consume_and_refill(e, s, image, dirs, 0);
+    return BBAI_OK;
+}
+static int64_t step_blocks(const bbai_env* e) { return (e->n + STEP_BLOCK - 1) / STEP_BLOCK; }
+static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64,
+                       uint8_t* dones, int auto_reset, hipStream_t s, int enum_done) {
+    StepPlan p;
+    { int rc = step_prepare(e, auto_reset, s, p); if (rc != BBAI_OK) return rc; }
+    { int rc = step_kernel(e, p, actions, image, dirs, rewards, rewards64, dones, auto_reset, s, enum_done, 0, step_blocks(e)); if (rc != BBAI_OK) return rc; }
+    return step_finish(e, p, image, dirs, dones, auto_reset, s);
 }
 
 int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64,
@@ -1909,9 +2025,10 @@ int bbai_set_atlas(bbai_env* e, const uint8_t* tiles, int n_tiles, const uint8_t
 // moved from 10.8 to 11.4 ns between boxes and between two processes on one box, an idle chip puts it elsewhere than the loop does
 // (a first-render tuner), and a perturb-and-observe controller on the launches' own durations paid more for its event pairs and its
 // hovering than it gained.  The one counter's 1.50 ms is the same on all of them: it ships; the gate stays as a knob.
-static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, void* stream) {
+static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, void* stream, int64_t n_render = -1 /* envs input / pixels hold (default: the batch); the shape follows the BATCH size */) {
     CallScope call(e, (hipStream_t)stream);
     if (call.rc != BBAI_OK) return call.rc;
+    const int64_t nr = n_render < 0 ? e->n : n_render;
     {
     ProfScope prof_(e, 2, (hipStream_t)stream);
     // From 262 144 envs up: k_render_q -- ONE persistent 1024-thread block per CU, 8-env groups handed out by ONE ticket
@@ -1941,10 +2058,10 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
     if (qm > 0) {
         const int cus = e->n_cus > 0 ? e->n_cus : 256;
 #define RENDER_Q(GG, TT, NC, KK) do { \
-            const int64_t tickets = ((e->n + GG - 1) / GG + KK - 1) / KK; \
+            const int64_t tickets = ((nr + GG - 1) / GG + KK - 1) / KK; \
             const int64_t want = e->render_queue_blocks > 0 ? e->render_queue_blocks : (e->render_queue_bpc > 0 ? (int64_t)cus * e->render_queue_bpc : (int64_t)cus * 1024 / TT); \
             const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, tickets)); \
-            hipLaunchKernelGGL((k_render_q<GG, TT, NC, KK>), dim3(blocks), dim3(TT), 0, (hipStream_t)stream, e->n, input, pixels, \
+            hipLaunchKernelGGL((k_render_q<GG, TT, NC, KK>), dim3(blocks), dim3(TT), 0, (hipStream_t)stream, nr, input, pixels, \
                                e->atlas, e->lut, e->n_tiles, e->render_tickets, pace); } while (0)
         switch (qm) {          // (shapes other than 1 stay for measurements: tests/test_gpu_parity.py checks every one byte for byte)
         default:
@@ -1969,8 +2086,8 @@ static int render_launch(bbai_env* e, const uint8_t* input, uint8_t* pixels, voi
     int G = e->render_group, T = e->render_tpb;
     if (G != 2 && G != 4 && G != 8) G = big ? 8 : 2;
     if (T != 256 && T != 512 && T != 1024) T = big ? 1024 : 512;
-    const dim3 grid((unsigned)((e->n + G - 1) / G));
-#define RENDER_LAUNCH(GG, TT) hipLaunchKernelGGL((k_render<GG, TT>), grid, dim3(TT), 0, (hipStream_t)stream, e->n, input, pixels, e->atlas, e->lut, e->n_tiles)
+    const dim3 grid((unsigned)((nr + G - 1) / G));
+#define RENDER_LAUNCH(GG, TT) hipLaunchKernelGGL((k_render<GG, TT>), grid, dim3(TT), 0, (hipStream_t)stream, nr, input, pixels, e->atlas, e->lut, e->n_tiles)
 #define RENDER_G(GG) do { if (T == 1024) RENDER_LAUNCH(GG, 1024); else if (T == 512) RENDER_LAUNCH(GG, 512); else RENDER_LAUNCH(GG, 256); } while (0)
     if (G == 2) RENDER_G(2); else if (G == 4) RENDER_G(4); else RENDER_G(8);
 #undef RENDER_G
@@ -1987,6 +2104,68 @@ int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream
     if (e->n_tiles <= 0) { snprintf(g_err, sizeof(g_err), "render before set_atlas"); return BBAI_ERR_STATE; }
     ON_DEVICE(e->device);
     return render_launch(e, image, pixels, stream);
+}
+
+}  // extern "C"
+
+// step + render of a pixel batch as ONE call.  The render is a pure store stream at the chip's fill rate (k_render_q: 1.50 ms per
+// 1 048 576 envs) and k_step (0.10 ms) runs in FRONT of it with the store pipes idle -- 6 % of the headline step.  Split: the batch is
+// stepped in two halves; the second half's k_step goes to a stream of its own and runs UNDER the first half's render (the render's blocks hold
+// 56 VGPRs and 20 KB of LDS per CU: room for k_step's waves next to them):
+//     caller's stream:  gate . k_step(A) . k_render(A) ........ [wait B] . tokens / window close . k_render(B)
+//     split stream:             k_step(B) ........
+// Same kernels, same bytes (tests/test_gpu_parity.py::test_step_render_split_*).  Only with the fused / in-place consume (a k_consume launch
+// would need both halves) and from STEP_RENDER_SPLIT_MIN envs; option "step_render_split" (1 / 0; -1 = STEP_RENDER_SPLIT_DEFAULT).
+constexpr int64_t STEP_RENDER_SPLIT_MIN = 262144;
+#ifndef STEP_RENDER_SPLIT_DEFAULT
+#define STEP_RENDER_SPLIT_DEFAULT 0
+#endif
+static int step_render_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64, uint8_t* dones,
+                              int auto_reset, uint8_t* pixels, hipStream_t s, int enum_done) {
+    StepPlan p;
+    {
+        CallScope call(e, s);
+        if (call.rc != BBAI_OK) return call.rc;
+        { int rc = step_prepare(e, auto_reset, s, p); if (rc != BBAI_OK) return rc; }
+        const int want = e->step_render_split < 0 ? STEP_RENDER_SPLIT_DEFAULT : e->step_render_split;
+        const int64_t nb = step_blocks(e), hb = nb / 2;
+        const bool split = want && pixels && e->n >= STEP_RENDER_SPLIT_MIN && (p.fused || !auto_reset) && hb > 0;
+        if (!split) {
+            { int rc = step_kernel(e, p, actions, image, dirs, rewards, rewards64, dones, auto_reset, s, enum_done, 0, nb); if (rc != BBAI_OK) return rc; }
+            { int rc = step_finish(e, p, image, dirs, dones, auto_reset, s); if (rc != BBAI_OK) return rc; }
+            { int rc = call.leave(); if (rc != BBAI_OK) return rc; }
+            return pixels ? render_launch(e, image, pixels, s) : BBAI_OK;
+        }
+        const int64_t na = hb * STEP_BLOCK;                   // envs of the first half (a multiple of every render group size)
+        // the second half's k_step, on the split stream, behind everything the caller's stream holds so far (the gate included)
+        HIP_TRY(hipEventRecord(e->ev_split0, s));
+        HIP_TRY(hipStreamWaitEvent(e->split, e->ev_split0, 0));
+        { int rc = step_kernel(e, p, actions, image, dirs, rewards, rewards64, dones, auto_reset, e->split, enum_done, hb, nb - hb); if (rc != BBAI_OK) return rc; }
+        HIP_TRY(hipEventRecord(e->ev_splitB, e->split));
+        { int rc = step_kernel(e, p, actions, image, dirs, rewards, rewards64, dones, auto_reset, s, enum_done, 0, hb); if (rc != BBAI_OK) return rc; }
+        { int rc = call.leave(); if (rc != BBAI_OK) return rc; }
+        { int rc = render_launch(e, image, pixels, s, na); if (rc != BBAI_OK) return rc; }
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_splitB, 0));
+        {
+            CallScope call2(e, s);
+            if (call2.rc != BBAI_OK) return call2.rc;
+            { int rc = step_finish(e, p, image, dirs, dones, auto_reset, s); if (rc != BBAI_OK) return rc; }
+            { int rc = call2.leave(); if (rc != BBAI_OK) return rc; }
+        }
+        return render_launch(e, image + na * OBS_BYTES, pixels + na * (int64_t)PIX_BYTES, s, e->n - na);
+    }
+}
+
+extern "C" {
+
+int bbai_step_render(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64,
+                     uint8_t* dones, int auto_reset, uint8_t* pixels, void* stream) {
+    if (!e || !actions || !image || !dirs || !rewards || !dones || !pixels) ARG_FAIL("null handle or buffer");
+    if (!e->live) { snprintf(g_err, sizeof(g_err), "step before reset"); return BBAI_ERR_STATE; }
+    if (auto_reset && !e->seeded) { snprintf(g_err, sizeof(g_err), "auto-reset step before seed"); return BBAI_ERR_STATE; }
+    if (e->n_tiles <= 0) { snprintf(g_err, sizeof(g_err), "render before set_atlas"); return BBAI_ERR_STATE; }
+    ON_DEVICE(e->device);
+    return step_render_launch(e, actions, image, dirs, rewards, rewards64, dones, auto_reset, pixels, (hipStream_t)stream, e->done_action_enum);
 }
 
 // Register (or clear with NULL) a caller-owned uint8[n][72] device buffer that the engine keeps filled with the
@@ -2352,15 +2531,7 @@ int bbai_rollout(bbai_env* e, int T, const uint8_t* actions, uint8_t* image, uin
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)e->n;
     for (int t = 0; t < T; ++t) {
-        {
-            CallScope call(e, s);
-            if (call.rc != BBAI_OK) return call.rc;
-            int rc = step_launch(e, actions + (size_t)t * n, image, dirs, rewards, rewards64, dones, auto_reset, s, e->done_action_enum);
-            if (rc != BBAI_OK) return rc;
-            rc = call.leave();
-            if (rc != BBAI_OK) return rc;
-        }
-        if (pixels) { int rc = render_launch(e, image, pixels, stream); if (rc != BBAI_OK) return rc; }
+        { int rc = step_render_launch(e, actions + (size_t)t * n, image, dirs, rewards, rewards64, dones, auto_reset, pixels, s, e->done_action_enum); if (rc != BBAI_OK) return rc; }
         if (tap) {
             const size_t c = (size_t)tap->count, orow = (size_t)(tap->obs_row0 + t), row = (size_t)(tap->row0 + t);
             int rc = tap_launch(tap->count, tap->pix_count, tap->ids_dev, image, dirs, rewards64, dones, pixels, tap->image_out + orow * c * OBS_BYTES,
@@ -2426,6 +2597,7 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     else if (!strcmp(name, "pregen_min")) e->pregen_min = std::max(0, v);
     else if (!strcmp(name, "consume_fused")) e->consume_fused = v;
     else if (!strcmp(name, "gate_strict")) e->gate_strict = v != 0;
+    else if (!strcmp(name, "step_render_split")) e->step_render_split = v;
     else if (!strcmp(name, "done_action_enum")) e->done_action_enum = v != 0;       // (the one SEMANTIC switch in this list: include/bbai.h bbai_set_done_actions)
     else {
         snprintf(g_err, sizeof(g_err), "set_option: unknown option '%s'", name);
@@ -2455,6 +2627,7 @@ int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     else if (!strcmp(name, "pregen_min")) *out = e->pregen_min;
     else if (!strcmp(name, "consume_fused")) *out = e->consume_fused;
     else if (!strcmp(name, "gate_strict")) *out = e->gate_strict;
+    else if (!strcmp(name, "step_render_split")) *out = e->step_render_split;
     else if (!strcmp(name, "inplace")) *out = e->inplace;
     else if (!strcmp(name, "done_action_enum")) *out = e->done_action_enum;
     else if (!strcmp(name, "lookahead_period")) *out = e->period;

@@ -29,8 +29,8 @@ namespace bbai {
 constexpr int GEN_ES = 36;                       // >= round_up(MAX_W + 2*MARGIN, 4)
 constexpr int GEN_EH = MAX_W + 2 * MARGIN;       // 35
 
-struct GenWork {                                 // lives in LDS on the device
-    uint32_t mt[MT_N];
+struct GenWork {                                 // lives in LDS on the device (lane groups) or in a per-lane global scratch block (lane = level)
+    uint32_t* mt;                                // the env's MT19937 state: an LDS copy (lane groups), the env's own array (lane = level, host)
     uint8_t E[GEN_ES * GEN_EH];
     uint8_t I[MAX_W * MAX_W + 3];
     uint8_t app[MAX_OBJ], px[MAX_OBJ], py[MAX_OBJ];
@@ -84,18 +84,18 @@ BB_HD void mt_twist_chunk(Ctx ctx, uint32_t* mt, int lo, int hi) {
 }
 template <class Ctx>
 BB_COLD void mt_twist(Ctx ctx, uint32_t* mt) {
-    if (ctx.nlanes() == 1) {           // host: plain sequential generation
+    if constexpr (Ctx::kLanes == 1) {  // host, or lane = level on the device: plain sequential generation
         for (int k = 0; k < MT_N; ++k) {
             int m = k + 397; if (m >= MT_N) m -= MT_N;
             mt[k] = mt[m] ^ mt_mix(mt[k], mt[k + 1 < MT_N ? k + 1 : 0]);
         }
-        return;
+    } else {
+        ctx.sync();
+        mt_twist_chunk(ctx, mt, 0, 227);      // uses old[k+397]
+        mt_twist_chunk(ctx, mt, 227, 454);    // uses new[k-227] from the first chunk
+        mt_twist_chunk(ctx, mt, 454, 623);    // uses new[k-227] from the second chunk
+        mt_twist_chunk(ctx, mt, 623, 624);    // uses new[396] and new[0]
     }
-    ctx.sync();
-    mt_twist_chunk(ctx, mt, 0, 227);      // uses old[k+397]
-    mt_twist_chunk(ctx, mt, 227, 454);    // uses new[k-227] from the first chunk
-    mt_twist_chunk(ctx, mt, 454, 623);    // uses new[k-227] from the second chunk
-    mt_twist_chunk(ctx, mt, 623, 624);    // uses new[396] and new[0]
 }
 
 template <class Ctx>
@@ -115,6 +115,7 @@ struct Gen {
     }
     const LevelCfg& cfg;
     GenWork& w;
+    uint32_t* const mt;      // (= w.mt, held in a register: w may live in global memory)
     int mti;                 // MT19937 output index (wave-uniform)
     int nobj;
     int ax, ay, adir;
@@ -131,7 +132,7 @@ struct Gen {
     uint32_t inv_cols, inv_s1, inv_es;   // 2^16/d + 1: exact small-range division without the divider
 
     BB_HD Gen(Ctx c, const LevelCfg& cf, GenWork& wk, int mti_, int last_locked_)
-        : ctx(c), cfg(cf), w(wk), mti(mti_), nobj(0), ax(0), ay(0), adir(0), agent_set(false),
+        : ctx(c), cfg(cf), w(wk), mt(wk.mt), mti(mti_), nobj(0), ax(0), ay(0), adir(0), agent_set(false),
           locked_room(-1), last_locked(last_locked_), S(cf.room_size), rows(cf.num_rows), cols(cf.num_cols),
           gave_up(false), doors(0), locked_mask(0), inv_cols(65536u / (uint32_t)cf.num_cols + 1u),
           inv_s1(65536u / (uint32_t)(cf.room_size - 1) + 1u), inv_es(65536u / (uint32_t)cf.ES + 1u) {}
@@ -141,11 +142,11 @@ struct Gen {
     BB_HD int div_es(int v) const { return (int)(((uint32_t)v * inv_es) >> 16); }         // v < 2048
 
     // ---------------- MT19937 (numpy legacy RandomState bit stream) ----------------
-    BB_HD void twist() { mt_twist(ctx, w.mt); }
+    BB_HD void twist() { mt_twist(ctx, mt); }
     BB_HD uint32_t next_u32() {
         if (mti >= MT_N) { twist(); mti = 0; count(PH_TWISTS); }
         count(PH_DRAWS);
-        uint32_t y = w.mt[mti++];
+        uint32_t y = mt[mti++];
         y ^= (y >> 11);
         y ^= (y << 7) & 0x9d2c5680u;
         y ^= (y << 15) & 0xefc60000u;
@@ -378,7 +379,7 @@ struct Gen {
         uint32_t* pass = w.rowbuf[0];
         uint32_t* fl = w.rowbuf[1];
         ctx.sync();
-        if (ctx.nlanes() > 1) {
+        if constexpr (Ctx::kLanes > 1) {
             // device: lane l owns grid rows l, l + kLanes, ... (K rows per lane); rows exchange their flood masks with
             // group shuffles, the row above the first row of pass k being the last lane's row of pass k - 1
             constexpr int NL = Ctx::kLanes;

@@ -56,6 +56,7 @@ def load_library():
     lib.bbai_seed.argtypes = [P, P, I64]
     lib.bbai_reset.argtypes = [P, P, P, P]
     lib.bbai_step.argtypes = [P, P, P, P, P, P, P, I32, P]
+    lib.bbai_step_render.argtypes = [P, P, P, P, P, P, P, I32, P, P]
     lib.bbai_set_atlas.argtypes = [P, P, I32, P]
     lib.bbai_render.argtypes = [P, P, P, P]
     lib.bbai_set_token_buffer.argtypes = [P, P]
@@ -92,7 +93,7 @@ EXPORTED_SYMBOLS = (
     "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures", "bbai_bot_act", "bbai_bot_stats",
     "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load", "bbai_profile", "bbai_profile_read", "bbai_gae", "bbai_tap",
     "bbai_tap_ids", "bbai_set_call_events", "bbai_bot_rollout", "bbai_set_done_actions", "bbai_get_done_actions",
-    "bbai_set_option", "bbai_get_option", "bbai_rollout",
+    "bbai_set_option", "bbai_get_option", "bbai_rollout", "bbai_step_render",
 )
 
 
@@ -252,9 +253,11 @@ class BatchedBabyAIEnv(object):
     def _stream(self):
         return ctypes.c_void_p(self.torch.cuda.current_stream(self.dev_index).cuda_stream)
 
-    def _obs(self):
+    def _obs(self, rendered=False):
         img = self.image
-        if self.pixel:
+        if self.pixel and rendered:
+            img = self.pixels
+        elif self.pixel:
             ev = self._ev_begin()
             _check(self.lib, self.lib.bbai_render(self.handle, self.image.data_ptr(), self.pixels.data_ptr(),
                                                    self._stream()), "bbai_render")
@@ -305,6 +308,13 @@ class BatchedBabyAIEnv(object):
             raise ValueError("need %d actions" % self.num_envs)
         self._actions = actions     # keep alive until the launch is consumed
         ev = self._ev_begin()
+        if self.pixel and self.kernel_events is None:
+            # the wrapped env's step: transition + render as ONE call (include/bbai.h bbai_step_render)
+            _check(self.lib, self.lib.bbai_step_render(self.handle, actions.data_ptr(), self.image.data_ptr(),
+                                                        self.direction.data_ptr(), self.reward.data_ptr(), self.reward64.data_ptr(),
+                                                        self.done.data_ptr(), 1 if self.auto_reset else 0, self.pixels.data_ptr(),
+                                                        self._stream()), "bbai_step_render")
+            return self._obs(rendered=True), self.reward, self.done, {}
         _check(self.lib, self.lib.bbai_step(self.handle, actions.data_ptr(), self.image.data_ptr(),
                                              self.direction.data_ptr(), self.reward.data_ptr(), self.reward64.data_ptr(),
                                              self.done.data_ptr(),

@@ -105,6 +105,14 @@ int bbai_step(bbai_env* env, const uint8_t* actions_dev, uint8_t* image_dev, uin
 int bbai_set_atlas(bbai_env* env, const uint8_t* tiles_host, int n_tiles, const uint8_t* lut_host /* [2][256] */);
 int bbai_render(bbai_env* env, const uint8_t* image_dev, uint8_t* pixels_dev, void* stream);
 
+/* env.step(action) of a batch wrapped in RGBImgPartialObsWrapper (babyai/evaluate.py:91-92: `env = RGBImgPartialObsWrapper(env)`, whose
+ * step() returns the rendered observation) as ONE call: exactly bbai_step followed by bbai_render(image_dev -> pixels_dev), same bytes.
+ * With option "step_render_split" = 1 (and a batch of 262 144 envs or more, auto-reset consumed inside the step kernel) the batch is stepped
+ * in two halves and the second half's step kernel runs on a stream of the handle's own UNDER the first half's render; everything is joined
+ * on `stream` before the call's last launch, so callers see no difference but the time. */
+int bbai_step_render(bbai_env* env, const uint8_t* actions_dev, uint8_t* image_dev, uint8_t* dir_dev, float* reward_dev,
+                     double* reward64_dev, uint8_t* done_dev, int auto_reset, uint8_t* pixels_dev, void* stream);
+
 /* Mission text as token ids, device-resident (replaces the per-step regex tokenisation of every mission in
  * InstructionsPreprocessor, babyai/utils/format.py:59-75): register a caller-owned uint8[N][72] buffer; the engine
  * rewrites env i's row whenever env i starts a new episode.  Ids follow babyai_amd/missions.py VOCAB, 0 = padding. */
@@ -246,6 +254,8 @@ int bbai_get_done_actions(bbai_env* env);
  *   "render_group", "render_tpb"   envs / threads per one-shot render block (0 = by batch size)
  *   "step_prio", "pregen_group", "pregen_blocks", "pregen_min", "consume_fused"   as BBAI_STEP_PRIO / BBAI_PREGEN_GROUP /
  *                       BBAI_PREGEN_BLOCKS / BBAI_PREGEN_MIN / BBAI_CONSUME_FUSED
+ *   "step_render_split" bbai_step_render / bbai_rollout with pixels: 1 = step the batch in two halves, the second under the first half's
+ *                       render; 0 = never; -1 = the library's default
  *   "gate_strict"       1 = the step stream ALSO waits, at the start of every look-ahead window, for the refill launched two windows
  *                       earlier (rounds 1-4's rule); 0 (default) = it runs ahead of the refills as far as every env is sure to keep
  *                       a window's worth of ready levels (k_gate) -- a reset storm then refills under the steps

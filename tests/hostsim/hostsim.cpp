@@ -32,10 +32,9 @@ void hs_seed(uint64_t seed, uint32_t* mt) { seed_env(seed, mt); }
 int hs_generate(const LevelCfg* cfg, uint32_t* mt, int32_t* mti, uint8_t* rec, Hot* hot) {
     int last_locked = hot->last_locked == NONE8 ? -1 : hot->last_locked;
     static thread_local GenWork w;
-    memcpy(w.mt, mt, sizeof(w.mt));
+    w.mt = mt;                                   // (the generator advances the caller's state in place)
     Gen<HostCtx> g(HostCtx(), *cfg, w, *mti, last_locked);
     int max_steps = g.generate();
-    memcpy(mt, w.mt, sizeof(w.mt));
     *mti = g.mti;
     memset(rec, 0, cfg->rec_bytes);
     memcpy(rec, w.E, cfg->ES * cfg->EH);

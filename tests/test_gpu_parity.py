@@ -1559,6 +1559,39 @@ def test_steps_run_ahead_of_a_reset_storms_refill(gpu, level, n, period, layout,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("level,auto_reset", [("PickupLoc", True), ("GoTo", True), ("GoToLocal", False)])
+def test_step_render_split_equals_the_plain_step_and_render(gpu, level, auto_reset):
+    """include/bbai.h bbai_step_render with option "step_render_split": the batch stepped in two halves, the second half's step kernel on
+    the handle's split stream under the first half's render -- every byte of every output equals the unsplit call's, tokens and
+    auto-resets (in-place and in-wave consume) included, and bbai_rollout takes the same path."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from babyai_amd.action_stream import actions_torch
+    n = 262144 + 64 + 5
+    a = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, pixel=True, seeds=31, auto_reset=auto_reset)
+    b = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, pixel=True, seeds=31, auto_reset=auto_reset)
+    b.set_option("step_render_split", 1)
+    a.set_option("step_render_split", 0)
+    ta, tb = a.enable_instr_tokens(), b.enable_instr_tokens()
+    a.reset()
+    b.reset()
+    T = 48
+    acts = actions_torch(9, 0, T, 0, n, gpu)
+    for t in range(T - 8):
+        oa, ra, da, _ = a.step(acts[t])
+        ob, rb, db, _ = b.step(acts[t])
+        assert torch.equal(oa["image"], ob["image"]), (level, t)
+        assert torch.equal(a.image, b.image) and torch.equal(a.direction, b.direction) and torch.equal(a.reward64, b.reward64) and torch.equal(da, db), (level, t)
+        assert torch.equal(ta, tb), (level, t)
+    a.rollout(acts[T - 8:])
+    b.rollout(acts[T - 8:])
+    assert torch.equal(a.pixels, b.pixels) and torch.equal(a.image, b.image) and torch.equal(a.done, b.done) and torch.equal(ta, tb)
+    assert a.reset_count() == b.reset_count() and (a.reset_count() > n or not auto_reset)
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
 def test_a_refused_checkpoint_leaves_the_handle_as_it_was(gpu, monkeypatch):
     """bbai_checkpoint_load validates EVERYTHING before it touches the handle: a blob of another look-ahead period that is
     refused for another reason -- wrong done-action mode, truncated, another format version -- must not re-shape the ring on its way
@@ -1591,6 +1624,13 @@ def test_a_refused_checkpoint_leaves_the_handle_as_it_was(gpu, monkeypatch):
         a.load_checkpoint(blob)                       # period 4 into a period-2 handle, refused for its done-action bits
     assert a.get_option("lookahead_period") == 2
     lockstep(9)
+    donor = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=5)      # (created under BBAI_LOOKAHEAD=2 ...)
+    monkeypatch.setenv("BBAI_LOOKAHEAD", "4")
+    donor4 = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=5)     # (... and 4: a blob of another ring shape, same mode)
+    donor4.reset()
+    blob = donor4.save_checkpoint()
+    donor.close()
+    donor4.close()
     with pytest.raises(EngineError, match="size does not match"):
         a.load_checkpoint(blob[:-64])
     bad = blob.copy()

@@ -123,6 +123,12 @@ listatomic() {       # one list atomic per stepping wave, sub-lists, and a reade
     cd $REPO && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/ubench_listatomic tools/ubench_listatomic.hip 2>/dev/null
     timeout 200 /tmp/ubench_listatomic ${1:-4096} | tee $OUT/ubench_listatomic_${1:-4096}.jsonl | tail -40
 }
+genrate() {          # bulk level-generation rate (bbai_seed's first fill) per generator shape: genrate[:<groups ...>]  (tools/gen_rate.py)
+    cd /tmp
+    for g in ${@:-32 1}; do
+        BBAI_PREGEN_GROUP=$g timeout 300 python $REPO/tools/gen_rate.py 2>> $OUT/gen_rate.err | tee -a $OUT/gen_rate_by_group_width.jsonl
+    done
+}
 ubench() {           # the microbenchmarks DESIGN.md quotes (built here: hipcc is on the box)
     cd $REPO && for u in gather render fetchcal; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/ubench_$u tools/ubench_$u.hip 2>/dev/null; done
     timeout 120 python tools/membw.py > $OUT/membw.json 2> $OUT/membw.err
