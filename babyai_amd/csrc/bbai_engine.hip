@@ -130,8 +130,7 @@ struct bbai_env {
     int render_group;     // BBAI_RENDER_GROUP: 2, 4 or 8 envs per one-shot render block; anything else = by batch size (bbai_render)
     int pregen_cap;       // BBAI_PREGEN_BLOCKS: upper bound on look-ahead lane groups per launch (experiments)
     int pregen_min;       // BBAI_PREGEN_MIN / option "pregen_min": single-room levels: lane groups that work on a refill at least (k_pregen: entries / 32 otherwise); 0 = the whole grid, as mazes always get
-    int pregen_group;     // BBAI_PREGEN_GROUP: lanes per env in k_pregen: 32 (two envs per wave), 16, 64, or 1 = lane per env (GroupCtx<1>)
-    uint8_t* lane_scratch;   // pregen_group == 1: one GenWork per thread of the largest k_pregen grid (LANE_CAP threads); allocated on first use
+    int pregen_group;     // BBAI_PREGEN_GROUP: lanes per env in k_pregen: 32 (default: two envs per wave), 16 or 64
     int step_prio;        // BBAI_STEP_PRIO: s_setprio level of the step-path kernels' waves (they share CUs with k_pregen)
     // optional per-kernel timing (bbai_profile): HIP event pairs on the launch stream around k_step / k_consume / k_render
     bool prof_on;
@@ -744,25 +743,9 @@ struct GroupCtx {
     }
 };
 
-// G = 1: lane = level.  The generator's program is one SCALAR program per env (draw, test, branch, draw ...): with a lane group per env
-// every instruction of it is issued for ONE or two envs, whatever the group's width (two envs of a wave diverge almost all the time) --
-// the generator is bound by instruction issue.  With one lane per env an instruction serves every lane of the wave that
-// is at the same place of the program; the working set moves from LDS to a per-lane block of global memory (lane-private lines: L2 hits
-// for as long as the level lasts) and the MT19937 state is advanced in place.  Same templates, same draws: the host build (tests/hostsim)
-// is this very instantiation (kLanes == 1).
-template <>
-struct GroupCtx<1> {
-    static constexpr int kLanes = 1;
-    __device__ __forceinline__ int lane() const { return 0; }
-    __device__ __forceinline__ int nlanes() const { return 1; }
-    __device__ __forceinline__ void sync() const {}
-    __device__ __forceinline__ uint32_t shfl(uint32_t v, int) const { return v; }
-    __device__ __forceinline__ uint32_t shfl_up1(uint32_t) const { return 0u; }
-    __device__ __forceinline__ uint32_t shfl_down1(uint32_t) const { return 0u; }
-    __device__ __forceinline__ unsigned long long ballot(bool p) const { return p ? 1ull : 0ull; }
-    __device__ __forceinline__ bool any(bool p) const { return p; }
-};
-
+// (Lane = level -- GroupCtx<1>: the same templates with a one-lane context, working set in per-lane global memory, MT19937 state advanced in
+// place -- was built and measured in round 5 (profiles/r05/NOTES.md): 86-95 VGPRs, but every access to the working set becomes a global
+// round trip: bulk fill 2 x SLOWER (PickupLoc 7.4 -> 14.2 ns per level, GoTo 35 -> 82), in the step loop 2-7 x.  Removed.)
 // The look-ahead generator.  A workgroup is ONE wave carrying 64 / G envs; every group walks its share of the window's `pending`
 // bytes on its own: fetch an env that has levels pending, load its MT19937 state into the
 // group's LDS block, then one ATTEMPT of the generator's rejection loop per trip of the main loop (Gen::attempt) -- a
@@ -779,28 +762,21 @@ struct GroupCtx<1> {
 #define BBAI_PREGEN_WAVES 4
 #endif
 template <int KIND, int G, bool OBS /* in-place layout: the level's first observation is written next to it */>
-__global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16 || G == 1) ? 2 : BBAI_PREGEN_WAVES) void k_pregen(LevelCfg c, int64_t n, uint8_t* __restrict__ next_recs,
+__global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_WAVES) void k_pregen(LevelCfg c, int64_t n, uint8_t* __restrict__ next_recs,
                                                   Hot* __restrict__ next_hots, uint32_t* __restrict__ mts,
                                                   int32_t* __restrict__ mtis,
                                                   const int32_t* __restrict__ gen_list, const uint32_t* __restrict__ gen_count /* NULL: dense -- every env, the whole grid works */,
                                                   int depth,
                                                   uint8_t* __restrict__ pending, const uint8_t* __restrict__ first_slot,
                                                   unsigned long long* __restrict__ gen_failures, int min_groups,
-                                                  uint8_t* __restrict__ next_obs /* in-place layout: [D][n][OBS_SLOT], else NULL */,
-                                                  uint8_t* __restrict__ lane_scratch /* G == 1: one GenWork per thread of the grid */) {
+                                                  uint8_t* __restrict__ next_obs /* in-place layout: [D][n][OBS_SLOT], else NULL */) {
     constexpr int NG = 64 / G;
     typedef GroupCtx<G> Ctx;
     const Ctx ctx;
-    GenWork* wp;
-    if constexpr (G == 1) {
-        wp = (GenWork*)lane_scratch + ((size_t)blockIdx.x * 64 + threadIdx.x);
-    } else {
-        __shared__ GenWork ws[NG];
-        __shared__ uint32_t s_mt[NG][MT_N];
-        wp = &ws[threadIdx.x / G];
-        wp->mt = s_mt[threadIdx.x / G];
-    }
-    GenWork& w = *wp;
+    __shared__ GenWork ws[NG];
+    __shared__ uint32_t s_mt[NG][MT_N];
+    GenWork& w = ws[threadIdx.x / G];
+    w.mt = s_mt[threadIdx.x / G];
     const int lane = ctx.lane();
     // the refill list: prefix of the sub-list lengths (one word per lane, a wave scan, parked in LDS for the groups' searches)
     __shared__ uint32_t s_start[SHARDS + 1];
@@ -855,23 +831,17 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16 || G == 1) ? 2 : BB
             if (have) {
                 // the env's generator state: all of its loads in flight together (MT19937 words, position, first slot) -- as a
                 // load - store loop this was five dependent round trips before the first draw
-                if constexpr (G == 1) {
-                    w.mt = mts + env * MT_N;                  // advanced in place
-                    mti = mtis[env];
-                    slot = first_slot[env];
-                } else {
-                    const uint32_t* mt = mts + env * MT_N;
-                    constexpr int MTQ = (MT_N + G - 1) / G;
-                    uint32_t mtw[MTQ];
+                const uint32_t* mt = mts + env * MT_N;
+                constexpr int MTQ = (MT_N + G - 1) / G;
+                uint32_t mtw[MTQ];
 #pragma unroll
-                    for (int q = 0; q < MTQ; ++q) { const int k = lane + q * G; mtw[q] = mt[k < MT_N ? k : MT_N - 1]; }
-                    mti = mtis[env];
-                    slot = first_slot[env];
-                    ctx.sync();
+                for (int q = 0; q < MTQ; ++q) { const int k = lane + q * G; mtw[q] = mt[k < MT_N ? k : MT_N - 1]; }
+                mti = mtis[env];
+                slot = first_slot[env];
+                ctx.sync();
 #pragma unroll
-                    for (int q = 0; q < MTQ; ++q) { const int k = lane + q * G; if (k < MT_N) w.mt[k] = mtw[q]; }
-                    ctx.sync();
-                }
+                for (int q = 0; q < MTQ; ++q) { const int k = lane + q * G; if (k < MT_N) s_mt[threadIdx.x / G][k] = mtw[q]; }
+                ctx.sync();
                 const int prev = slot == 0 ? depth - 1 : slot - 1;          // holds the level generated just before
                 last_locked = next_hots[ring_at(prev, env, depth)].last_locked;   // LevelGen.locked_room survives episodes
                 last_locked = last_locked == NONE8 ? -1 : last_locked;
@@ -924,33 +894,6 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16 || G == 1) ? 2 : BB
             // group's share of a ballot per round; every lane runs the 7-row visibility sweep and writes its cells' three bytes
             // (the layout observe_emit writes: cell (vi, vj) at byte (7 vi + vj) * 3; the agent's own cell shows what it carries: nothing yet).
             uint8_t* ob = next_obs + ring_at(slot, env, depth) * OBS_SLOT;
-            if constexpr (G == 1) {
-                // lane = level: the 49 cells one after the other, twice (opacity mask, then the bytes) -- rolled loops, a handful of registers
-                unsigned long long opaque = 0;
-#pragma unroll 1
-                for (int cell = 0; cell < VIEW * VIEW; ++cell) {
-                    int x, y;
-                    view_to_world(g.ax, g.ay, g.adir, cell % VIEW, cell / VIEW, x, y);
-                    if (e_opaque(w.E[(y + MARGIN) * c.ES + (x + MARGIN)])) opaque |= 1ull << cell;
-                }
-                uint32_t opq[VIEW], vis[VIEW];
-#pragma unroll
-                for (int r = 0; r < VIEW; ++r) opq[r] = (uint32_t)(opaque >> (VIEW * r)) & 0x7Fu;
-                process_vis_rows(opq, vis);
-                unsigned long long visible = 0;
-#pragma unroll
-                for (int r = 0; r < VIEW; ++r) visible |= (unsigned long long)(vis[r] & 0x7Fu) << (VIEW * r);
-#pragma unroll 1
-                for (int cell = 0; cell < VIEW * VIEW; ++cell) {
-                    const int vi = cell % VIEW, vj = cell / VIEW;
-                    int x, y;
-                    view_to_world(g.ax, g.ay, g.adir, vi, vj, x, y);
-                    const int e = (vi == 3 && vj == 6) ? (int)E_EMPTY : (int)w.E[(y + MARGIN) * c.ES + (x + MARGIN)];
-                    const bool v = visible >> cell & 1;
-                    uint8_t* o = ob + (vi * VIEW + vj) * 3;
-                    o[0] = v ? e_type(e) : 0; o[1] = v ? e_color(e) : 0; o[2] = v ? e_state(e) : 0;
-                }
-            } else {
             constexpr int R = (VIEW * VIEW + G - 1) / G;
             constexpr unsigned long long GM = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
             int ec[R];
@@ -987,7 +930,6 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16 || G == 1) ? 2 : BB
                     o[0] = v ? e_type(e) : 0; o[1] = v ? e_color(e) : 0; o[2] = v ? e_state(e) : 0;
                 }
             }
-            }
         }
         if (lane == 0) {
             Hot h;
@@ -1006,11 +948,9 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16 || G == 1) ? 2 : BB
         slot = slot + 1 == depth ? 0 : slot + 1;
         attempts = 0;
         if (++done_levels == cnt) {                      // this env's levels are done: MT state back, buffer entry free
-            if constexpr (G != 1) {
-                uint32_t* mt = mts + env * MT_N;
-                ctx.sync();
-                for (int k = lane; k < MT_N; k += G) mt[k] = w.mt[k];
-            }
+            uint32_t* mt = mts + env * MT_N;
+            ctx.sync();
+            for (int k = lane; k < MT_N; k += G) mt[k] = s_mt[threadIdx.x / G][k];
             if (lane == 0) {
                 mtis[env] = mti;
                 pending[env] = 0;                        // buffer entry is free for a later window
@@ -1695,7 +1635,7 @@ void bbai_destroy(bbai_env* e) {
     if (e->ev_switch) (void)hipEventDestroy(e->ev_switch);
     for (int k = 0; k < NWIN; ++k) if (e->ev_refill[k]) (void)hipEventDestroy(e->ev_refill[k]);
     for (int k = 0; k < 3; ++k) for (int i = 0; i < PROF_RING; ++i) if (e->prof[k][i].a) { (void)hipEventDestroy(e->prof[k][i].a); (void)hipEventDestroy(e->prof[k][i].b); }
-    void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows, e->lane_scratch};
+    void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
     void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_meta, e->totals, e->flow, e->gen_list, e->gen_count, e->reset_list, e->counters,
                     e->atlas, e->lut, e->vplane, e->fcache, e->lsm, e->render_tickets, e->reset_slot, e->next_obs};
@@ -1707,7 +1647,6 @@ void bbai_destroy(bbai_env* e) {
 
 // k_pregen is instantiated per level family so that a launch carries only that family's mission code, and per group
 // width G (envs per wave = 64 / G; BBAI_PREGEN_GROUP, default 32: two envs per wave)
-constexpr int64_t LANE_CAP = 262144;       // lane = level: threads of the largest generator grid (4 096 waves: four per SIMD of the part)
 template <int G>
 static void launch_pregen_g(const bbai_env* e, unsigned groups, bool listed /* false: dense -- every env, the whole grid works */, uint8_t* pending, const uint8_t* first_slot) {
     unsigned long long* fails = e->flow + FLOW_GEN_FAILURES;
@@ -1715,9 +1654,9 @@ static void launch_pregen_g(const bbai_env* e, unsigned groups, bool listed /* f
     // Demand-sized groups only where a level is cheap (single rooms, <= 60 us per group): a maze level costs a group ~300 us,
     // and GoTo at 131 072 envs stalls the step stream with 4 entries per group (0.0534 vs 0.0385 ms per step,
     // profiles/r04/pregen_min_ab.jsonl) -- mazes keep the whole grid.
-    const int min_groups = (G == 1 || e->cfg.num_rows * e->cfg.num_cols > 1) ? 0 : e->pregen_min;      // (lane = level: one entry per lane, all at once)
+    const int min_groups = e->cfg.num_rows * e->cfg.num_cols > 1 ? 0 : e->pregen_min;
 #define PREGEN_LAUNCH(KK, OO) hipLaunchKernelGGL((k_pregen<KK, G, OO>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, e->gen_list, \
-                                                listed ? e->gen_count : nullptr, e->depth, pending, first_slot, fails, min_groups, e->next_obs, e->lane_scratch)
+                                                listed ? e->gen_count : nullptr, e->depth, pending, first_slot, fails, min_groups, e->next_obs)
     if (e->cfg.kind == K_LEVELGEN) { if (e->next_obs) PREGEN_LAUNCH(K_LEVELGEN, true); else PREGEN_LAUNCH(K_LEVELGEN, false); }
     else if (e->cfg.kind == K_BONUS) { if (e->next_obs) PREGEN_LAUNCH(K_BONUS, true); else PREGEN_LAUNCH(K_BONUS, false); }
     else { if (e->next_obs) PREGEN_LAUNCH(K_GOTO, true); else PREGEN_LAUNCH(K_GOTO, false); }
@@ -1729,8 +1668,7 @@ static void launch_pregen(const bbai_env* e, unsigned groups, bool listed, uint8
     // GoToLocal 1 : 1.25 : 1.36; inside the step loop 32 is never behind 64 (GoToLocal 65 536 envs -3 %, PickupLoc 262 144
     // -6 %, GoTo 131 072 +-0) while 16 costs the step kernels of GoTo 131 072 9 % (fewer, fatter generator waves next to
     // them: 200 VGPRs and 20 KB of LDS each).
-    if (e->pregen_group == 1) launch_pregen_g<1>(e, groups, listed, pending, first_slot);
-    else if (e->pregen_group == 64) launch_pregen_g<64>(e, groups, listed, pending, first_slot);
+    if (e->pregen_group == 64) launch_pregen_g<64>(e, groups, listed, pending, first_slot);
     else if (e->pregen_group == 16) launch_pregen_g<16>(e, groups, listed, pending, first_slot);
     else launch_pregen_g<32>(e, groups, listed, pending, first_slot);
 }
@@ -1738,14 +1676,9 @@ static void launch_pregen(const bbai_env* e, unsigned groups, bool listed, uint8
 extern "C" {
 
 static unsigned pregen_grid(const bbai_env* e, int64_t count_hint) {
-    // one lane group per env, capped at pregen_cap groups in flight (the rest is reached by the groups' strides); lane = level: LANE_CAP lanes
-    int64_t g = std::min<int64_t>(count_hint, e->pregen_group == 1 ? LANE_CAP : (int64_t)e->pregen_cap);
+    // one lane group per env, capped at pregen_cap groups in flight (the rest is reached by the groups' strides)
+    int64_t g = std::min<int64_t>(count_hint, e->pregen_cap);
     return (unsigned)std::max<int64_t>(g, 1);
-}
-static int ensure_lane_scratch(bbai_env* e) {
-    if (e->pregen_group != 1 || e->lane_scratch) return BBAI_OK;
-    HIP_TRY(hipMalloc((void**)&e->lane_scratch, (size_t)LANE_CAP * sizeof(GenWork)));
-    return BBAI_OK;
 }
 
 // A handle's launches are ordered by ONE caller stream at a time (plus the private look-ahead stream, which is tied to
@@ -1846,7 +1779,6 @@ static int window_end(bbai_env* e, hipStream_t s, int tokens_mode /* k_tokens: 0
         const int64_t w = e->tick / B;
         HIP_TRY(hipEventRecord(e->ev_consumed, s));
         HIP_TRY(hipStreamWaitEvent(e->side, e->ev_consumed, 0));
-        { int rc = ensure_lane_scratch(e); if (rc != BBAI_OK) return rc; }
         HIP_TRY(hipMemsetAsync(e->gen_count, 0, SHARDS * GEN_COUNT_U32 * 4, e->side));
         hipLaunchKernelGGL(k_compact, dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->side, e->n, e->pending + (size_t)wb * e->n, e->gen_list, e->gen_count);
         const int64_t rh = std::max<int64_t>((int64_t)B * (e->n / 64), 64);
@@ -1890,7 +1822,6 @@ int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
     HIP_TRY(hipMemsetAsync(e->pending, 0, NWIN * (size_t)n, e->side));
     HIP_TRY(hipMemsetAsync(e->first_slot, 0, NWIN * (size_t)n, e->side));
     HIP_TRY(hipMemsetAsync(e->pending, e->depth - e->inplace, (size_t)n, e->side));      // (in-place: slot depth - 1 is the live one -- empty until the first reset)
-    { int rc = ensure_lane_scratch(e); if (rc != BBAI_OK) return rc; }
     launch_pregen(e, pregen_grid(e, n), false, e->pending, e->first_slot);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(e->win_meta, 0, NWIN * META_U32 * 4, e->side));
@@ -2127,9 +2058,9 @@ static int step_render_launch(bbai_env* e, const uint8_t* actions, uint8_t* imag
         CallScope call(e, s);
         if (call.rc != BBAI_OK) return call.rc;
         { int rc = step_prepare(e, auto_reset, s, p); if (rc != BBAI_OK) return rc; }
-        const int want = e->step_render_split < 0 ? STEP_RENDER_SPLIT_DEFAULT : e->step_render_split;
+        const int want = e->step_render_split < 0 ? (STEP_RENDER_SPLIT_DEFAULT && e->n >= STEP_RENDER_SPLIT_MIN) : e->step_render_split;      // (an explicit 1: any size)
         const int64_t nb = step_blocks(e), hb = nb / 2;
-        const bool split = want && pixels && e->n >= STEP_RENDER_SPLIT_MIN && (p.fused || !auto_reset) && hb > 0;
+        const bool split = want && pixels && (p.fused || !auto_reset) && hb > 0;
         if (!split) {
             { int rc = step_kernel(e, p, actions, image, dirs, rewards, rewards64, dones, auto_reset, s, enum_done, 0, nb); if (rc != BBAI_OK) return rc; }
             { int rc = step_finish(e, p, image, dirs, dones, auto_reset, s); if (rc != BBAI_OK) return rc; }

@@ -19,7 +19,8 @@ N GPUs (`scaling: "strong"`; 131 072 envs per GPU at N = 8).  `--weak` keeps 1 0
 (`scaling: "weak"`); `--envs` sets the per-GPU count by hand.
 
 What one run proves about itself (all in the one JSON line rank 0 prints):
-  * the loop    per step one bbai_step [+ bbai_render] + bbai_tap_ids call from Python, like any caller's loop; --rollout-entry
+  * the loop    per step one bbai_step (pixel batches: bbai_step_render, the wrapped env's step = transition + render) + bbai_tap_ids call from
+                Python, like any caller's loop; --rollout-entry
                 enqueues a block's K steps with ONE call of the engine's open-loop rollout entry instead (include/bbai.h bbai_rollout,
                 the same launches) -- measured equal on every config, 65 536-env steps included: the GPU sets the pace.
   * timing      W warmup steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both sides; a rank's
@@ -590,7 +591,7 @@ def main():
                    "max_over_median": st["max_over_median"], "value_at_min": K * E * world / bs[0],
                    "value_at_max": K * E * world / bs[-1],
                    "loop": "one bbai_rollout call per block: the engine enqueues K x (step [+ render] + tap)" if (args.rollout_entry and not args.dump_digest) else
-                           "per-step calls from Python: bbai_step [+ bbai_render] + bbai_tap_ids",
+                           "per-step calls from Python: bbai_step (pixel batches: bbai_step_render = the same step + render as one call) + bbai_tap_ids",
                    "clock": "per block: opening barrier -> K steps -> this rank's device idle; the block = max over ranks; the closing barrier "
                             "and the max-reduce run after every rank's clock has stopped (barrier_ms)",
                    "barrier_ms": {"median": median(m["barrier_s"]) * 1e3, "max": max(m["barrier_s"]) * 1e3} if m["barrier_s"] else None,

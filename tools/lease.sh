@@ -55,6 +55,17 @@ bench() {            # one BASELINE config as its own line: bench:C2 [extra args
     cd /tmp && timeout 600 python $REPO/bench.py --config $1 --no-extra-configs ${@:2} > $OUT/bench_$1.json 2>> $OUT/bench.err
     python $REPO/tools/summarize_profile.py --line $OUT/bench_$1.json
 }
+benchenv() {         # one BASELINE config under an environment setting: benchenv:BBAI_GATE_STRICT=1:C4[:extra bench args]
+    local kv=$1 cfg=$2; shift 2
+    cd /tmp && env "$kv" timeout 600 python $REPO/bench.py --config $cfg --no-extra-configs --no-cpu-baseline ${@} > $OUT/bench_${cfg}_$kv.json 2>> $OUT/bench.err
+    python - <<PY
+import json
+d = json.loads(open("$OUT/bench_${cfg}_$kv.json").read().strip().splitlines()[-1])
+t = d["timing"]
+print("$kv $cfg ms/step mean %.4f median %.4f max/med %.2f blocks %s parity %s" % (d["ms_per_step"], t["block_ms"]["median"] / d["steps"], t["max_over_median"],
+      [round(b, 1) for b in t["block_ms_list"]], (d.get("parity") or {}).get("mismatches_all_ranks")))
+PY
+}
 ab() {               # tools/ab.py presets
     cd /tmp
     case $1 in
