@@ -37,6 +37,7 @@ __device__ unsigned long long g_bot_prof[32];        // experiment builds: phase
 #include "bbai_types.hpp"
 #include "bbai_gen.hpp"
 #include "bbai_step.hpp"
+#include "bbai_view.hpp"
 #include "bbai_bot.hpp"
 #include "bbai_seed.hpp"
 
@@ -215,7 +216,12 @@ constexpr int STEP_BLOCK = 64;
 #define BBAI_PREFETCH_ID 0
 #endif
 
-// Observation with the 7x7 window staged in LDS (the k_step path).  49 scattered byte loads per lane keep the
+// BBAI_VIEW_LDS=1 (A/B builds): rounds 2-4's view -- the window parked in LDS and read back cell by cell (view_cells / encode_view below).  The shipped
+// path is bbai_view.hpp: the same view as byte permutes on packed registers (k_step: -~900 of ~2 600 vector instructions, -63 LDS operations per env-step).
+#ifndef BBAI_VIEW_LDS
+#define BBAI_VIEW_LDS 0
+#endif
+// Observation with the 7x7 window staged in LDS (rounds 2-4's k_step path).  49 scattered byte loads per lane keep the
 // texture-address unit busy for most of k_step (tools/step_ab.py ablation), so the window is fetched in WORLD
 // orientation as 7 rows x 3 aligned dwords, byte-aligned with v_alignbyte, parked in 56 dword-aligned bytes inside the
 // lane's own LDS obs row (`scr`, bbai_step.hpp row_scratch), and read back in VIEW orientation (rotation = per-direction
@@ -620,8 +626,13 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
                 if (idf >= 0 && nid >= 0) idf = nid;
             }
             int fe2;
-            uint32_t cp[13], vis[VIEW];
+            uint32_t cp[13];
+#if BBAI_VIEW_LDS
+            uint32_t vis[VIEW];
             view_cells(wd, txm & 3, dir, (uint32_t)ce, nfe, s_rows + row_scratch(lane), cp, vis, fe2);
+#else
+            view_cells_perm(wd, txm & 3, dir, (uint32_t)ce, nfe, cp, fe2);       // (bbai_view.hpp: rotation, occlusion and masking in registers)
+#endif
             // "env.reset() for THIS env, now" (A_RESET_ENV, bbai_step.hpp): the episode ends with done = 1, reward = 0
             const bool done = action == A_RESET_ENV ? true : finish_step(c, r, h, stale, action, fe2, reward, lsm, idf, enum_done != 0);
             if (lsm_arr) lsm_arr[env] = (uint8_t)lsm.bits;
@@ -634,7 +645,11 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
             if (rewards64) rewards64[env] = reward;        // the reference's Python float, bit for bit (levelgen.py:59-61)
             dones[env] = done ? 1 : 0;
             dirs[env] = h.dir;
+#if BBAI_VIEW_LDS
             encode_view(cp, vis, RowPacker(s_rows, lane));
+#else
+            encode_cells(cp, RowPacker(s_rows, lane));
+#endif
         }
         // frozen envs keep re-emitting their last outputs: copy them through LDS unchanged
         else {
@@ -1440,13 +1455,14 @@ static int validate_cfg(const LevelCfg& c) {
 }
 
 static int inplace_by_default(const LevelCfg& c, int64_t n_envs) {
-    // Measured (profiles/r04/inplace_*.jsonl, ms per step classic -> in-place): GoToLocal 32 768 envs 0.0253 -> 0.0183, 65 536 0.0341 -> 0.0322
-    // (bench loop with its tap: 0.0443 -> 0.0398), PickupLoc 262 144 0.0780 -> 0.0733 (once the window's count entries had lines of their own:
-    // WIN_ENTRY); mazes lose at every size (no window plane in this layout: BossLevel 1 048 576 0.111 -> 0.133).  Single rooms up to a
-    // 12-GiB ring (~ 310 k envs): beyond that nothing was measured with the final kernel, and the window plane the classic layout has
-    // starts to matter with the batch size.
-    if (c.num_rows * c.num_cols > 1) return 0;
-    return (size_t)n_envs * c.rec_bytes * (2 * MAX_PERIOD + 1) <= ((size_t)12 << 30) ? 1 : 0;
+    // Measured, ms per step classic -> in-place, settings alternated in one process (tools/ab.py).  Round 4 (profiles/r04/inplace_*.jsonl): GoToLocal 32 768
+    // envs 0.0253 -> 0.0183, 65 536 0.0341 -> 0.0322, PickupLoc 262 144 0.0780 -> 0.0733; mazes lose at every size (no window plane in this layout:
+    // BossLevel 1 048 576 0.111 -> 0.133).  Round 5, after the list atomic left the step path (profiles/r05/inplace_size_sweep.jsonl): GoToLocal 262 144
+    // 0.0832 -> 0.0720, GoToLocal 1 048 576 0.333 -> 0.305, PickupLoc 524 288 0.140 -> 0.127, PickupLoc 1 048 576 0.321 -> 0.331 (the one point where the
+    // classic layout is ahead, by 3 %).  So: every single-room batch (the ring's own 64-GiB cap -- bbai_create -- bounds it; a ring that does not fit
+    // falls back to a shorter look-ahead period, never to another layout).
+    (void)n_envs;
+    return c.num_rows * c.num_cols > 1 ? 0 : 1;
 }
 
 int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env** out) {

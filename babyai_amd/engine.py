@@ -56,7 +56,8 @@ def load_library():
     lib.bbai_seed.argtypes = [P, P, I64]
     lib.bbai_reset.argtypes = [P, P, P, P]
     lib.bbai_step.argtypes = [P, P, P, P, P, P, P, I32, P]
-    lib.bbai_step_render.argtypes = [P, P, P, P, P, P, P, I32, P, P]
+    if hasattr(lib, "bbai_step_render"):        # (A/B runs against older experiment builds, BBAI_ENGINE_LIB: they lack the newer entries)
+        lib.bbai_step_render.argtypes = [P, P, P, P, P, P, P, I32, P, P]
     lib.bbai_set_atlas.argtypes = [P, P, I32, P]
     lib.bbai_render.argtypes = [P, P, P, P]
     lib.bbai_set_token_buffer.argtypes = [P, P]
@@ -308,7 +309,7 @@ class BatchedBabyAIEnv(object):
             raise ValueError("need %d actions" % self.num_envs)
         self._actions = actions     # keep alive until the launch is consumed
         ev = self._ev_begin()
-        if self.pixel and self.kernel_events is None:
+        if self.pixel and self.kernel_events is None and hasattr(self.lib, "bbai_step_render"):
             # the wrapped env's step: transition + render as ONE call (include/bbai.h bbai_step_render)
             _check(self.lib, self.lib.bbai_step_render(self.handle, actions.data_ptr(), self.image.data_ptr(),
                                                         self.direction.data_ptr(), self.reward.data_ptr(), self.reward64.data_ptr(),

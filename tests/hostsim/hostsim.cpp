@@ -6,6 +6,7 @@
 #include "../../babyai_amd/csrc/bbai_types.hpp"
 #include "../../babyai_amd/csrc/bbai_gen.hpp"
 #include "../../babyai_amd/csrc/bbai_step.hpp"
+#include "../../babyai_amd/csrc/bbai_view.hpp"
 #include "../../babyai_amd/csrc/bbai_bot.hpp"
 #include "../../babyai_amd/csrc/bbai_seed.hpp"
 
@@ -112,6 +113,14 @@ int hs_step(const LevelCfg* cfg, uint8_t* rec, Hot* hot, uint64_t* stale, int ac
 
 void hs_observe(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, uint8_t* out) {
     observe_env(*cfg, rec, *hot, out);
+}
+// the same observation through k_step's register pipeline (bbai_view.hpp view_cells_perm + encode_cells); returns the front cell's appearance
+int hs_observe_perm(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, int nfe, uint8_t* out) {
+    alignas(16) uint8_t rows[ROWS_FRONT + OBS_BYTES + 16];
+    memset(rows, 0xEE, sizeof(rows));
+    const int fe2 = observe_env_perm(*cfg, rec, *hot, nfe, rows);
+    memcpy(out, rows + ROWS_FRONT, OBS_BYTES);
+    return fe2;
 }
 
 // ---- k_step's LDS row packing (bbai_step.hpp RowPacker), one lane at a time in the caller's lane order ---------------------

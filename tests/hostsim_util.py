@@ -26,6 +26,7 @@ def lib():
         L.hs_step64.argtypes = [P, P, P, P, ctypes.c_int, P]
         L.hs_step64_prefetch.argtypes = [P, P, P, P, ctypes.c_int, P, P]
         L.hs_observe.argtypes = [P, P, P, P]
+        L.hs_observe_perm.argtypes = [P, P, P, ctypes.c_int, P]
         L.hs_fill_layout.argtypes = [P]
         L.hs_start_carry.argtypes = [P, P, P, P]
         L.hs_bot_decide.argtypes = [P, P, P, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -61,7 +62,10 @@ class HostEnv(object):
         return img
 
     def observe(self):
-        self.L.hs_observe(ctypes.byref(self.cfg), self.rec.ctypes.data, self.hot.ctypes.data, self.out.ctypes.data)
+        if self.prefetch_order:     # ... and the observation through k_step's register pipeline (bbai_view.hpp view_cells_perm + encode_cells)
+            self.L.hs_observe_perm(ctypes.byref(self.cfg), self.rec.ctypes.data, self.hot.ctypes.data, -1, self.out.ctypes.data)
+        else:
+            self.L.hs_observe(ctypes.byref(self.cfg), self.rec.ctypes.data, self.hot.ctypes.data, self.out.ctypes.data)
         return self.out.reshape(7, 7, 3).copy()
 
     prefetch_order = False      # True: step in k_step's order of operations (bbai_step.hpp step_env_prefetch)
