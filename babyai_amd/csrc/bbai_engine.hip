@@ -130,6 +130,7 @@ struct bbai_env {
     int render_tpb;       // BBAI_RENDER_TPB: 256 / 512 / 1024 threads per render block; anything else = by batch size
     int render_group;     // BBAI_RENDER_GROUP: 2, 4 or 8 envs per one-shot render block; anything else = by batch size (bbai_render)
     int pregen_cap;       // BBAI_PREGEN_BLOCKS: upper bound on look-ahead lane groups per launch (experiments)
+    int pregen_per_group; // BBAI_PREGEN_PER_GROUP / option "pregen_per_group": single-room levels: list entries per working lane group of a refill (default 32 = one per tick of the longest window)
     int pregen_min;       // BBAI_PREGEN_MIN / option "pregen_min": single-room levels: lane groups that work on a refill at least (k_pregen: entries / 32 otherwise); 0 = the whole grid, as mazes always get
     int pregen_group;     // BBAI_PREGEN_GROUP: lanes per env in k_pregen: 32 (default: two envs per wave), 16 or 64
     int step_prio;        // BBAI_STEP_PRIO: s_setprio level of the step-path kernels' waves (they share CUs with k_pregen)
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
                                                   const int32_t* __restrict__ gen_list, const uint32_t* __restrict__ gen_count /* NULL: dense -- every env, the whole grid works */,
                                                   int depth,
                                                   uint8_t* __restrict__ pending, const uint8_t* __restrict__ first_slot,
-                                                  unsigned long long* __restrict__ gen_failures, int min_groups,
+                                                  unsigned long long* __restrict__ gen_failures, int min_groups, int per_group /* list entries a working group should get */,
                                                   uint8_t* __restrict__ next_obs /* in-place layout: [D][n][OBS_SLOT], else NULL */) {
     constexpr int NG = 64 / G;
     typedef GroupCtx<G> Ctx;
@@ -815,7 +816,7 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
     // the generator no longer keeps up and the step stream waits.  Surplus blocks leave at once.
     int64_t stride = (int64_t)gridDim.x * NG;
     if (gen_count && min_groups > 0) {
-        int64_t active = count / MAX_PERIOD;
+        int64_t active = count / per_group;
         active = active < min_groups ? min_groups : active;
         active = (active + NG - 1) / NG * NG;                   // whole blocks: every group of a block that stays has its own residue
         stride = active < stride ? active : stride;
@@ -1615,6 +1616,8 @@ static int create_finish(bbai_env* e) {
         e->pregen_cap = ev ? std::max(64, atoi(ev)) : 256 * 32 * 4;
         const char* mv = getenv("BBAI_PREGEN_MIN");
         e->pregen_min = mv ? std::max(0, atoi(mv)) : 2048;
+        const char* pp = getenv("BBAI_PREGEN_PER_GROUP");
+        e->pregen_per_group = pp ? std::max(1, atoi(pp)) : MAX_PERIOD;
         const char* pg = getenv("BBAI_PREGEN_GROUP");
         e->pregen_group = pg ? atoi(pg) : 32;
         const char* sp = getenv("BBAI_STEP_PRIO");
@@ -1672,7 +1675,7 @@ static void launch_pregen_g(const bbai_env* e, unsigned groups, bool listed /* f
     // profiles/r04/pregen_min_ab.jsonl) -- mazes keep the whole grid.
     const int min_groups = e->cfg.num_rows * e->cfg.num_cols > 1 ? 0 : e->pregen_min;
 #define PREGEN_LAUNCH(KK, OO) hipLaunchKernelGGL((k_pregen<KK, G, OO>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, e->gen_list, \
-                                                listed ? e->gen_count : nullptr, e->depth, pending, first_slot, fails, min_groups, e->next_obs)
+                                                listed ? e->gen_count : nullptr, e->depth, pending, first_slot, fails, min_groups, e->pregen_per_group, e->next_obs)
     if (e->cfg.kind == K_LEVELGEN) { if (e->next_obs) PREGEN_LAUNCH(K_LEVELGEN, true); else PREGEN_LAUNCH(K_LEVELGEN, false); }
     else if (e->cfg.kind == K_BONUS) { if (e->next_obs) PREGEN_LAUNCH(K_BONUS, true); else PREGEN_LAUNCH(K_BONUS, false); }
     else { if (e->next_obs) PREGEN_LAUNCH(K_GOTO, true); else PREGEN_LAUNCH(K_GOTO, false); }
@@ -2542,6 +2545,7 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     else if (!strcmp(name, "pregen_group")) e->pregen_group = v;
     else if (!strcmp(name, "pregen_blocks")) e->pregen_cap = std::max(64, v);
     else if (!strcmp(name, "pregen_min")) e->pregen_min = std::max(0, v);
+    else if (!strcmp(name, "pregen_per_group")) e->pregen_per_group = std::max(1, v);
     else if (!strcmp(name, "consume_fused")) e->consume_fused = v;
     else if (!strcmp(name, "gate_strict")) e->gate_strict = v != 0;
     else if (!strcmp(name, "step_render_split")) e->step_render_split = v;
@@ -2572,6 +2576,7 @@ int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     else if (!strcmp(name, "pregen_group")) *out = e->pregen_group;
     else if (!strcmp(name, "pregen_blocks")) *out = e->pregen_cap;
     else if (!strcmp(name, "pregen_min")) *out = e->pregen_min;
+    else if (!strcmp(name, "pregen_per_group")) *out = e->pregen_per_group;
     else if (!strcmp(name, "consume_fused")) *out = e->consume_fused;
     else if (!strcmp(name, "gate_strict")) *out = e->gate_strict;
     else if (!strcmp(name, "step_render_split")) *out = e->step_render_split;

@@ -115,8 +115,10 @@ struct Gen {
     }
     const LevelCfg& cfg;
     GenWork& w;
-    uint32_t* const mt;      // (= w.mt, held in a register: w may live in global memory)
+    uint32_t* const mt;      // (= w.mt, held in a register)
     int mti;                 // MT19937 output index (wave-uniform)
+    uint32_t nxt;            // mt[mti], fetched one draw AHEAD: the generator is a chain of draw -> test -> branch -> draw, and every
+                             // link used to start with an LDS round trip
     int nobj;
     int ax, ay, adir;
     bool agent_set;
@@ -132,7 +134,7 @@ struct Gen {
     uint32_t inv_cols, inv_s1, inv_es;   // 2^16/d + 1: exact small-range division without the divider
 
     BB_HD Gen(Ctx c, const LevelCfg& cf, GenWork& wk, int mti_, int last_locked_)
-        : ctx(c), cfg(cf), w(wk), mt(wk.mt), mti(mti_), nobj(0), ax(0), ay(0), adir(0), agent_set(false),
+        : ctx(c), cfg(cf), w(wk), mt(wk.mt), mti(mti_), nxt(wk.mt[mti_ < MT_N ? mti_ : 0]), nobj(0), ax(0), ay(0), adir(0), agent_set(false),
           locked_room(-1), last_locked(last_locked_), S(cf.room_size), rows(cf.num_rows), cols(cf.num_cols),
           gave_up(false), doors(0), locked_mask(0), inv_cols(65536u / (uint32_t)cf.num_cols + 1u),
           inv_s1(65536u / (uint32_t)(cf.room_size - 1) + 1u), inv_es(65536u / (uint32_t)cf.ES + 1u) {}
@@ -144,9 +146,11 @@ struct Gen {
     // ---------------- MT19937 (numpy legacy RandomState bit stream) ----------------
     BB_HD void twist() { mt_twist(ctx, mt); }
     BB_HD uint32_t next_u32() {
-        if (mti >= MT_N) { twist(); mti = 0; count(PH_TWISTS); }
+        if (mti >= MT_N) { twist(); mti = 0; nxt = mt[0]; count(PH_TWISTS); }
         count(PH_DRAWS);
-        uint32_t y = mt[mti++];
+        uint32_t y = nxt;
+        ++mti;
+        nxt = mt[mti < MT_N ? mti : 0];         // (for the next draw; after word 623 the twist reloads it)
         y ^= (y >> 11);
         y ^= (y << 7) & 0x9d2c5680u;
         y ^= (y << 15) & 0xefc60000u;
@@ -157,8 +161,7 @@ struct Gen {
     BB_HD int rand_int(int lo, int hi) {
         uint32_t rng = (uint32_t)(hi - lo - 1);
         if (rng == 0) return lo;
-        uint32_t mask = rng;
-        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        const uint32_t mask = 0xFFFFFFFFu >> __builtin_clz(rng);       // smallest 2^k - 1 >= rng (numpy's mask), rng >= 1
         uint32_t v;
         do { v = next_u32() & mask; } while (v > rng);
         return lo + (int)v;

@@ -36,6 +36,7 @@ judged() {           # the driver's command
 rejudged() {         # after trace + pmc: condense them ON THE BOX (profiles/pmc_latest.json of this copy) and run the driver's command once
                      # more, so that the line quotes the counter passes of its own sources
     cd $REPO && python tools/summarize_profile.py $TAG > $OUT/summarize.log 2>&1
+    mkdir -p $OUT/condensed && cp profiles/$TAG/* profiles/pmc_latest.json $OUT/condensed/ 2>/dev/null
     cd /tmp && timeout 600 $B > $OUT/bench_boss_pixel_1M_with_traffic.json 2> $OUT/bench_boss_pixel_1M_with_traffic.err
     python $REPO/tools/summarize_profile.py --line $OUT/bench_boss_pixel_1M_with_traffic.json | head -1
 }
@@ -174,7 +175,19 @@ profcfg() {          # profcfg:<config>[:<bench args>] -- the evidence set of ON
     timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_ACTIVE_INST_VALU \
         --kernel-trace --output-format csv -d $OUT/pmc_sq_$cfg -o t -- $B1 > /dev/null 2> $OUT/rocprof_sq_$cfg.log
     cd $REPO && python tools/summarize_profile.py $TAG --config $cfg 2>&1 | tail -12
+    mkdir -p $OUT/condensed && cp profiles/$TAG/* profiles/pmc_latest.json $OUT/condensed/ 2>/dev/null     # (the box's profiles/ does not travel back: gpurun_out/ does)
     find $OUT -name "*.csv" -size +8M -delete
+}
+benchlib() {         # one BASELINE config on another engine build: benchlib:<name>:<path to .so relative to the repo>:<config>[:bench args] -> bench_<config>_<name>.json
+    local name=$1 so=$2 cfg=$3; shift 3
+    cd /tmp && BBAI_ENGINE_LIB=$REPO/$so timeout 600 python $REPO/bench.py --config $cfg --no-extra-configs --no-cpu-baseline ${@} > $OUT/bench_${cfg}_$name.json 2>> $OUT/bench.err
+    python - <<PY
+import json
+d = json.loads(open("$OUT/bench_${cfg}_$name.json").read().strip().splitlines()[-1])
+t = d["timing"]
+print("$name $cfg ms/step mean %.4f median %.4f max/med %.2f kernels %s parity %s" % (d["ms_per_step"], t["block_ms"]["median"] / d["steps"], t["max_over_median"],
+      d["roofline"]["kernel_avg_ms"], (d.get("parity") or {}).get("mismatches_all_ranks")))
+PY
 }
 tracecfg() {         # rocprofv3 kernel trace of one BASELINE config (tracecfg:C2): launch gaps on the small shards
     cd /tmp && rm -rf $OUT/trace_$1
