@@ -807,13 +807,16 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
         __syncthreads();
         count = (int64_t)s_start[SHARDS];
     }
-    // How many lane groups WORK on a window's refill: the grid is sized for the worst case (every env finished on every tick), the
-    // list usually holds a fraction of that, and every resident generator wave holds registers and LDS that the step kernels'
-    // workgroups queue for.  A refill has a whole window (B ticks) to land, so ~B list entries per group keep pace with the
-    // consumption: active = entries / 32, at least `min_groups` (the launch must not become its slowest level x a long queue),
-    // at most the grid.  Measured (profiles/r04/pregen_cap_priority_group_ab.jsonl, groups in flight 32 768 -> 4 096 / 2 048):
-    // PickupLoc 262 144 envs 0.0870 -> 0.0811 ms per step, GoToLocal 65 536 0.0371 -> 0.0342; 1 024 / 512 groups: 0.209 / 0.092 --
-    // the generator no longer keeps up and the step stream waits.  Surplus blocks leave at once.
+    // How many lane groups WORK on a window's refill (single rooms): the grid is sized for the worst case (every env finished on every
+    // tick), the list usually holds a fraction of that, and every resident generator wave holds registers and LDS that the step kernels'
+    // workgroups queue for -- but a refill that takes as long as a window paces the whole step stream (k_gate).  active = entries /
+    // per_group, at least `min_groups`, at most the grid; surplus blocks leave at once.  Round 4 (k_step + k_consume, 25 + 15 us per
+    // step at 65 536 envs) found entries / 32 and >= 2 048 groups best.  Round 5, with k_step at 16 us, no second launch and the
+    // stream free to run ahead of the refills, the SAME sweep says: more groups, shorter refills (profiles/r05/pregen_sizing_sweep.jsonl,
+    // ms per step): GoToLocal 65 536 envs 0.0319 at 2 048 groups, 0.0205 at 4 096, 0.0179 at 6 144, 0.0199 at 8 192, 0.0206 with the whole grid;
+    // GoToLocal 32 768: 0.0181 / 0.0122 / 0.0127 at 2 048 / 4 096 / 8 192; PickupLoc 262 144: 0.0755 at entries / 32, 0.067 at / 16, 0.059-0.063
+    // at / 12 ... / 4; GoToLocal 262 144: 0.0706 / 0.0644 / 0.0618 / 0.0655 at / 32, 16, 8, 4; PickupLoc 524 288: 0.134 / 0.121 / 0.124 / 0.132.
+    // Shipped: entries / 12, at least 6 144 groups.
     int64_t stride = (int64_t)gridDim.x * NG;
     if (gen_count && min_groups > 0) {
         int64_t active = count / per_group;
@@ -1615,9 +1618,9 @@ static int create_finish(bbai_env* e) {
         const char* ev = getenv("BBAI_PREGEN_BLOCKS");
         e->pregen_cap = ev ? std::max(64, atoi(ev)) : 256 * 32 * 4;
         const char* mv = getenv("BBAI_PREGEN_MIN");
-        e->pregen_min = mv ? std::max(0, atoi(mv)) : 2048;
+        e->pregen_min = mv ? std::max(0, atoi(mv)) : 6144;
         const char* pp = getenv("BBAI_PREGEN_PER_GROUP");
-        e->pregen_per_group = pp ? std::max(1, atoi(pp)) : MAX_PERIOD;
+        e->pregen_per_group = pp ? std::max(1, atoi(pp)) : 12;
         const char* pg = getenv("BBAI_PREGEN_GROUP");
         e->pregen_group = pg ? atoi(pg) : 32;
         const char* sp = getenv("BBAI_STEP_PRIO");
