@@ -1616,7 +1616,11 @@ static int create_finish(bbai_env* e) {
         const char* cv = getenv("BBAI_CALL_EVENTS");
         e->call_events = cv && atoi(cv) != 0;
         const char* ev = getenv("BBAI_PREGEN_BLOCKS");
-        e->pregen_cap = ev ? std::max(64, atoi(ev)) : 256 * 32 * 4;
+        // lane groups of a refill launch at most: 16 384 = two generator waves per SIMD of the part, the other half of every SIMD stays with the step
+        // kernels (profiles/r05/pregen_residency_cap_ab.jsonl, ms per step at 32 768 / 16 384 / 8 192 / 4 096 groups: GoTo 131 072 envs 0.0438 / 0.0390 /
+        // 0.0395 / 0.0478; BossLevel encoded 1 048 576 0.110 / 0.104 / 0.104; BossLevel pixels 131 072: no difference).  bbai_seed's first fill
+        // (nothing else runs) takes the whole part: 32 768.
+        e->pregen_cap = ev ? std::max(64, atoi(ev)) : 16384;
         const char* mv = getenv("BBAI_PREGEN_MIN");
         e->pregen_min = mv ? std::max(0, atoi(mv)) : 6144;
         const char* pp = getenv("BBAI_PREGEN_PER_GROUP");
@@ -1844,7 +1848,7 @@ int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
     HIP_TRY(hipMemsetAsync(e->pending, 0, NWIN * (size_t)n, e->side));
     HIP_TRY(hipMemsetAsync(e->first_slot, 0, NWIN * (size_t)n, e->side));
     HIP_TRY(hipMemsetAsync(e->pending, e->depth - e->inplace, (size_t)n, e->side));      // (in-place: slot depth - 1 is the live one -- empty until the first reset)
-    launch_pregen(e, pregen_grid(e, n), false, e->pending, e->first_slot);
+    launch_pregen(e, (unsigned)std::max<int64_t>(1, std::min<int64_t>(n, std::max(e->pregen_cap, 32768))), false, e->pending, e->first_slot);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(e->win_meta, 0, NWIN * META_U32 * 4, e->side));
     HIP_TRY(hipMemsetAsync(e->vset, 0, (size_t)n * 64, e->side));
