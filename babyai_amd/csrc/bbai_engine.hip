@@ -1,27 +1,27 @@
 // bbai_engine.hip -- HIP kernels + C ABI of the batched BabyAI engine (gfx950 / MI355X).
 //
 // Kernels (all integer / byte work, HBM- and latency-bound; no MFMA by design):
-//   k_step         lane = env.  Coalesced SoA loads of the 16-byte hot state, action, stale set and
-//                  verifier program; per-lane transition + verifier on the env's record; the 7x7
-//                  window is fetched as 7 rows x 3 dwords, staged in LDS and read back in view
-//                  orientation; the 147-byte encodings of a block's 256 envs are staged in LDS and
-//                  written back as one contiguous, dword-coalesced span.  Finished envs are
-//                  compacted into the reset list with one wave-aggregated atomic per wave.
-//   k_pregen<F>    (one instantiation per level family F) wave = env: the NEXT levels of an env's MT19937 stream are generated wave-uniformly
-//                  with the whole working set in LDS (bbai_gen.hpp) into the env's look-ahead ring.
-//                  step() draws no randomness, so an env's level sequence is a pure function of
-//                  its seed: generation runs ahead of need on a second HIP stream, one launch per
-//                  window of B consume-ticks, and overlaps the render kernel / the caller's policy
-//                  instead of sitting on the step path.
-//   k_consume      wave = env over the reset list: look-ahead slot -> live state (coalesced copy), SoA verifier
-//                  view, first observation of the new episode.
-//   k_tokens       lane = env over the reset list: mission text as fixed-vocabulary token ids.
-//   k_render       RGBImgPartialObsWrapper as a pure tile-atlas gather: atlas + per-cell tile ids
-//                  in LDS, 16 bytes per lane per store, a wave writes 1 KiB of contiguous pixels; one 2- or 8-env group per
-//                  one-shot block of 512 / 1024 threads (by batch size, bbai_render).
-//
+//   k_step<VP, FUSE>  lane = env, one wave per block.  Coalesced SoA loads of the 16-byte hot state, action, stale set and verifier program;
+//                  per-lane transition + verifier on the env's record; the 7x7 window is fetched as 7 rows x 3 dwords (one 128-byte line
+//                  of the window plane, VP) and rotated, occluded and masked in REGISTERS (bbai_view.hpp: byte permutes, SWAR opacity,
+//                  dot-product row masks); the 147-byte encodings of the block's 64 envs are staged in LDS at the output pitch and leave as one
+//                  contiguous 16-byte-per-lane span.  Finished envs: FUSE 1 -- the stepping wave consumes their look-ahead slots itself
+//                  (consume_env); FUSE 3 (in-place layout) -- every finished lane moves its own env on to its next ring slot
+//                  (advance_load / advance_finish); FUSE 0 -- compacted into a reset list for k_consume.  The fused paths leave NO
+//                  returning atomic and no list behind: one fire-and-forget add to a sharded total per wave, per-env bytes for the refill.
+//   k_pregen<F, G, OBS>  (F = level family) one env per group of G lanes: the NEXT levels of an env's MT19937 stream, working set in LDS
+//                  (bbai_gen.hpp), into the env's look-ahead ring (OBS: + the level's first observation).  step() draws no randomness, so an
+//                  env's level sequence is a pure function of its seed: generation runs ahead of need on a second HIP stream, one launch per
+//                  window of B consume-ticks over the list k_compact builds from the window's `pending` bytes.
+//   k_compact / k_mark / k_gate   the windows' turnover: the refill's work list (look-ahead stream), the refill's completion count, and
+//                  the step stream's wait for "every env is sure to keep a window's worth of ready levels" (see NWIN below).
+//   k_consume      wave = env over the reset list (unfused steps, reset()): look-ahead slot -> live state, SoA verifier view, first observation.
+//   k_tokens       lane = env: mission text as fixed-vocabulary token ids of the envs that started a new episode.
+//   k_render_q / k_render   RGBImgPartialObsWrapper as a pure tile-atlas gather: atlas + per-cell tile ids in LDS, 16 bytes per lane per
+//                  store, a wave writes 1 KiB of contiguous pixels; persistent blocks fed by ONE ticket counter from 262 144 envs
+//                  (k_render_q), one-shot (512, 2) blocks below.
 //   k_bot<W>       lane = env: one decision of the reference's GOFAI expert (babyai/bot.py) per env, W = occupancy target
-//                  (bbai_bot.hpp); only launched by bbai_bot_act.
+//                  (bbai_bot.hpp); only launched by bbai_bot_act / bbai_bot_rollout.
 //
 // Reference semantics: see bbai_step.hpp / bbai_gen.hpp / bbai_bot.hpp headers for file:line citations.
 #include <hip/hip_runtime.h>
@@ -208,8 +208,8 @@ __device__ __forceinline__ void count_resets(unsigned long long* __restrict__ to
 // The in-wave consume (FUSE) RELIES on it: the LDS traffic of a block is ordered by the wave's program order alone.
 constexpr int STEP_BLOCK = 64;
 #ifndef BBAI_STEP_WAVES
-#define BBAI_STEP_WAVES 1          // minimum waves per SIMD the register allocation of k_step has to allow (106 VGPRs = 4 waves; forcing 5 spills:
-#endif                             // profiles/r04/NOTES.md section 6)
+#define BBAI_STEP_WAVES 1          // minimum waves per SIMD the register allocation of k_step has to allow (the compiler's own figures:
+#endif                             // babyai_amd/kernel_resources.json, quoted in DESIGN.md section 4; the block's 9.4 KB of LDS stop at 17 blocks per CU)
 // BBAI_PREFETCH_ID=1 (experiment): the id-plane entry of the front cell fetched WITH the window.  Measured slower everywhere
 // (step_variants_ab.jsonl: BossLevel encoded 1M k_step 0.130 -> 0.148 ms, GoTo 131 072 0.021 -> 0.028): one more line per
 // env-step costs more than the verifier's occasional extra round trip.  Off.
@@ -2066,13 +2066,17 @@ int bbai_render(bbai_env* e, const uint8_t* image, uint8_t* pixels, void* stream
 }  // extern "C"
 
 // step + render of a pixel batch as ONE call.  The render is a pure store stream at the chip's fill rate (k_render_q: 1.50 ms per
-// 1 048 576 envs) and k_step (0.10 ms) runs in FRONT of it with the store pipes idle -- 6 % of the headline step.  Split: the batch is
-// stepped in two halves; the second half's k_step goes to a stream of its own and runs UNDER the first half's render (the render's blocks hold
-// 56 VGPRs and 20 KB of LDS per CU: room for k_step's waves next to them):
+// 1 048 576 envs) and k_step (0.10 ms) runs in FRONT of it with the store pipes idle -- 6 % of the headline step.  Split (option
+// "step_render_split" = 1): the batch is stepped in two halves; the second half's k_step goes to a stream of its own and runs UNDER the
+// first half's render (the render's blocks hold 56 VGPRs and 20 KB of LDS per CU: room for k_step's waves next to them):
 //     caller's stream:  gate . k_step(A) . k_render(A) ........ [wait B] . tokens / window close . k_render(B)
 //     split stream:             k_step(B) ........
-// Same kernels, same bytes (tests/test_gpu_parity.py::test_step_render_split_*).  Only with the fused / in-place consume (a k_consume launch
-// would need both halves) and from STEP_RENDER_SPLIT_MIN envs; option "step_render_split" (1 / 0; -1 = STEP_RENDER_SPLIT_DEFAULT).
+// Same kernels, same bytes (tests/test_gpu_parity.py::test_step_render_split_*).  MEASURED SLOWER at every size, settings alternated in
+// one process (profiles/r05/step_render_split_ab.jsonl, ms per step unsplit / split): 1 048 576 envs 1.599 / 1.609, 524 288 0.806 / 0.808,
+// 262 144 0.413 / 0.423, 131 072 0.210 / 0.222 -- the two half renders together cost more than the one (0.7565 x 2 vs 1.5007 ms: the
+// store stream's pacing restarts) and the joins are not free; k_step under the render gains less than that.  Hence off by default; the
+// entry point stays: it is the wrapped env's step() as one call.  Only with the fused / in-place consume (a k_consume launch would need
+// both halves).
 constexpr int64_t STEP_RENDER_SPLIT_MIN = 262144;
 #ifndef STEP_RENDER_SPLIT_DEFAULT
 #define STEP_RENDER_SPLIT_DEFAULT 0
