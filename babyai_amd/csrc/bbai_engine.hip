@@ -1247,6 +1247,8 @@ __global__ __launch_bounds__(RENDER_BLOCK) void k_render(int64_t n, const uint8_
 //   * the counters clean up after themselves: the last block to leave (a departure counter) zeroes them for the next launch,
 //     so the step path carries no memset.
 // Tile rows and tickets are double-buffered: one barrier per group.
+// (The counters are the handle's: two renders of one handle never overlap -- every entry point orders a call on another stream behind the
+// handle's previous call, enter_call -- and a launch that was aborted by a device fault leaves a handle that is unusable anyway.)
 template <int RENDER_GROUP, int RENDER_BLOCK, int NC, int K>
 __global__ __launch_bounds__(RENDER_BLOCK) void k_render_q(int64_t n, const uint8_t* __restrict__ image,
                                                            uint8_t* __restrict__ pixels, const uint8_t* __restrict__ atlas,
