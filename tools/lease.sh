@@ -37,6 +37,7 @@ rejudged() {         # after trace + pmc: condense them ON THE BOX (profiles/pmc
                      # more, so that the line quotes the counter passes of its own sources
     cd $REPO && python tools/summarize_profile.py $TAG > $OUT/summarize.log 2>&1
     mkdir -p $OUT/condensed && cp profiles/$TAG/* profiles/pmc_latest.json $OUT/condensed/ 2>/dev/null
+    rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
     cd /tmp && timeout 600 $B > $OUT/bench_boss_pixel_1M_with_traffic.json 2> $OUT/bench_boss_pixel_1M_with_traffic.err
     python $REPO/tools/summarize_profile.py --line $OUT/bench_boss_pixel_1M_with_traffic.json | head -1
 }
@@ -141,6 +142,10 @@ genrate() {          # bulk level-generation rate (bbai_seed's first fill) per g
         BBAI_PREGEN_GROUP=$g timeout 300 python $REPO/tools/gen_rate.py 2>> $OUT/gen_rate.err | tee -a $OUT/gen_rate_by_group_width.jsonl
     done
 }
+genprof() {          # phase profile of the level generator (tools/genprof.hip): genprof[:<level> ...]
+    cd $REPO && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/genprof tools/genprof.hip 2>/dev/null
+    for l in ${@:-GoToLocal PickupLoc GoTo BossLevel}; do timeout 120 /tmp/genprof $l | tee -a $OUT/genprof.txt; done
+}
 ubench() {           # the microbenchmarks DESIGN.md quotes (built here: hipcc is on the box)
     cd $REPO && for u in gather render fetchcal; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/ubench_$u tools/ubench_$u.hip 2>/dev/null; done
     timeout 120 python tools/membw.py > $OUT/membw.json 2> $OUT/membw.err
@@ -175,8 +180,8 @@ profcfg() {          # profcfg:<config>[:<bench args>] -- the evidence set of ON
     timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_ACTIVE_INST_VALU \
         --kernel-trace --output-format csv -d $OUT/pmc_sq_$cfg -o t -- $B1 > /dev/null 2> $OUT/rocprof_sq_$cfg.log
     cd $REPO && python tools/summarize_profile.py $TAG --config $cfg 2>&1 | tail -12
-    mkdir -p $OUT/condensed && cp profiles/$TAG/* profiles/pmc_latest.json $OUT/condensed/ 2>/dev/null     # (the box's profiles/ does not travel back: gpurun_out/ does)
-    find $OUT -name "*.csv" -size +8M -delete
+    mkdir -p $OUT/condensed && cp profiles/$TAG/* profiles/pmc_latest.json $OUT/condensed/ 2>/dev/null     # (the box's profiles/ does not travel back: gpurun_out/ does,
+    rm -rf $OUT/stats_$cfg $OUT/pmc_fetch_$cfg $OUT/pmc_write_$cfg $OUT/pmc_sq_$cfg                          #  up to 64 MiB: the raw passes stay on the box)
 }
 benchlib() {         # one BASELINE config on another engine build: benchlib:<name>:<path to .so relative to the repo>:<config>[:bench args] -> bench_<config>_<name>.json
     local name=$1 so=$2 cfg=$3; shift 3
