@@ -792,7 +792,6 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
     __shared__ GenWork ws[NG];
     __shared__ uint32_t s_mt[NG][MT_N];
     GenWork& w = ws[threadIdx.x / G];
-    w.mt = s_mt[threadIdx.x / G];
     const int lane = ctx.lane();
     // the refill list: prefix of the sub-list lengths (one word per lane, a wave scan, parked in LDS for the groups' searches)
     __shared__ uint32_t s_start[SHARDS + 1];
@@ -869,7 +868,7 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
         }
         if (__ballot(have) == 0ull) break;               // every group of the wave has run out of work
         if (!have) continue;
-        Gen<Ctx> g(ctx, c, w, mti, last_locked);
+        Gen<Ctx> g(ctx, c, w, s_mt[threadIdx.x / G], mti, last_locked);
         bool ok = g.template attempt<KIND>();
         mti = g.mti;
         last_locked = g.last_locked;

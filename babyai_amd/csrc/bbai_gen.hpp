@@ -29,8 +29,9 @@ namespace bbai {
 constexpr int GEN_ES = 36;                       // >= round_up(MAX_W + 2*MARGIN, 4)
 constexpr int GEN_EH = MAX_W + 2 * MARGIN;       // 35
 
-struct GenWork {                                 // lives in LDS on the device (lane groups) or in a per-lane global scratch block (lane = level)
-    uint32_t* mt;                                // the env's MT19937 state: an LDS copy (lane groups), the env's own array (lane = level, host)
+struct GenWork {                                 // lives in LDS on the device; the env's MT19937 state sits next to it (k_pregen: s_mt) and reaches
+                                                 // Gen as a POINTER ARGUMENT, never through a field: a pointer loaded from memory is a generic
+                                                 // pointer, and every draw became a flat_load + s_waitcnt vmcnt(0) lgkmcnt(0) instead of a ds_read
     uint8_t E[GEN_ES * GEN_EH];
     uint8_t I[MAX_W * MAX_W + 3];
     uint8_t app[MAX_OBJ], px[MAX_OBJ], py[MAX_OBJ];
@@ -115,7 +116,7 @@ struct Gen {
     }
     const LevelCfg& cfg;
     GenWork& w;
-    uint32_t* const mt;      // (= w.mt, held in a register)
+    uint32_t* const mt;      // the env's MT19937 state (device: LDS; host: the caller's array, advanced in place)
     int mti;                 // MT19937 output index (wave-uniform)
     uint32_t nxt;            // mt[mti], fetched one draw AHEAD: the generator is a chain of draw -> test -> branch -> draw, and every
                              // link used to start with an LDS round trip
@@ -133,8 +134,8 @@ struct Gen {
     uint32_t locked_mask;    // bit r: room r is behind a locked door (Room.locked)
     uint32_t inv_cols, inv_s1, inv_es;   // 2^16/d + 1: exact small-range division without the divider
 
-    BB_HD Gen(Ctx c, const LevelCfg& cf, GenWork& wk, int mti_, int last_locked_)
-        : ctx(c), cfg(cf), w(wk), mt(wk.mt), mti(mti_), nxt(wk.mt[mti_ < MT_N ? mti_ : 0]), nobj(0), ax(0), ay(0), adir(0), agent_set(false),
+    BB_HD Gen(Ctx c, const LevelCfg& cf, GenWork& wk, uint32_t* mt_, int mti_, int last_locked_)
+        : ctx(c), cfg(cf), w(wk), mt(mt_), mti(mti_), nxt(mt_[mti_ < MT_N ? mti_ : 0]), nobj(0), ax(0), ay(0), adir(0), agent_set(false),
           locked_room(-1), last_locked(last_locked_), S(cf.room_size), rows(cf.num_rows), cols(cf.num_cols),
           gave_up(false), doors(0), locked_mask(0), inv_cols(65536u / (uint32_t)cf.num_cols + 1u),
           inv_s1(65536u / (uint32_t)(cf.room_size - 1) + 1u), inv_es(65536u / (uint32_t)cf.ES + 1u) {}

@@ -34,8 +34,7 @@ int hs_generate(const LevelCfg* cfg, uint32_t* mt, int32_t* mti, uint8_t* rec, H
     int last_locked = hot->last_locked == NONE8 ? -1 : hot->last_locked;
     static thread_local GenWork w;
     memset((void*)&w, 0xA5, sizeof(w));          // (the device's working set starts as whatever LDS held: nothing may be read before it is written)
-    w.mt = mt;                                   // (the generator advances the caller's state in place)
-    Gen<HostCtx> g(HostCtx(), *cfg, w, *mti, last_locked);
+    Gen<HostCtx> g(HostCtx(), *cfg, w, mt, *mti, last_locked);      // (the generator advances the caller's state in place)
     int max_steps = g.generate();
     *mti = g.mti;
     memset(rec, 0, cfg->rec_bytes);

@@ -37,7 +37,6 @@ __global__ __launch_bounds__(64, 4) void k_prof(LevelCfg c, int n, int rounds, u
     __shared__ uint32_t s_mt[2][MT_N];
     const int grp = threadIdx.x / G, lane = threadIdx.x & (G - 1);
     GenWork& w = ws[grp];
-    w.mt = s_mt[grp];
     const ProfCtx ctx;
     for (int env = blockIdx.x * 2 + grp; env < n; env += gridDim.x * 2) {
         uint32_t* mt = mts + (size_t)env * MT_N;
@@ -47,7 +46,7 @@ __global__ __launch_bounds__(64, 4) void k_prof(LevelCfg c, int n, int rounds, u
         int mti = MT_N, last = -1;
         for (int r = 0; r < rounds; ++r) {
             const unsigned long long t0 = clock64();
-            Gen<ProfCtx> g(ctx, c, w, mti, last);
+            Gen<ProfCtx> g(ctx, c, w, s_mt[grp], mti, last);
             g.template generate_kind<KIND>();
             mti = g.mti; last = g.last_locked;
             const unsigned long long t1 = clock64();
