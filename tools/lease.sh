@@ -146,6 +146,10 @@ genprof() {          # phase profile of the level generator (tools/genprof.hip):
     cd $REPO && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/genprof tools/genprof.hip 2>/dev/null
     for l in ${@:-GoToLocal PickupLoc GoTo BossLevel}; do timeout 120 /tmp/genprof $l | tee -a $OUT/genprof.txt; done
 }
+saluvalu() {         # do scalar-bound and vector-bound waves of a CU add up? (tools/ubench_salu_valu.hip)
+    cd $REPO && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/ubench_salu_valu tools/ubench_salu_valu.hip 2>/dev/null
+    timeout 120 /tmp/ubench_salu_valu | tee $OUT/ubench_salu_valu.jsonl
+}
 ubench() {           # the microbenchmarks DESIGN.md quotes (built here: hipcc is on the box)
     cd $REPO && for u in gather render fetchcal; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/ubench_$u tools/ubench_$u.hip 2>/dev/null; done
     timeout 120 python tools/membw.py > $OUT/membw.json 2> $OUT/membw.err
