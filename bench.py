@@ -51,7 +51,8 @@ What one run proves about itself (all in the one JSON line rank 0 prints):
                 the oracle.  `configs` in the line; a mismatch there exits 3 like one in the headline.  --no-extra-configs skips them.
   * setup_ms    what is outside the metric: bbai_create, bbai_seed (incl. the first fill of the look-ahead rings), first reset.
   * cpu_baseline  the oracle on the usable host cores over the same seeds and action stream (rank 0; a reported
-                baseline), with the measured reference/port ratio of the build container when it is on file.
+                baseline), with the measured reference/port ratio of the build container when it is on file; every other
+                workload of `configs` gets its own short sample on the same cores (`configs.*.cpu_baseline`).
 
 Envs shard embarrassingly (babyai_amd/shard.py): rank r owns a contiguous range of global envs with seeds base + global
 index; no collective on the step path.
