@@ -24,6 +24,13 @@
 // QUEUED visits the same positions in the same order with the same predecessors, and bounds the queue by W*H.
 // (2) every search of one decision runs on the same grid from the same state, so two resumable search trees per
 // decision (see `search`) replace the reference's one-or-two searches per query.
+//
+// Execution model (round 5): Bot<Ctx> -- ONE LANE GROUP = ONE ENV, Ctx::kLanes lanes wide, as in bbai_gen.hpp.  The subgoal machine is
+// group-uniform code (every lane of the group computes the same values; shared state is only written with values all lanes agree on),
+// the data-parallel parts split over the lanes: the 49 view cells of _process_obs, the grid rows of the search masks, the four
+// neighbours of a popped position (queue order kept by a ballot prefix), the acceptance scan over the positions a search has popped,
+// the grid scan for keys.  Ctx contract: kLanes, lane(), nlanes(), sync() (the group's memory accesses before / after are ordered),
+// ballot(pred) (bit k = lane k of the group).  OneLane (the host build, and k_bot's lane = env form) makes all of it sequential.
 #pragma once
 #include "bbai_types.hpp"
 #include "bbai_step.hpp"
@@ -49,6 +56,14 @@ enum { BP_DECIDE = 0, BP_OBS = 1, BP_AFTER = 2, BP_FIND_OBJ = 3, BP_PATH = 4, BP
        BP_INIT = 9, BP_KEYS = 10 };
 
 namespace bbai {
+
+struct OneLane {
+    static constexpr int kLanes = 1;
+    BB_HD int lane() const { return 0; }
+    BB_HD int nlanes() const { return 1; }
+    BB_HD void sync() const {}
+    BB_HD unsigned long long ballot(bool p) const { return p ? 1ull : 0ull; }
+};
 
 constexpr int BOT_STACK = 48;       // default subgoal stack depth (overflow => dead, counted); BBAI_BOT_STACK raises it
 constexpr int BOT_KEYS = 12;        // same-colour keys a key descriptor can list (overflow => dead, counted)
@@ -98,8 +113,10 @@ struct BotWork {
     uint16_t* base;
     int stride;
     int cells;                      // W * H of the level: the four arrays are packed to the grid actually in use
-    uint32_t* rows_fast;            // [R_FAST][rows_h] x rstride_fast
-    uint32_t* rows_slow;            // [R_ALL - R_FAST][MAX_W] x rstride_slow
+    uint16_t* near_q = nullptr;     // lane-group kernel: search 1's predecessor + queue arrays [2][cells] in LDS (search 2's stay in `base`)
+    uint32_t* rows_fast;            // [fast_n][rows_h] x rstride_fast
+    uint32_t* rows_slow;            // [R_ALL - fast_n][MAX_W] x rstride_slow
+    int fast_n = R_FAST;            // row-mask arrays held in rows_fast (lane-group kernel: all four)
     int rstride_fast, rstride_slow, rows_h;
     uint16_t* ring;                 // the newest `ring_size` (power of two) queue entries of search 1, entry i at
     int ring_stride, ring_size;     // ring[(i & (ring_size - 1)) * ring_stride]; 0 = no ring (host).  A FIFO's live part is
@@ -107,29 +124,38 @@ struct BotWork {
                                     // for a dependent global load per position
     int eager;                      // 1: run search 1 to exhaustion at the top of every decision, while the lanes of a wave are
                                     // still together (queries then only look things up); 0: expand lazily inside the queries
-    BB_HD uint16_t& at(int arr, int i) const { return base[(int64_t)(arr * cells + i) * stride]; }
+    BB_HD uint16_t& at(int arr, int i) const {
+        if (near_q && arr < WK_PREV2) return near_q[arr * cells + i];
+        return base[(int64_t)(arr * cells + i) * stride];
+    }
     BB_HD uint32_t& row(int arr, int y) const {
-        return arr < R_FAST ? rows_fast[(arr * rows_h + y) * rstride_fast] : rows_slow[(int64_t)((arr - R_FAST) * MAX_W + y) * rstride_slow];
+        return arr < fast_n ? rows_fast[(arr * rows_h + y) * rstride_fast] : rows_slow[(int64_t)((arr - fast_n) * MAX_W + y) * rstride_slow];
     }
 };
 
+template <class Ctx>
 struct Bot {
+    Ctx ctx;
     const LevelCfg& c;
     const uint8_t* rec;
     const Hot& h;
     uint64_t stale;
-    BotState& s;
-    Subgoal* stk;                   // s's stack (behind the struct)
+    BotState& s;                    // shared by the group's lanes: written only with values every lane agrees on
+    Subgoal* stk;                   // the subgoal stack (`cap` entries)
     int cap;
     BotWork w;
     const uint8_t *E, *I, *app, *pos;
     const Prog* prog;
     bool raised;
+    // per-lane copies of what a decision reads of the previous one and rewrites at its end (a lane must not see another lane's update)
+    int sp;
+    uint8_t prev_ax, prev_ay, prev_carry, door_was_open, prev_fwd_type;
 
-    BB_HD Bot(const LevelCfg& c_, const uint8_t* rec_, const Hot& h_, uint64_t stale_, BotState& s_, int cap_, const BotWork& w_)
-        : c(c_), rec(rec_), h(h_), stale(stale_), s(s_), stk((Subgoal*)(&s_ + 1)), cap(cap_), w(w_), raised(false) {
+    BB_HD Bot(Ctx ctx_, const LevelCfg& c_, const uint8_t* rec_, const Hot& h_, uint64_t stale_, BotState& s_, Subgoal* stk_, int cap_, const BotWork& w_)
+        : ctx(ctx_), c(c_), rec(rec_), h(h_), stale(stale_), s(s_), stk(stk_), cap(cap_), w(w_), raised(false) {
         E = rec; I = rec + c.off_I; app = rec + c.off_app; pos = rec + c.off_pos;
         prog = (const Prog*)(rec + c.off_prog);
+        sp = s.sp; prev_ax = s.prev_ax; prev_ay = s.prev_ay; prev_carry = s.prev_carry; door_was_open = s.door_was_open; prev_fwd_type = s.prev_fwd_type;
     }
 
     // ---- small helpers -------------------------------------------------------------------------------------
@@ -150,10 +176,10 @@ struct Bot {
     }
 
     BB_HD void push(const Subgoal& g) {
-        if (s.sp >= cap) { die(DEAD_CAPACITY); return; }
-        stk[s.sp++] = g;
+        if (sp >= cap) { die(DEAD_CAPACITY); return; }
+        stk[sp++] = g;
     }
-    BB_HD void pop() { if (s.sp) --s.sp; }
+    BB_HD void pop() { if (sp) --sp; }
     BB_HD static Subgoal mk(int kind, int reason = RS_NONE) {
         Subgoal g = {};
         g.kind = (uint8_t)kind; g.reason = (uint8_t)reason; g.dtype = DT_NONE;
@@ -229,12 +255,34 @@ struct Bot {
     // arrays are indexed y * W + x.
     BB_HD static int pk(int x, int y) { return y << 5 | x; }
     BB_HD int pidx(int p) const { return (p >> 5) * c.W + (p & 31); }
+    // (a group's lanes leave expand() with the queue, the predecessors and the row masks ordered: sync() on every path that wrote)
     BB_HD void expand(int prev, int q, int& qn, int st, bool ignore_blockers) const {
         const int p = st & 1023, d = st >> 10;
         const int x = p & 31, y = p >> 5;
         // seen, and (empty | open door | with ignore_blockers: any object that is not a wall or a closed door)
         if (!(w.row(ignore_blockers ? R_EXP2 : R_EXP1, y) >> x & 1)) return;
         const int rv = ignore_blockers ? R_VIS2 : R_VIS1;
+        if constexpr (Ctx::kLanes >= 4) {
+            // lanes 0..3 take one neighbour each, in the reference's order (di,dj), (dj,di), (-dj,-di), (-di,-dj); the ballot's prefix count
+            // gives each accepted neighbour its place in the queue.  Neighbours 0 / 3 and 1 / 2 are opposite: the horizontal pair shares
+            // row y of the queued-mask, so each of the two writes BOTH bits (same value from both lanes); the vertical pair owns its rows.
+            const int k = ctx.lane();
+            const int ndk = k == 0 ? d : k == 1 ? (d ^ 1) : k == 2 ? (3 - d) : (d ^ 2);
+            const int nx = x + dir_dx(ndk), ny = y + dir_dy(ndk);
+            const bool ok = k < 4 && in_grid(nx, ny) && !(w.row(rv, ny) >> nx & 1);
+            const unsigned m = (unsigned)ctx.ballot(ok) & 15u;
+            if (!m) return;                                        // (group-uniform)
+            if (ok) {
+                uint32_t bits = 1u << nx;
+                if (ny == y && (m >> (3 - k) & 1)) bits |= 1u << (2 * x - nx);
+                w.row(rv, ny) |= bits;
+                w.at(prev, ny * c.W + nx) = (uint16_t)p;
+                w.at(q, qn + __builtin_popcount(m & ((1u << k) - 1u))) = (uint16_t)(pk(nx, ny) | ndk << 10);
+            }
+            qn += __builtin_popcount(m);
+            ctx.sync();
+            return;
+        }
         const int nd[4] = {d, d ^ 1, 3 - d, d ^ 2};              // (di,dj), (dj,di), (-dj,-di), (-di,-dj)
         for (int k = 0; k < 4; ++k) {
             const int nx = x + dir_dx(nd[k]), ny = y + dir_dy(nd[k]);
@@ -263,9 +311,15 @@ struct Bot {
             while (!queued(rv, target) && head < qn) expand(prev, q, qn, w.at(q, head++), ignore_blockers);
             return queued(rv, target) ? target : -1;
         }
-        for (int i = 0; i < head; ++i) {
-            const int p = w.at(q, i) & 1023;
-            if (accept(a, p & 31, p >> 5, cell(p & 31, p >> 5))) return p;
+        for (int base = 0; base < head; base += ctx.nlanes()) {   // the popped positions, nlanes() at a time, first accepted wins
+            const int i = base + ctx.lane();
+            bool ok = false;
+            if (i < head) {
+                const int p = w.at(q, i) & 1023;
+                ok = accept(a, p & 31, p >> 5, cell(p & 31, p >> 5));
+            }
+            const unsigned long long m = ctx.ballot(ok);
+            if (m) return w.at(q, base + __builtin_ctzll(m)) & 1023;
         }
         while (head < qn) {
             const int st = w.at(q, head);
@@ -282,7 +336,7 @@ struct Bot {
         // a grid row = W appearance bytes at a dword-aligned pitch: fetched as 7 independent dwords (25 cells + the margin's
         // odd byte) and tested from registers -- no load waits on another
         constexpr int LEAD = MARGIN & 3;
-        for (int y = 0; y < c.H; ++y) {
+        for (int y = ctx.lane(); y < c.H; y += ctx.nlanes()) {
             const uint32_t sv = s.vis[y];
             const uint32_t* rp = (const uint32_t*)(E + (y + MARGIN) * c.ES + (MARGIN & ~3));
             uint32_t d[7];
@@ -301,6 +355,7 @@ struct Bot {
             if (second) { w.row(R_EXP2, y) = ex; w.row(R_VIS2, y) = w.row(R_VIS1, y); }     // search 2 starts from all search 1 reached
             else { w.row(R_EXP1, y) = ex; w.row(R_VIS1, y) = 0; }
         }
+        ctx.sync();
     }
     BB_HD void start1() const {
         if (qn1 >= 0) return;
@@ -311,16 +366,19 @@ struct Bot {
         w.at(WK_PREV1, pidx(start)) = 0xFFFE;
         if (w.ring_size) w.ring[0] = (uint16_t)(start | h.dir << 10);
         w.at(WK_Q1, qn1++) = (uint16_t)(start | h.dir << 10);
+        ctx.sync();
     }
     BB_HD void start2() const {                                    // needs search 1 complete (it is: its query just failed)
         if (qn2 >= 0) return;
         build_rows(true);
-        head2 = qn2 = 0;
-        for (int i = 0; i < qn1; ++i) {                            // every position search 1 reached, direction (1,0)
+        head2 = 0;
+        for (int i = ctx.lane(); i < qn1; i += ctx.nlanes()) {     // every position search 1 reached, direction (1,0)
             const int p = w.at(WK_Q1, i) & 1023;
             w.at(WK_PREV2, pidx(p)) = 0xFFFE;
-            w.at(WK_Q2, qn2++) = (uint16_t)p;
+            w.at(WK_Q2, i) = (uint16_t)p;
         }
+        qn2 = qn1;
+        ctx.sync();
     }
 
     struct Path { bool found; bool nonempty; int len; int nx, ny; int fxp, fyp; bool with_blockers; };
@@ -384,14 +442,20 @@ struct Bot {
         BOT_PROF(BP_KEYS);
         Subgoal g = mk(SG_GONEXT);
         g.dtype = DT_KEYS;
-        for (int x = 0; x < c.W; ++x)
-            for (int y = 0; y < c.H; ++y) {
-                const int e = cell(x, y);
-                if (e_type(e) == T_KEY && e_color(e) == color) {
-                    if (g.nkeys >= BOT_KEYS) { die(DEAD_CAPACITY); return g; }
-                    g.keys[g.nkeys++] = (uint16_t)((I[i_index(c, x, y)] - 2) << 10 | x << 5 | y);
-                }
+        const int cells = c.W * c.H;
+        for (int base = 0; base < cells; base += ctx.nlanes()) {       // x-major, nlanes() cells at a time
+            const int idx = base + ctx.lane();
+            bool hit = false;
+            if (idx < cells) {
+                const int e = cell(idx / c.H, idx % c.H);
+                hit = e_type(e) == T_KEY && e_color(e) == color;
             }
+            for (unsigned long long m = ctx.ballot(hit); m; m &= m - 1) {
+                const int j = base + __builtin_ctzll(m), x = j / c.H, y = j % c.H;
+                if (g.nkeys >= BOT_KEYS) { die(DEAD_CAPACITY); return g; }
+                g.keys[g.nkeys++] = (uint16_t)((I[i_index(c, x, y)] - 2) << 10 | x << 5 | y);
+            }
+        }
         return g;
     }
 
@@ -490,23 +554,23 @@ struct Bot {
     // ---- subgoals -----------------------------------------------------------------------------------------------
     BB_HD void plan_undo(int action) {                                                  // :109-137
         if (action == A_FORWARD) {
-            if (s.prev_ax != h.ax || s.prev_ay != h.ay) push(go_pos(h.ax, h.ay));
+            if (prev_ax != h.ax || prev_ay != h.ay) push(go_pos(h.ax, h.ay));
         } else if (action == A_LEFT) {
             push(go_pos(h.ax + rx(), h.ay + ry()));
         } else if (action == A_RIGHT) {
             push(go_pos(h.ax - rx(), h.ay - ry()));
-        } else if (action == A_DROP && s.prev_carry != h.carry) {
+        } else if (action == A_DROP && prev_carry != h.carry) {
             const int t = e_type(cell(fx(), fy()));
             if (!(t == T_KEY || t == T_BOX || t == T_BALL)) { die(); return; }
             push(mk(SG_PICKUP));
-        } else if (action == A_PICKUP && s.prev_carry != h.carry) {
+        } else if (action == A_PICKUP && prev_carry != h.carry) {
             push(mk(SG_DROP));
         } else if (action == A_TOGGLE) {
             const int e = cell(fx(), fy());
             if (e_type(e) == T_DOOR) {
-                if (s.door_was_open == 2) { die(); return; }        // AttributeError: fwd_door_was_open
+                if (door_was_open == 2) { die(); return; }          // AttributeError: fwd_door_was_open
                 const int open = e_state(e) == S_OPEN;
-                if (s.door_was_open != open) push(mk(open ? SG_CLOSE : SG_OPEN));
+                if (door_was_open != open) push(mk(open ? SG_CLOSE : SG_OPEN));
             }
         }
     }
@@ -748,8 +812,8 @@ struct Bot {
     BB_HD void init() {                                                                // Bot.__init__
         for (int y = 0; y < MAX_W; ++y) s.vis[y] = 0;
         for (int o = 0; o < c.maxo; ++o) { s.ipos[o][0] = pos[2 * o]; s.ipos[o][1] = pos[2 * o + 1]; }
-        s.sp = 0; s.dead = DEAD_NO;
-        s.prev_ax = s.prev_ay = 0; s.prev_carry = NONE8; s.door_was_open = 2; s.prev_fwd_type = 0;
+        sp = 0; s.dead = DEAD_NO;
+        prev_ax = prev_ay = 0; prev_carry = NONE8; door_was_open = 2; prev_fwd_type = 0;
         const int root = prog->root;
         if (root == R_ACTION || root == R_AND) process_side(0, prog->n_a);
         else if (root == R_BEFORE) { process_side(2, prog->n_b); process_side(0, prog->n_a); }      // b then a
@@ -759,51 +823,69 @@ struct Bot {
     BB_HD void process_obs() {                                                         // :658-687
         BOT_PROF(BP_OBS);
         uint32_t opq[VIEW], vis[VIEW];
-        for (int vj = 0; vj < VIEW; ++vj) {
-            uint32_t o = 0;
-            for (int vi = 0; vi < VIEW; ++vi) {
-                int x, y; view_to_world(h.ax, h.ay, h.dir, vi, vj, x, y);
-                if (e_opaque(cell(x, y))) o |= 1u << vi;
+        unsigned long long opaque = 0;                             // bit vj * 7 + vi, the 49 view cells nlanes() at a time
+        for (int base = 0; base < VIEW * VIEW; base += ctx.nlanes()) {
+            const int idx = base + ctx.lane();
+            bool o = false;
+            if (idx < VIEW * VIEW) {
+                int x, y; view_to_world(h.ax, h.ay, h.dir, idx % VIEW, idx / VIEW, x, y);
+                o = e_opaque(cell(x, y));
             }
-            opq[vj] = o;
+            opaque |= ctx.ballot(o) << base;
         }
+        for (int vj = 0; vj < VIEW; ++vj) opq[vj] = (uint32_t)(opaque >> (VIEW * vj)) & 127u;
         process_vis_rows(opq, vis);
-        for (int vj = 0; vj < VIEW; ++vj)
-            for (int vi = 0; vi < VIEW; ++vi) {
+        // one world row per lane: the view axis that runs along world y is vi when the agent faces +-x, vj otherwise
+        const bool vi_is_y = dir_dx(h.dir) != 0;
+        for (int l = ctx.lane(); l < VIEW; l += ctx.nlanes()) {
+            uint32_t mask = 0;
+            int row = -1;
+            for (int m = 0; m < VIEW; ++m) {
+                const int vi = vi_is_y ? l : m, vj = vi_is_y ? m : l;
                 if (!(vis[vj] >> vi & 1)) continue;
                 int x, y; view_to_world(h.ax, h.ay, h.dir, vi, vj, x, y);
-                if (in_grid(x, y)) s.vis[y] |= 1u << x;
+                if (in_grid(x, y)) { mask |= 1u << x; row = y; }
             }
+            if (row >= 0) s.vis[row] |= mask;
+        }
+        ctx.sync();
     }
 
     // Bot.replan(action_taken).  action_taken < 0 = None.  Returns the suggested action or BOT_DEAD.
     BB_HD int replan(int action_taken) {
         if (s.dead) return BOT_DEAD;
         process_obs();
-        if (w.eager && s.sp) {              // same tree, same pop order: only WHEN it is expanded changes
+        if (w.eager && sp) {                // same tree, same pop order: only WHEN it is expanded changes
             BOT_PROF(BP_INIT);
             start1();
             while (head1 < qn1) { const int st = q1_get(head1, qn1); ++head1; expand(WK_PREV1, WK_Q1, qn1, st, false); }
         }
-        if (action_taken == A_TOGGLE && s.prev_fwd_type == T_BOX) { die(); return BOT_DEAD; }   // DisappearedBoxError
-        if (s.sp) after_action(stk[s.sp - 1], action_taken);
+        if (action_taken == A_TOGGLE && prev_fwd_type == T_BOX) { die(); return BOT_DEAD; }     // DisappearedBoxError
+        // (top(): every lane has read the subgoal before any lane's pushes overwrite its slot)
+        if (sp) after_action(top(), action_taken);
         if (raised) return BOT_DEAD;
-        while (s.sp && exploratory(stk[s.sp - 1])) pop();
+        while (sp && exploratory(stk[sp - 1])) pop();
         int suggested = -1;
         int iters = 0;
-        while (s.sp) {
-            { BOT_PROF(BP_BEFORE); suggested = before_action(stk[s.sp - 1]); }
+        while (sp) {
+            { BOT_PROF(BP_BEFORE); suggested = before_action(top()); }
             if (raised) return BOT_DEAD;
             if (suggested >= 0) break;
             if (++iters > BOT_MAX_ITERS) { die(); return BOT_DEAD; }
         }
-        if (!s.sp) suggested = A_DONE;
+        if (!sp) suggested = A_DONE;
         // _remember_current_state (:689-695)
-        s.prev_ax = h.ax; s.prev_ay = h.ay; s.prev_carry = h.carry;
+        prev_ax = h.ax; prev_ay = h.ay; prev_carry = h.carry;
         const int fe = cell(fx(), fy());
-        if (e_type(fe) == T_DOOR) s.door_was_open = e_state(fe) == S_OPEN;
-        s.prev_fwd_type = is_none(fe) ? 0 : (uint8_t)e_type(fe);
+        if (e_type(fe) == T_DOOR) door_was_open = e_state(fe) == S_OPEN;
+        prev_fwd_type = is_none(fe) ? 0 : (uint8_t)e_type(fe);
         return suggested;
+    }
+    BB_HD Subgoal top() const { const Subgoal g = stk[sp - 1]; ctx.sync(); return g; }
+    // what the next decision reads back (every lane stores the same values)
+    BB_HD void remember() const {
+        s.sp = (uint16_t)sp;
+        s.prev_ax = prev_ax; s.prev_ay = prev_ay; s.prev_carry = prev_carry; s.door_was_open = door_was_open; s.prev_fwd_type = prev_fwd_type;
     }
 };
 
@@ -812,14 +894,25 @@ struct Bot {
 // episode (so it can be switched on in the middle of an episode, like constructing `Bot(env)` there).  A Bot started
 // mid-episode orders each descriptor's obj_set by the objects' positions at that moment; the reference uses their
 // positions at reset, which differ only if a described object was carried somewhere else before.
+// `s` and `stk` (the subgoal stack, `stack_cap` entries) may live in different memories (k_botg stages `s` in LDS); a lane group
+// passes its Ctx and shares s / stk / w.
+template <class Ctx>
+BB_HD int bot_decide(Ctx ctx, const LevelCfg& c, const uint8_t* rec, const Hot& h, uint64_t stale, BotState& s, Subgoal* stk, int stack_cap,
+                     const BotWork& w, bool first, int action_taken) {
+    BOT_PROF(BP_DECIDE);
+    first = first || h.step == 0 || s.next_step != h.step;
+    ctx.sync();                                       // (every lane has read next_step)
+    Bot<Ctx> b(ctx, c, rec, h, stale, s, stk, stack_cap, w);
+    s.next_step = (uint16_t)(h.step + 1);
+    if (first) { b.init(); action_taken = -1; }
+    const int a = b.raised ? BOT_DEAD : b.replan(action_taken);
+    ctx.sync();                                       // (no lane still reads what remember() rewrites)
+    b.remember();
+    return a;
+}
 BB_HD int bot_decide(const LevelCfg& c, const uint8_t* rec, const Hot& h, uint64_t stale, BotState& s, int stack_cap, const BotWork& w,
                      bool first, int action_taken) {
-    BOT_PROF(BP_DECIDE);
-    Bot b(c, rec, h, stale, s, stack_cap, w);
-    first = first || h.step == 0 || s.next_step != h.step;
-    s.next_step = (uint16_t)(h.step + 1);
-    if (first) { b.init(); action_taken = -1; if (b.raised) return BOT_DEAD; }
-    return b.replan(action_taken);
+    return bot_decide(OneLane(), c, rec, h, stale, s, (Subgoal*)(&s + 1), stack_cap, w, first, action_taken);
 }
 
 }  // namespace bbai

@@ -164,6 +164,8 @@ struct bbai_env {
     int bot_stack;        // subgoal stack capacity per env (BBAI_BOT_STACK, default 48)
     uint16_t* bot_work;   // [bot_threads][BOT_WORK_WORDS] BFS scratch per resident thread
     uint32_t* bot_rows;   // [bot_threads][2 * MAX_W] row masks of the second (through-blockers) search
+    int bot_group;        // lanes per env of the expert kernel: 0 = lane = env (k_bot), 16 = one 16-lane group per env (k_botg); BBAI_BOT_GROUP / option
+    int bot_waves;        // k_botg's waves-per-SIMD build (register cap): 2 or 4
     int bot_eager;        // BBAI_BOT_EAGER (default 1): expand the first search tree at the top of every decision
     int64_t bot_threads;
     uint64_t* bot_stats;  // [2] decisions that ended in a dead bot: by the reference's rules / by our capacity limits
@@ -1155,6 +1157,62 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_bot(LevelCfg c, int64_t 
     }
 }
 
+// The expert as ONE LANE GROUP PER ENV (G lanes, 64 / G envs per wave; bbai_bot.hpp "Execution model"): the subgoal machine runs
+// group-uniform, the view, the mask rows, the neighbours of a popped position and the acceptance / key scans are split over the lanes.
+// Per group in LDS: the four row-mask arrays [R_ALL][H], search 1's predecessor + queue arrays [2][W * H] uint16 (the eager first
+// search never leaves LDS), and the env's BotState for the length of the decision (the subgoal stack stays in global memory: a
+// decision touches its top).  Search 2's arrays (only when search 1 failed) are per-resident-group global scratch.
+__host__ __device__ inline int botg_group_words(const LevelCfg& c) {
+    return R_ALL * c.H + (2 * c.W * c.H * 2 + 3) / 4 + (int)sizeof(BotState) / 4;
+}
+template <int G, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_botg(LevelCfg c, int64_t n, const uint8_t* __restrict__ recs, const uint8_t* __restrict__ ring, int depth,
+                                             const Hot* __restrict__ hots, const uint64_t* __restrict__ stales, uint8_t* __restrict__ states, int stack_cap,
+                                             uint16_t* __restrict__ works, int eager, const uint8_t* __restrict__ prev_actions, uint8_t* __restrict__ out,
+                                             unsigned long long* __restrict__ stats, int dead_action, uint8_t* __restrict__ gave_up) {
+    extern __shared__ uint32_t s_botg[];
+    constexpr int NG = 64 / G, SW = (int)sizeof(BotState) / 4;
+    const GroupCtx<G> ctx;
+    const int lane = ctx.lane();
+    const int cells = c.W * c.H;
+    uint32_t* blk = s_botg + ((int)threadIdx.x / G) * botg_group_words(c);
+    const int64_t group = (int64_t)blockIdx.x * NG + (int)threadIdx.x / G, ngroups = (int64_t)gridDim.x * NG;
+    BotWork w;
+    w.eager = eager;
+    w.ring = nullptr; w.ring_stride = 0; w.ring_size = 0;
+    w.rows_fast = blk; w.rstride_fast = 1; w.rows_h = c.H; w.fast_n = R_ALL;
+    w.rows_slow = nullptr; w.rstride_slow = 0;
+    w.cells = cells;
+    w.near_q = (uint16_t*)(blk + R_ALL * c.H);
+    w.base = works + group * (int64_t)(4 * cells);          // (arrays 2, 3: search 2)
+    w.stride = 1;
+    uint32_t* sst = blk + R_ALL * c.H + (2 * cells * 2 + 3) / 4;
+    BotState& st = *(BotState*)sst;
+    const size_t sbytes = bot_state_bytes(stack_cap);
+    for (int64_t i = group; i < n; i += ngroups) {
+        const Hot h = hots[i];
+        if (h.frozen) {
+            if (lane == 0) { out[i] = A_DONE; if (gave_up) gave_up[i] = 0; }
+            continue;
+        }
+        uint32_t* gst = (uint32_t*)(states + i * (int64_t)sbytes);
+        for (int k = lane; k < SW; k += G) sst[k] = gst[k];
+        ctx.sync();
+        const bool first = h.step == 0 || st.next_step != h.step;
+        const int taken = (prev_actions && !first) ? prev_actions[i] : -1;
+        const bool was_dead = !first && st.dead;
+        const int a = bot_decide(ctx, c, live_rec(c, n, i, (uint8_t*)recs, (uint8_t*)ring, depth, h.slot), h, stales[i], st, (Subgoal*)(gst + SW), stack_cap, w, first, taken);
+        ctx.sync();
+        if (lane == 0) {
+            out[i] = (uint8_t)(a == BOT_DEAD ? dead_action : a);
+            if (gave_up) gave_up[i] = a == BOT_DEAD ? 1 : 0;
+            if (a == BOT_DEAD && !was_dead) atomicAdd(&stats[st.dead == DEAD_CAPACITY ? 1 : 0], 1ull);
+        }
+        for (int k = lane; k < SW; k += G) gst[k] = sst[k];
+        ctx.sync();
+    }
+}
+
 // env.seed(s) for every env: lane = env.  Each lane writes its own 624-word state (2496-byte pitch): a wave's 64 open
 // lines stay in L2 until they are full, so HBM sees each state line once.
 __global__ __launch_bounds__(64) void k_seed(int64_t n, const uint64_t* __restrict__ seeds, uint32_t* __restrict__ mts, int32_t* __restrict__ mtis) {
@@ -1483,6 +1541,9 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     bbai_env* e = new bbai_env();
     memset(e, 0, sizeof(*e));
     e->cfg = c; e->n = n_envs; e->device = device;
+    e->bot_group = 0; e->bot_waves = 2;
+    { const char* ev = getenv("BBAI_BOT_GROUP"); if (ev) e->bot_group = atoi(ev); }
+    { const char* ev = getenv("BBAI_BOT_WAVES"); if (ev) e->bot_waves = atoi(ev); }
     hipError_t err = hipSuccess;
     auto alloc = [&](void** p, size_t bytes) { if (err == hipSuccess) err = hipMalloc(p, bytes); };
     alloc((void**)&e->rec, (size_t)n_envs * c.rec_bytes);
@@ -2379,8 +2440,22 @@ static int bot_launch(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions
     // registers; capping it at 256 (2 waves/SIMD, spills to scratch) is +35 % on maze levels (BossLevel 1M envs 22.8 ->
     // 17.0 ms) and -10 % on single rooms, 128 registers (4 waves/SIMD) loses everywhere, real calls instead of inlining too.
     const bool maze = e->cfg.num_rows * e->cfg.num_cols > 1;
-    const dim3 grid((unsigned)(e->bot_threads / 64)), block(64);
     unsigned long long* stats = (unsigned long long*)e->bot_stats;
+    if (e->bot_group) {                                     // one lane group per env (k_botg)
+        const int G = e->bot_group, W = e->bot_waves;
+        const int64_t threads = std::min<int64_t>((e->n * G + 63) / 64 * 64, (int64_t)256 * 4 * W * 64);
+        const dim3 ggrid((unsigned)(threads / 64)), gblock(64);
+        const size_t glds = (size_t)(64 / G) * botg_group_words(e->cfg) * 4;
+#define BBAI_BOTG(GG, WW) hipLaunchKernelGGL((k_botg<GG, WW>), ggrid, gblock, glds, s, e->cfg, e->n, e->rec, e->inplace ? e->next_rec : nullptr, e->depth, e->hot, \
+                                              e->stale, e->bot_state, e->bot_stack, e->bot_work, e->bot_eager, prev_actions, actions, stats, dead_action, gave_up)
+        if (G == 16 && W == 2) BBAI_BOTG(16, 2);
+        else if (G == 16 && W == 4) BBAI_BOTG(16, 4);
+        else { snprintf(g_err, sizeof(g_err), "no k_botg build for %d lanes per env at %d waves per SIMD", G, W); return BBAI_ERR_ARG; }
+#undef BBAI_BOTG
+        HIP_TRY(hipGetLastError());
+        return BBAI_OK;
+    }
+    const dim3 grid((unsigned)(e->bot_threads / 64)), block(64);
     const size_t lds = (size_t)R_FAST * e->cfg.H * 64 * 4 + (size_t)BOT_RING * 64 * 2;     // BossLevel: 11.3 + 8 KB -> 8 waves per CU
     if (maze)
         hipLaunchKernelGGL(k_bot<2>, grid, block, lds, s, e->cfg, e->n, e->rec, e->inplace ? e->next_rec : nullptr, e->depth, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
@@ -2560,6 +2635,8 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     else if (!strcmp(name, "pregen_per_group")) e->pregen_per_group = std::max(1, v);
     else if (!strcmp(name, "consume_fused")) e->consume_fused = v;
     else if (!strcmp(name, "gate_strict")) e->gate_strict = v != 0;
+    else if (!strcmp(name, "bot_group")) e->bot_group = v;
+    else if (!strcmp(name, "bot_waves")) e->bot_waves = v;
     else if (!strcmp(name, "step_render_split")) e->step_render_split = v;
     else if (!strcmp(name, "done_action_enum")) e->done_action_enum = v != 0;       // (the one SEMANTIC switch in this list: include/bbai.h bbai_set_done_actions)
     else {
@@ -2591,6 +2668,8 @@ int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     else if (!strcmp(name, "pregen_per_group")) *out = e->pregen_per_group;
     else if (!strcmp(name, "consume_fused")) *out = e->consume_fused;
     else if (!strcmp(name, "gate_strict")) *out = e->gate_strict;
+    else if (!strcmp(name, "bot_group")) *out = e->bot_group;
+    else if (!strcmp(name, "bot_waves")) *out = e->bot_waves;
     else if (!strcmp(name, "step_render_split")) *out = e->step_render_split;
     else if (!strcmp(name, "inplace")) *out = e->inplace;
     else if (!strcmp(name, "done_action_enum")) *out = e->done_action_enum;

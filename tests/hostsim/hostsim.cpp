@@ -8,6 +8,8 @@
 #include "../../babyai_amd/csrc/bbai_step.hpp"
 #include "../../babyai_amd/csrc/bbai_view.hpp"
 #include "../../babyai_amd/csrc/bbai_bot.hpp"
+#include <ucontext.h>
+#include <cstdlib>
 #include "../../babyai_amd/csrc/bbai_seed.hpp"
 
 using namespace bbai;
@@ -148,12 +150,112 @@ int hs_bot_stack_depth(const uint8_t* state) { return ((const BotState*)state)->
 static int g_bot_eager = 0;
 void hs_bot_set_eager(int on) { g_bot_eager = on; }
 
+}  // extern "C"
+
+// Lane groups on the host: the group's lanes are fibers (ucontext) that run ONE AT A TIME from collective to collective -- every
+// ballot() / sync() of bbai_bot.hpp's Ctx contract hands control back to a scheduler, which resumes the lanes once all of them have
+// arrived.  Stricter than a wavefront (a lane runs its whole segment before the next lane starts it, so code that only works in
+// lockstep, or that misses a sync() between one lane's write and another's read, fails here), deterministic, single-threaded.
+struct EmuGroup {
+    static constexpr int MAXL = 64;
+    static constexpr size_t STACK = 512 * 1024;
+    int lanes = 0, cur = 0;
+    ucontext_t main_ctx, fib[MAXL];
+    char* stacks = nullptr;
+    bool done[MAXL];
+    int waiting_kind[MAXL];          // 0 = running / done, 1 = sync, 2 = ballot
+    unsigned long long bits = 0, result = 0;
+    int ret[MAXL];
+    const char* error = nullptr;
+    // the decision's arguments
+    const LevelCfg* cfg; const uint8_t* rec; const Hot* hot; uint64_t stale; BotState* state; Subgoal* stk; int cap; BotWork work; bool first; int action;
+};
+static thread_local EmuGroup* g_emu = nullptr;
+static unsigned long long emu_collective(int kind, bool p) {
+    EmuGroup* g = g_emu;
+    const int me = g->cur;
+    if (p) g->bits |= 1ull << me;
+    g->waiting_kind[me] = kind;
+    swapcontext(&g->fib[me], &g->main_ctx);
+    return g->result;
+}
+template <int G>
+struct EmuCtx {
+    static constexpr int kLanes = G;
+    int lane() const { return g_emu->cur; }
+    int nlanes() const { return G; }
+    void sync() const { (void)emu_collective(1, false); }
+    unsigned long long ballot(bool p) const { return emu_collective(2, p); }
+};
+template <int G>
+static void emu_lane_entry() {
+    EmuGroup* g = g_emu;
+    const int me = g->cur;
+    const int a = bot_decide(EmuCtx<G>(), *g->cfg, g->rec, *g->hot, g->stale, *g->state, g->stk, g->cap, g->work, g->first, g->action);
+    g = g_emu;
+    g->ret[me] = a;
+    g->done[me] = true;
+    g->waiting_kind[me] = 0;
+}
+template <int G>
+static int emu_decide(EmuGroup& g) {
+    if (!g.stacks) g.stacks = (char*)malloc(EmuGroup::MAXL * EmuGroup::STACK);
+    g.lanes = G; g.bits = 0; g.result = 0; g.error = nullptr;
+    for (int l = 0; l < G; ++l) {
+        g.done[l] = false; g.waiting_kind[l] = 0; g.ret[l] = -2;
+        getcontext(&g.fib[l]);
+        g.fib[l].uc_stack.ss_sp = g.stacks + (size_t)l * EmuGroup::STACK;
+        g.fib[l].uc_stack.ss_size = EmuGroup::STACK;
+        g.fib[l].uc_link = &g.main_ctx;
+        makecontext(&g.fib[l], (void (*)())emu_lane_entry<G>, 0);
+    }
+    g_emu = &g;
+    for (;;) {
+        for (int l = 0; l < G; ++l)
+            if (!g.done[l]) { g.cur = l; swapcontext(&g.main_ctx, &g.fib[l]); }
+        int n_done = 0, kind = 0;
+        bool mixed = false;
+        for (int l = 0; l < G; ++l) {
+            if (g.done[l]) { ++n_done; continue; }
+            if (kind && g.waiting_kind[l] != kind) mixed = true;
+            kind = g.waiting_kind[l];
+        }
+        if (n_done == G) break;
+        if (n_done || mixed) { g.error = "the lanes of a group diverged around a collective"; break; }
+        g.result = g.bits; g.bits = 0;
+    }
+    g_emu = nullptr;
+    if (g.error) return -3;
+    for (int l = 1; l < G; ++l) if (g.ret[l] != g.ret[0]) return -4;      // the lanes disagree on the decision
+    return g.ret[0];
+}
+extern "C" {
+static int g_bot_lanes = 1;
+void hs_bot_set_lanes(int lanes) { g_bot_lanes = lanes; }
+
 int hs_bot_decide(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, const uint64_t* stale, uint8_t* state, int stack_cap,
                   int first, int action_taken) {
     static thread_local uint16_t buf[BOT_WORK_WORDS];
     static thread_local uint32_t rows[R_ALL * MAX_W];
     BotWork work; work.base = buf; work.stride = 1; work.cells = cfg->W * cfg->H;
-    work.eager = g_bot_eager; static thread_local uint16_t ring[8]; work.ring = ring; work.ring_stride = 1; work.ring_size = 8;   /* tiny: the fall-back to the queue proper is exercised */ work.rows_fast = rows; work.rstride_fast = 1; work.rows_h = MAX_W; work.rows_slow = rows + R_FAST * MAX_W; work.rstride_slow = 1;
+    work.eager = g_bot_eager;
+    if (g_bot_lanes > 1) {            // the lane-group kernel's layout: all four row masks together, search 1's arrays apart, no ring
+        static thread_local uint16_t near_q[2 * BOT_MAX_CELLS];
+        static thread_local EmuGroup group;
+        work.near_q = near_q;
+        work.ring = nullptr; work.ring_stride = 0; work.ring_size = 0;
+        work.rows_fast = rows; work.rstride_fast = 1; work.rows_h = cfg->H; work.fast_n = R_ALL; work.rows_slow = nullptr; work.rstride_slow = 0;
+        group.cfg = cfg; group.rec = rec; group.hot = hot; group.stale = *stale; group.state = (BotState*)state;
+        group.stk = (Subgoal*)((BotState*)state + 1); group.cap = stack_cap; group.work = work; group.first = first != 0; group.action = action_taken;
+        switch (g_bot_lanes) {
+        case 4: return emu_decide<4>(group);
+        case 8: return emu_decide<8>(group);
+        case 16: return emu_decide<16>(group);
+        case 32: return emu_decide<32>(group);
+        default: return -5;
+        }
+    }
+    static thread_local uint16_t ring[8]; work.ring = ring; work.ring_stride = 1; work.ring_size = 8;   /* tiny: the fall-back to the queue proper is exercised */ work.rows_fast = rows; work.rstride_fast = 1; work.rows_h = MAX_W; work.rows_slow = rows + R_FAST * MAX_W; work.rstride_slow = 1;
     return bot_decide(*cfg, rec, *hot, *stale, *(BotState*)state, stack_cap, work, first != 0, action_taken);
 }
 

@@ -31,6 +31,7 @@ def lib():
         L.hs_start_carry.argtypes = [P, P, P, P]
         L.hs_bot_decide.argtypes = [P, P, P, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.hs_bot_set_eager.argtypes = [ctypes.c_int]
+        L.hs_bot_set_lanes.argtypes = [ctypes.c_int]
         L.hs_bot_dead_reason.argtypes = [P]
         L.hs_bot_stack_depth.argtypes = [P]
         _lib = L

@@ -69,6 +69,28 @@ def test_bot_decisions_match_reference(path, mode, eager):
     assert capacity == 0 or "UnlockToUnlock" in path
 
 
+@pytest.fixture(params=[4, 16, 32], ids=["4-lanes", "16-lanes", "32-lanes"])
+def lanes(request):
+    """The lane-group form of the expert (k_botg on the device), its lanes emulated as fibers that run one at a time between the
+    group's collectives (tests/hostsim/hostsim.cpp EmuGroup): the 49 view cells, the mask rows, the four neighbours of a popped
+    position, the acceptance scans and the key scan split over the lanes -- same decisions, or the group form is wrong."""
+    from hostsim_util import lib
+    lib().hs_bot_set_lanes(request.param)
+    lib().hs_bot_set_eager(1)
+    yield request.param
+    lib().hs_bot_set_lanes(1)
+    lib().hs_bot_set_eager(0)
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_lane_group_decisions_match_reference(path, lanes):
+    for mode in ("pure", "advised"):
+        mismatches, capacity = replay(path, mode)
+        assert not mismatches, (mode, mismatches[:3])       # (a = -3 / -4: the emulator saw the lanes diverge / disagree)
+        assert capacity == 0 or "UnlockToUnlock" in path
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("level,n_envs,steps", [("BossLevel", 24, 300), ("SynthSeq", 16, 200), ("KeyCorridorS6R3", 8, 250)])
 def test_bot_differential_against_live_reference(level, n_envs, steps):

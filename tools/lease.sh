@@ -111,6 +111,14 @@ botbench() {         # expert-driven env-steps/s per config (tools/bot_bench.py)
         timeout 300 python $REPO/tools/bot_bench.py $cfg 2>> $OUT/bot_bench.err | tail -1 | tee -a $OUT/bot_bench.jsonl
     done
 }
+botab() {            # the expert's kernels side by side on one box: lane = env (k_bot) against lane groups (k_botg), same episodes expected
+    cd /tmp
+    for cfg in "BossLevel 1048576 30" "GoToLocal 65536 200" "PickupLoc 262144 100" "GoTo 131072 100"; do
+        for mode in ${BOTAB_MODES:-0-2 16-2 16-4}; do       # <lanes per env (0: lane = env)>-<waves per SIMD of the build>
+            BBAI_BOT_GROUP=${mode%%-*} BBAI_BOT_WAVES=${mode##*-} timeout 300 python $REPO/tools/bot_bench.py $cfg 2>> $OUT/bot_ab.err | tail -1 | tee -a $OUT/bot_ab.jsonl
+        done
+    done
+}
 soak() {             # scattered envs of large batches vs the oracle over many steps (tools/gpu_soak.py)
     cd $REPO && timeout 900 python - > $OUT/soak_random.txt 2>&1 <<PY
 import sys
