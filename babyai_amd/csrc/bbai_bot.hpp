@@ -55,6 +55,10 @@ struct BotProfScope {
 enum { BP_DECIDE = 0, BP_OBS = 1, BP_AFTER = 2, BP_FIND_OBJ = 3, BP_PATH = 4, BP_SEARCH = 5, BP_ROWS = 6, BP_DROP_POS = 7, BP_BEFORE = 8,
        BP_INIT = 9, BP_KEYS = 10 };
 
+#ifndef BBAI_BOT_COUNT
+#define BBAI_BOT_COUNT(what)          // (tests/hostsim counts pops / queries per decision with this; nothing in the product)
+#endif
+
 namespace bbai {
 
 struct OneLane {
@@ -259,6 +263,7 @@ struct Bot {
     BB_HD void expand(int prev, int q, int& qn, int st, bool ignore_blockers) const {
         const int p = st & 1023, d = st >> 10;
         const int x = p & 31, y = p >> 5;
+        BBAI_BOT_COUNT(ignore_blockers ? 1 : 0);
         // seen, and (empty | open door | with ignore_blockers: any object that is not a wall or a closed door)
         if (!(w.row(ignore_blockers ? R_EXP2 : R_EXP1, y) >> x & 1)) return;
         const int rv = ignore_blockers ? R_VIS2 : R_VIS1;
@@ -385,6 +390,7 @@ struct Bot {
 
     BB_HD Path shortest_path(const Accept& a, bool try_with_blockers) const {          // :772-806
         BOT_PROF(BP_PATH);
+        BBAI_BOT_COUNT(2);
         Path p = {};
         start1();
         int len = 0, next = -1;

@@ -165,7 +165,6 @@ struct bbai_env {
     uint16_t* bot_work;   // [bot_threads][BOT_WORK_WORDS] BFS scratch per resident thread
     uint32_t* bot_rows;   // [bot_threads][2 * MAX_W] row masks of the second (through-blockers) search
     int bot_group;        // lanes per env of the expert kernel: 0 = lane = env (k_bot), 16 = one 16-lane group per env (k_botg); BBAI_BOT_GROUP / option
-    int bot_waves;        // k_botg's waves-per-SIMD build (register cap): 2 or 4
     int bot_eager;        // BBAI_BOT_EAGER (default 1): expand the first search tree at the top of every decision
     int64_t bot_threads;
     uint64_t* bot_stats;  // [2] decisions that ended in a dead bot: by the reference's rules / by our capacity limits
@@ -1541,9 +1540,7 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     bbai_env* e = new bbai_env();
     memset(e, 0, sizeof(*e));
     e->cfg = c; e->n = n_envs; e->device = device;
-    e->bot_group = 0; e->bot_waves = 2;
     { const char* ev = getenv("BBAI_BOT_GROUP"); if (ev) e->bot_group = atoi(ev); }
-    { const char* ev = getenv("BBAI_BOT_WAVES"); if (ev) e->bot_waves = atoi(ev); }
     hipError_t err = hipSuccess;
     auto alloc = [&](void** p, size_t bytes) { if (err == hipSuccess) err = hipMalloc(p, bytes); };
     alloc((void**)&e->rec, (size_t)n_envs * c.rec_bytes);
@@ -2442,16 +2439,15 @@ static int bot_launch(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions
     const bool maze = e->cfg.num_rows * e->cfg.num_cols > 1;
     unsigned long long* stats = (unsigned long long*)e->bot_stats;
     if (e->bot_group) {                                     // one lane group per env (k_botg)
-        const int G = e->bot_group, W = e->bot_waves;
-        const int64_t threads = std::min<int64_t>((e->n * G + 63) / 64 * 64, (int64_t)256 * 4 * W * 64);
-        const dim3 ggrid((unsigned)(threads / 64)), gblock(64);
-        const size_t glds = (size_t)(64 / G) * botg_group_words(e->cfg) * 4;
-#define BBAI_BOTG(GG, WW) hipLaunchKernelGGL((k_botg<GG, WW>), ggrid, gblock, glds, s, e->cfg, e->n, e->rec, e->inplace ? e->next_rec : nullptr, e->depth, e->hot, \
-                                              e->stale, e->bot_state, e->bot_stack, e->bot_work, e->bot_eager, prev_actions, actions, stats, dead_action, gave_up)
-        if (G == 16 && W == 2) BBAI_BOTG(16, 2);
-        else if (G == 16 && W == 4) BBAI_BOTG(16, 4);
-        else { snprintf(g_err, sizeof(g_err), "no k_botg build for %d lanes per env at %d waves per SIMD", G, W); return BBAI_ERR_ARG; }
-#undef BBAI_BOTG
+        // Measured (profiles/r05/NOTES.md section 11): same decisions, 1.9-2.4 x SLOWER than lane = env -- a group executes 3.4 x the
+        // instructions per env (the subgoal machine runs redundantly on the group's lanes, 4 envs share a wave's issue slots instead
+        // of 64) and only gets 1.8 x the instructions per cycle back.  Kept as an option for experiments, off by default.
+        constexpr int G = 16;
+        if (e->bot_group != G) { snprintf(g_err, sizeof(g_err), "no k_botg build for %d lanes per env (only 16)", e->bot_group); return BBAI_ERR_ARG; }
+        const int64_t threads = std::min<int64_t>((e->n * G + 63) / 64 * 64, (int64_t)256 * 8 * 64);
+        const size_t glds = (size_t)(64 / G) * botg_group_words(e->cfg) * 4;     // BossLevel: 4 x 2.5 KB
+        hipLaunchKernelGGL((k_botg<G, 2>), dim3((unsigned)(threads / 64)), dim3(64), glds, s, e->cfg, e->n, e->rec, e->inplace ? e->next_rec : nullptr, e->depth, e->hot,
+                           e->stale, e->bot_state, e->bot_stack, e->bot_work, e->bot_eager, prev_actions, actions, stats, dead_action, gave_up);
         HIP_TRY(hipGetLastError());
         return BBAI_OK;
     }
@@ -2636,7 +2632,6 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     else if (!strcmp(name, "consume_fused")) e->consume_fused = v;
     else if (!strcmp(name, "gate_strict")) e->gate_strict = v != 0;
     else if (!strcmp(name, "bot_group")) e->bot_group = v;
-    else if (!strcmp(name, "bot_waves")) e->bot_waves = v;
     else if (!strcmp(name, "step_render_split")) e->step_render_split = v;
     else if (!strcmp(name, "done_action_enum")) e->done_action_enum = v != 0;       // (the one SEMANTIC switch in this list: include/bbai.h bbai_set_done_actions)
     else {
@@ -2669,7 +2664,6 @@ int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     else if (!strcmp(name, "consume_fused")) *out = e->consume_fused;
     else if (!strcmp(name, "gate_strict")) *out = e->gate_strict;
     else if (!strcmp(name, "bot_group")) *out = e->bot_group;
-    else if (!strcmp(name, "bot_waves")) *out = e->bot_waves;
     else if (!strcmp(name, "step_render_split")) *out = e->step_render_split;
     else if (!strcmp(name, "inplace")) *out = e->inplace;
     else if (!strcmp(name, "done_action_enum")) *out = e->done_action_enum;

@@ -259,6 +259,9 @@ int bbai_get_done_actions(bbai_env* env);
  *   "gate_strict"       1 = the step stream ALSO waits, at the start of every look-ahead window, for the refill launched two windows
  *                       earlier (rounds 1-4's rule); 0 (default) = it runs ahead of the refills as far as every env is sure to keep
  *                       a window's worth of ready levels (k_gate) -- a reset storm then refills under the steps
+ *   "bot_group"         the expert's kernel (bbai_bot_act / bbai_bot_rollout): 0 (default) = one lane per env (k_bot), 16 = one 16-lane
+ *                       group per env with the first search in LDS (k_botg: same decisions, measured ~2 x slower -- an experiment
+ *                       kept for reference); also BBAI_BOT_GROUP at bbai_create
  *   "done_action_enum"  the one semantic switch, meaningful in done-action mode only: see bbai_set_done_actions
  * BBAI_ERR_ARG for an unknown name. */
 int bbai_set_option(bbai_env* env, const char* name, int64_t value);

@@ -7,6 +7,8 @@
 #include "../../babyai_amd/csrc/bbai_gen.hpp"
 #include "../../babyai_amd/csrc/bbai_step.hpp"
 #include "../../babyai_amd/csrc/bbai_view.hpp"
+static long long g_bot_counts[8];
+#define BBAI_BOT_COUNT(what) (++g_bot_counts[what])
 #include "../../babyai_amd/csrc/bbai_bot.hpp"
 #include <ucontext.h>
 #include <cstdlib>
@@ -230,6 +232,7 @@ static int emu_decide(EmuGroup& g) {
     return g.ret[0];
 }
 extern "C" {
+void hs_bot_counts(long long* out, int reset) { for (int k = 0; k < 8; ++k) { out[k] = g_bot_counts[k]; if (reset) g_bot_counts[k] = 0; } }
 static int g_bot_lanes = 1;
 void hs_bot_set_lanes(int lanes) { g_bot_lanes = lanes; }
 

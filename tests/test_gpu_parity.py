@@ -906,6 +906,37 @@ def test_generate_demos_matches_reference_script(gpu, level, rollout):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("level,n,steps", [("BossLevel", 2048, 200), ("GoToLocal", 4096, 120), ("KeyCorridorS6R3", 1024, 200),
+                                           ("PutNextS7N4", 1024, 120), ("UnlockToUnlock", 512, 200), ("SynthSeq", 1024, 160)])
+def test_lane_group_expert_decides_like_the_lane_per_env_expert(gpu, level, n, steps):
+    """k_botg (option bot_group = 16: one 16-lane group per env, search 1 in LDS) against k_bot (lane = env) on twin handles, the
+    lane-per-env expert driving both with 5 % random actions: every suggestion, every give-up, the same statistics.  (The group form
+    of the header is pinned to the reference's bot by tests/test_hostsim_bot.py's fiber emulation on all 105 levels.)"""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    a = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=77000)
+    b = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=77000)
+    b.set_option("bot_group", 16)
+    assert b.get_option("bot_group") == 16 and a.get_option("bot_group") == 0
+    a.reset()
+    b.reset()
+    gen = torch.Generator(device=gpu).manual_seed(3)
+    prev = None
+    for t in range(steps):
+        ga, gb = a.bot_actions(prev), b.bot_actions(prev)
+        assert torch.equal(ga, gb), (level, t, (ga != gb).nonzero()[:4].tolist())
+        rnd = torch.randint(0, 7, (n,), device=gpu, dtype=torch.uint8, generator=gen)
+        noisy = torch.rand((n,), device=gpu, generator=gen) < 0.05
+        prev = torch.where(noisy | (ga == 255), rnd, ga)
+        _, _, da, _ = a.step(prev)
+        _, _, db, _ = b.step(prev)
+        assert torch.equal(da, db)
+    assert a.bot_stats() == b.bot_stats()
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
 def test_bot_device_equals_host_build_on_every_level(gpu):
     """All 105 levels: k_bot against the host build of bbai_bot.hpp (which tests/test_hostsim_bot.py pins to the
     reference on every level), bot-driven with 6 % random actions so the undo logic runs too."""

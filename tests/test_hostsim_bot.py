@@ -69,26 +69,52 @@ def test_bot_decisions_match_reference(path, mode, eager):
     assert capacity == 0 or "UnlockToUnlock" in path
 
 
-@pytest.fixture(params=[4, 16, 32], ids=["4-lanes", "16-lanes", "32-lanes"])
-def lanes(request):
-    """The lane-group form of the expert (k_botg on the device), its lanes emulated as fibers that run one at a time between the
-    group's collectives (tests/hostsim/hostsim.cpp EmuGroup): the 49 view cells, the mask rows, the four neighbours of a popped
-    position, the acceptance scans and the key scan split over the lanes -- same decisions, or the group form is wrong."""
+WIDTH_LEVELS = ("BossLevel", "SynthSeq", "KeyCorridorS6R3", "UnlockToUnlock", "PutNextS7N4Carrying", "BlockedUnlockPickup", "GoToImpUnlock",
+                "PickupDist", "MoveTwoAcrossS8N9", "GoToLocal")
+
+
+def _lanes(n):
     from hostsim_util import lib
-    lib().hs_bot_set_lanes(request.param)
+    lib().hs_bot_set_lanes(n)
     lib().hs_bot_set_eager(1)
-    yield request.param
+
+
+def _one_lane():
+    from hostsim_util import lib
     lib().hs_bot_set_lanes(1)
     lib().hs_bot_set_eager(0)
 
 
 @pytest.mark.timeout(1800)
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
-def test_lane_group_decisions_match_reference(path, lanes):
-    for mode in ("pure", "advised"):
-        mismatches, capacity = replay(path, mode)
-        assert not mismatches, (mode, mismatches[:3])       # (a = -3 / -4: the emulator saw the lanes diverge / disagree)
-        assert capacity == 0 or "UnlockToUnlock" in path
+def test_lane_group_decisions_match_reference(path):
+    """The lane-group form of the expert (k_botg on the device: 16 lanes per env), its lanes emulated as fibers that run one at a time
+    between the group's collectives (tests/hostsim/hostsim.cpp EmuGroup): the 49 view cells, the mask rows, the four neighbours of a
+    popped position, the acceptance scans and the key scan split over the lanes -- same decisions, or the group form is wrong.
+    (a = -3 / -4 in a mismatch: the emulator saw the lanes diverge around a collective / disagree on the decision.)"""
+    _lanes(16)
+    try:
+        # (advised: 12 % random actions, so the undo logic runs too; the levels with the longest plans also in pure mode)
+        for mode in ("advised", "pure") if os.path.basename(path)[:-4] in WIDTH_LEVELS else ("advised",):
+            mismatches, capacity = replay(path, mode)
+            assert not mismatches, (mode, mismatches[:3])
+            assert capacity == 0 or "UnlockToUnlock" in path
+    finally:
+        _one_lane()
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("lanes", [4, 32])
+@pytest.mark.parametrize("level", WIDTH_LEVELS)
+def test_lane_group_width_does_not_matter(level, lanes):
+    """Other group widths (chunking of the scans, 4 = every lane expands a neighbour) on the levels with the longest plans."""
+    path = os.path.join(HERE, "golden", "bot", level + ".npz")
+    _lanes(lanes)
+    try:
+        mismatches, _ = replay(path, "advised")
+        assert not mismatches, mismatches[:3]
+    finally:
+        _one_lane()
 
 
 @pytest.mark.timeout(900)

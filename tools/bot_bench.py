@@ -38,5 +38,4 @@ t0 = time.perf_counter()
 succ, eps = run(20, 20 + steps)
 dt = time.perf_counter() - t0
 print(json.dumps({"level": level, "envs": n, "steps": steps, "bot_env_steps_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3,
-                  "episodes": eps, "success_rate": succ / max(eps, 1), "bot": env.bot_stats(),
-                  "bot_group": env.get_option("bot_group"), "bot_waves": env.get_option("bot_waves")}))
+                  "episodes": eps, "success_rate": succ / max(eps, 1), "bot": env.bot_stats(), "bot_group": env.get_option("bot_group")}))

@@ -114,10 +114,36 @@ botbench() {         # expert-driven env-steps/s per config (tools/bot_bench.py)
 botab() {            # the expert's kernels side by side on one box: lane = env (k_bot) against lane groups (k_botg), same episodes expected
     cd /tmp
     for cfg in "BossLevel 1048576 30" "GoToLocal 65536 200" "PickupLoc 262144 100" "GoTo 131072 100"; do
-        for mode in ${BOTAB_MODES:-0-2 16-2 16-4}; do       # <lanes per env (0: lane = env)>-<waves per SIMD of the build>
-            BBAI_BOT_GROUP=${mode%%-*} BBAI_BOT_WAVES=${mode##*-} timeout 300 python $REPO/tools/bot_bench.py $cfg 2>> $OUT/bot_ab.err | tail -1 | tee -a $OUT/bot_ab.jsonl
+        for mode in ${BOTAB_MODES:-0 16}; do       # lanes per env (0: lane = env)
+            BBAI_BOT_GROUP=$mode timeout 300 python $REPO/tools/bot_bench.py $cfg 2>> $OUT/bot_ab.err | tail -1 | tee -a $OUT/bot_ab.jsonl
         done
     done
+}
+botpmc() {           # where the expert's waves spend their cycles: SQ + instruction-cache counters of k_bot / k_botg (BossLevel 262 144, 10 steps)
+    cd /tmp
+    rocprofv3 -L 2>/dev/null | grep -o -i -E "\b(SQC?_[A-Z_]*(ICACHE|IFETCH)[A-Z_]*|SQ_INSTS_[A-Z_]+)\b" | sort -u > $OUT/counters_avail.txt
+    for mode in ${BOTAB_MODES:-0 16}; do
+        n=0
+        for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES" \
+                   "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+            n=$((n + 1))
+            BBAI_BOT_GROUP=$mode timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/botpmc_${mode}_$n -o bot \
+                -- python $REPO/tools/bot_bench.py BossLevel 262144 10 > $OUT/botpmc_${mode}_$n.log 2>&1
+        done
+    done
+    python - <<PY | tee $OUT/botpmc.txt
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for path in glob.glob("$OUT/botpmc_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if k.startswith("k_bot"):
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in sorted(agg.items()):
+    print(k, {c: round(sorted(v)[len(v) // 2]) for c, v in sorted(d.items())}, "launches", len(next(iter(d.values()))))
+PY
+    for f in $OUT/botpmc_*_2.log; do tail -n 1 $f; done
+    rm -rf $OUT/botpmc_*_[12]
 }
 soak() {             # scattered envs of large batches vs the oracle over many steps (tools/gpu_soak.py)
     cd $REPO && timeout 900 python - > $OUT/soak_random.txt 2>&1 <<PY
