@@ -182,8 +182,21 @@ def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None, af
     `after_block(i)` between blocks (untimed).  `run_steps(t0, k)`, when given, REPLACES the per-step loop and `after_step`: it
     enqueues steps t0 .. t0 + k - 1 (tap included) in one call -- the engine's open-loop rollout entry (include/bbai.h
     bbai_rollout; bench.py --rollout-entry).  Returns the list of per-block seconds (max over ranks); `local_out`
-    (a list) receives this rank's own per-block seconds."""
+    (a list) receives this rank's own per-block seconds.  The cyclic garbage collector is off for the length of the loop (as
+    `timeit` does): a generation-2 pass between two launches is a multi-millisecond host stall that no kernel caused."""
+    import gc
     import time
+    gc_was_on = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        return _timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step, after_block, before_block, local_out, barrier_out, run_steps, time)
+    finally:
+        if gc_was_on:
+            gc.enable()
+
+
+def _timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step, after_block, before_block, local_out, barrier_out, run_steps, time):
     t = 0
     if run_steps is not None:
         if warmup:
