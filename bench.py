@@ -602,7 +602,7 @@ def main():
                    "loop": "one bbai_rollout call per block: the engine enqueues K x (step [+ render] + tap)" if (args.rollout_entry and not args.dump_digest) else
                            "per-step calls from Python: bbai_step (pixel batches: bbai_step_render = the same step + render as one call) + bbai_tap_ids",
                    "clock": "per block: opening barrier -> K steps -> this rank's device idle; the block = max over ranks; the closing barrier "
-                            "and the max-reduce run after every rank's clock has stopped (barrier_ms)",
+                            "and the max-reduce run after every rank's clock has stopped (barrier_ms); Python's cyclic garbage collector is off inside the loop (as timeit does)",
                    "barrier_ms": {"median": median(m["barrier_s"]) * 1e3, "max": max(m["barrier_s"]) * 1e3} if m["barrier_s"] else None,
                    "profiled_blocks": len(profiled),
                    "profiled_block_ms": {"min": min(profiled) * 1e3, "median": prof_med * 1e3, "max": max(profiled) * 1e3} if profiled else None,
