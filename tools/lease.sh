@@ -145,6 +145,14 @@ PY
     for f in $OUT/botpmc_*_2.log; do tail -n 1 $f; done
     rm -rf $OUT/botpmc_*_[12]
 }
+botprof() {          # phase timers of the expert (tools/bot_prof.py) on the -DBBAI_BOT_PROF build that travelled in tools/_prof/
+    cd /tmp
+    for cfg in "BossLevel 262144 20" "GoToLocal 65536 60"; do
+        for mode in ${BOTAB_MODES:-0 16}; do
+            BBAI_BOT_GROUP=$mode BBAI_ENGINE_LIB=$REPO/tools/_prof/libbbai_botprof.so timeout 300 python $REPO/tools/bot_prof.py $cfg 2>> $OUT/bot_prof.err | tail -1 | tee -a $OUT/bot_prof.jsonl
+        done
+    done
+}
 soak() {             # scattered envs of large batches vs the oracle over many steps (tools/gpu_soak.py)
     cd $REPO && timeout 900 python - > $OUT/soak_random.txt 2>&1 <<PY
 import sys
