@@ -470,55 +470,73 @@ struct Bot {
     // (IndexError swallowed, :649-653) -- reproduced as is.
     BB_HD bool find_obj_pos(const Subgoal& g, bool adjacent, int& obj, int& ox, int& oy) {
         BOT_PROF(BP_FIND_OBJ);
-        uint8_t set_list[MAX_OBJ], poss[MAX_OBJ][2];
-        int n_set = 0, n_poss = 0;
-        if (g.dtype == DT_KEYS) {
-            n_set = n_poss = g.nkeys;
-            for (int i = 0; i < n_set; ++i) {
-                set_list[i] = (uint8_t)(g.keys[i] >> 10); poss[i][0] = (g.keys[i] >> 5) & 31; poss[i][1] = g.keys[i] & 31;
-            }
-        } else {
-            const uint64_t set = prog->set[g.a >> 1][g.a & 1];
-            uint16_t key_s[MAX_OBJ], key_p[MAX_OBJ];
-            for (uint64_t m = set; m; m &= m - 1) {
-                const int o = __builtin_ctzll(m);
-                {   // obj_set: order of the scan at reset
-                    const uint16_t k = (uint16_t)(s.ipos[o][0] << 8 | s.ipos[o][1]);
-                    int j = n_set++;
-                    for (; j > 0 && key_s[j - 1] > k; --j) { key_s[j] = key_s[j - 1]; set_list[j] = set_list[j - 1]; }
-                    key_s[j] = k; set_list[j] = (uint8_t)o;
-                }
-                if (obj_in_grid(o) || (stale >> o & 1)) {   // obj_poss: still recorded since the last refresh
-                    const uint16_t k = (uint16_t)(pos[2 * o] << 8 | pos[2 * o + 1]);
-                    int j = n_poss++;
-                    for (; j > 0 && key_p[j - 1] > k; --j) { key_p[j] = key_p[j - 1]; poss[j][0] = poss[j - 1][0]; poss[j][1] = poss[j - 1][1]; }
-                    key_p[j] = k; poss[j][0] = pos[2 * o]; poss[j][1] = pos[2 * o + 1];
-                }
-            }
-        }
         // ObjDesc(type=None, colour='grey') also matches every WALL cell (bonus_levels.py PickupDist; walls are grey):
         // the walls sit in obj_set / obj_poss in scan order with the objects, and the first visible wall the search
         // cannot reach (a corner) trips the reference's assertion.  Rare, so the merged lists are streamed.
         const bool walls = g.dtype == DT_DESC && prog->desc[g.a >> 1][g.a & 1].type == 0 &&
                            prog->desc[g.a >> 1][g.a & 1].color == C_GREY;
         if (walls) return find_obj_pos_with_walls(prog->set[g.a >> 1][g.a & 1], adjacent, obj, ox, oy);
-        if (n_set == 0) { die(); return false; }                  // assert len(obj_desc.obj_set) > 0
-        int best = 999;
+        // One candidate of the reference's loop over zip(obj_set, obj_poss); `order` = its index in that loop.  The loop keeps the FIRST
+        // minimum of d, i.e. the minimum of (d, order): candidates may be offered in any order.
+        int best = 999, best_order = 0x7FFFFFFF;
         bool have = false;
-        for (int i = 0; i < n_set; ++i) {
-            if (set_list[i] == h.carry) continue;
-            if (i >= n_poss) continue;                             // IndexError -> pass
-            const int px = poss[i][0], py = poss[i][1];
-            if (!seen(px, py)) continue;
+        auto consider = [&](int so, int px, int py, int order) {
+            if (so == h.carry) return;
+            if (!seen(px, py)) return;
             Path p = shortest_path(acc_pos(px, py), true);
-            if (!p.found) { die(); return false; }                 // assert shortest_path_to_obj is not None
+            if (!p.found) { die(); return; }                       // assert shortest_path_to_obj is not None
             int d = p.len;
             if (p.with_blockers) d = p.len + (carrying() ? 7 : 4);
             if (d == 0) d = adjacent ? 3 : 2;
             if (adjacent && d == 1) d = 3;
-            if (d < best) { best = d; have = true; obj = set_list[i]; ox = px; oy = py; }
+            if (d < best || (d == best && order < best_order)) { best = d; best_order = order; have = true; obj = so; ox = px; oy = py; }
+        };
+        if (g.dtype == DT_KEYS) {                                  // frozen lists, already in the reference's order
+            if (g.nkeys == 0) { die(); return false; }             // assert len(obj_desc.obj_set) > 0
+            for (int i = 0; i < g.nkeys && !raised; ++i) consider(g.keys[i] >> 10, (g.keys[i] >> 5) & 31, g.keys[i] & 31, i);
+            return have && !raised;
         }
-        return have;
+        const uint64_t set = prog->set[g.a >> 1][g.a & 1];
+        if (!set) { die(); return false; }
+        // Common case: every object of the descriptor is still recorded, at the position the episode started it on.  Then obj_set
+        // (sorted by the start positions) and obj_poss (sorted by the recorded ones) pair every object with ITS position, and the
+        // loop index of a pair is the rank of its position key: no list has to be built (the lists live in per-lane scratch, and their
+        // insertion sorts were a third of a BossLevel decision: profiles/r05/NOTES.md section 11).
+        bool aligned = true;
+        for (uint64_t m = set; m && aligned; m &= m - 1) {
+            const int o = __builtin_ctzll(m);
+            aligned = (obj_in_grid(o) || (stale >> o & 1)) && pos[2 * o] == s.ipos[o][0] && pos[2 * o + 1] == s.ipos[o][1];
+        }
+        if (aligned) {
+            for (uint64_t m = set; m && !raised; m &= m - 1) {
+                const int o = __builtin_ctzll(m);
+                consider(o, pos[2 * o], pos[2 * o + 1], pos[2 * o] << 8 | pos[2 * o + 1]);
+            }
+            return have && !raised;
+        }
+        // Otherwise the two lists, each ONE packed array (a shift of the insertion sort moves one element per list):
+        // ks[i] = start-position key << 8 | object (obj_set order), kp[i] = recorded position x << 8 | y (obj_poss order)
+        uint32_t ks[MAX_OBJ];
+        uint16_t kp[MAX_OBJ];
+        int n_set = 0, n_poss = 0;
+        for (uint64_t m = set; m; m &= m - 1) {
+            const int o = __builtin_ctzll(m);
+            {   // obj_set: order of the scan at reset (the keys are distinct positions; the object id in the low byte never decides)
+                const uint32_t v = (uint32_t)(s.ipos[o][0] << 8 | s.ipos[o][1]) << 8 | (uint32_t)o;
+                int j = n_set++;
+                for (; j > 0 && ks[j - 1] > v; --j) ks[j] = ks[j - 1];
+                ks[j] = v;
+            }
+            if (obj_in_grid(o) || (stale >> o & 1)) {   // obj_poss: still recorded since the last refresh
+                const uint16_t k = (uint16_t)(pos[2 * o] << 8 | pos[2 * o + 1]);
+                int j = n_poss++;
+                for (; j > 0 && kp[j - 1] > k; --j) kp[j] = kp[j - 1];
+                kp[j] = k;
+            }
+        }
+        for (int i = 0; i < n_set && i < n_poss && !raised; ++i)   // (i >= len(obj_poss): IndexError -> pass)
+            consider((int)(ks[i] & 0xFFu), kp[i] >> 8, kp[i] & 0xFF, i);
+        return have && !raised;
     }
 
     // next entry of obj_set (which = 0, episode-start positions) / obj_poss (which = 1, recorded positions) at or after

@@ -321,17 +321,21 @@ struct Gen {
         int start = room_of(ax, ay);
         int nrooms = rows * cols;
         int itrs = 0;
-        for (;;) {
+        uint32_t reach = 1u << start;
+        bool grew = true;                             // the closure only changes when a door was added: most trips of the loop draw a
+        for (;;) {                                    // triple that is rejected, and keep the closure they came with
             if (itrs > 5000) return false;            // RecursionError('connect_all failed')
             ++itrs;
-            // rooms reachable from the start room through existing doors: bit-parallel closure
-            const uint32_t d0 = (uint32_t)doors & 0x1FFu, d1 = (uint32_t)(doors >> 16) & 0x1FFu;
-            const uint32_t d2 = (uint32_t)(doors >> 32) & 0x1FFu, d3 = (uint32_t)(doors >> 48) & 0x1FFu;
-            uint32_t reach = 1u << start;
-            for (int pass = 0; pass < nrooms; ++pass) {
-                uint32_t nr = reach | ((reach & d0) << 1) | ((reach & d1) << cols) | ((reach & d2) >> 1) | ((reach & d3) >> cols);
-                if (nr == reach) break;
-                reach = nr;
+            if (grew) {
+                // rooms reachable from the start room through existing doors: bit-parallel closure (it only ever grows)
+                const uint32_t d0 = (uint32_t)doors & 0x1FFu, d1 = (uint32_t)(doors >> 16) & 0x1FFu;
+                const uint32_t d2 = (uint32_t)(doors >> 32) & 0x1FFu, d3 = (uint32_t)(doors >> 48) & 0x1FFu;
+                for (int pass = 0; pass < nrooms; ++pass) {
+                    uint32_t nr = reach | ((reach & d0) << 1) | ((reach & d1) << cols) | ((reach & d2) >> 1) | ((reach & d3) >> cols);
+                    if (nr == reach) break;
+                    reach = nr;
+                }
+                grew = false;
             }
             if (__builtin_popcount(reach) == nrooms) return true;
             int i = rand_int(0, cols);
@@ -349,6 +353,7 @@ struct Gen {
                 color = color_name_to_idx(q);
             }
             if (add_door(r, k, color, false) < 0) return false;
+            grew = true;
         }
     }
     // RoomGrid.add_distractors(i=None, j=None).  first_id receives the first new id.
