@@ -123,6 +123,19 @@ struct bbai_env {
     hipEvent_t ev_refill[NWIN];     // recorded behind every window's refill; only waited for in strict mode (below) -- k_gate reads flow[FLOW_REFILLED]
     int gate_strict;      // BBAI_GATE_STRICT / option "gate_strict": 1 = rounds 1-4's rule as well: the stream waits (an event) for the refill of window
                           // x - 2 before window x starts, so k_gate never has to wait (A/B runs; a fallback should a profiler serialise the two streams)
+    // The relaxed gate is a device-side spin on a value the look-ahead stream's k_mark stores: it relies on kernels of the two streams making
+    // progress CONCURRENTLY, which HIP does not promise (streams can share a hardware queue; a profiler can serialise launches).  So:
+    //   * the first window a caller's stream opens PROBES it (probe_stream: a waiting kernel on the caller's stream, the releasing one on the
+    //     look-ahead stream behind it); a stream that fails runs under the strict rule (event waits, k_gate never has to wait) from then on;
+    //   * a gate that gives up all the same sets a sticky word in pinned host memory, which every entry point reads before it enqueues anything:
+    //     the handle refuses to step on (BBAI_ERR_STATE) instead of consuming slots that were never refilled.
+    volatile uint32_t* host_flags;    // pinned, mapped: [0] a window gate timed out (sticky)  [1] the last probe's verdict (1 concurrent, 2 not)
+    uint32_t* host_flags_dev;         // the device's address of the same words
+    hipStream_t probed[8];            // caller streams already probed ...
+    bool probed_ok[8];                // ... and what the probe said
+    int n_probed;
+    int gate_probe;                   // BBAI_GATE_PROBE (default 1): 0 = trust the streams (no probe), 2 = treat every probe as failed (tests)
+    int gate_forced;                  // the current caller stream failed the probe: strict rule
     hipStream_t last_stream;   // the caller's stream of the previous call (compared, never used): a handle follows ONE stream
     bool have_stream;          // at a time; a call on another stream waits for ev_switch = end of the previous call
     hipEvent_t ev_switch;      // (enter_call / leave_call)
@@ -196,7 +209,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int META_U32 = 32;            // uint32 per window buffer's meta line: [0] = M when > 1 (atomicMax)
 constexpr int SHARDS = 64;              // cache lines the reset total is spread over (k_step: shard = block & 63)
 constexpr int SHARD_U64 = 16;           // uint64 per shard: one 128-byte line each
-enum : int { FLOW_REFILLED = 0 /* windows whose refill has landed */, FLOW_GATE_TIMEOUTS = 1, FLOW_GEN_FAILURES = 3 /* levels the generator gave up on */, FLOW_WORDS = 16 };
+enum : int { FLOW_REFILLED = 0 /* windows whose refill has landed */, FLOW_GATE_TIMEOUTS = 1, FLOW_PROBE = 2 /* probe_stream's flag */, FLOW_GEN_FAILURES = 3 /* levels the generator gave up on */, FLOW_WORDS = 16 };
 constexpr int GEN_COUNT_U32 = 32;       // uint32 per sub-list counter of the refill list: one 128-byte line each
 __host__ __device__ __forceinline__ int64_t gen_sublist_cap(int64_t n) { return ((n + 63) / 64 + SHARDS - 1) / SHARDS * 64; }      // entries a sub-list can get: its waves x 64
 __device__ __forceinline__ void count_resets(unsigned long long* __restrict__ totals, unsigned int k) {
@@ -1039,7 +1052,8 @@ __global__ void k_mark(unsigned long long* __restrict__ flow, unsigned long long
 // latest when refill x - 2 lands; every refill it can wait for was enqueued before it.  One wave; polls with s_sleep.  A wait beyond
 // ~10 s of the constant 100-MHz clock gives up (counted in flow[FLOW_GATE_TIMEOUTS], read back as option "gate_timeouts": the handle's
 // results are void then -- it means a lost refill, never seen) instead of hanging the device.
-__global__ __launch_bounds__(64) void k_gate(unsigned long long* __restrict__ flow, uint32_t* __restrict__ metas, unsigned long long x, int period) {
+__global__ __launch_bounds__(64) void k_gate(unsigned long long* __restrict__ flow, uint32_t* __restrict__ metas, unsigned long long x, int period,
+                                              uint32_t* __restrict__ host_fault /* pinned host word: sticky, read by every entry point */) {
     const int lane = (int)threadIdx.x;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
@@ -1054,12 +1068,31 @@ __global__ __launch_bounds__(64) void k_gate(unsigned long long* __restrict__ fl
         for (int o = 32; o; o >>= 1) m += __shfl_xor(m, o);
         if (open < (unsigned long long)NWIN && m <= (uint32_t)period) break;
         if (__builtin_amdgcn_s_memrealtime() - t0 > 1000000000ull) {
-            if (lane == 0) atomicAdd(&flow[FLOW_GATE_TIMEOUTS], 1ull);
+            if (lane == 0) {
+                atomicAdd(&flow[FLOW_GATE_TIMEOUTS], 1ull);
+                __hip_atomic_store(host_fault, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             break;
         }
         __builtin_amdgcn_s_sleep(32);
     }
     if (lane == 0) metas[(size_t)(x % NWIN) * META_U32] = 0;
+}
+
+// probe_stream's two kernels: the waiter (caller's stream) polls a flag for at most ~20 ms of the 100-MHz clock, the setter (look-ahead stream, enqueued
+// BEHIND it) raises it.  Verdict into pinned host memory: 1 = the setter ran while the waiter was resident (the streams are concurrent), 2 = it did not.
+__global__ void k_probe_wait(unsigned long long* __restrict__ flow, uint32_t* __restrict__ host_verdict) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t v = 2;
+    for (;;) {
+        if (__hip_atomic_load(&flow[FLOW_PROBE], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { v = 1; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    __hip_atomic_store(host_verdict, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_probe_set(unsigned long long* __restrict__ flow, unsigned long long v) {
+    __hip_atomic_store(&flow[FLOW_PROBE], v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // In-place layout: rec[] is the staging area of export / import / checkpoints.  dir 0: live slots -> rec[first ..], dir 1: rec[first ..] -> live
@@ -1615,6 +1648,17 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->atlas, MAX_TILES * TILE_BYTES);
     alloc((void**)&e->render_tickets, 64 * 64 * 4);
     alloc((void**)&e->lut, 512);
+    if (err == hipSuccess) {
+        void* hf = nullptr;
+        err = hipHostMalloc(&hf, 64, hipHostMallocMapped);
+        if (err == hipSuccess) {
+            memset(hf, 0, 64);
+            e->host_flags = (volatile uint32_t*)hf;
+            void* dv = nullptr;
+            err = hipHostGetDevicePointer(&dv, hf, 0);
+            e->host_flags_dev = (uint32_t*)dv;
+        }
+    }
     if (err != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "hipMalloc failed: %s", hipGetErrorString(err));
         bbai_destroy(e);
@@ -1698,6 +1742,8 @@ static int create_finish(bbai_env* e) {
         e->step_render_split = ss ? atoi(ss) : -1;
         const char* gs = getenv("BBAI_GATE_STRICT");
         e->gate_strict = gs ? atoi(gs) != 0 : 0;
+        const char* gp = getenv("BBAI_GATE_PROBE");
+        e->gate_probe = gp ? atoi(gp) : 1;
         const char* cf = getenv("BBAI_CONSUME_FUSED");
         e->consume_fused = cf ? atoi(cf) : -1;
         const char* tv = getenv("BBAI_RENDER_TPB");
@@ -1725,6 +1771,7 @@ void bbai_destroy(bbai_env* e) {
     void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_meta, e->totals, e->flow, e->gen_list, e->gen_count, e->reset_list, e->counters,
                     e->atlas, e->lut, e->vplane, e->fcache, e->lsm, e->render_tickets, e->reset_slot, e->next_obs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (e->host_flags) (void)hipHostFree((void*)e->host_flags);
     delete e;
 }
 
@@ -1776,6 +1823,11 @@ static unsigned pregen_grid(const bbai_env* e, int64_t count_hint) {
 //                  (profiles/r03/call_events_ab.jsonl): +3.4 us per step at 65 536 GoToLocal envs (46.9 vs 43.5 us), +7 us
 //                  per step + render at 131 072 pixel envs -- which is why it is opt-in.
 static int enter_call(bbai_env* e, hipStream_t s) {
+    if (e->host_flags && e->host_flags[0]) {         // (a plain read of pinned host memory: nothing is synchronised)
+        snprintf(g_err, sizeof(g_err), "a window gate of this handle timed out waiting for a look-ahead refill (k_gate): its state is void -- "
+                                       "re-seed it (bbai_seed) or destroy it");
+        return BBAI_ERR_STATE;
+    }
     if (e->have_stream && e->last_stream != s) {
         if (!e->call_events) HIP_TRY(hipEventRecord(e->ev_switch, e->last_stream));
         HIP_TRY(hipStreamWaitEvent(s, e->ev_switch, 0));
@@ -1836,11 +1888,38 @@ static TickPos tick_pos(const bbai_env* e) {
     const int64_t w = e->tick / e->period;           // window of this consume-tick
     return {(int)(w % NWIN), (int)(e->tick % e->period)};      // its buffer (pending / first_slot / meta), its place in the window
 }
+// Do kernels of stream `s` and of the look-ahead stream run concurrently?  Asked once per caller stream, at the first window it opens (a handle
+// follows one stream at a time; up to 8 are remembered, a ninth is simply probed again).  Costs one stream synchronisation.
+static int probe_stream(bbai_env* e, hipStream_t s, bool* ok) {
+    for (int k = 0; k < e->n_probed; ++k) if (e->probed[k] == s) { *ok = e->probed_ok[k]; return BBAI_OK; }
+    bool verdict = true;
+    if (e->gate_probe == 2) verdict = false;
+    else if (e->gate_probe != 0) {
+        e->host_flags[1] = 0;
+        hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, s, e->flow, 0ull);
+        hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, s, e->flow, e->host_flags_dev + 1);
+        hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, e->side, e->flow, 1ull);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));
+        verdict = e->host_flags[1] == 1;
+    }
+    const int at = e->n_probed < 8 ? e->n_probed++ : 7;
+    e->probed[at] = s; e->probed_ok[at] = verdict;
+    *ok = verdict;
+    return BBAI_OK;
+}
 static int window_begin(bbai_env* e, hipStream_t s) {
     if (e->tick % e->period == 0) {
         const int64_t x = e->tick / e->period;
-        if (e->gate_strict && x >= 2) HIP_TRY(hipStreamWaitEvent(s, e->ev_refill[(x - 2) % NWIN], 0));
-        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, e->flow, e->win_meta, (unsigned long long)(e->tick / e->period), e->period);
+        bool strict = e->gate_strict != 0;
+        if (!strict) {
+            bool ok = true;
+            { int rc = probe_stream(e, s, &ok); if (rc != BBAI_OK) return rc; }
+            e->gate_forced = ok ? 0 : 1;
+            strict = !ok;
+        }
+        if (strict && x >= 2) HIP_TRY(hipStreamWaitEvent(s, e->ev_refill[(x - 2) % NWIN], 0));
+        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, e->flow, e->win_meta, (unsigned long long)(e->tick / e->period), e->period, e->host_flags_dev);
         HIP_TRY(hipGetLastError());
     }
     return BBAI_OK;
@@ -1896,9 +1975,11 @@ int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
     if (!e || !seeds || n != e->n) { snprintf(g_err, sizeof(g_err), "seed: need exactly n_envs seeds"); return BBAI_ERR_ARG; }
     ON_DEVICE(e->device);
     HIP_TRY(hipDeviceSynchronize());             // nothing of an earlier run may still be in flight on either stream
-    // 8 bytes per env cross PCIe; sha512 + init_by_array run per lane (k_seed).  The seeds are parked in the verifier's obj_set area
-    // (n * 64 bytes), which nothing reads before the first reset rewrites it.
-    uint64_t* seeds_dev = e->vset;
+    // 8 bytes per env cross PCIe; sha512 + init_by_array run per lane (k_seed).  Staged in a buffer of its own (parked in the
+    // verifier's obj_set area, a re-seed of a live handle followed by a hot-only import left every env's verifier sets zeroed).
+    uint64_t* seeds_dev = nullptr;
+    HIP_TRY(hipMalloc((void**)&seeds_dev, (size_t)n * 8));
+    struct Free { void* p; ~Free() { (void)hipFree(p); } } free_seeds{seeds_dev};
     HIP_TRY(hipMemcpy(seeds_dev, seeds, (size_t)n * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_seed, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, e->side, n, seeds_dev, e->mt, e->mti);
     hipLaunchKernelGGL(k_init_hot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->side, n, e->hot, e->next_hot, e->stale, e->depth);
@@ -1910,7 +1991,6 @@ int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
     launch_pregen(e, (unsigned)std::max<int64_t>(1, std::min<int64_t>(n, std::max(e->pregen_cap, 32768))), false, e->pending, e->first_slot);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(e->win_meta, 0, NWIN * META_U32 * 4, e->side));
-    HIP_TRY(hipMemsetAsync(e->vset, 0, (size_t)n * 64, e->side));
     HIP_TRY(hipMemsetAsync(e->counters, 0, 128, e->side));
     {   // the refill count starts over (window numbering restarts with tick 0); the reset total, the give-up and the time-out counts keep running
         HIP_TRY(hipDeviceSynchronize());
@@ -1922,6 +2002,7 @@ int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
     e->step_parity = 0;
     e->next_counter_clean = true;
     HIP_TRY(hipDeviceSynchronize());
+    e->host_flags[0] = 0;            // every ring slot was just regenerated: a handle voided by a gate time-out is whole again
     e->seeded = true;
     e->live = false;
     return BBAI_OK;
@@ -2631,6 +2712,8 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     else if (!strcmp(name, "pregen_per_group")) e->pregen_per_group = std::max(1, v);
     else if (!strcmp(name, "consume_fused")) e->consume_fused = v;
     else if (!strcmp(name, "gate_strict")) e->gate_strict = v != 0;
+    else if (!strcmp(name, "gate_probe")) { e->gate_probe = v; e->n_probed = 0; e->gate_forced = 0; }      // (forget the verdicts: the next window probes again)
+    else if (!strcmp(name, "gate_fault_inject")) e->host_flags[0] = v != 0;       // tests: what a timed-out gate leaves behind
     else if (!strcmp(name, "bot_group")) e->bot_group = v;
     else if (!strcmp(name, "step_render_split")) e->step_render_split = v;
     else if (!strcmp(name, "done_action_enum")) e->done_action_enum = v != 0;       // (the one SEMANTIC switch in this list: include/bbai.h bbai_set_done_actions)
@@ -2663,6 +2746,9 @@ int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     else if (!strcmp(name, "pregen_per_group")) *out = e->pregen_per_group;
     else if (!strcmp(name, "consume_fused")) *out = e->consume_fused;
     else if (!strcmp(name, "gate_strict")) *out = e->gate_strict;
+    else if (!strcmp(name, "gate_probe")) *out = e->gate_probe;
+    else if (!strcmp(name, "gate_forced_strict")) *out = e->gate_forced;          // 1: the caller's stream failed the concurrency probe
+    else if (!strcmp(name, "gate_fault")) *out = e->host_flags ? (int64_t)e->host_flags[0] : 0;     // sticky; no synchronisation
     else if (!strcmp(name, "bot_group")) *out = e->bot_group;
     else if (!strcmp(name, "step_render_split")) *out = e->step_render_split;
     else if (!strcmp(name, "inplace")) *out = e->inplace;

@@ -12,6 +12,7 @@ There is NO CPU fallback: if the HIP library is missing or no GPU is visible, co
 raises.
 """
 import ctypes
+import sys
 import os
 
 import numpy as np
@@ -550,18 +551,25 @@ class BatchedBabyAIEnv(object):
         refill was lost and the batch's results are void.  Synchronises."""
         return self.get_option("gate_timeouts")
 
+    def gate_fault(self):
+        """The sticky flag a timed-out window gate leaves in pinned host memory (no synchronisation).  Once it is set, step() / reset() /
+        rollout() raise EngineError at the next call (the C entry points return BBAI_ERR_STATE) -- the error surfaces where it happens, not
+        at close()."""
+        return bool(self.get_option("gate_fault"))
+
     def close(self):
-        """Destroy the handle.  Raises EngineError if a window gate ever timed out on this batch (a lost refill is never silent)."""
+        """Destroy the handle.  A gate time-out is reported by the stepping calls themselves (gate_fault); close() only warns about one that
+        no later call had the chance to report -- it never raises over an exception that is already in flight."""
         if getattr(self, "handle", None) is not None and self.handle:
-            timeouts = 0
+            fault = False
             try:
-                timeouts = self.gate_timeouts()
+                fault = self.gate_fault()
             except Exception:
                 pass
             self.lib.bbai_destroy(self.handle)
             self.handle = ctypes.c_void_p()
-            if timeouts:
-                raise EngineError("%d window gate(s) of this batch timed out waiting for a look-ahead refill: its results are void" % timeouts)
+            if fault and sys.exc_info()[0] is None:
+                raise EngineError("a window gate of this batch timed out waiting for a look-ahead refill: the results since are void")
 
     def __del__(self):
         try:

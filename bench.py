@@ -147,9 +147,9 @@ def parse_args(argv=None):
     ap.add_argument("--max-blocks", type=int, default=64)
     ap.add_argument("--parity-envs", type=int, default=1024, help="envs of every shard, scattered over it, checked against the oracle (0 = off)")
     ap.add_argument("--parity-pixel-envs", type=int, default=64)
-    ap.add_argument("--parity-budget", type=int, default=600000,
+    ap.add_argument("--parity-budget", type=int, default=300000,
                     help="oracle env-steps the parity check may cost: long runs check every step of fewer envs")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0, help="the headline's CPU baseline: the oracle port on the host cores over a bounded sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prewarm-seconds", type=float, default=1.0, help="untimed GPU activity before the warmup steps")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (test rigs: ranks may share a GPU)")
@@ -159,11 +159,12 @@ def parse_args(argv=None):
     ap.add_argument("--extra-configs", action="store_true", help="measure the other configs with --gpus N > 1 too (sharded over the N ranks)")
     ap.add_argument("--extra-seconds", type=float, default=0.3, help="timed work per extra config")
     ap.add_argument("--extra-parity-envs", type=int, default=256)
-    ap.add_argument("--extra-parity-budget", type=int, default=400000, help="oracle env-steps per extra config")
-    ap.add_argument("--extra-cpu-seconds", type=float, default=2.5, help="CPU baseline (the oracle port on the host cores) per extra workload; 0 = only the ratio on file")
+    ap.add_argument("--extra-parity-budget", type=int, default=150000, help="oracle env-steps per extra config")
+    ap.add_argument("--extra-cpu-seconds", type=float, default=1.0, help="CPU baseline (the oracle port on the host cores) per extra workload; 0 = only the ratio on file")
     ap.add_argument("--extra-parity-horizon", type=int, default=1024, help="steps over which ALL --extra-parity-envs are followed (then a spread of them)")
     ap.add_argument("--profile-tail", action="store_true", help="all plain blocks first (one contiguous rollout), the profiled blocks behind them (default: alternating; the extra configs always run this way)")
     ap.add_argument("--rollout-entry", action="store_true", help="one bbai_rollout call per block instead of one bbai_step / bbai_render / bbai_tap_ids call per step from Python (the same launches)")
+    ap.add_argument("--full-out", default=None, help="where the FULL record goes (default <repo>/gpurun_out/bench_full.json); stdout carries the compact judged line only")
     ap.add_argument("--dump-digest", default=None, help="write per-env output digests of this rank to <prefix>.rank<r>.npy")
     args = ap.parse_args(argv)
     if args.gpus < 1:
@@ -221,6 +222,116 @@ def block_stats(blocks, K, E, world):
     return {"mean": mean, "median": med, "p90": p90, "min": bs[0], "max": bs[-1],
             "value_mean": K * E * world / mean, "value_median": K * E * world / med,
             "mean_over_median": mean / med, "max_over_median": bs[-1] / med}
+
+
+def _sig(x, n=7):
+    """floats to n significant digits (the judged line is a record, not a dump)"""
+    if isinstance(x, float):
+        return float("%.*g" % (n, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+JUDGED_LINE_MAX_BYTES = 6000
+
+
+def compact_line(out, full_path=None):
+    """The ONE stdout line: what the driver parses and the judge reads, well under 6 KB whatever the run measured.  Everything else --
+    every block's time, the per-kernel averages, provenance strings, the per-config baselines' samples -- is the FULL record
+    (`--full-out`, default gpurun_out/bench_full.json), which this line names.  Round 5's single 32-KB line could not be parsed by the
+    harness: a measurement nobody downstream can read is not a measurement (tests/test_bench_helpers.py::test_judged_line_is_small)."""
+    def pick(d, keys):
+        return {k: d.get(k) for k in keys if d is not None and k in d} if d else None
+
+    r = out.get("roofline") or {}
+    roof = pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_of_achievable", "achievable_ceiling",
+                    "alg_bytes_per_launch", "avg_launch_ms", "whole_step_alg_GBs"))
+    if roof is not None:
+        roof["traffic_over_alg"] = (r["traffic"] / r["alg_bytes_per_launch"]) if r.get("traffic") and r.get("alg_bytes_per_launch") else None
+        roof["whole_step_frac"] = (r["whole_step_alg_GBs"] / r["peak"]) if r.get("whole_step_alg_GBs") and r.get("peak") else None
+    cb = out.get("cpu_baseline")
+    if cb is not None:
+        cbc = pick(cb, ("value", "unit", "cores", "kind", "single_core_value", "reference_over_port", "error"))
+        if cb.get("sample"):
+            cbc["sample"] = cb["sample"][:200]
+        cb = cbc
+    par = out.get("parity")
+    if par is not None:
+        par = pick(par, ("envs", "envs_all_ranks", "steps", "pixel_envs", "mismatches", "mismatches_all_ranks", "checker_errors_all_ranks", "error"))
+    t = out.get("timing") or {}
+    bm = t.get("block_ms") or {}
+    K = out.get("steps") or 1
+    cfgs = None
+    if out.get("configs"):
+        cfgs = {}
+        for name, c in out["configs"].items():
+            if "error" in c:
+                cfgs[name] = {"error": str(c["error"])[:120]}
+                continue
+            cr = c.get("roofline") or {}
+            cfgs[name] = {"envs": c.get("envs"), "ms_per_step": c.get("ms_per_step"), "ms_median": c.get("ms_per_step_median"),
+                          "max_over_median": c.get("max_over_median"),
+                          "kernel": cr.get("kernel"), "kernel_ms": cr.get("avg_launch_ms"), "frac": cr.get("frac"),
+                          "step_frac": (cr["whole_step_alg_GBs"] / cr["peak"]) if cr.get("whole_step_alg_GBs") and cr.get("peak") else None,
+                          "traffic_ratio": (cr["traffic"] / cr["alg_bytes_per_launch"]) if cr.get("traffic") and cr.get("alg_bytes_per_launch") else None,
+                          "mismatches": (c.get("parity") or {}).get("mismatches"),
+                          "parity_steps": (c.get("parity") or {}).get("steps"),
+                          "cpu": (c.get("cpu_baseline") or {}).get("value")}
+    si = out.get("scaling_implied")
+    if si:
+        si = {"basis": "1-GPU runs of each per-GPU shard size on this box (no collective on the step path); implied, not measured",
+              "one_gpu_ms_per_step": si.get("one_gpu_ms_per_step"),
+              "gpus": {g: pick(v, ("envs_per_gpu", "ms_per_step_shard", "implied_value", "implied_efficiency")) for g, v in (si.get("gpus") or {}).items()},
+              "C4": si.get("C4")}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    line["config"] = pick(out.get("config"), ("workload", "envs_per_gpu", "total_envs", "resets_in_timed_region", "parallelism"))
+    line["roofline"] = roof
+    line["cpu_baseline"] = cb
+    line["parity"] = par
+    line["timing"] = {"blocks": t.get("blocks"), "ms_median": (bm.get("median") / K) if bm.get("median") else None,
+                      "ms_max": (bm.get("max") / K) if bm.get("max") else None, "mean_over_median": t.get("mean_over_median"),
+                      "timed_seconds": t.get("timed_seconds"), "profiled_ms_per_step": t.get("profiled_ms_per_step")}
+    line["kernel_avg_ms"] = r.get("kernel_avg_ms")
+    rc = out.get("rccl") or {}
+    line["rccl"] = pick(rc, ("world", "backend", "allreduce_of_ones", "distinct_devices", "per_rank_ms_per_step_min", "per_rank_ms_per_step_max", "launched_by"))
+    if out.get("obs_gather"):
+        line["obs_gather"] = pick(out["obs_gather"], ("ms", "GBs_into_rank0", "error"))
+    line["configs"] = cfgs
+    line["scaling_implied"] = si
+    line["gate_timeouts"] = out.get("gate_timeouts")
+    line["state_layout"] = out.get("state_layout")
+    line["build"] = out.get("build")
+    line["wall_seconds"] = out.get("wall_seconds")
+    line["full_record"] = full_path
+    line = _sig(line)
+    s = json.dumps(line, separators=(",", ":"))
+    if len(s) > JUDGED_LINE_MAX_BYTES:          # never again: shed the optional parts, largest first, until it fits
+        for k in ("kernel_avg_ms", "timing", "rccl", "configs", "scaling_implied"):
+            line[k] = None if k != "configs" else {n: {"ms_per_step": c.get("ms_per_step"), "mismatches": c.get("mismatches")} for n, c in (line["configs"] or {}).items()}
+            s = json.dumps(line, separators=(",", ":"))
+            if len(s) <= JUDGED_LINE_MAX_BYTES:
+                break
+    return s
+
+
+def write_full_record(out, path):
+    """The full record next to the judged line; never fatal (a read-only tree falls back to the temp dir)."""
+    import tempfile
+    for cand in (path, os.path.join(tempfile.gettempdir(), "bbai_bench_full.json")):
+        try:
+            d = os.path.dirname(os.path.abspath(cand))
+            os.makedirs(d, exist_ok=True)
+            with open(cand, "w") as f:
+                json.dump(out, f)
+                f.write("\n")
+            return cand
+        except OSError:
+            continue
+    return None
 
 
 def traffic_of(level, E, pixel, dom):
@@ -404,11 +515,12 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
         torch.cuda.synchronize()
     prof = env.profile_read()
     env.profile(False)
+    gate_timeouts = int(ranks.sum(env.gate_timeouts()))      # (synchronises; outside the timed blocks) a window gate that gave up = a void run
     m = {"level": level, "pixel": pixel, "E": E, "total_envs": total_envs, "first": first, "K": K, "W": W, "S1": S1, "S2": S2, "want": want,
          "blocks": blocks, "profiled": profiled, "local_blocks": local_blocks, "barrier_s": barrier_s,
          "kernel_ms": {k: v[0] for k, v in prof.items() if v[0] is not None},
          "kernel_launches": {k: v[1] for k, v in prof.items() if v[0] is not None},
-         "resets": resets, "setup_ms": setup_ms,
+         "resets": resets, "setup_ms": setup_ms, "gate_timeouts": gate_timeouts,
          "state_layout": "in-place (the look-ahead slot is the live record)" if env.get_option("inplace") else "classic (live record per env, k_consume / in-wave copy on reset)",
          "lookahead_period": env.get_option("lookahead_period"),
          "log1": log1, "log2": log2, "ids2": ids2, "PP1": PP1, "PP2": PP2, "sel2": sel2, "env": env}
@@ -620,7 +732,7 @@ def main():
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
                      "whole_step_alg_GBs": value / world * bytes_per_step / 1e9,
                      "kernel_avg_ms": kernel_ms, "kernel_launches": kernel_launches, "measured_on": "rank 0"},
-        "parity": None, "cpu_baseline": None, "configs": None,
+        "parity": None, "cpu_baseline": None, "configs": None, "gate_timeouts": m["gate_timeouts"],
         "build": {"commit": git_head(), "csrc_sha": csrc_sha()},
     }
     # the OPTIONAL gather of the encoded observations to rank 0 (north_star: "only an optional xGMI gather of obs to
@@ -667,6 +779,8 @@ def main():
 
     # ---- outside the timed region: the oracle re-derives what the taps recorded --------------------------------------
     exit_code = 0
+    if m["gate_timeouts"]:
+        exit_code = 5                       # a window gate gave up waiting for a refill (k_gate): the run is void, whatever it printed
     par = replay(ctx, m)
     if par is not None:
         bad = ranks.sum(par["mismatches"] or 0)
@@ -691,6 +805,8 @@ def main():
                 cfgs[name] = {"error": mc["error"]}
                 exit_code = exit_code or 4
                 continue
+            if mc["gate_timeouts"]:
+                exit_code = 5
             pc = replay(ctx, mc)
             bad = ranks.sum((pc or {}).get("mismatches") or 0)
             broken = ranks.sum(1 if (pc is not None and pc["mismatches"] is None) else 0)
@@ -703,6 +819,7 @@ def main():
             cst = block_stats(mc["blocks"], Kc, Ec, world)
             ctraffic = traffic_of(c["level"], Ec, c["pixel"], cdom)
             cfgs[name] = {
+                "envs": Ec * world, "gate_timeouts": mc["gate_timeouts"],
                 "workload": "BabyAI-%s-v0 %s obs, %d envs in total = %d per GPU x %d, random actions, auto-reset" % (
                     c["level"], "56x56x3 pixel (RGBImgPartialObsWrapper)" if c["pixel"] else "7x7x3 encoded", c["total"], Ec, world),
                 "reference": c["ref"], "value": cst["value_mean"], "unit": "env-steps/s", "ms_per_step": cst["mean"] / Kc * 1e3,
@@ -739,6 +856,11 @@ def main():
                                      "implied_efficiency": out["ms_per_step"] / (n_g * t_shard)}
             out["scaling_implied"] = {"basis": "single-GPU runs of each per-GPU shard size, same process, same box; no collective on the step path",
                                       "one_gpu_ms_per_step": out["ms_per_step"], "gpus": imp}
+            c4, c4s = cfgs.get("C4"), cfgs.get("C4-shard")      # BASELINE.json configs[3] (encoded GoTo, 1 048 576 envs over 8 GPUs): the same inference
+            if c4 and c4s and "error" not in c4 and "error" not in c4s:
+                out["scaling_implied"]["C4"] = {"gpus": 8, "envs_per_gpu": c4s["envs"], "one_gpu_ms_per_step": c4["ms_per_step"],
+                                                "ms_per_step_shard": c4s["ms_per_step"], "implied_value": 1048576 / (c4s["ms_per_step"] * 1e-3),
+                                                "implied_efficiency": c4["ms_per_step"] / (8 * c4s["ms_per_step"])}
     ranks.barrier()
     if rank == 0 and not args.no_cpu_baseline:
         try:
@@ -763,7 +885,13 @@ def main():
         pool.terminate()
     out["wall_seconds"] = time.perf_counter() - t_start
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        # ONE stdout line, compact (compact_line); the full record goes to a side file -- BBAI_BENCH_LINE=full (tools/, tests) prints
+        # the full record as the line instead
+        full_path = write_full_record(out, args.full_out or os.path.join(ROOT, "gpurun_out", "bench_full.json"))
+        if os.environ.get("BBAI_BENCH_LINE") == "full":
+            print(json.dumps(out), flush=True)
+        else:
+            print(compact_line(out, os.path.relpath(full_path, ROOT) if full_path and full_path.startswith(ROOT) else full_path), flush=True)
     ranks.barrier()
     ranks.close()
     sys.exit(exit_code)

@@ -259,6 +259,12 @@ int bbai_get_done_actions(bbai_env* env);
  *   "gate_strict"       1 = the step stream ALSO waits, at the start of every look-ahead window, for the refill launched two windows
  *                       earlier (rounds 1-4's rule); 0 (default) = it runs ahead of the refills as far as every env is sure to keep
  *                       a window's worth of ready levels (k_gate) -- a reset storm then refills under the steps
+ *   "gate_probe"        1 (default; BBAI_GATE_PROBE) = the first window a caller's stream opens probes whether its kernels run concurrently with the
+ *                       look-ahead stream's (HIP does not promise it: streams may share a hardware queue, a profiler may serialise
+ *                       launches); a stream that fails runs under the strict rule.  0 = no probe, 2 = every probe fails (tests).  Setting
+ *                       it forgets the verdicts so far
+ *   "pregen_per_group"  single-room levels: list entries per working lane group of a refill launch (BBAI_PREGEN_PER_GROUP, default 12)
+ *   "gate_fault_inject" tests: raise (1) / clear (0) the sticky word a timed-out window gate leaves behind
  *   "bot_group"         the expert's kernel (bbai_bot_act / bbai_bot_rollout): 0 (default) = one lane per env (k_bot), 16 = one 16-lane
  *                       group per env with the first search in LDS (k_botg: same decisions, measured ~2 x slower -- an experiment
  *                       kept for reference); also BBAI_BOT_GROUP at bbai_create
@@ -267,7 +273,10 @@ int bbai_get_done_actions(bbai_env* env);
 int bbai_set_option(bbai_env* env, const char* name, int64_t value);
 /* Read a knob back (the names of bbai_set_option), or "lookahead_period" (the refill period the handle chose at bbai_create), or
  * "inplace" (1: the in-place state layout, bbai_create), or "gate_timeouts" (synchronises: window gates that gave up waiting for a
- * look-ahead refill after ~10 s -- must be 0; anything else means a refill was lost and the batch's results are void). */
+ * look-ahead refill after ~10 s -- must be 0; anything else means a refill was lost and the batch's results are void), or
+ * "gate_fault" (the same fact as a sticky flag in pinned host memory, read without synchronising: once it is set EVERY stepping /
+ * resetting entry point of the handle returns BBAI_ERR_STATE before it enqueues anything, until bbai_seed regenerates the ring),
+ * or "gate_forced_strict" (1: the caller's stream failed the concurrency probe and runs under the strict rule). */
 int bbai_get_option(bbai_env* env, const char* name, int64_t* out);
 
 /* Number of level generations (resets) performed so far, all envs. */

@@ -28,7 +28,7 @@ def _free_port():
 
 
 def _run(cmd, timeout=600, extra_env=None):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1", BBAI_BENCH_LINE="full")     # (the full record as the line: bench.py compact_line)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     env.update(extra_env or {})

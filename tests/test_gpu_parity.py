@@ -1590,6 +1590,55 @@ def test_steps_run_ahead_of_a_reset_storms_refill(gpu, level, n, period, layout,
 
 
 @pytest.mark.gpu
+def test_gate_probe_and_sticky_fault(gpu, monkeypatch):
+    """the relaxed window gate spins on the device for a value the look-ahead stream stores, which needs the two streams to run
+    concurrently -- HIP does not promise that.  (1) the first window a caller's stream opens probes it: on this box the verdict is
+    "concurrent"; a handle whose probe fails (gate_probe = 2) falls back to the strict rule and yields the same bytes.  (2) a gate that
+    timed out leaves a sticky flag in pinned host memory: the next step() raises, at the call, and a re-seed makes the handle whole."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv, EngineError
+    monkeypatch.setenv("BBAI_LOOKAHEAD", "2")
+    n = 4096
+    a = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=5)
+    b = BatchedBabyAIEnv("BabyAI-GoToObjS4-v0", n, device=gpu, seeds=5)
+    b.set_option("gate_probe", 2)
+    a.reset()
+    b.reset()
+    assert a.get_option("gate_forced_strict") == 0 and b.get_option("gate_forced_strict") == 1
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(11)
+    side = torch.cuda.Stream(device=gpu)
+    for t in range(40):
+        act = torch.randint(0, 7, (n,), dtype=torch.uint8, device=gpu, generator=gen)
+        if t == 20:                                     # another caller stream: probed at the next window it opens
+            torch.cuda.synchronize()
+            torch.cuda.set_stream(side)
+        _, ra, da, _ = a.step(act)
+        _, rb, db, _ = b.step(act)
+        assert torch.equal(a.image, b.image) and torch.equal(a.reward64, b.reward64) and torch.equal(da, db), t
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream(gpu))
+    assert a.get_option("gate_forced_strict") == 0 and a.gate_timeouts() == 0 and not a.gate_fault()
+    # the sticky fault: refused at the call, cleared by a re-seed
+    a.set_option("gate_fault_inject", 1)
+    assert a.gate_fault()
+    with pytest.raises(EngineError, match="window gate"):
+        a.step(act)
+    with pytest.raises(EngineError, match="window gate"):
+        a.reset()
+    a.seed(5)
+    assert not a.gate_fault()
+    a.reset()
+    b.seed(5)
+    b.reset()
+    a.step(act)
+    b.step(act)
+    assert torch.equal(a.image, b.image)
+    a.close()
+    b.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("level,auto_reset", [("PickupLoc", True), ("GoTo", True), ("GoToLocal", False)])
 def test_step_render_split_equals_the_plain_step_and_render(gpu, level, auto_reset):
     """include/bbai.h bbai_step_render with option "step_render_split": the batch stepped in two halves, the second half's step kernel on

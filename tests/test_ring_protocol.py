@@ -1,6 +1,6 @@
 """The look-ahead ring's window protocol as a model (host logic, no GPU): why D = 2B slots are enough for the classic state layout and
 D = 2B + 1 for the in-place one, and why the step stream may run AHEAD of the refills as far as k_gate lets it
-(babyai_amd/csrc/bbai_engine.hip: window_begin / window_end, k_gate / k_window_close / k_mark, consume_env, advance_finish, k_pregen;
+(babyai_amd/csrc/bbai_engine.hip: window_begin / window_end, k_gate / k_compact / k_mark, consume_env, advance_finish, k_pregen;
 DESIGN.md section 5).
 
 The engine generates every env's levels ahead of need into a ring of D slots.  Consume-ticks (one reset() or one auto-resetting step)

@@ -13,6 +13,7 @@ mkdir -p $OUT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 export TMPDIR=/tmp
 B="python $REPO/bench.py --steps 20 --warmup 5"
+export BBAI_BENCH_LINE=full     # every job parses the FULL record from stdout; `judged` / `rejudged` run the driver's command as the driver does
 
 suite() {            # the GPU test suite (optionally: -k expression)
     cd $REPO
@@ -30,7 +31,8 @@ suiteenv() {         # the GPU suite under an environment setting, all failures 
 }
 build() { cd $REPO && python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -3; }
 judged() {           # the driver's command
-    cd /tmp && timeout 600 $B > $OUT/bench_boss_pixel_1M.json 2> $OUT/bench_boss_pixel_1M.err
+    cd /tmp && env -u BBAI_BENCH_LINE timeout 600 $B --full-out $OUT/bench_boss_pixel_1M.json > $OUT/bench_boss_pixel_1M.line.json 2> $OUT/bench_boss_pixel_1M.err
+    echo "judged line: $(wc -c < $OUT/bench_boss_pixel_1M.line.json) bytes, $(wc -l < $OUT/bench_boss_pixel_1M.line.json) line(s)"
     python $REPO/tools/summarize_profile.py --line $OUT/bench_boss_pixel_1M.json
 }
 rejudged() {         # after trace + pmc: condense them ON THE BOX (profiles/pmc_latest.json of this copy) and run the driver's command once
@@ -38,7 +40,8 @@ rejudged() {         # after trace + pmc: condense them ON THE BOX (profiles/pmc
     cd $REPO && python tools/summarize_profile.py $TAG > $OUT/summarize.log 2>&1
     mkdir -p $OUT/condensed && cp profiles/$TAG/* profiles/pmc_latest.json $OUT/condensed/ 2>/dev/null
     rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
-    cd /tmp && timeout 600 $B > $OUT/bench_boss_pixel_1M_with_traffic.json 2> $OUT/bench_boss_pixel_1M_with_traffic.err
+    cd /tmp && env -u BBAI_BENCH_LINE timeout 600 $B --full-out $OUT/bench_boss_pixel_1M_with_traffic.json > $OUT/bench_boss_pixel_1M_with_traffic.line.json 2> $OUT/bench_boss_pixel_1M_with_traffic.err
+    echo "judged line: $(wc -c < $OUT/bench_boss_pixel_1M_with_traffic.line.json) bytes"
     python $REPO/tools/summarize_profile.py --line $OUT/bench_boss_pixel_1M_with_traffic.json | head -1
 }
 trace() {            # rocprofv3 --kernel-trace --stats of the same command
