@@ -59,6 +59,10 @@ enum { BP_DECIDE = 0, BP_OBS = 1, BP_AFTER = 2, BP_FIND_OBJ = 3, BP_PATH = 4, BP
 #define BBAI_BOT_COUNT(what)          // (tests/hostsim counts pops / queries per decision with this; nothing in the product)
 #endif
 
+#ifndef BBAI_BOT_ALIGNED_OK
+#define BBAI_BOT_ALIGNED_OK true     // _find_obj_pos: take the list-free pairing when every object of the descriptor is still where the episode put it
+#endif
+
 namespace bbai {
 
 struct OneLane {
@@ -502,7 +506,9 @@ struct Bot {
         // (sorted by the start positions) and obj_poss (sorted by the recorded ones) pair every object with ITS position, and the
         // loop index of a pair is the rank of its position key: no list has to be built (the lists live in per-lane scratch, and their
         // insertion sorts were a third of a BossLevel decision: profiles/r05/NOTES.md section 11).
-        bool aligned = true;
+        // (BBAI_BOT_ALIGNED_OK: the host harness can switch the shortcut off -- tests/test_hostsim_bot.py replays every reference-bot fixture
+        // through the packed lists alone and must see the same decisions)
+        bool aligned = BBAI_BOT_ALIGNED_OK;
         for (uint64_t m = set; m && aligned; m &= m - 1) {
             const int o = __builtin_ctzll(m);
             aligned = (obj_in_grid(o) || (stale >> o & 1)) && pos[2 * o] == s.ipos[o][0] && pos[2 * o + 1] == s.ipos[o][1];

@@ -156,6 +156,7 @@ struct bbai_env {
     int64_t tick;         // number of consume_and_refill calls so far
     uint8_t* vplane;      // [n][v_bytes] window plane (bbai_types.hpp): one 128-byte line per window-origin class; BBAI_VPLANE=0: none
     uint16_t* fcache;     // [n] appearance of the front cell (low byte) and of the carried object (high byte) after the last step
+    uint8_t* cplane;      // [n][cpl_bytes] C plane rows of the small single rooms (bbai_types.hpp cpl_ok; in-place layout only); BBAI_CPLANE=0: none
     uint8_t* lsm;         // [n] done-action verifier mode only (BABYAI_DONE_ACTIONS / bbai_set_done_actions): bit k = leaf k's
                           //     lastStepMatch (babyai/levels/verifier.py:213-230); NULL = the normal mode
     unsigned int* render_tickets;   // [64][64] ticket counters of k_render_q + its departure counter; zero between launches (the kernel leaves them so)
@@ -381,6 +382,20 @@ __device__ __forceinline__ u32x4 v_segment(const LevelCfg& c, const uint8_t* __r
     return out;
 }
 
+// An env's C plane row (bbai_types.hpp) from its record by ONE wave: lane l = plane cell (l & 7, l >> 3); lanes < cpl_ids = the id bytes (an
+// object stands on the grid iff the id plane holds it at its recorded position).  consume_env (reset()) and k_sync_cpl (imports).
+__device__ __forceinline__ void cpl_build_wave(const LevelCfg& c, const uint8_t* __restrict__ rec, uint8_t* __restrict__ row, int lane) {
+    const int x = lane & 7, y = lane >> 3;
+    const int e = (x < c.W && y < c.H) ? (int)rec[e_index(c, x, y)] : (int)E_WALL;
+    int v = 0xFF;
+    if (lane < c.maxo) {
+        const int ox = rec[c.off_pos + 2 * lane], oy = rec[c.off_pos + 2 * lane + 1];
+        if (ox < c.W && oy < c.H && rec[c.off_I + i_index(c, ox, oy)] == lane + 2) v = oy << 3 | ox;
+    }
+    row[lane] = (uint8_t)e;
+    if (lane < cpl_ids(c)) row[CPL_PLANE + lane] = (uint8_t)v;
+}
+
 // ---- the in-place layout (bbai_env::inplace, chosen at bbai_create) ------------------------------------------------------------
 // Classic layout: every env has a live record of its own (rec[env]); a finished env's next level is COPIED out of its look-ahead
 // slot (1.3 - 1.7 KB + the window plane), by a k_consume launch behind every step or by the stepping wave.  On reset-heavy small
@@ -396,7 +411,7 @@ __device__ __forceinline__ u32x4 v_segment(const LevelCfg& c, const uint8_t* __r
 // lie together.  (Slot-major, rounds 1-4a, put the 64 envs of a stepping wave into up to 64 regions n * rec_bytes apart as soon as
 // the live records are ring slots: profiles/r04/inplace_ring_depth_ab.jsonl, k_step 0.029 -> 0.035 ms from D = 5 to D = 65.)
 __device__ __forceinline__ int64_t ring_at(int slot, int64_t env, int depth) { return env * depth + slot; }
-constexpr int OBS_SLOT = 160;           // bytes per first observation in next_obs (147 used; sixteen-byte loads)
+constexpr int OBS_BLOCK = 160;          // bytes of a next_obs slot that hold the first observation (147 used; sixteen-byte loads); OBS_SLOT / CPL_OFF: bbai_types.hpp
 __device__ __forceinline__ int live_slot(int next_slot, int depth) { return (next_slot ? next_slot : depth) - 1; }
 __device__ __forceinline__ uint8_t* live_rec(const LevelCfg& c, int64_t n, int64_t env, uint8_t* recs, uint8_t* ring, int depth, int next_slot) {
     (void)n;
@@ -419,7 +434,8 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
                                             uint32_t* __restrict__ win_meta, uint8_t* __restrict__ obs_dst, uint8_t* __restrict__ dirs,
                                             uint8_t* __restrict__ vplane /* or NULL */,
                                             uint16_t* __restrict__ fcache, uint8_t* __restrict__ lsm_arr /* or NULL */,
-                                            bool inplace = false /* the slot BECOMES the live record: no copy; the slot the episode leaves is what gets refilled */) {
+                                            bool inplace = false /* the slot BECOMES the live record: no copy; the slot the episode leaves is what gets refilled */,
+                                            uint8_t* __restrict__ cplane = nullptr /* in-place small rooms: the env's C plane row is rebuilt from the slot */) {
     const int nvec = c.rec_bytes >> 4;
     uint8_t* nrec = next_recs + ring_at(slot, env, depth) * (int64_t)c.rec_bytes;
     Hot h = next_hots[ring_at(slot, env, depth)];
@@ -460,6 +476,8 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
             for (int j = 0; j < SGB; ++j) { const int sg = s0 + 64 * j; if (sg < nseg) *(u32x4*)(vrow + (sg >> 3) * VLINE + (sg & 7) * 16) = seg[j]; }
         }
     }
+    uint8_t* crow = cplane ? cplane + env * (int64_t)cpl_bytes(c) : nullptr;
+    if (crow) cpl_build_wave(c, nrec, crow, lane);
     // the verifier's SoA view of the new program
     if (lane < 8) vsets[(int64_t)lane * n + env] = pset;
     if (lane == 8) vheads[env] = vh;
@@ -477,11 +495,16 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the segment stores of every lane have landed; the patch goes over them
                 v_patch(c, vrow, sx, sy, E_EMPTY);
             }
+            if (crow) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the row bytes of the other lanes)
+                crow[8 * sy + sx] = (uint8_t)E_EMPTY;
+                crow[CPL_PLANE + start_carry] = 0xFF;
+            }
             if (e_index(c, sx, sy) == e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))) fe0 = E_EMPTY;
             ce0 = nrec[c.off_app + start_carry];
             apply_start_carry(c, inplace ? nrec : recs + env * (int64_t)c.rec_bytes, h, stale0, start_carry);
         }
-        if (vplane) fcache[env] = (uint16_t)(fe0 | (ce0 << 8));
+        if (vplane || crow) fcache[env] = (uint16_t)(fe0 | (ce0 << 8));
         hots[env] = h;
         stales[env] = stale0;
         if (lsm_arr) lsm_arr[env] = 0;                  // fresh instruction objects: lastStepMatch = False (verifier.py:213-214)
@@ -500,14 +523,17 @@ __device__ __forceinline__ void consume_env(const LevelCfg& c, int64_t n, int64_
 // inplace_own_lane_observation_ab.jsonl) -- so it is ONE round trip, and it is issued the moment the lane knows its episode is over
 // (advance_load, right behind the step's own stores); advance_finish swaps the SoA state of the env and puts the observation into
 // the lane's LDS row.  Nothing here waits for another wave: the window keeps no list (see NWIN above).
+template <bool CP>
 struct AdvanceRegs {
-    u32x4 hv, tail /* Prog bytes 96..111: kind[4], root, n_a, n_b, strict, start_carry */, o[OBS_SLOT / 16];
+    u32x4 hv, tail /* Prog bytes 96..111: kind[4], root, n_a, n_b, strict, start_carry */, o[OBS_BLOCK / 16];
+    u32x4 cp[CP ? (CPL_PLANE + CPL_MAX_IDS) / 16 : 1];      // the next level's C plane row
     uint64_t ps[8];
     uint32_t pend;
 };
+template <bool CP>
 __device__ __forceinline__ void advance_load(const LevelCfg& c, int64_t env, int next /* hot.slot: the slot that becomes live */, int depth,
                                              const uint8_t* ring, const Hot* __restrict__ next_hots, const uint8_t* __restrict__ next_obs,
-                                             const uint8_t* __restrict__ pending, AdvanceRegs& r) {
+                                             const uint8_t* __restrict__ pending, AdvanceRegs<CP>& r) {
     const int64_t at = ring_at(next, env, depth);
     const uint8_t* nrec = ring + at * (int64_t)c.rec_bytes;
     r.hv = *(const u32x4*)(next_hots + at);
@@ -518,12 +544,19 @@ __device__ __forceinline__ void advance_load(const LevelCfg& c, int64_t env, int
     r.pend = pending[env];
     const u32x4* ob = (const u32x4*)(next_obs + at * OBS_SLOT);
 #pragma unroll
-    for (int k = 0; k < OBS_SLOT / 16; ++k) r.o[k] = ob[k];
+    for (int k = 0; k < OBS_BLOCK / 16; ++k) r.o[k] = ob[k];
+    if constexpr (CP) {
+        const u32x4* cr = (const u32x4*)(next_obs + at * OBS_SLOT + CPL_OFF);
+#pragma unroll
+        for (int k = 0; k < (CPL_PLANE + CPL_MAX_IDS) / 16; ++k) r.cp[k] = cr[k];      // (the slot holds 96 bytes whatever the level's id count)
+    }
 }
-__device__ __forceinline__ void advance_finish(const LevelCfg& c, int64_t n, int64_t env, int lane, int next, int depth, uint8_t* ring, const AdvanceRegs& r,
+template <bool CP>
+__device__ __forceinline__ void advance_finish(const LevelCfg& c, int64_t n, int64_t env, int lane, int next, int depth, uint8_t* ring, const AdvanceRegs<CP>& r,
                                                Hot* __restrict__ hots, uint64_t* __restrict__ stales, uint32_t* __restrict__ vheads, uint64_t* __restrict__ vsets,
                                                uint8_t* __restrict__ pending, uint8_t* __restrict__ first_slot, uint32_t* __restrict__ win_meta,
-                                               uint8_t* __restrict__ s_rows, uint8_t* __restrict__ dirs, uint8_t* __restrict__ lsm_arr) {
+                                               uint8_t* __restrict__ s_rows, uint8_t* __restrict__ dirs, uint8_t* __restrict__ lsm_arr,
+                                               uint8_t* __restrict__ cplane, uint16_t* __restrict__ fcache) {
     static_assert(sizeof(Prog) == 112 && offsetof(Prog, kind) == 96 && offsetof(Prog, start_carry) == 104, "Prog tail");
     Hot h;
     __builtin_memcpy(&h, &r.hv, sizeof(h));
@@ -539,8 +572,27 @@ __device__ __forceinline__ void advance_finish(const LevelCfg& c, int64_t n, int
         rp.finish();
     }
     uint64_t stale0 = 0;
+    uint32_t ce0 = E_EMPTY;
+    if constexpr (CP) {
+        u32x4* crow = (u32x4*)(cplane + env * (int64_t)cpl_bytes(c));
+        const int nv = cpl_bytes(c) >> 4;
+#pragma unroll
+        for (int k = 0; k < (CPL_PLANE + CPL_MAX_IDS) / 16; ++k) if (k < nv) crow[k] = r.cp[k];
+    }
     // PutNext*Carrying (consume_env): the first observation shows the object on the grid; now it is in the agent's hands
-    if (start_carry != NONE8) apply_start_carry(c, ring + ring_at(next, env, depth) * (int64_t)c.rec_bytes, h, stale0, start_carry);
+    if (start_carry != NONE8) {
+        uint8_t* nrec = ring + ring_at(next, env, depth) * (int64_t)c.rec_bytes;
+        if constexpr (CP) {
+            const int sx = nrec[c.off_pos + 2 * start_carry], sy = nrec[c.off_pos + 2 * start_carry + 1];
+            ce0 = nrec[c.off_app + start_carry];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the row above has landed; the patch goes over it
+            uint8_t* crow = cplane + env * (int64_t)cpl_bytes(c);
+            crow[8 * sy + sx] = (uint8_t)E_EMPTY;
+            crow[CPL_PLANE + start_carry] = 0xFF;
+        }
+        apply_start_carry(c, nrec, h, stale0, start_carry);
+    }
+    if constexpr (CP) fcache[env] = (uint16_t)(E_EMPTY | (ce0 << 8));
 #pragma unroll
     for (int k = 0; k < 8; ++k) vsets[(int64_t)k * n + env] = r.ps[k];
     vheads[env] = vh;
@@ -564,7 +616,8 @@ struct FuseArgs {
     uint8_t* next_recs; const Hot* next_hots; const uint8_t* next_obs; int depth;
     uint8_t* pending; uint8_t* first_slot; uint32_t* win_meta; unsigned long long* totals;
 };
-template <bool VP, int FUSE /* 0: finished envs listed for k_consume; 1: consumed by the stepping wave (consume_env); 3: in-place layout (advance_load / advance_finish) */>
+template <bool VP, int FUSE /* 0: finished envs listed for k_consume; 1: consumed by the stepping wave (consume_env); 3: in-place layout (advance_load / advance_finish) */,
+          bool CP = false /* in-place small single rooms: pose-independent C plane row instead of the record's planes (bbai_types.hpp) */>
 __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c, int64_t n, uint8_t* __restrict__ recs,
                                                      Hot* __restrict__ hots, uint64_t* __restrict__ stales,
                                                      uint32_t* vheads, uint64_t* vsets /* read by every lane, WRITTEN for the envs the wave moves on (FUSE): no restrict */,
@@ -575,7 +628,9 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
                                                      int prio, uint8_t* __restrict__ vplane, uint16_t* __restrict__ fcache,
                                                      uint8_t* __restrict__ lsm_arr /* NULL, or the done-action mode's per-env bits */,
                                                      int enum_done /* done-action mode: this step's `done` actions are the enum member (bbai_step.hpp verify_side) */,
-                                                     FuseArgs fuse, int64_t block0 /* first 64-env block of this launch (bbai_step_render steps the batch in two halves) */) {
+                                                     FuseArgs fuse, int64_t block0 /* first 64-env block of this launch (bbai_step_render steps the batch in two halves) */,
+                                                     uint8_t* __restrict__ cplane /* CP: [n][cpl_bytes] */) {
+    static_assert(!CP || (FUSE == 3 && !VP), "the C plane belongs to the in-place layout");
     // the block's observation rows at the OUTPUT pitch of 147 bytes (bbai_step.hpp RowPacker), 16 bytes of front padding
     __shared__ __attribute__((aligned(16))) uint8_t s_obs[ROWS_FRONT + STEP_BLOCK * OBS_BYTES + 16];
     uint8_t* const s_rows = s_obs + ROWS_FRONT;
@@ -585,8 +640,9 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
     const int64_t env = env0 + lane;
     const bool active = env < n;
     bool want_reset = false;
+    bool frozen_copy = false; // CP: a frozen lane's row copy, deferred until every lane has read its parked plane (below)
     int my_slot = 0;
-    AdvanceRegs adv;          // (in-place layout: the finished lanes' next-slot loads)
+    AdvanceRegs<CP> adv;      // (in-place layout: the finished lanes' next-slot loads)
     if (active) {
         // everything the step needs from the SoA arrays in ONE memory round trip, before the frozen test (the loads the
         // branch would otherwise delay are a second round trip on every step's critical path)
@@ -594,8 +650,22 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
         uint64_t stale = stales[env];
         VProg vp; vp.bind(vheads[env], vsets + env, n);
         int action = actions[env];
-        uint32_t fc = VP ? (uint32_t)fcache[env] : 0u;
+        uint32_t fc = (VP || CP) ? (uint32_t)fcache[env] : 0u;
         Lsm lsm = {lsm_arr ? (uint32_t)lsm_arr[env] : 0u, lsm_arr != nullptr};
+        // CP: the env's whole grid + object positions come with the SoA state -- nothing below depends on a second memory round trip
+        u32x4 pv[4] = {}, iv[2] = {};
+        uint8_t* crow = nullptr;
+        if constexpr (CP) {
+            crow = cplane + env * (int64_t)cpl_bytes(c);
+            const u32x4* cr = (const u32x4*)crow;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pv[k] = cr[k];
+            iv[0] = cr[4];
+            const u32x4 none = {~0u, ~0u, ~0u, ~0u};
+            iv[1] = none;
+            if (cpl_ids(c) > 16) iv[1] = cr[5];
+            asm volatile("" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(iv[0]), "+v"(iv[1]));
+        }
         // (the empty asm pins the loaded values here: the compiler would otherwise sink the loads into the branch)
         asm volatile("" : "+v"(hv), "+v"(stale), "+v"(vp.head), "+v"(vp.set00), "+v"(action), "+v"(fc));
         Hot h;
@@ -607,7 +677,18 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
             const EnvRef r = env_ref(c, rec, vp);
             uint8_t* vrow = VP ? vplane + env * (int64_t)v_bytes(c) : nullptr;
             int fe, ce;
-            if (VP) {
+            // CP: the lane's plane parked in LDS (8 rows x 8 bytes at a 72-byte lane pitch, inside the block's obs-row area: every lane's reads of
+            // it precede, in the one wave's program order, every lane's row writes at the end of the step), for the per-lane row / cell addressing
+            uint8_t* const pl = s_obs + lane * 72;
+            if constexpr (CP) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    *(uint2*)(pl + 16 * k) = make_uint2(pv[k][0], pv[k][1]);
+                    *(uint2*)(pl + 16 * k + 8) = make_uint2(pv[k][2], pv[k][3]);
+                }
+                fe = pl[8 * (h.ay + dir_dy(h.dir)) + h.ax + dir_dx(h.dir)];
+                ce = (int)(fc >> 8);
+            } else if (VP) {
                 fe = (int)(fc & 0xFFu); ce = (int)(fc >> 8);
             } else {
                 fe = r.E[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];
@@ -619,7 +700,10 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
             const int txm = h.ax + MARGIN + (dir == 0 ? 0 : dir == 2 ? -6 : -3);
             const int tym = h.ay + MARGIN + (dir == 1 ? 0 : dir == 3 ? -6 : -3);
             uint32_t wd[3 * VIEW];
-            if (VP) {
+            uint32_t wl[VIEW], wh[VIEW];
+            if constexpr (CP) {
+                window_rows_cpl(pl, c.H, h.ax, h.ay, dir, wl, wh);
+            } else if (VP) {
                 const uint8_t* line = vrow + ((tym >> 1) * v_nxo(c) + (txm >> 3)) * VLINE + (tym & 1) * 16 + (txm & 4);
                 window_fetch((const uint32_t*)line, 4, wd);
             } else {
@@ -632,12 +716,24 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
 #if BBAI_PREFETCH_ID
             idf = r.I[i_index(c, h.ax + dir_dx(dir), h.ay + dir_dy(dir))];
 #endif
+            const int fpos = (h.ay + dir_dy(dir)) << 3 | (h.ax + dir_dx(dir));      // CP: the front cell in C plane coordinates
+            if constexpr (CP) {
+                const uint32_t idw[8] = {iv[0][0], iv[0][1], iv[0][2], iv[0][3], iv[1][0], iv[1][1], iv[1][2], iv[1][3]};
+                idf = cid_lookup(idw, 8, fpos);                 // (what r.I would say about an object there; 0 = none)
+            }
             // pickup / drop / toggle, while the window is on its way
             int nfe = -1;
             if (action != A_RESET_ENV) {
                 int nid = -1;
                 nfe = apply_objects(c, r, h, stale, action, fe, ce, idf, &nid);
                 if (VP && nfe >= 0) v_patch(c, vrow, h.ax + dir_dx(dir), h.ay + dir_dy(dir), nfe);
+                if constexpr (CP) {          // the env's C plane row follows the record: the cell, and who stands (or no longer stands) on it
+                    if (nfe >= 0) crow[fpos] = (uint8_t)nfe;
+                    if (nid >= 0) {
+                        if (idf >= 2) crow[CPL_PLANE + idf - 2] = 0xFF;              // picked up / an opened box
+                        if (nid >= 2) crow[CPL_PLANE + nid - 2] = (uint8_t)fpos;     // dropped / a box's content
+                    }
+                }
                 if (idf >= 0 && nid >= 0) idf = nid;
             }
             int fe2;
@@ -646,7 +742,8 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
             uint32_t vis[VIEW];
             view_cells(wd, txm & 3, dir, (uint32_t)ce, nfe, s_rows + row_scratch(lane), cp, vis, fe2);
 #else
-            view_cells_perm(wd, txm & 3, dir, (uint32_t)ce, nfe, cp, fe2);       // (bbai_view.hpp: rotation, occlusion and masking in registers)
+            if constexpr (CP) view_rows_perm(wl, wh, dir, (uint32_t)ce, nfe, cp, fe2);
+            else view_cells_perm(wd, txm & 3, dir, (uint32_t)ce, nfe, cp, fe2);       // (bbai_view.hpp: rotation, occlusion and masking in registers)
 #endif
             // "env.reset() for THIS env, now" (A_RESET_ENV, bbai_step.hpp): the episode ends with done = 1, reward = 0
             const bool done = action == A_RESET_ENV ? true : finish_step(c, r, h, stale, action, fe2, reward, lsm, idf, enum_done != 0);
@@ -655,7 +752,7 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
             want_reset = done && auto_reset;
             hots[env] = h;
             stales[env] = stale;
-            if (VP) fcache[env] = (uint16_t)((uint32_t)fe2 | ((uint32_t)ce << 8));
+            if (VP || CP) fcache[env] = (uint16_t)((uint32_t)fe2 | ((uint32_t)ce << 8));
             rewards[env] = (float)reward;
             if (rewards64) rewards64[env] = reward;        // the reference's Python float, bit for bit (levelgen.py:59-61)
             dones[env] = done ? 1 : 0;
@@ -674,10 +771,25 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
                 dones[env] = 1;
                 want_reset = true;
             }
+            if constexpr (CP) {
+                frozen_copy = true;
+            } else {
+                const uint8_t* src = image + env * OBS_BYTES;
+                for (int b = 0; b < OBS_BYTES; ++b) s_rows[lane * OBS_BYTES + b] = src[b];
+            }
+        }
+        if constexpr (FUSE == 3) { if (want_reset) advance_load<CP>(c, env, my_slot, fuse.depth, fuse.next_recs, fuse.next_hots, fuse.next_obs, fuse.pending, adv); }
+    }
+    if constexpr (CP) {
+        // The stepping lanes parked their planes INSIDE the obs-row area (at a 72-byte pitch: over other lanes' rows).  Their own rows are written
+        // after every plane read by the wave's program order; a frozen lane's row copy sits in the other arm of a branch, which the compiler may
+        // emit FIRST -- the parked planes then went over rows already copied (caught by test_manyenvs_freeze).  So it waits here, behind a
+        // convergent fence that no arm of that branch can cross.
+        __builtin_amdgcn_wave_barrier();
+        if (frozen_copy) {
             const uint8_t* src = image + env * OBS_BYTES;
             for (int b = 0; b < OBS_BYTES; ++b) s_rows[lane * OBS_BYTES + b] = src[b];
         }
-        if constexpr (FUSE == 3) { if (want_reset) advance_load(c, env, my_slot, fuse.depth, fuse.next_recs, fuse.next_hots, fuse.next_obs, fuse.pending, adv); }
     }
     // finished envs.  Unfused: compacted into the reset list for k_consume (one returning atomic per wave).  Fused / in-place: counted
     // (one fire-and-forget add to this block's shard of the total) and moved on by this wave itself.
@@ -698,8 +810,8 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
                 // in-place layout: every finished lane moves its own env on (its stores to its own SoA entries stay in program order)
                 if (lane == leader) count_resets(fuse.totals, (unsigned int)__popcll(bal));
                 if (want_reset)
-                    advance_finish(c, n, env, lane, my_slot, fuse.depth, fuse.next_recs, adv, hots, stales, vheads, vsets, fuse.pending, fuse.first_slot,
-                                   fuse.win_meta, s_rows, dirs, lsm_arr);
+                    advance_finish<CP>(c, n, env, lane, my_slot, fuse.depth, fuse.next_recs, adv, hots, stales, vheads, vsets, fuse.pending, fuse.first_slot,
+                                       fuse.win_meta, s_rows, dirs, lsm_arr, cplane, fcache);
             } else {
                 // Everything this wave stored to the records, window planes and SoA entries of these envs must have landed
                 // before other lanes overwrite them (a terminal pickup patches the record the consume is about to replace).
@@ -804,7 +916,7 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
     typedef GroupCtx<G> Ctx;
     const Ctx ctx;
     __shared__ GenWork ws[NG];
-    __shared__ uint32_t s_mt[NG][MT_N];
+    __shared__ uint32_t s_mt[NG][MT_N + MT_CH];      // the env's MT19937 state + the generator's chunk of tempered outputs (bbai_gen.hpp MT_CH)
     GenWork& w = ws[threadIdx.x / G];
     const int lane = ctx.lane();
     // the refill list: prefix of the sub-list lengths (one word per lane, a wave scan, parked in LDS for the groups' searches)
@@ -843,6 +955,7 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
     bool have = false;
     int64_t env = 0;
     int cnt = 0, done_levels = 0, slot = 0, mti = 0, last_locked = -1, attempts = 0;
+    bool dirty = false;           // the env's state words were regenerated (a twist) since they were loaded: only then do they go back
     for (;;) {
         if (!have) {
             while (it < count) {
@@ -877,14 +990,15 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
                 const int prev = slot == 0 ? depth - 1 : slot - 1;          // holds the level generated just before
                 last_locked = next_hots[ring_at(prev, env, depth)].last_locked;   // LevelGen.locked_room survives episodes
                 last_locked = last_locked == NONE8 ? -1 : last_locked;
-                done_levels = 0; attempts = 0;
+                done_levels = 0; attempts = 0; dirty = false;
             }
         }
         if (__ballot(have) == 0ull) break;               // every group of the wave has run out of work
         if (!have) continue;
-        Gen<Ctx> g(ctx, c, w, s_mt[threadIdx.x / G], mti, last_locked);
+        Gen<Ctx> g(ctx, c, w, s_mt[threadIdx.x / G], s_mt[threadIdx.x / G] + MT_N, mti, last_locked);
         bool ok = g.template attempt<KIND>();
         mti = g.mti;
+        dirty |= g.twisted;
         last_locked = g.last_locked;
         // last-resort guard (Gen::MAX_ATTEMPTS): never seen; keeps an impossible level from hanging the device
         const bool gave_up = !ok && ++attempts >= Gen<Ctx>::MAX_ATTEMPTS;
@@ -962,6 +1076,23 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
                     o[0] = v ? e_type(e) : 0; o[1] = v ? e_color(e) : 0; o[2] = v ? e_state(e) : 0;
                 }
             }
+            // ... and, for the small single rooms, the level's C plane row (bbai_types.hpp): the grid at pitch 8 + where every object stands
+            if (cpl_ok(c)) {
+                uint8_t* row = ob + CPL_OFF;
+                for (int d = lane; d < CPL_PLANE / 4; d += G) {
+                    const int y = d >> 1, x0 = (d & 1) * 4;
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int x = x0 + b;
+                        const uint32_t e = (x < c.W && y < c.H) ? (uint32_t)w.E[(y + MARGIN) * c.ES + (x + MARGIN)] : (uint32_t)E_WALL;
+                        v |= e << (8 * b);
+                    }
+                    ((uint32_t*)row)[d] = v;
+                }
+                for (int k = lane; k < CPL_MAX_IDS; k += G)
+                    row[CPL_PLANE + k] = (k < g.nobj && w.px[k] != NONE8) ? (uint8_t)(w.py[k] << 3 | w.px[k]) : (uint8_t)0xFF;
+            }
         }
         if (lane == 0) {
             Hot h;
@@ -980,9 +1111,12 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
         slot = slot + 1 == depth ? 0 : slot + 1;
         attempts = 0;
         if (++done_levels == cnt) {                      // this env's levels are done: MT state back, buffer entry free
-            uint32_t* mt = mts + env * MT_N;
-            ctx.sync();
-            for (int k = lane; k < MT_N; k += G) mt[k] = s_mt[threadIdx.x / G][k];
+            // draws only advance the index: the 624 state words change at a twist alone (every 624 draws -- one single-room level in seven)
+            if (dirty) {
+                uint32_t* mt = mts + env * MT_N;
+                ctx.sync();
+                for (int k = lane; k < MT_N; k += G) mt[k] = s_mt[threadIdx.x / G][k];
+            }
             if (lane == 0) {
                 mtis[env] = mti;
                 pending[env] = 0;                        // buffer entry is free for a later window
@@ -1004,7 +1138,7 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
                                                  uint8_t* __restrict__ image, uint8_t* __restrict__ dirs,
                                                  uint32_t* __restrict__ other_counter, int prio,
                                                  uint8_t* __restrict__ vplane /* or NULL */, uint16_t* __restrict__ fcache,
-                                                 uint8_t* __restrict__ lsm_arr /* or NULL */, int inplace) {
+                                                 uint8_t* __restrict__ lsm_arr /* or NULL */, int inplace, uint8_t* __restrict__ cplane /* or NULL */) {
     if (prio) __builtin_amdgcn_s_setprio(3);
     const int64_t count = all ? n : (int64_t)counter[0];
     const int lane = threadIdx.x & 63;
@@ -1013,7 +1147,7 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
         const int64_t env = all ? it : (int64_t)reset_list[it];
         const int slot = all ? (int)hots[env].slot : (int)reset_slot[it];       // (k_step listed it next to the env: no round trip through the env's state)
         consume_env(c, n, env, slot, lane, recs, hots, stales, next_recs, next_hots, vheads, vsets, depth, pending, first_slot,
-                    win_meta, image + env * OBS_BYTES, dirs, vplane, fcache, lsm_arr, inplace != 0);
+                    win_meta, image + env * OBS_BYTES, dirs, vplane, fcache, lsm_arr, inplace != 0, cplane);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&totals[0], (unsigned long long)count);
@@ -1150,6 +1284,24 @@ __global__ __launch_bounds__(256) void k_sync_view(LevelCfg c, int64_t first, in
     }
 }
 
+// ... and the C plane rows + the carried object's appearance of the small single rooms (in-place layout): one wave per env, from the staged records
+__global__ __launch_bounds__(256) void k_sync_cpl(LevelCfg c, int64_t first, int64_t count, const uint8_t* __restrict__ recs,
+                                                  const Hot* __restrict__ hots, uint8_t* __restrict__ cplane, uint16_t* __restrict__ fcache) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t it = wave; it < count; it += nwaves) {
+        const int64_t env = first + it;
+        const uint8_t* rec = recs + env * (int64_t)c.rec_bytes;
+        cpl_build_wave(c, rec, cplane + env * (int64_t)cpl_bytes(c), lane);
+        if (lane == 0) {
+            const Hot h = hots[env];
+            const uint32_t fe = rec[e_index(c, h.ax + dir_dx(h.dir), h.ay + dir_dy(h.dir))];
+            const uint32_t ce = h.carry != NONE8 ? rec[c.off_app + h.carry] : (uint32_t)E_EMPTY;
+            fcache[env] = (uint16_t)(fe | (ce << 8));
+        }
+    }
+}
+
 // The reference's expert for every env (babyai/bot.py Bot.replan): lane = env, grid-stride over the batch with one BFS
 // scratch block per resident thread.  A new episode (step_count == 0) starts a fresh Bot.
 template <int WAVES_PER_SIMD>
@@ -1188,6 +1340,15 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_bot(LevelCfg c, int64_t 
         if (a == BOT_DEAD && !was_dead) atomicAdd(&stats[st.dead == DEAD_CAPACITY ? 1 : 0], 1ull);
     }
 }
+
+// BBAI_BOT_GROUP_BUILD=1 (experiment builds only; the shipped library has no k_botg): the expert as one 16-lane group per env.  Built, verified on
+// the host emulation of lane groups (tests/test_hostsim_bot.py, which stays) and on the device, measured 1.9-2.4 x SLOWER than lane = env
+// (profiles/r05/NOTES.md section 11); a 4-waves-per-SIMD build of it produced different decisions, never explained -- 250 KB of dead-by-default
+// code with an open question attached does not belong in the product.
+#ifndef BBAI_BOT_GROUP_BUILD
+#define BBAI_BOT_GROUP_BUILD 0
+#endif
+#if BBAI_BOT_GROUP_BUILD
 
 // The expert as ONE LANE GROUP PER ENV (G lanes, 64 / G envs per wave; bbai_bot.hpp "Execution model"): the subgoal machine runs
 // group-uniform, the view, the mask rows, the neighbours of a popped position and the acceptance / key scans are split over the lanes.
@@ -1244,6 +1405,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_botg(LevelCfg c, int64_t
         ctx.sync();
     }
 }
+#endif
 
 // env.seed(s) for every env: lane = env.  Each lane writes its own 624-word state (2496-byte pitch): a wave's 64 open
 // lines stay in L2 until they are full, so HBM sees each state line once.
@@ -1601,6 +1763,11 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
             alloc((void**)&e->vplane, (size_t)n_envs * v_bytes(c));
             alloc((void**)&e->fcache, (size_t)n_envs * 2);
         }
+        const char* cv = getenv("BBAI_CPLANE");              // 0: the in-place step path of rounds 4-5 (window out of the record; A/B runs)
+        if (e->inplace && cpl_ok(c) && !(cv && atoi(cv) == 0)) {
+            alloc((void**)&e->cplane, (size_t)n_envs * cpl_bytes(c));
+            alloc((void**)&e->fcache, (size_t)n_envs * 2);
+        }
     }
     {
         // Refill period B (ticks per look-ahead refill, BBAI_LOOKAHEAD); ring depth D = 2B.  One k_pregen launch per
@@ -1699,6 +1866,10 @@ static int create_finish(bbai_env* e) {
         HIP_TRY(hipMemset(e->vplane, 0, (size_t)n_envs * v_bytes(c)));
         HIP_TRY(hipMemset(e->fcache, 0, (size_t)n_envs * 2));
     }
+    if (e->cplane) {
+        HIP_TRY(hipMemset(e->cplane, 0, (size_t)n_envs * cpl_bytes(c)));
+        HIP_TRY(hipMemset(e->fcache, 0, (size_t)n_envs * 2));
+    }
     {
         // The look-ahead stream.  (Confining it to a subset of the CUs with a CU mask was measured in round 3 --
         // profiles/r03/pregen_cus_ab.jsonl: 32 / 64 / 96 / 128 CUs change no step time by more than 1 %, and a masked stream is a
@@ -1769,7 +1940,7 @@ void bbai_destroy(bbai_env* e) {
     void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
     void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_meta, e->totals, e->flow, e->gen_list, e->gen_count, e->reset_list, e->counters,
-                    e->atlas, e->lut, e->vplane, e->fcache, e->lsm, e->render_tickets, e->reset_slot, e->next_obs};
+                    e->atlas, e->lut, e->vplane, e->fcache, e->lsm, e->render_tickets, e->reset_slot, e->next_obs, e->cplane};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (e->host_flags) (void)hipHostFree((void*)e->host_flags);
     delete e;
@@ -1966,7 +2137,7 @@ static int consume_and_refill(bbai_env* e, hipStream_t s, uint8_t* image, uint8_
                        e->hot, e->stale, e->next_rec, e->next_hot, e->vhead, e->vset, e->reset_list, e->reset_slot, e->counters + 16 * e->step_parity, all,
                        e->totals, e->depth, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n,
                        e->win_meta + (size_t)wb * META_U32, image, dirs,
-                       e->counters + 16 * (e->step_parity ^ 1), e->step_prio, e->vplane, e->fcache, e->lsm, e->inplace);
+                       e->counters + 16 * (e->step_parity ^ 1), e->step_prio, e->vplane, e->fcache, e->lsm, e->inplace, e->cplane);
     }
     return window_end(e, s, all ? 1 : 0, nullptr);
 }
@@ -2065,8 +2236,10 @@ static int step_kernel(bbai_env* e, const StepPlan& p, const uint8_t* actions, u
                        uint8_t* dones, int auto_reset, hipStream_t ks, int enum_done, int64_t block0, int64_t nblocks) {
     ProfScope prof_(e, 0, ks);
 #define STEP_LAUNCH(VV, FF) hipLaunchKernelGGL((k_step<VV, FF>), dim3((unsigned)nblocks), dim3(STEP_BLOCK), 0, ks, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, \
-                                           image, dirs, rewards, rewards64, dones, auto_reset, e->reset_list, e->reset_slot, p.counter, e->step_prio, e->vplane, e->fcache, e->lsm, enum_done, p.fa, block0)
-    if (e->inplace) STEP_LAUNCH(false, 3);
+                                           image, dirs, rewards, rewards64, dones, auto_reset, e->reset_list, e->reset_slot, p.counter, e->step_prio, e->vplane, e->fcache, e->lsm, enum_done, p.fa, block0, e->cplane)
+    if (e->inplace && e->cplane) hipLaunchKernelGGL((k_step<false, 3, true>), dim3((unsigned)nblocks), dim3(STEP_BLOCK), 0, ks, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions,
+                                                    image, dirs, rewards, rewards64, dones, auto_reset, e->reset_list, e->reset_slot, p.counter, e->step_prio, e->vplane, e->fcache, e->lsm, enum_done, p.fa, block0, e->cplane);
+    else if (e->inplace) STEP_LAUNCH(false, 3);
     else if (p.fused) { if (e->vplane) STEP_LAUNCH(true, 1); else STEP_LAUNCH(false, 1); }
     else { if (e->vplane) STEP_LAUNCH(true, 0); else STEP_LAUNCH(false, 0); }
 #undef STEP_LAUNCH
@@ -2308,6 +2481,12 @@ int bbai_export_state(bbai_env* e, int64_t first, int64_t count, uint8_t* rec, u
 
 // window plane + front-cell cache follow the records (they are derived state: not part of exports or checkpoints)
 static int sync_view(bbai_env* e, int64_t first, int64_t count) {
+    if (e->cplane) {         // (in-place layout: e->rec is the staging area every import / checkpoint load has just filled with the live records)
+        hipLaunchKernelGGL(k_sync_cpl, dim3((unsigned)std::min<int64_t>((count + 3) / 4, 16384)), dim3(256), 0, 0, e->cfg, first, count, e->rec, e->hot,
+                           e->cplane, e->fcache);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
     if (!e->vplane) return BBAI_OK;
     hipLaunchKernelGGL(k_sync_view, dim3((unsigned)std::min<int64_t>((count + 3) / 4, 16384)), dim3(256), 0, 0, e->cfg, first, count, e->rec, e->hot,
                        e->vplane, e->fcache);
@@ -2341,6 +2520,8 @@ int bbai_import_state(bbai_env* e, int64_t first, int64_t count, const uint8_t* 
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
     }
+    // (a hot / stale-only import: the C plane rows are rebuilt from the staging records, which must then hold the LIVE ones)
+    if (!rec && e->cplane && count > 0) { int rc = live_copy(e, first, count, 0); if (rc != BBAI_OK) return rc; }
     if (count > 0) { int rc = sync_view(e, first, count); if (rc != BBAI_OK) return rc; }
     e->live = true;
     return BBAI_OK;
@@ -2353,7 +2534,7 @@ struct CkptHeader {
     uint64_t magic; int32_t version, period; int64_t n; LevelCfg cfg; int32_t depth, step_parity, next_counter_clean, seeded, live;
     int32_t has_lsm, pad0, pad1; int32_t bot_stack; int64_t tick; int64_t bot_threads;
 };
-constexpr int CKPT_VERSION = 3;        // 3: listless windows (NWIN buffers, meta lines, sharded totals, flow words); 2: env-major look-ahead ring
+constexpr int CKPT_VERSION = 4;        // 4: 256-byte next_obs slots (the C plane rows of the small rooms); 3: listless windows (NWIN buffers, meta lines, sharded totals, flow words); 2: env-major look-ahead ring
 struct Seg { void* p; size_t bytes; };
 // the blob's segments for a handle shaped (period, depth) with / without expert state and done-action bits
 static int ckpt_segments(const bbai_env* e, int depth, bool with_bot, int bot_stack, bool with_lsm, Seg* out) {
@@ -2519,6 +2700,9 @@ static int bot_launch(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions
     // 17.0 ms) and -10 % on single rooms, 128 registers (4 waves/SIMD) loses everywhere, real calls instead of inlining too.
     const bool maze = e->cfg.num_rows * e->cfg.num_cols > 1;
     unsigned long long* stats = (unsigned long long*)e->bot_stats;
+#if !BBAI_BOT_GROUP_BUILD
+    if (e->bot_group) { snprintf(g_err, sizeof(g_err), "this library was built without the lane-group expert (k_botg: an experiment build, -DBBAI_BOT_GROUP_BUILD=1)"); return BBAI_ERR_ARG; }
+#else
     if (e->bot_group) {                                     // one lane group per env (k_botg)
         // Measured (profiles/r05/NOTES.md section 11): same decisions, 1.9-2.4 x SLOWER than lane = env -- a group executes 3.4 x the
         // instructions per env (the subgoal machine runs redundantly on the group's lanes, 4 envs share a wave's issue slots instead
@@ -2532,14 +2716,15 @@ static int bot_launch(bbai_env* e, const uint8_t* prev_actions, uint8_t* actions
         HIP_TRY(hipGetLastError());
         return BBAI_OK;
     }
+#endif
     const dim3 grid((unsigned)(e->bot_threads / 64)), block(64);
     const size_t lds = (size_t)R_FAST * e->cfg.H * 64 * 4 + (size_t)BOT_RING * 64 * 2;     // BossLevel: 11.3 + 8 KB -> 8 waves per CU
-    if (maze)
-        hipLaunchKernelGGL(k_bot<2>, grid, block, lds, s, e->cfg, e->n, e->rec, e->inplace ? e->next_rec : nullptr, e->depth, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
-                           e->bot_rows, e->bot_eager, prev_actions, actions, stats, dead_action, gave_up);
-    else
-        hipLaunchKernelGGL(k_bot<1>, grid, block, lds, s, e->cfg, e->n, e->rec, e->inplace ? e->next_rec : nullptr, e->depth, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
-                           e->bot_rows, e->bot_eager, prev_actions, actions, stats, dead_action, gave_up);
+    // ONE instantiation for every geometry: round 5's packed lists took the kernel from ~400 wanted registers to a shape that fits 256 with 24 spilled, and
+    // the single rooms then prefer two waves per SIMD as well (profiles/r05/bot_round5_experiments.jsonl: PickupLoc 262 144 1.09 -> 0.95 ms per decision + step,
+    // GoToLocal 65 536 0.357 -> 0.353); round 1's k_bot<1> for them is gone.
+    (void)maze;
+    hipLaunchKernelGGL(k_bot<2>, grid, block, lds, s, e->cfg, e->n, e->rec, e->inplace ? e->next_rec : nullptr, e->depth, e->hot, e->stale, e->bot_state, e->bot_stack, e->bot_work,
+                       e->bot_rows, e->bot_eager, prev_actions, actions, stats, dead_action, gave_up);
     HIP_TRY(hipGetLastError());
     return BBAI_OK;
 }
@@ -2752,6 +2937,7 @@ int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     else if (!strcmp(name, "bot_group")) *out = e->bot_group;
     else if (!strcmp(name, "step_render_split")) *out = e->step_render_split;
     else if (!strcmp(name, "inplace")) *out = e->inplace;
+    else if (!strcmp(name, "cplane")) *out = e->cplane ? 1 : 0;
     else if (!strcmp(name, "done_action_enum")) *out = e->done_action_enum;
     else if (!strcmp(name, "lookahead_period")) *out = e->period;
     else if (!strcmp(name, "gate_timeouts")) {      // (synchronises) window gates that gave up waiting for a refill: must be 0 (k_gate)

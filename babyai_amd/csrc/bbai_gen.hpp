@@ -99,6 +99,19 @@ BB_COLD void mt_twist(Ctx ctx, uint32_t* mt) {
     }
 }
 
+// MT19937 output tempering.  The generator's inner loops are chains of draw -> mask -> compare -> redraw, and a draw used to be ten
+// vector instructions of tempering executed by every lane of the group for one value.  Now the group's lanes temper MT_CH consecutive
+// state words at once into a small buffer (`tw`, next to the state in LDS) whenever the output index crosses a multiple of MT_CH
+// (624 = 39 x 16, so the twist boundary is one of them): a draw is a read of that buffer.
+constexpr int MT_CH = 16;
+BB_HD uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
 template <class Ctx>
 struct Gen {
     Ctx ctx;
@@ -117,9 +130,16 @@ struct Gen {
     const LevelCfg& cfg;
     GenWork& w;
     uint32_t* const mt;      // the env's MT19937 state (device: LDS; host: the caller's array, advanced in place)
+    uint32_t* const tw;      // MT_CH tempered outputs: words [mti & ~(MT_CH - 1), + MT_CH) of the state (device: LDS, behind the state)
     int mti;                 // MT19937 output index (wave-uniform)
-    uint32_t nxt;            // mt[mti], fetched one draw AHEAD: the generator is a chain of draw -> test -> branch -> draw, and every
-                             // link used to start with an LDS round trip
+    uint32_t nxt;            // the output for index mti, fetched one draw AHEAD: the generator is a chain of draw -> test -> branch -> draw,
+                             // and every link used to start with an LDS round trip
+    bool twisted;            // the state words were regenerated at least once (k_pregen: only then does the state go back to memory)
+    uint64_t occ;            // grids of <= 64 cells (every single room up to 8 x 8): bit y * W + x = the cell holds a wall or an object --
+                             // the placement loops test a register bit instead of waiting for an id-plane byte from LDS
+    uint64_t wallb;          // ... and the cells build_rooms made walls (occ & ~wallb = the objects)
+    uint32_t seen;           // bit (type - T_KEY) * 6 + colour: a key / ball / box of that look exists (add_distractors(all_unique))
+    bool small;              // cfg.W * cfg.H <= 64
     int nobj;
     int ax, ay, adir;
     bool agent_set;
@@ -134,11 +154,15 @@ struct Gen {
     uint32_t locked_mask;    // bit r: room r is behind a locked door (Room.locked)
     uint32_t inv_cols, inv_s1, inv_es;   // 2^16/d + 1: exact small-range division without the divider
 
-    BB_HD Gen(Ctx c, const LevelCfg& cf, GenWork& wk, uint32_t* mt_, int mti_, int last_locked_)
-        : ctx(c), cfg(cf), w(wk), mt(mt_), mti(mti_), nxt(mt_[mti_ < MT_N ? mti_ : 0]), nobj(0), ax(0), ay(0), adir(0), agent_set(false),
+    BB_HD Gen(Ctx c, const LevelCfg& cf, GenWork& wk, uint32_t* mt_, uint32_t* tw_, int mti_, int last_locked_)
+        : ctx(c), cfg(cf), w(wk), mt(mt_), tw(tw_), mti(mti_), nxt(0), twisted(false), occ(0), wallb(0), seen(0), small(cf.W * cf.H <= 64),
+          nobj(0), ax(0), ay(0), adir(0), agent_set(false),
           locked_room(-1), last_locked(last_locked_), S(cf.room_size), rows(cf.num_rows), cols(cf.num_cols),
           gave_up(false), doors(0), locked_mask(0), inv_cols(65536u / (uint32_t)cf.num_cols + 1u),
-          inv_s1(65536u / (uint32_t)(cf.room_size - 1) + 1u), inv_es(65536u / (uint32_t)cf.ES + 1u) {}
+          inv_s1(65536u / (uint32_t)(cf.room_size - 1) + 1u), inv_es(65536u / (uint32_t)cf.ES + 1u) {
+        // in the middle of a chunk (the previous level stopped there): temper it again; on a boundary the first draw does
+        if (mti & (MT_CH - 1)) { fill_chunk(mti & ~(MT_CH - 1)); nxt = tw[mti & (MT_CH - 1)]; }
+    }
 
     BB_HD int div_cols(int v) const { return (int)(((uint32_t)v * inv_cols) >> 16); }     // v < 64
     BB_HD int div_s1(int v) const { return (int)(((uint32_t)v * inv_s1) >> 16); }         // v < 64
@@ -146,16 +170,29 @@ struct Gen {
 
     // ---------------- MT19937 (numpy legacy RandomState bit stream) ----------------
     BB_HD void twist() { mt_twist(ctx, mt); }
+    // tw[0 .. MT_CH) = tempered mt[base .. base + MT_CH), base a multiple of MT_CH below MT_N: one word per lane
+    BB_HD void fill_chunk(int base) {
+        ctx.sync();
+        if constexpr (Ctx::kLanes == 1) {
+            for (int k = 0; k < MT_CH; ++k) tw[k] = mt_temper(mt[base + k]);
+        } else {
+            static_assert(Ctx::kLanes == 1 || Ctx::kLanes >= MT_CH, "one tempered word per lane");
+            const int l = ctx.lane();
+            if (l < MT_CH) tw[l] = mt_temper(mt[base + l]);
+        }
+        ctx.sync();
+    }
     BB_HD uint32_t next_u32() {
-        if (mti >= MT_N) { twist(); mti = 0; nxt = mt[0]; count(PH_TWISTS); }
+        if ((mti & (MT_CH - 1)) == 0) {          // every MT_CH draws.  (Inline on purpose: a non-inlined MEMBER would pin the whole Gen object to
+                                                 // scratch memory -- 464 bytes per lane when it was tried; only the twist itself is a call)
+            if (mti >= MT_N) { twist(); mti = 0; twisted = true; count(PH_TWISTS); }
+            fill_chunk(mti);
+            nxt = tw[0];
+        }
         count(PH_DRAWS);
-        uint32_t y = nxt;
+        const uint32_t y = nxt;
         ++mti;
-        nxt = mt[mti < MT_N ? mti : 0];         // (for the next draw; after word 623 the twist reloads it)
-        y ^= (y >> 11);
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= (y >> 18);
+        nxt = tw[mti & (MT_CH - 1)];            // (for the next draw; on a chunk boundary refill() replaces it)
         return y;
     }
     // RandomState.randint(lo, hi): masked rejection on 32-bit outputs; range 1 => no draw.
@@ -177,7 +214,12 @@ struct Gen {
     // ---------------- grid helpers ----------------
     BB_HD int eidx(int x, int y) const { return (y + MARGIN) * cfg.ES + (x + MARGIN); }
     BB_HD int iidx(int x, int y) const { return y * cfg.W + x; }
-    BB_HD void set_cell(int x, int y, int e, int id) { w.E[eidx(x, y)] = (uint8_t)e; w.I[iidx(x, y)] = (uint8_t)id; }
+    BB_HD void set_cell(int x, int y, int e, int id) {
+        w.E[eidx(x, y)] = (uint8_t)e; w.I[iidx(x, y)] = (uint8_t)id;
+        if (small) { const uint64_t b = 1ull << (y * cfg.W + x); occ = id ? (occ | b) : (occ & ~b); }
+    }
+    BB_HD bool occupied(int x, int y) const { return small ? (occ >> (y * cfg.W + x) & 1ull) != 0 : w.I[iidx(x, y)] != 0; }
+    BB_HD void note_obj(int e) { if (e_type(e) >= T_KEY) seen |= 1u << ((e_type(e) - T_KEY) * 6 + e_color(e)); }
     BB_HD int room_of(int x, int y) const { return div_s1(y) * cols + div_s1(x); }
     BB_HD void room_ij(int r, int& i, int& j) const { j = div_cols(r); i = r - j * cols; }
     BB_HD bool has_neighbor(int r, int k) const {
@@ -206,6 +248,15 @@ struct Gen {
         }
         doors = 0;
         locked_mask = 0;
+        seen = 0;
+        occ = 0;
+        if (small) {                              // the walls as a bitboard: whole rows on the room boundaries, the boundary columns elsewhere
+            uint64_t in_row = 0;
+            for (int x = 0; x < cfg.W; x += S - 1) in_row |= 1ull << x;
+            const uint64_t full_row = (1ull << cfg.W) - 1ull;
+            for (int y = 0; y < cfg.H; ++y) occ |= ((y - div_s1(y) * (S - 1)) == 0 ? full_row : in_row) << (y * cfg.W);
+        }
+        wallb = occ;
         ctx.sync();
         for (int j = 0; j < rows; ++j)
             for (int i = 0; i < cols; ++i) {
@@ -243,7 +294,7 @@ struct Gen {
             ++tries;
             int x = rand_int(tx, xh);
             int y = rand_int(ty, yh);
-            if (w.I[iidx(x, y)] != 0) continue;
+            if (occupied(x, y)) continue;
             if (agent_set && x == ax && y == ay) continue;
             if (reject_next) {
                 int d = (x > ax ? x - ax : ax - x) + (y > ay ? y - ay : ay - y);
@@ -262,6 +313,7 @@ struct Gen {
         int e = e_make(type, color, 0);
         w.app[id] = e; w.px[id] = x; w.py[id] = y; w.cont[id] = NONE8;
         set_cell(x, y, e, id + 2);
+        note_obj(e);
         return id;
     }
     // RoomGrid.add_door with explicit index / colour / locked flag.
@@ -362,12 +414,7 @@ struct Gen {
         while (count < num) {
             int color = rand_color();
             int type = T_KEY + rand_int(0, 3);        // ['key','ball','box']
-            if (all_unique) {
-                bool dup = false;
-                for (int o = 0; o < nobj; ++o)
-                    if (e_type(w.app[o]) != T_DOOR && e_type(w.app[o]) == type && e_color(w.app[o]) == color) dup = true;
-                if (dup) continue;
-            }
+            if (all_unique && (seen >> ((type - T_KEY) * 6 + color) & 1u)) continue;     // (type, colour) of an existing key / ball / box
             int r = room;
             if (r < 0) {
                 int ri = rand_int(0, cols);
@@ -383,7 +430,30 @@ struct Gen {
     // check_objs_reachable (levelgen.py:201-253) as a row-bitmask flood fill: spread through
     // passable cells (empty or door); an object is reached if it lies in, or 4-adjacent to,
     // the flooded region.
+    // Grids of <= 64 cells: the same flood fill on ONE 64-bit board in registers (no LDS rows, no shuffles, no ballots): passable =
+    // free cells + doors, the flood spreads by four masked shifts, an object is reached when its cell lies in the flood's 4-neighbourhood.
+    BB_HD bool objs_reachable_small() {
+        const int W = cfg.W, H = cfg.H;
+        uint64_t col0 = 0;
+        for (int y = 0; y < H; ++y) col0 |= 1ull << (y * W);
+        const uint64_t board = W * H == 64 ? ~0ull : (1ull << (W * H)) - 1ull;
+        const uint64_t not0 = ~col0, notL = ~(col0 << (W - 1));
+        uint64_t objs = occ & ~wallb;                    // (an object hidden inside a box is not on the grid: not in occ)
+        uint64_t pass = ~occ & board;
+        if (doors)                                       // doors stand where walls were: passable, and objects that must be reached (single rooms have none)
+            for (int o = 0; o < nobj; ++o)
+                if (e_type(w.app[o]) == T_DOOR) { const uint64_t b = 1ull << (w.py[o] * W + w.px[o]); pass |= b; objs |= b; }
+        uint64_t f = 1ull << (ay * W + ax);
+        for (;;) {
+            const uint64_t g = (f | ((f << 1) & not0) | ((f >> 1) & notL) | (f << W) | (f >> W)) & pass;
+            if ((g | f) == f) break;
+            f |= g;
+        }
+        const uint64_t near = f | ((f << 1) & not0) | ((f >> 1) & notL) | (f << W) | (f >> W);
+        return (objs & ~near) == 0;
+    }
     BB_HD bool objs_reachable() {
+        if (small) return objs_reachable_small();
         const int W = cfg.W, H = cfg.H;
         uint32_t* pass = w.rowbuf[0];
         uint32_t* fl = w.rowbuf[1];
@@ -723,6 +793,7 @@ struct Gen {
         int id = nobj++;
         w.app[id] = e_make(type, color, 0); w.px[id] = x; w.py[id] = y; w.cont[id] = NONE8;
         set_cell(x, y, w.app[id], id + 2);
+        note_obj(e_make(type, color, 0));
         return id;
     }
     BB_HD void one_leaf(int kind, bool strict = false) {
@@ -822,6 +893,7 @@ struct Gen {
             if (box < 0 || nobj >= cfg.maxo) return false;
             int key = nobj++;                            // lives inside the box until it is toggled
             w.app[key] = e_make(T_KEY, e_color(w.app[door]), 0); w.px[key] = NONE8; w.py[key] = NONE8; w.cont[key] = NONE8;
+            note_obj(e_make(T_KEY, e_color(w.app[door]), 0));
             w.cont[box] = (uint8_t)key;
             if (!place_agent(R11)) return false;
             one_leaf(L_OPEN); set_desc_tcl(0, 0, T_DOOR, 7, LOC_NONE);
@@ -849,6 +921,7 @@ struct Gen {
             int bx = w.px[door] - 1, by = w.py[door];
             w.app[ball] = e_make(T_BALL, color, 0); w.px[ball] = bx; w.py[ball] = by; w.cont[ball] = NONE8;
             set_cell(bx, by, w.app[ball], ball + 2);
+            note_obj(e_make(T_BALL, color, 0));
             if (add_object(0, T_KEY, e_color(w.app[door])) < 0) return false;
             if (!place_agent(0)) return false;
             one_leaf(L_PICKUP); set_desc_tcl(0, 0, T_BOX, 7, LOC_NONE);

@@ -210,6 +210,26 @@ BB_HD int v_nxo(const LevelCfg& c) { return ((c.ES - VIEW) >> 3) + 1; }
 BB_HD int v_nyo(const LevelCfg& c) { return ((c.EH - VIEW) >> 1) + 1; }
 BB_HD int v_bytes(const LevelCfg& c) { return v_nxo(c) * v_nyo(c) * VLINE; }
 
+// ---- compact plane ("C plane"): the whole grid of a small single room, per env, next to the SoA state ----------------------------
+// A single room of at most 8 x 8 cells IS 64 appearance bytes (everything outside is wall), and none of them depends on the agent's
+// pose.  k_step's in-place path used to fetch the front cell (record), then -- the pose known -- the 7 x 7 window out of the record's
+// margin plane (7 rows at pitch ES = 20: 2-3 lines for 49 bytes; profiles/r05: 2.3-2.7 x the algorithmic bytes), then the id-plane
+// entry of the front cell: three DEPENDENT round trips on a kernel that is nothing but a chain of them.  The C plane row of an env --
+//   bytes 0 .. 63           E[y][x] at pitch 8, y < 8 (cells outside W x H hold E_WALL)
+//   bytes 64 .. 64 + ids    cid[k] = (y << 3 | x) of object k while it stands on the grid, 0xFF otherwise (carried, consumed box, hidden)
+// -- is contiguous over the envs ([n][cpl_bytes]: a wave reads 64 rows as one dense span, every fetched byte used) and is loaded WITH the
+// SoA state in the step's first round trip; the front cell, the window (wall fill + byte alignment in registers, rows through LDS) and
+// the front cell's object id (a byte search over cid) then cost no memory access at all.  Derived state like the window plane of the
+// mazes: the generator writes a row next to every look-ahead level (next_obs slot, CPL_OFF), a finished env copies its next one in,
+// k_step's rare grid writes patch it, imports and checkpoint loads rebuild it from the records (k_sync_cpl).
+constexpr int CPL_PLANE = 64;
+constexpr int CPL_MAX_IDS = 32;
+BB_HD bool cpl_ok(const LevelCfg& c) { return c.num_rows * c.num_cols == 1 && c.W <= 8 && c.H <= 8 && c.maxo <= CPL_MAX_IDS; }
+BB_HD int cpl_ids(const LevelCfg& c) { return c.maxo <= 16 ? 16 : 32; }
+BB_HD int cpl_bytes(const LevelCfg& c) { return CPL_PLANE + cpl_ids(c); }          // 80 or 96: multiples of 16
+constexpr int OBS_SLOT = 256;           // bytes per look-ahead level in next_obs (in-place layout): the first observation (147 of 160) ...
+constexpr int CPL_OFF = 160;            // ... and its C plane row (<= 96 bytes)
+
 BB_HD int e_index(const LevelCfg& c, int x, int y) { return (y + MARGIN) * c.ES + (x + MARGIN); }
 BB_HD int i_index(const LevelCfg& c, int x, int y) { return y * c.W + x; }
 

@@ -96,13 +96,19 @@ BB_HD uint32_t spread_mask(uint32_t v) {
 // object action of this very step changed after the window was fetched.
 // Out: cp[13] = the 49 cells in the encoding's order (cell (vi, vj) = byte 7 vi + vj), ALREADY MASKED by visibility (an unseen cell is 0,
 // whose three channels encode as 0, 0, 0); fe2 = the (unmasked) appearance of view cell (3, 5) for the verifier and the next step.
+// view_rows_perm: the same from the window's rows themselves -- wl[r] = columns 0..3 of world row r of the window, wh[r] = columns 4..6 (+ a pad byte).
+BB_HD void view_rows_perm(const uint32_t* wl, const uint32_t* wh, int dir, uint32_t ce, int nfe, uint32_t* cp, int& fe2);
 BB_HD void view_cells_perm(const uint32_t* wd, int off, int dir, uint32_t ce, int nfe, uint32_t* cp, int& fe2) {
-    uint32_t wl[VIEW], wh[VIEW], tl[VIEW], th[VIEW];
+    uint32_t wl[VIEW], wh[VIEW];
 #pragma unroll
     for (int r = 0; r < VIEW; ++r) {
         wl[r] = bb_alignbyte(wd[3 * r + 1], wd[3 * r], (uint32_t)off);
         wh[r] = bb_alignbyte(wd[3 * r + 2], wd[3 * r + 1], (uint32_t)off);
     }
+    view_rows_perm(wl, wh, dir, ce, nfe, cp, fe2);
+}
+BB_HD void view_rows_perm(const uint32_t* wl, const uint32_t* wh, int dir, uint32_t ce, int nfe, uint32_t* cp, int& fe2) {
+    uint32_t tl[VIEW], th[VIEW];
     transpose7(wl, wh, tl, th);
     // view (vi, vj) -> window (row, column): dir 3 (vj, vi), dir 0 (vi, 6 - vj), dir 1 (6 - vj, 6 - vi), dir 2 (6 - vi, vj).  So the view's
     // y-row Y[vj] (bytes over vi) is   dir 3: W[vj]   dir 1: W[6 - vj] reversed   dir 0: T[6 - vj]   dir 2: T[vj] reversed.
@@ -150,6 +156,70 @@ BB_HD void view_cells_perm(const uint32_t* wd, int off, int dir, uint32_t ce, in
         }
     }
     cp[12] = xh[6] >> 16 & 0xFFu;                                // cell 48 = row 6, byte 6
+}
+
+// The window's rows out of an env's C plane (bbai_types.hpp): `pl` = 8 rows of 8 appearance bytes (row y at pl + 8 y, 8-byte aligned; cells
+// beyond W hold E_WALL), H = rows that exist.  World row ty + r of the window is a plane row or all wall; its columns tx .. tx + 6 are
+// bytes tx + 8 .. tx + 14 of the 24-byte virtual row [8 x wall | the plane row | 8 x wall]: three of its six dwords picked by tx, aligned
+// by tx & 3.  (k_step: `pl` is the lane's copy of the row in LDS, loaded with the SoA state -- no memory access depends on the pose.)
+BB_HD void window_rows_cpl(const uint8_t* pl, int H, int ax, int ay, int dir, uint32_t* wl, uint32_t* wh) {
+    const int tx = ax + (dir == 0 ? 0 : dir == 2 ? -6 : -3);
+    const int ty = ay + (dir == 1 ? 0 : dir == 3 ? -6 : -3);
+    const int s = tx + 8;                        // 2 .. 15 (the agent stands inside the walls: 1 <= ax <= 6)
+    const int q = s >> 2;
+    const uint32_t o = (uint32_t)(s & 3);
+    constexpr uint32_t WW = (uint32_t)E_WALL * 0x01010101u;
+#pragma unroll
+    for (int r = 0; r < VIEW; ++r) {
+        const int y = ty + r;
+        const bool inr = (unsigned)y < (unsigned)H;
+        const uint32_t* row = (const uint32_t*)(pl + 8 * (inr ? y : 0));
+        const uint32_t l0 = row[0], h0 = row[1];
+        const uint32_t lo = inr ? l0 : WW, hi = inr ? h0 : WW;
+        const uint32_t a = q == 2 ? lo : q == 3 ? hi : WW;
+        const uint32_t b = q == 1 ? lo : q == 2 ? hi : WW;
+        const uint32_t c = q == 0 ? lo : q == 1 ? hi : WW;
+        wl[r] = bb_alignbyte(b, a, o);
+        wh[r] = bb_alignbyte(c, b, o);
+    }
+}
+// cid[k] == pos for the smallest such k, as id-plane entry (k + 2); 0 when no object stands there.  `ids` = the C plane row's id bytes as
+// dwords (4 or 8 of them), pos = (y << 3 | x).  SWAR byte equality: a byte of x ^ (pos * 0x01010101) is zero iff it matches.
+BB_HD int cid_lookup(const uint32_t* ids, int ndw, int pos) {
+    const uint32_t pp = (uint32_t)pos * 0x01010101u;
+    int found = 0;
+#pragma unroll
+    for (int d = 7; d >= 0; --d) {
+        if (d >= ndw) continue;
+        const uint32_t x = ids[d] ^ pp;
+        const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;       // bit 7 of byte b set if byte b of x is zero (no false positives below the first hit)
+        if (z) found = 4 * d + (__builtin_ctz(z) >> 3) + 2;
+    }
+    return found;
+}
+BB_HD void encode_cells(const uint32_t* cp, RowPacker o);
+// observe_env through the C plane path (host build / tests): plane -> rows -> view -> encoding.  `pl` as above; ce = the carried object's appearance.
+BB_HD int observe_cpl_perm(const uint8_t* pl, int H, const Hot& h, uint32_t ce, int nfe, uint8_t* rows) {
+    uint32_t wl[VIEW], wh[VIEW], cp[13];
+    int fe2;
+    window_rows_cpl(pl, H, h.ax, h.ay, h.dir, wl, wh);
+    view_rows_perm(wl, wh, h.dir, ce, nfe, cp, fe2);
+    encode_cells(cp, RowPacker(rows + ROWS_FRONT, 0));
+    return fe2;
+}
+// An env's C plane row from its record (generator write-out on the host, k_sync_cpl): plane + id bytes.
+BB_HD void cpl_from_record(const LevelCfg& c, const uint8_t* rec, uint8_t* row) {
+    for (int y = 0; y < 8; ++y)
+        for (int x = 0; x < 8; ++x) row[8 * y + x] = (x < c.W && y < c.H) ? rec[e_index(c, x, y)] : (uint8_t)E_WALL;
+    const int nid = cpl_ids(c);
+    for (int k = 0; k < nid; ++k) {
+        uint8_t v = 0xFF;
+        if (k < c.maxo) {
+            const int x = rec[c.off_pos + 2 * k], y = rec[c.off_pos + 2 * k + 1];
+            if (x < c.W && y < c.H && rec[c.off_I + i_index(c, x, y)] == k + 2) v = (uint8_t)(y << 3 | x);      // (on the grid iff the id plane says so)
+        }
+        row[CPL_PLANE + k] = v;
+    }
 }
 
 // Grid.encode of the masked cells: a dword of four appearance bytes e0..e3 becomes the 12 encoding bytes

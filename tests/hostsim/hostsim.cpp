@@ -9,6 +9,8 @@
 #include "../../babyai_amd/csrc/bbai_view.hpp"
 static long long g_bot_counts[8];
 #define BBAI_BOT_COUNT(what) (++g_bot_counts[what])
+static bool g_bot_aligned_ok = true;         // hs_bot_set_aligned(0): _find_obj_pos always through the packed lists (property test of the shortcut)
+#define BBAI_BOT_ALIGNED_OK g_bot_aligned_ok
 #include "../../babyai_amd/csrc/bbai_bot.hpp"
 #include <ucontext.h>
 #include <cstdlib>
@@ -38,7 +40,9 @@ int hs_generate(const LevelCfg* cfg, uint32_t* mt, int32_t* mti, uint8_t* rec, H
     int last_locked = hot->last_locked == NONE8 ? -1 : hot->last_locked;
     static thread_local GenWork w;
     memset((void*)&w, 0xA5, sizeof(w));          // (the device's working set starts as whatever LDS held: nothing may be read before it is written)
-    Gen<HostCtx> g(HostCtx(), *cfg, w, mt, *mti, last_locked);      // (the generator advances the caller's state in place)
+    uint32_t tw[MT_CH];                          // the tempered chunk (device: LDS, behind the state)
+    memset(tw, 0xA5, sizeof(tw));
+    Gen<HostCtx> g(HostCtx(), *cfg, w, mt, tw, *mti, last_locked);      // (the generator advances the caller's state in place)
     int max_steps = g.generate();
     *mti = g.mti;
     memset(rec, 0, cfg->rec_bytes);
@@ -126,6 +130,26 @@ int hs_observe_perm(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, int
     return fe2;
 }
 
+// ... and through the C plane path of the small single rooms (bbai_view.hpp window_rows_cpl + view_rows_perm): the env's row is built from the
+// record (cpl_from_record: what the generator / k_sync_cpl write), the observation from the row alone.  row_out: cpl_bytes(cfg) bytes.
+int hs_cpl_ok(const LevelCfg* cfg) { return cpl_ok(*cfg) ? cpl_bytes(*cfg) : 0; }
+int hs_observe_cpl(const LevelCfg* cfg, const uint8_t* rec, const Hot* hot, int nfe, uint8_t* out, uint8_t* row_out) {
+    alignas(16) uint8_t rows[ROWS_FRONT + OBS_BYTES + 16];
+    alignas(16) uint8_t row[CPL_PLANE + CPL_MAX_IDS];
+    memset(rows, 0xEE, sizeof(rows));
+    cpl_from_record(*cfg, rec, row);
+    const uint32_t ce = hot->carry != NONE8 ? rec[cfg->off_app + hot->carry] : (uint32_t)E_EMPTY;
+    const int fe2 = observe_cpl_perm(row, cfg->H, *hot, ce, nfe, rows);
+    memcpy(out, rows + ROWS_FRONT, OBS_BYTES);
+    if (row_out) memcpy(row_out, row, cpl_bytes(*cfg));
+    return fe2;
+}
+int hs_cid_lookup(const uint8_t* ids, int nbytes, int pos) {
+    uint32_t d[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    memcpy(d, ids, nbytes);
+    return cid_lookup(d, nbytes / 4, pos);
+}
+
 // ---- k_step's LDS row packing (bbai_step.hpp RowPacker), one lane at a time in the caller's lane order ---------------------
 // rows_in: [n][37] dwords (147 bytes + one pad byte each); lds: ROWS_FRONT + n * 147 + 16 bytes, pre-filled by the caller;
 // scratch_fill != 0 also scribbles over every lane's window scratch first (it must stay inside the lane's own row).
@@ -151,6 +175,7 @@ int hs_bot_stack_depth(const uint8_t* state) { return ((const BotState*)state)->
 // Returns the suggested action, or 255 once the bot is dead (state->dead says why).
 static int g_bot_eager = 0;
 void hs_bot_set_eager(int on) { g_bot_eager = on; }
+void hs_bot_set_aligned(int on) { g_bot_aligned_ok = on != 0; }
 
 }  // extern "C"
 

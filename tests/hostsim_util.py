@@ -27,6 +27,10 @@ def lib():
         L.hs_step64_prefetch.argtypes = [P, P, P, P, ctypes.c_int, P, P]
         L.hs_observe.argtypes = [P, P, P, P]
         L.hs_observe_perm.argtypes = [P, P, P, ctypes.c_int, P]
+        L.hs_bot_set_aligned.argtypes = [ctypes.c_int]
+        L.hs_cpl_ok.argtypes = [P]
+        L.hs_observe_cpl.argtypes = [P, P, P, ctypes.c_int, P, P]
+        L.hs_cid_lookup.argtypes = [P, ctypes.c_int, ctypes.c_int]
         L.hs_fill_layout.argtypes = [P]
         L.hs_start_carry.argtypes = [P, P, P, P]
         L.hs_bot_decide.argtypes = [P, P, P, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int]

@@ -920,6 +920,18 @@ def test_lane_group_expert_decides_like_the_lane_per_env_expert(gpu, level, n, s
     assert b.get_option("bot_group") == 16 and a.get_option("bot_group") == 0
     a.reset()
     b.reset()
+    try:
+        b.bot_actions()
+    except Exception as exc:                 # the shipped library carries no k_botg (an experiment build: -DBBAI_BOT_GROUP_BUILD=1)
+        if "built without the lane-group expert" in str(exc):
+            a.close()
+            b.close()
+            pytest.skip("k_botg is an experiment build, not part of the shipped library")
+        raise
+    b.close()
+    b = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=77000)
+    b.set_option("bot_group", 16)
+    b.reset()
     gen = torch.Generator(device=gpu).manual_seed(3)
     prev = None
     for t in range(steps):

@@ -69,6 +69,25 @@ def test_bot_decisions_match_reference(path, mode, eager):
     assert capacity == 0 or "UnlockToUnlock" in path
 
 
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_find_obj_pos_shortcut_equals_the_packed_lists(path):
+    """bbai_bot.hpp's _find_obj_pos pairs every object with its own position, position key as loop order, when every object of
+    the descriptor is still recorded where the episode started it -- equivalent to zip(obj_set, obj_poss) only because the start
+    positions are distinct and nothing of the set has moved.  Property test: the shortcut switched OFF (every query through the two
+    sorted lists), every reference-bot fixture with its 20 % random actions (carried, dropped, stale objects) must replay to the same
+    decisions as with it ON (test_bot_decisions_match_reference)."""
+    from hostsim_util import lib
+    lib().hs_bot_set_aligned(0)
+    lib().hs_bot_set_eager(1)
+    try:
+        for mode in ("pure", "advised"):
+            mismatches, _ = replay(path, mode)
+            assert not mismatches, (mode, mismatches[:3])
+    finally:
+        lib().hs_bot_set_aligned(1)
+        lib().hs_bot_set_eager(0)
+
+
 WIDTH_LEVELS = ("BossLevel", "SynthSeq", "KeyCorridorS6R3", "UnlockToUnlock", "PutNextS7N4Carrying", "BlockedUnlockPickup", "GoToImpUnlock",
                 "PickupDist", "MoveTwoAcrossS8N9", "GoToLocal")
 

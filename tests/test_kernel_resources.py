@@ -22,7 +22,7 @@ def test_resource_report_belongs_to_the_current_sources():
     g, rep = _load()
     assert rep["built_from"] == g._digest(g._csrc(), g.hip_command(g.HIP_LIB)), "kernel_resources.json is from other sources: rebuild"
     k = rep["kernels"]
-    for name in ("k_step<true, 1>", "k_step<false, 3>", "k_pregen<1, 32, false>", "k_pregen<0, 32, true>", "k_render_q<8, 1024, 1, 1>", "k_compact", "k_gate"):
+    for name in ("k_step<true, 1, false>", "k_step<false, 3, true>", "k_step<false, 3, false>", "k_pregen<1, 32, false>", "k_pregen<0, 32, true>", "k_render_q<8, 1024, 1, 1>", "k_compact", "k_gate"):
         assert name in k, name
     # what the design relies on: the step kernels keep four waves per SIMD and touch no scratch memory; the render one block per CU
     for name, r in k.items():

@@ -34,7 +34,7 @@ struct ProfCtx {                                   // bbai_engine.hip GroupCtx<3
 template <int KIND>
 __global__ __launch_bounds__(64, 4) void k_prof(LevelCfg c, int n, int rounds, uint32_t* mts, unsigned long long* out, unsigned long long* per_level) {
     __shared__ GenWork ws[2];
-    __shared__ uint32_t s_mt[2][MT_N];
+    __shared__ uint32_t s_mt[2][MT_N + MT_CH];
     const int grp = threadIdx.x / G, lane = threadIdx.x & (G - 1);
     GenWork& w = ws[grp];
     const ProfCtx ctx;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64, 4) void k_prof(LevelCfg c, int n, int rounds, u
         int mti = MT_N, last = -1;
         for (int r = 0; r < rounds; ++r) {
             const unsigned long long t0 = clock64();
-            Gen<ProfCtx> g(ctx, c, w, s_mt[grp], mti, last);
+            Gen<ProfCtx> g(ctx, c, w, s_mt[grp], s_mt[grp] + MT_N, mti, last);
             g.template generate_kind<KIND>();
             mti = g.mti; last = g.last_locked;
             const unsigned long long t1 = clock64();

@@ -201,6 +201,23 @@ ubench() {           # the microbenchmarks DESIGN.md quotes (built here: hipcc i
     timeout 300 /tmp/ubench_render ${1:-1048576} ${2:-queue} > $OUT/ubench_render_${2:-queue}.jsonl 2> $OUT/ubench_render.err
     cat $OUT/membw.json; tail -30 $OUT/ubench_render_${2:-queue}.jsonl
 }
+halfline() {         # 64-byte half-line gathers against 128-byte line gathers at k_step's shape (tools/ubench_halfline.hip), + the FETCH_SIZE of each
+    cd $REPO && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/ubench_halfline tools/ubench_halfline.hip 2>/dev/null
+    timeout 120 /tmp/ubench_halfline | tee $OUT/ubench_halfline.jsonl
+    cd /tmp && rm -rf $OUT/halfline_fetch && timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/halfline_fetch -o h -- /tmp/ubench_halfline > /dev/null 2> $OUT/halfline_fetch.log
+    python - <<PY | tee $OUT/ubench_halfline_fetch.txt
+import csv, glob, collections
+acc = collections.defaultdict(list)
+for path in glob.glob("$OUT/halfline_fetch/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(path)):
+        if r.get("Counter_Name") == "FETCH_SIZE":
+            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+for k, v in sorted(acc.items()):
+    v.sort()
+    print("%-28s launches=%d FETCH_SIZE median=%.0f KB (x 2 on gfx950 = %.1f MB = %.1f B per lane)" % (k, len(v), v[len(v) // 2], 2 * v[len(v) // 2] / 1024, 2 * v[len(v) // 2] * 1024 / 1048576))
+PY
+    rm -rf $OUT/halfline_fetch
+}
 lib() {              # the same ab spec under two engine builds, alternated twice: lib:<other.so>:<ab args as for ab:>
     local other=$1; shift
     for rep in 1 2; do
