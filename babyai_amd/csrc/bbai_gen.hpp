@@ -137,7 +137,6 @@ struct Gen {
     bool twisted;            // the state words were regenerated at least once (k_pregen: only then does the state go back to memory)
     uint64_t occ;            // grids of <= 64 cells (every single room up to 8 x 8): bit y * W + x = the cell holds a wall or an object --
                              // the placement loops test a register bit instead of waiting for an id-plane byte from LDS
-    uint64_t wallb;          // ... and the cells build_rooms made walls (occ & ~wallb = the objects)
     uint32_t seen;           // bit (type - T_KEY) * 6 + colour: a key / ball / box of that look exists (add_distractors(all_unique))
     bool small;              // cfg.W * cfg.H <= 64
     int nobj;
@@ -155,7 +154,7 @@ struct Gen {
     uint32_t inv_cols, inv_s1, inv_es;   // 2^16/d + 1: exact small-range division without the divider
 
     BB_HD Gen(Ctx c, const LevelCfg& cf, GenWork& wk, uint32_t* mt_, uint32_t* tw_, int mti_, int last_locked_)
-        : ctx(c), cfg(cf), w(wk), mt(mt_), tw(tw_), mti(mti_), nxt(0), twisted(false), occ(0), wallb(0), seen(0), small(cf.W * cf.H <= 64),
+        : ctx(c), cfg(cf), w(wk), mt(mt_), tw(tw_), mti(mti_), nxt(0), twisted(false), occ(0), seen(0), small(cf.W * cf.H <= 64),
           nobj(0), ax(0), ay(0), adir(0), agent_set(false),
           locked_room(-1), last_locked(last_locked_), S(cf.room_size), rows(cf.num_rows), cols(cf.num_cols),
           gave_up(false), doors(0), locked_mask(0), inv_cols(65536u / (uint32_t)cf.num_cols + 1u),
@@ -218,6 +217,14 @@ struct Gen {
         w.E[eidx(x, y)] = (uint8_t)e; w.I[iidx(x, y)] = (uint8_t)id;
         if (small) { const uint64_t b = 1ull << (y * cfg.W + x); occ = id ? (occ | b) : (occ & ~b); }
     }
+    // the cells build_rooms makes walls, as a bitboard (grids of <= 64 cells): whole rows on the room boundaries, the boundary columns elsewhere
+    BB_HD uint64_t wall_board() const {
+        uint64_t in_row = 0, b = 0;
+        for (int x = 0; x < cfg.W; x += S - 1) in_row |= 1ull << x;
+        const uint64_t full_row = (1ull << cfg.W) - 1ull;
+        for (int y = 0; y < cfg.H; ++y) b |= ((y - div_s1(y) * (S - 1)) == 0 ? full_row : in_row) << (y * cfg.W);
+        return b;
+    }
     BB_HD bool occupied(int x, int y) const { return small ? (occ >> (y * cfg.W + x) & 1ull) != 0 : w.I[iidx(x, y)] != 0; }
     BB_HD void note_obj(int e) { if (e_type(e) >= T_KEY) seen |= 1u << ((e_type(e) - T_KEY) * 6 + e_color(e)); }
     BB_HD int room_of(int x, int y) const { return div_s1(y) * cols + div_s1(x); }
@@ -249,14 +256,7 @@ struct Gen {
         doors = 0;
         locked_mask = 0;
         seen = 0;
-        occ = 0;
-        if (small) {                              // the walls as a bitboard: whole rows on the room boundaries, the boundary columns elsewhere
-            uint64_t in_row = 0;
-            for (int x = 0; x < cfg.W; x += S - 1) in_row |= 1ull << x;
-            const uint64_t full_row = (1ull << cfg.W) - 1ull;
-            for (int y = 0; y < cfg.H; ++y) occ |= ((y - div_s1(y) * (S - 1)) == 0 ? full_row : in_row) << (y * cfg.W);
-        }
-        wallb = occ;
+        occ = small ? wall_board() : 0ull;
         ctx.sync();
         for (int j = 0; j < rows; ++j)
             for (int i = 0; i < cols; ++i) {
@@ -438,7 +438,7 @@ struct Gen {
         for (int y = 0; y < H; ++y) col0 |= 1ull << (y * W);
         const uint64_t board = W * H == 64 ? ~0ull : (1ull << (W * H)) - 1ull;
         const uint64_t not0 = ~col0, notL = ~(col0 << (W - 1));
-        uint64_t objs = occ & ~wallb;                    // (an object hidden inside a box is not on the grid: not in occ)
+        uint64_t objs = occ & ~wall_board();             // (recomputed, not kept: two registers less in every placement loop; an object hidden inside a box is not in occ)
         uint64_t pass = ~occ & board;
         if (doors)                                       // doors stand where walls were: passable, and objects that must be reached (single rooms have none)
             for (int o = 0; o < nobj; ++o)

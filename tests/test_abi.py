@@ -121,7 +121,12 @@ def test_product_never_touches_the_oracle_or_the_reference():
     # bench.py reaches the oracle only as the checker / the reported baseline: after the timed region, cpu_baseline module only
     uses = [m.start() for m in re.finditer(r"(from|import) oracle", bench)]
     assert len(uses) == 1 and bench[uses[0]:uses[0] + 40].startswith("from oracle import cpu_baseline")
-    # ... and the module is only CALLED after the timed blocks (the pool it forks up front idles until then)
+    # ... and the module is never CALLED beside a timed block: the parity replays come after the last one; the CPU baselines run in ONE
+    # function, on a thread that is started before the GPU runtime exists and JOINED before the first warm-up step (after_seed)
     last_block = bench.rindex("shard.timed_blocks(")
+    pre = bench.index("def _baselines_before_the_gpu_work():")
+    pre_end = bench.index('baselines["thread"].start()')
     for m in re.finditer(r"cpu_baseline\.(parity_replay|run)\(", bench):
-        assert m.start() > last_block
+        assert m.start() > last_block or pre < m.start() < pre_end, bench[m.start() - 80:m.start() + 40]
+    join = bench.index('baselines["thread"].join()')
+    assert bench.index("def after_seed():") < join < bench.index("m = measure(ctx, level, pixel"), "the CPU legs must be complete before the GPU is stepped"
