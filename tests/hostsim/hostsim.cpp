@@ -5,6 +5,7 @@
 #include <string.h>
 #include "../../babyai_amd/csrc/bbai_types.hpp"
 #include "../../babyai_amd/csrc/bbai_gen.hpp"
+#include "../../babyai_amd/csrc/bbai_genl.hpp"
 #include "../../babyai_amd/csrc/bbai_step.hpp"
 #include "../../babyai_amd/csrc/bbai_view.hpp"
 static long long g_bot_counts[8];
@@ -66,6 +67,49 @@ int hs_generate(const LevelCfg* cfg, uint32_t* mt, int32_t* mti, uint8_t* rec, H
     *hot = h;
     return g.nobj;
 }
+
+// The lane = level generator (bbai_genl.hpp) on the host: a lane's word array and a plain MT19937 state.  Same outputs as hs_generate
+// expected, byte for byte (tests/test_hostsim_genl.py).  Returns nobj, or -1 when the level kind is not covered by this generator.
+struct HostLaneMem {
+    uint32_t w[160];
+    uint32_t* mt; int mti;
+    uint32_t ld(int k) const { return w[k]; }
+    void st(int k, uint32_t v) { w[k] = v; }
+    uint32_t next_u32() {
+        if (mti >= MT_N) { mt_twist(HostCtx(), mt); mti = 0; }
+        return mt_temper(mt[mti++]);
+    }
+};
+int hs_generate_lane(const LevelCfg* cfg, uint32_t* mt, int32_t* mti, uint8_t* rec, Hot* hot) {
+    if (!lane_gen_ok(*cfg)) return -1;
+    static thread_local HostLaneMem mem;
+    memset((void*)mem.w, 0xA5, sizeof(mem.w));   // (the device's LDS starts as whatever it held)
+    mem.mt = mt; mem.mti = *mti;
+    static thread_local uint8_t tmpl[4096];
+    lane_build_template(*cfg, tmpl);
+    int last_locked = hot->last_locked == NONE8 ? -1 : hot->last_locked;
+    GenL<HostLaneMem> g(mem, *cfg, last_locked);
+    for (int attempts = 0;; ++attempts) {
+        if (attempts >= Gen<HostCtx>::MAX_ATTEMPTS) return -2;
+        bool ok = cfg->kind == K_LEVELGEN ? g.attempt<K_LEVELGEN>() : g.attempt<K_GOTO>();
+        if (ok) break;
+    }
+    *mti = mem.mti;
+    memset(rec, 0xEE, cfg->rec_bytes);           // (the record is written completely)
+    alignas(16) static thread_local uint8_t arec[4096];
+    g.write_record(arec, tmpl);
+    memcpy(rec, arec, cfg->rec_bytes);
+    Hot h;
+    memset(&h, 0, sizeof(h));
+    h.ax = g.ax; h.ay = g.ay; h.dir = g.adir; h.carry = NONE8;
+    h.step = 0; h.max_steps = (uint16_t)g.max_steps();
+    h.pre4 = 0xFFFFFFFFu;
+    h.last_locked = g.last_locked < 0 ? NONE8 : (uint8_t)g.last_locked;
+    *hot = h;
+    return g.nobj;
+}
+uint32_t hs_untemper(uint32_t y) { return mt_untemper(y); }
+uint32_t hs_temper(uint32_t y) { return mt_temper(y); }
 
 // PutNext*Carrying (bonus_levels.py:821-829): AFTER the first observation the object leaves the grid into the
 // agent's hands.  Call once after hs_generate + hs_observe; returns 1 if something was picked up.

@@ -22,6 +22,11 @@ def lib():
         P = ctypes.c_void_p
         L.hs_seed.argtypes = [ctypes.c_uint64, P]
         L.hs_generate.argtypes = [P, P, P, P, P]
+        L.hs_generate_lane.argtypes = [P, P, P, P, P]
+        L.hs_untemper.argtypes = [ctypes.c_uint32]
+        L.hs_untemper.restype = ctypes.c_uint32
+        L.hs_temper.argtypes = [ctypes.c_uint32]
+        L.hs_temper.restype = ctypes.c_uint32
         L.hs_step.argtypes = [P, P, P, P, ctypes.c_int, P]
         L.hs_step64.argtypes = [P, P, P, P, ctypes.c_int, P]
         L.hs_step64_prefetch.argtypes = [P, P, P, P, ctypes.c_int, P, P]

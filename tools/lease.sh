@@ -187,6 +187,26 @@ genrate() {          # bulk level-generation rate (bbai_seed's first fill) per g
         BBAI_PREGEN_GROUP=$g timeout 300 python $REPO/tools/gen_rate.py 2>> $OUT/gen_rate.err | tee -a $OUT/gen_rate_by_group_width.jsonl
     done
 }
+genpmc() {           # instruction counters of the level generator's bulk fill (tools/gen_rate.py): VALU / SALU / LDS instructions and cycles per level
+    cd /tmp
+    for pass in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
+        n=$(echo $pass | cut -d' ' -f1)
+        rm -rf $OUT/genpmc_$n
+        timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/genpmc_$n -o g -- python $REPO/tools/gen_rate.py PickupLoc 262144 8 GoToLocal 65536 16 GoTo 131072 8 BossLevel 262144 4 > $OUT/genpmc_$n.log 2>&1
+    done
+    python - <<PY | tee $OUT/genpmc.txt
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for path in glob.glob("$OUT/genpmc_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if k.startswith("k_pregen"):
+            agg[(k, r.get("Grid_Size", r.get("Grid_Size_X", "?")))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for (k, grid), d in sorted(agg.items()):
+    print(k, "grid", grid, {c: (len(v), sum(v) / len(v)) for c, v in sorted(d.items())})
+PY
+    rm -rf $OUT/genpmc_SQ_*
+}
 genprof() {          # phase profile of the level generator (tools/genprof.hip): genprof[:<level> ...]
     cd $REPO && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/genprof tools/genprof.hip 2>/dev/null
     for l in ${@:-GoToLocal PickupLoc GoTo BossLevel}; do timeout 120 /tmp/genprof $l | tee -a $OUT/genprof.txt; done
