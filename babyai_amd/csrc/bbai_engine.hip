@@ -29,13 +29,16 @@
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <vector>
 
 #if defined(BBAI_BOT_PROF)
 __device__ unsigned long long g_bot_prof[32];        // experiment builds: phase timers of the expert (bbai_bot.hpp)
 #endif
 #include "../../include/bbai.h"
 #include "bbai_types.hpp"
+#include "bbai_kernels.hpp"
 #include "bbai_gen.hpp"
+#include "bbai_genl.hpp"
 #include "bbai_step.hpp"
 #include "bbai_view.hpp"
 #include "bbai_bot.hpp"
@@ -146,6 +149,13 @@ struct bbai_env {
     int pregen_per_group; // BBAI_PREGEN_PER_GROUP / option "pregen_per_group": single-room levels: list entries per working lane group of a refill (default 32 = one per tick of the longest window)
     int pregen_min;       // BBAI_PREGEN_MIN / option "pregen_min": single-room levels: lane groups that work on a refill at least (k_pregen: entries / 32 otherwise); 0 = the whole grid, as mazes always get
     int pregen_group;     // BBAI_PREGEN_GROUP: lanes per env in k_pregen: 32 (default: two envs per wave), 16 or 64
+    // the lane = level generator (bbai_genl.hpp, k_pregen_lane): every LevelGen parameterisation and the single-instruction levels without a lock-first prologue
+    uint32_t* mtt;        // [n][2][MT_N] tempered outputs of the latest and the previous MT19937 generation of every env (NULL: kind not covered)
+    uint8_t* mtpar;       // [n] which half holds the latest generation
+    uint8_t* lane_tmpl;   // the kind's record template + C plane (lane_build_template)
+    int lane_words;       // LDS words per lane (lane_layout)
+    int pregen_lane;      // BBAI_PREGEN_LANE / option "pregen_lane": 1 (default where covered) = k_pregen_lane generates, 0 = the lane-group kernel k_pregen
+    int lane_blocks;      // BBAI_LANE_BLOCKS / option "lane_blocks": upper bound on its waves per launch
     int step_prio;        // BBAI_STEP_PRIO: s_setprio level of the step-path kernels' waves (they share CUs with k_pregen)
     // optional per-kernel timing (bbai_profile): HIP event pairs on the launch stream around k_step / k_consume / k_render
     bool prof_on;
@@ -207,12 +217,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 //     UNDER the following windows instead of stopping the step stream, as long as no env finishes B more times meanwhile.
 //   * NWIN window buffers (pending / first_slot / meta) so that up to B + 1 refills can be outstanding.
 // tests/test_ring_protocol.py models the rule (sufficient, and the ring depths stay tight).
-constexpr int META_U32 = 32;            // uint32 per window buffer's meta line: [0] = M when > 1 (atomicMax)
-constexpr int SHARDS = 64;              // cache lines the reset total is spread over (k_step: shard = block & 63)
-constexpr int SHARD_U64 = 16;           // uint64 per shard: one 128-byte line each
-enum : int { FLOW_REFILLED = 0 /* windows whose refill has landed */, FLOW_GATE_TIMEOUTS = 1, FLOW_PROBE = 2 /* probe_stream's flag */, FLOW_GEN_FAILURES = 3 /* levels the generator gave up on */, FLOW_WORDS = 16 };
-constexpr int GEN_COUNT_U32 = 32;       // uint32 per sub-list counter of the refill list: one 128-byte line each
-__host__ __device__ __forceinline__ int64_t gen_sublist_cap(int64_t n) { return ((n + 63) / 64 + SHARDS - 1) / SHARDS * 64; }      // entries a sub-list can get: its waves x 64
 __device__ __forceinline__ void count_resets(unsigned long long* __restrict__ totals, unsigned int k) {
     atomicAdd(&totals[(blockIdx.x & (SHARDS - 1)) * SHARD_U64], (unsigned long long)k);        // (result unused: a no-return atomic)
 }
@@ -407,10 +411,7 @@ __device__ __forceinline__ void cpl_build_wave(const LevelCfg& c, const uint8_t*
 // levels of the classic ring); the slot an episode leaves is the one the window's refill regenerates.  rec[] stays allocated as the
 // staging area of export / import / checkpoints.  No window plane in this layout (the window comes out of the record's appearance
 // plane: measures equal on the shards this is for).
-// The look-ahead ring is ENV-MAJOR: entry (slot, env) of next_rec / next_hot / next_obs is number env * depth + slot -- an env's D levels
-// lie together.  (Slot-major, rounds 1-4a, put the 64 envs of a stepping wave into up to 64 regions n * rec_bytes apart as soon as
-// the live records are ring slots: profiles/r04/inplace_ring_depth_ab.jsonl, k_step 0.029 -> 0.035 ms from D = 5 to D = 65.)
-__device__ __forceinline__ int64_t ring_at(int slot, int64_t env, int depth) { return env * depth + slot; }
+// (ring_at -- the ENV-MAJOR look-ahead ring's addressing -- lives in bbai_kernels.hpp)
 constexpr int OBS_BLOCK = 160;          // bytes of a next_obs slot that hold the first observation (147 used; sixteen-byte loads); OBS_SLOT / CPL_OFF: bbai_types.hpp
 __device__ __forceinline__ int live_slot(int next_slot, int depth) { return (next_slot ? next_slot : depth) - 1; }
 __device__ __forceinline__ uint8_t* live_rec(const LevelCfg& c, int64_t n, int64_t env, uint8_t* recs, uint8_t* ring, int depth, int next_slot) {
@@ -860,30 +861,7 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
 // One env per group of G lanes, 64 / G envs per wavefront (bbai_gen.hpp "Execution model").  sync() orders the group's LDS
 // accesses: it is reached under divergent control flow (the groups of a wave are in different places of the generator),
 // so it is a wave-local fence, never a workgroup barrier -- the workgroup is one wave.
-template <int G>
-struct GroupCtx {
-    static constexpr int kLanes = G;
-    __device__ __forceinline__ int lane() const { return (int)threadIdx.x & (G - 1); }
-    __device__ __forceinline__ int nlanes() const { return G; }
-    __device__ __forceinline__ void sync() const {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    __device__ __forceinline__ uint32_t shfl(uint32_t v, int src) const { return __shfl(v, src, G); }
-    __device__ __forceinline__ uint32_t shfl_up1(uint32_t v) const { uint32_t t = __shfl_up(v, 1, G); return lane() == 0 ? 0u : t; }
-    __device__ __forceinline__ uint32_t shfl_down1(uint32_t v) const { uint32_t t = __shfl_down(v, 1, G); return lane() == G - 1 ? 0u : t; }
-    __device__ __forceinline__ unsigned long long ballot(bool p) const {     // the group's share of the wave's ballot: bit k = lane k of the group
-        const unsigned long long b = __ballot(p);
-        constexpr unsigned long long m = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
-        return (b >> ((int)threadIdx.x & ~(G - 1) & 63)) & m;
-    }
-    __device__ __forceinline__ bool any(bool p) const {
-        const unsigned long long b = __ballot(p);
-        constexpr unsigned long long m = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
-        return ((b >> ((int)threadIdx.x & ~(G - 1) & 63)) & m) != 0ull;
-    }
-};
+// (GroupCtx<G>: bbai_kernels.hpp)
 
 // (Lane = level -- GroupCtx<1>: the same templates with a one-lane context, working set in per-lane global memory, MT19937 state advanced in
 // place -- was built and measured in round 5 (profiles/r05/NOTES.md): 86-95 VGPRs, but every access to the working set becomes a global
@@ -1124,6 +1102,33 @@ __global__ __launch_bounds__(64, (KIND == K_BONUS || G == 16) ? 2 : BBAI_PREGEN_
             have = false;
         }
     }
+}
+
+// Derived / canonical forms of the lane generator's RNG state.
+//   k_mt_sync:  after anything that wrote (mts, mtis) in the canonical form (imports, checkpoint loads, the lane-group generator): the latest
+//               generation's tempered outputs into half 0, parity 0.
+//   k_mt_canon: before anything that reads the canonical form (checkpoint saves, the lane-group generator): an env whose position lies in
+//               the PREVIOUS generation gets that generation's raw words back (un-tempered from its half) and position + 624.
+__global__ __launch_bounds__(256) void k_mt_sync(int64_t n, const uint32_t* __restrict__ mts, uint32_t* __restrict__ mtt, uint8_t* __restrict__ mtpar) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * MT_N) return;
+    const int64_t env = i / MT_N;
+    const int k = (int)(i - env * MT_N);
+    mtt[env * (2 * MT_N) + k] = mt_temper(mts[i]);
+    if (k == 0) mtpar[env] = 0;
+}
+__global__ __launch_bounds__(256) void k_mt_canon(int64_t n, uint32_t* __restrict__ mts, uint32_t* __restrict__ mtt, uint8_t* __restrict__ mtpar, int32_t* __restrict__ mtis) {
+    // one wave per env (the position is read by every lane before lane 0 rewrites it: the wave runs in lockstep up to the barrier)
+    const int64_t env = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (env >= n) return;
+    const int pos = mtis[env];
+    const int par = mtpar[env];
+    __builtin_amdgcn_wave_barrier();
+    if (pos >= 0) return;
+    const uint32_t* prev = mtt + env * (2 * MT_N) + (par ^ 1) * MT_N;
+    for (int k = lane; k < MT_N; k += 64) mts[env * MT_N + k] = mt_untemper(prev[k]);
+    if (lane == 0) { mtis[env] = pos + MT_N; mtpar[env] = (uint8_t)(par ^ 1); }
 }
 
 // look-ahead slot -> live state for the envs that finished (or all, on reset()): one wave copies one record
@@ -1769,6 +1774,26 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
             alloc((void**)&e->fcache, (size_t)n_envs * 2);
         }
     }
+    if (lane_gen_ok(c) && (!e->inplace || cpl_ok(c))) {
+        // Default: the single rooms.  Measured (profiles/r06/NOTES.md): bulk fills 2.2 - 2.9 ns per level against 6 - 7 (PickupLoc 262 144: 0.057 -> 0.043 ms
+        // per step); the mazes' bulk rates are 17 (GoTo) and 31 (BossLevel) ns against 30 and 20, and a maze refill of a few thousand levels
+        // lasts milliseconds as ONE level per lane where the lane-group kernel needs a third of that -- the mazes keep k_pregen.
+        const char* lv = getenv("BBAI_PREGEN_LANE");
+        e->pregen_lane = lv ? (atoi(lv) != 0) : (c.num_rows * c.num_cols == 1);
+        const char* lb = getenv("BBAI_LANE_BLOCKS");
+        e->lane_blocks = lb ? std::max(1, atoi(lb)) : 16384;
+        e->lane_words = lane_layout(c).words;
+        alloc((void**)&e->mtt, (size_t)n_envs * 2 * MT_N * 4);
+        alloc((void**)&e->mtpar, (size_t)n_envs);
+        alloc((void**)&e->lane_tmpl, (size_t)lane_template_bytes(c));
+        if (err == hipSuccess) {
+            std::vector<uint8_t> t((size_t)lane_template_bytes(c));
+            lane_build_template(c, t.data());
+            err = hipMemcpy(e->lane_tmpl, t.data(), t.size(), hipMemcpyHostToDevice);
+            if (err == hipSuccess) err = hipMemset(e->mtpar, 0, (size_t)n_envs);
+            if (err == hipSuccess) err = hipMemset(e->mtt, 0, (size_t)n_envs * 2 * MT_N * 4);
+        }
+    }
     {
         // Refill period B (ticks per look-ahead refill, BBAI_LOOKAHEAD); ring depth D = 2B.  One k_pregen launch per
         // window lasts as long as its slowest level (hundreds of microseconds to milliseconds: rejection sampling has a
@@ -1940,7 +1965,7 @@ void bbai_destroy(bbai_env* e) {
     void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
     void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_meta, e->totals, e->flow, e->gen_list, e->gen_count, e->reset_list, e->counters,
-                    e->atlas, e->lut, e->vplane, e->fcache, e->lsm, e->render_tickets, e->reset_slot, e->next_obs, e->cplane};
+                    e->atlas, e->lut, e->vplane, e->fcache, e->lsm, e->render_tickets, e->reset_slot, e->next_obs, e->cplane, e->mtt, e->mtpar, e->lane_tmpl};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (e->host_flags) (void)hipHostFree((void*)e->host_flags);
     delete e;
@@ -1965,7 +1990,18 @@ static void launch_pregen_g(const bbai_env* e, unsigned groups, bool listed /* f
     else { if (e->next_obs) PREGEN_LAUNCH(K_GOTO, true); else PREGEN_LAUNCH(K_GOTO, false); }
 #undef PREGEN_LAUNCH
 }
-static void launch_pregen(const bbai_env* e, unsigned groups, bool listed, uint8_t* pending, const uint8_t* first_slot) {
+// k_pregen_lane lives in a translation unit of its own (bbai_genlane.hip: compiled without machine-CSE, see there)
+static void launch_pregen_lane(const bbai_env* e, int64_t entries_hint, bool listed, uint8_t* pending, const uint8_t* first_slot) {
+    LaneLaunch a;
+    a.cfg = e->cfg; a.n = e->n; a.next_rec = e->next_rec; a.next_hot = e->next_hot; a.mt = e->mt; a.mtt = e->mtt; a.mtpar = e->mtpar; a.mti = e->mti;
+    a.gen_list = e->gen_list; a.gen_count = listed ? e->gen_count : nullptr; a.depth = e->depth; a.pending = pending; a.first_slot = first_slot;
+    a.fails = e->flow + FLOW_GEN_FAILURES; a.next_obs = e->next_obs; a.tmpl = e->lane_tmpl; a.lane_words = e->lane_words;
+    a.blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((entries_hint + 63) / 64, e->lane_blocks));
+    a.stream = e->side;
+    bbai_lane_launch(a);
+}
+static void launch_pregen(const bbai_env* e, unsigned groups, bool listed, uint8_t* pending, const uint8_t* first_slot, int64_t entries_hint) {
+    if (e->pregen_lane) { launch_pregen_lane(e, entries_hint, listed, pending, first_slot); return; }
     // Measured (profiles/r03/gen_rate_by_group_width.jsonl, pregen_group_width_in_bench.jsonl): levels per second of a bulk
     // fill 64 -> 32 -> 16 lanes per env: BossLevel 1 : 1.16 : 1.18, GoTo 1 : 1.13 : 1.17, PickupLoc 1 : 1.20 : 1.27,
     // GoToLocal 1 : 1.25 : 1.36; inside the step loop 32 is never behind 64 (GoToLocal 65 536 envs -3 %, PickupLoc 262 144
@@ -2117,7 +2153,7 @@ static int window_end(bbai_env* e, hipStream_t s, int tokens_mode /* k_tokens: 0
         HIP_TRY(hipMemsetAsync(e->gen_count, 0, SHARDS * GEN_COUNT_U32 * 4, e->side));
         hipLaunchKernelGGL(k_compact, dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->side, e->n, e->pending + (size_t)wb * e->n, e->gen_list, e->gen_count);
         const int64_t rh = std::max<int64_t>((int64_t)B * (e->n / 64), 64);
-        launch_pregen(e, pregen_grid(e, rh), true, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n);
+        launch_pregen(e, pregen_grid(e, rh), true, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n, std::min<int64_t>(e->n, 2 * rh));
         hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, e->side, e->flow, (unsigned long long)(w + 1));
         HIP_TRY(hipEventRecord(e->ev_refill[wb], e->side));
         HIP_TRY(hipGetLastError());
@@ -2159,7 +2195,8 @@ int bbai_seed(bbai_env* e, const uint64_t* seeds, int64_t n) {
     HIP_TRY(hipMemsetAsync(e->pending, 0, NWIN * (size_t)n, e->side));
     HIP_TRY(hipMemsetAsync(e->first_slot, 0, NWIN * (size_t)n, e->side));
     HIP_TRY(hipMemsetAsync(e->pending, e->depth - e->inplace, (size_t)n, e->side));      // (in-place: slot depth - 1 is the live one -- empty until the first reset)
-    launch_pregen(e, (unsigned)std::max<int64_t>(1, std::min<int64_t>(n, std::max(e->pregen_cap, 32768))), false, e->pending, e->first_slot);
+    if (e->mtpar) HIP_TRY(hipMemsetAsync(e->mtpar, 0, (size_t)n, e->side));      // (position 624 of generation 0: the first draw's twist fills the other half)
+    launch_pregen(e, (unsigned)std::max<int64_t>(1, std::min<int64_t>(n, std::max(e->pregen_cap, 32768))), false, e->pending, e->first_slot, n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(e->win_meta, 0, NWIN * META_U32 * 4, e->side));
     HIP_TRY(hipMemsetAsync(e->counters, 0, 128, e->side));
@@ -2552,6 +2589,23 @@ static int ckpt_segments(const bbai_env* e, int depth, bool with_bot, int bot_st
     return k;
 }
 
+// the lane generator's RNG state <-> the canonical (mts, mtis in [0, 624]) form: both streams idle
+static int mt_canon(bbai_env* e) {
+    if (!e->mtt) return BBAI_OK;
+    hipLaunchKernelGGL(k_mt_canon, dim3((unsigned)((e->n + 3) / 4)), dim3(256), 0, 0, e->n, e->mt, e->mtt, e->mtpar, e->mti);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return BBAI_OK;
+}
+static int mt_sync(bbai_env* e) {
+    if (!e->mtt) return BBAI_OK;
+    const int64_t total = e->n * MT_N;
+    hipLaunchKernelGGL(k_mt_sync, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, e->n, e->mt, e->mtt, e->mtpar);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return BBAI_OK;
+}
+
 int64_t bbai_checkpoint_bytes(bbai_env* e) {
     if (!e) return -1;
     Seg seg[24];
@@ -2566,6 +2620,8 @@ int bbai_checkpoint_save(bbai_env* e, void* host_buf, int64_t bytes) {
     ON_DEVICE(e->device);
     HIP_TRY(hipDeviceSynchronize());             // both streams idle: the ring and the windows' bookkeeping are at rest, every refill has landed
     { int rc = live_copy(e, 0, e->n, 0); if (rc != BBAI_OK) return rc; }       // (in-place layout: the blob's record segment = the live slots)
+    { int rc = mt_canon(e); if (rc != BBAI_OK) return rc; }                    // (the blob holds the canonical MT19937 form: every position in [0, 624])
+    { int rc = mt_sync(e); if (rc != BBAI_OK) return rc; }
     CkptHeader h;
     memset(&h, 0, sizeof(h));
     h.magic = 0x42424149434b5054ull; h.version = CKPT_VERSION; h.period = e->period; h.n = e->n; h.cfg = e->cfg; h.depth = e->depth;
@@ -2650,6 +2706,7 @@ int bbai_checkpoint_load(bbai_env* e, const void* host_buf, int64_t bytes) {
     // (the saved run was idle: every refill it had launched has landed, and flow[FLOW_REFILLED] in the blob says so)
     for (int i = 0; i < NWIN; ++i) HIP_TRY(hipEventRecord(e->ev_refill[i], e->side));
     HIP_TRY(hipDeviceSynchronize());
+    { int rc = mt_sync(e); if (rc != BBAI_OK) return rc; }
     return sync_view(e, 0, e->n);
 }
 
@@ -2892,6 +2949,17 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     else if (!strcmp(name, "render_tpb")) e->render_tpb = v;
     else if (!strcmp(name, "step_prio")) e->step_prio = v;
     else if (!strcmp(name, "pregen_group")) e->pregen_group = v;
+    else if (!strcmp(name, "pregen_lane")) {
+        if (!e->mtt) { if (v) ARG_FAIL("pregen_lane: this level kind / layout is not covered by the lane generator"); }
+        else if ((v != 0) != (e->pregen_lane != 0)) {
+            HIP_TRY(hipDeviceSynchronize());
+            // the lane-group kernel reads and writes the canonical form; the lane kernel needs the tempered halves behind it
+            { int rc = mt_canon(e); if (rc != BBAI_OK) return rc; }
+            { int rc = mt_sync(e); if (rc != BBAI_OK) return rc; }
+            e->pregen_lane = v != 0;
+        }
+    }
+    else if (!strcmp(name, "lane_blocks")) e->lane_blocks = std::max(1, v);
     else if (!strcmp(name, "pregen_blocks")) e->pregen_cap = std::max(64, v);
     else if (!strcmp(name, "pregen_min")) e->pregen_min = std::max(0, v);
     else if (!strcmp(name, "pregen_per_group")) e->pregen_per_group = std::max(1, v);
@@ -2926,6 +2994,8 @@ int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     else if (!strcmp(name, "render_tpb")) *out = e->render_tpb;
     else if (!strcmp(name, "step_prio")) *out = e->step_prio;
     else if (!strcmp(name, "pregen_group")) *out = e->pregen_group;
+    else if (!strcmp(name, "pregen_lane")) *out = e->pregen_lane;
+    else if (!strcmp(name, "lane_blocks")) *out = e->lane_blocks;
     else if (!strcmp(name, "pregen_blocks")) *out = e->pregen_cap;
     else if (!strcmp(name, "pregen_min")) *out = e->pregen_min;
     else if (!strcmp(name, "pregen_per_group")) *out = e->pregen_per_group;

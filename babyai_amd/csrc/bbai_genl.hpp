@@ -43,13 +43,18 @@
 #include "bbai_types.hpp"
 #include "bbai_gen.hpp"
 
+#ifndef BBAI_GENL_TRACE
+#define BBAI_GENL_TRACE(m, tag, val)      // (tools/genl_check.hip defines it: where device and host part ways)
+#endif
+
 namespace bbai {
 
 // The families this generator covers: every LevelGen parameterisation and the hand-written single-instruction levels without the
 // lock-first prologue.  (Bonus scripts and lock-first levels stay on the lane-group generator.)
 BB_HD bool lane_gen_ok(const LevelCfg& c) { return c.kind == K_LEVELGEN || (c.kind == K_GOTO && !c.lock); }
 
-struct LaneLayout { int obj, row, door, prog, words; };     // word offsets of a lane's regions
+struct LaneLayout { int obj, row, door, prog, fifo, words; };     // word offsets of a lane's regions
+constexpr int LANE_FIFO_WORDS = 16;                        // the draw FIFO (LaneRng below)
 constexpr int LANE_PROG_WORDS = (int)(sizeof(Prog) / 4);    // 28; the flood rows of the reachability test alias them (H <= 25)
 BB_HD LaneLayout lane_layout(const LevelCfg& c) {
     LaneLayout L;
@@ -58,7 +63,8 @@ BB_HD LaneLayout lane_layout(const LevelCfg& c) {
     L.row = c.maxo;
     L.door = L.row + (small ? 0 : c.H);
     L.prog = L.door + c.num_rows * c.num_cols;
-    L.words = L.prog + LANE_PROG_WORDS;
+    L.fifo = L.prog + LANE_PROG_WORDS;
+    L.words = L.fifo + LANE_FIFO_WORDS;
     return L;
 }
 static_assert(MAX_W <= LANE_PROG_WORDS, "flood rows alias the program words");
@@ -77,6 +83,92 @@ BB_HD uint32_t mt_untemper(uint32_t y) {
     y = y ^ (t >> 11);
     return y;
 }
+
+// A lane's view of its env's MT19937 stream (device: LaneMemDev in bbai_genlane.hip; host: the emulation in tests/hostsim): the raw state
+// of the latest generation, the tempered outputs of the latest (half `par`) and the previous generation, and a FIFO of LANE_FIFO outputs
+// in the lane's own words.  A draw out of memory is a dependent round trip of a microsecond on a chain that is nothing but draw -> test ->
+// branch (the first device build: 3 000 cycles per draw); a draw out of the FIFO is an LDS read.  The FIFO is topped up where the wave
+// is converged -- GenL calls topup() at the head of every loop that draws -- with all of a lane's loads in flight together; a draw that
+// finds it empty all the same (a long placement loop) refills it by itself.  `p` = position, relative to the latest generation's start, of
+// the next word to FETCH; the consumer is avail() words behind.
+BB_COLD_FN void lane_twist_alone(uint32_t* mt, uint32_t* tt) {
+    // A fetch past the end of the latest generation INSIDE an attempt (it consumed more than the 624 draws the wave guarantees at its top):
+    // this one lane regenerates its env's state by itself -- the textbook in-place recurrence, then the tempered copy into the other half.
+    for (int k = 0; k < MT_N; ++k) {
+        int m = k + 397; if (m >= MT_N) m -= MT_N;
+        mt[k] = mt[m] ^ mt_mix(mt[k], mt[k + 1 < MT_N ? k + 1 : 0]);
+    }
+    for (int k = 0; k < MT_N; ++k) tt[k] = mt_temper(mt[k]);
+}
+constexpr int LANE_FIFO = LANE_FIFO_WORDS;   // words (a power of two)
+constexpr int LANE_FIFO_LOW = 8;     // topup() fills when fewer are left
+struct LaneFill { int p, par; uint32_t wr; };
+// Fill the FIFO as far as the generation in hand reaches (never across a twist, never across the seam between the two halves: the next
+// call continues).  Only when it is EMPTY and the latest generation is used up does the lane twist, alone.  Out of line: one copy per
+// kernel, called from the draw's slow path and from topup().
+template <class Mem>
+BB_COLD LaneFill lane_fill(Mem m, uint32_t* mts_env, uint32_t* mtt_env, int p, int par, uint32_t rd, uint32_t wr, int fifo0) {
+    if (p >= MT_N && rd == wr) {
+        lane_twist_alone(mts_env, mtt_env + (par ^ 1) * MT_N);
+        par ^= 1;
+        p = 0;
+    }
+    const int room = LANE_FIFO - (int)(wr - rd);
+    const int left = p < 0 ? -p : MT_N - p;
+    const int n = room < left ? room : left;
+    const uint32_t* src = mtt_env + (p < 0 ? (par ^ 1) * MT_N + MT_N + p : par * MT_N + p);
+    uint32_t v[LANE_FIFO];
+#pragma unroll
+    for (int j = 0; j < LANE_FIFO; ++j) v[j] = j < n ? src[j] : 0u;          // (all loads in flight before the first store)
+#pragma unroll
+    for (int j = 0; j < LANE_FIFO; ++j) if (j < n) m.st(fifo0 + (int)((wr + (uint32_t)j) & (LANE_FIFO - 1)), v[j]);
+    LaneFill r; r.p = p + n; r.par = par; r.wr = wr + (uint32_t)n;
+    return r;
+}
+template <class Mem>
+struct LaneRng {
+    uint32_t* mts_env;
+    uint32_t* mtt_env;               // [2][MT_N]
+    int p, par;
+    uint32_t rd, wr;
+    int fifo0;                       // the FIFO's first word in the lane's words (lane_layout)
+    BB_HD Mem& self() { return *static_cast<Mem*>(this); }
+    BB_HD int avail() const { return (int)(wr - rd); }
+    BB_HD int position() const { return p - avail(); }          // the consumer's: what goes back to mtis
+    BB_HD void start(int pos, int par_) { p = pos; par = par_; rd = wr = 0; }
+    BB_HD void twisted() { p -= MT_N; par ^= 1; }               // the wave twisted this lane's env (k_pregen_lane): same words, one generation back
+    BB_HD void refill() {
+        const LaneFill r = lane_fill(self(), mts_env, mtt_env, p, par, rd, wr, fifo0);
+        p = r.p; par = r.par; wr = r.wr;
+    }
+    BB_HD uint32_t next_u32() {
+        if (rd == wr) refill();
+        const uint32_t y = self().ld(fifo0 + (int)(rd & (LANE_FIFO - 1)));
+        ++rd;
+        return y;
+    }
+    BB_HD bool low() const { return avail() < LANE_FIFO_LOW; }
+    // RandomState.randint's masked rejection: the first of the next outputs with (output & mask) <= rng.  As a loop over next_u32() the wave
+    // runs it for its unluckiest lane (64 lanes, a quarter of the colour draws rejected: four trips where a lane needs 1.3), each trip an LDS
+    // round trip.  Here the next FOUR outputs are read at once and the first acceptable one is picked -- straight-line code; the loop is only
+    // left for a lane whose FIFO holds fewer than four words or whose four candidates were all rejected (a range of 3, 5 or 6 values: 0.4 %).
+    BB_HD uint32_t draw_masked(uint32_t mask, uint32_t rng) {
+        if (mask != rng && avail() >= 4) {       // (a power-of-two range accepts its first output: one plain draw)
+            const uint32_t v0 = self().ld(fifo0 + (int)(rd & (LANE_FIFO - 1))) & mask;
+            const uint32_t v1 = self().ld(fifo0 + (int)((rd + 1) & (LANE_FIFO - 1))) & mask;
+            const uint32_t v2 = self().ld(fifo0 + (int)((rd + 2) & (LANE_FIFO - 1))) & mask;
+            const uint32_t v3 = self().ld(fifo0 + (int)((rd + 3) & (LANE_FIFO - 1))) & mask;
+            if (v0 <= rng) { rd += 1; return v0; }
+            if (v1 <= rng) { rd += 2; return v1; }
+            if (v2 <= rng) { rd += 3; return v2; }
+            if (v3 <= rng) { rd += 4; return v3; }
+            rd += 4;
+        }
+        uint32_t v;
+        do { v = next_u32() & mask; } while (v > rng);
+        return v;
+    }
+};
 
 // The record template of a level kind: what every level of the kind has in common -- wall margin, wall lines, empty cells, id plane
 // (1 on walls), empty tables (contents NONE8), zeroed program -- rec_bytes, followed by the 64-byte C plane of a small single room
@@ -98,7 +190,8 @@ inline void lane_build_template(const LevelCfg& c, uint8_t* t) {
         for (int x = 0; x < 8; ++x) p[8 * y + x] = (x < c.W && y < c.H) ? t[e_index(c, x, y)] : (uint8_t)E_WALL;
 }
 
-// M contract: ld(word) / st(word, value) on the lane's word array (lane_layout), next_u32() = the env's next MT19937 output.
+// M contract: ld(word) / st(word, value) on the lane's word array (lane_layout), next_u32() = the env's next MT19937 output, topup() =
+// "the wave is converged here and about to draw" (a hint: the device tops the lanes' draw FIFOs up, the host does nothing).
 template <class M>
 struct GenL {
     M& m;
@@ -144,9 +237,7 @@ struct GenL {
         const uint32_t rng = (uint32_t)(hi - lo - 1);
         if (rng == 0) return lo;
         const uint32_t mask = 0xFFFFFFFFu >> __builtin_clz(rng);
-        uint32_t v;
-        do { v = next_u32() & mask; } while (v > rng);
-        return lo + (int)v;
+        return lo + (int)m.draw_masked(mask, rng);
     }
     BB_HD bool rand_bool() { return rand_int(0, 2) == 0; }
     BB_HD double rand_float01() {
@@ -217,6 +308,7 @@ struct GenL {
         for (;;) {
             if (tries > 1000) return false;
             ++tries;
+            if ((tries & 3) == 0) m.topup();
             const int x = rand_int(tx, xh);
             const int y = rand_int(ty, yh);
             if (occupied(x, y)) continue;
@@ -252,6 +344,9 @@ struct GenL {
         doors |= 1ull << (16 * ((k + 2) & 3) + neighbor(r, k));
         return id;
     }
+    // RoomGrid.place_agent: a room, then poses (place_obj + a direction) until the cell in front is empty or a wall.  The reference nests the
+    // placement's rejection loop inside the pose loop; here ONE loop makes one placement try per trip -- the lanes of a wave are at different
+    // poses and tries, and a nested loop would run every inner loop for its unluckiest lane.  Same draws in the same order for every lane.
     BB_HD bool place_agent(int room = -1) {
         int r = room;
         if (r < 0) {
@@ -259,16 +354,26 @@ struct GenL {
             const int j = rand_int(0, rows);
             r = j * cols + i;
         }
-        for (int pose_tries = 0; pose_tries <= 1000; ++pose_tries) {     // (termination guard: bbai_gen.hpp place_agent)
-            agent_set = false;
-            int x, y;
-            if (!place_pos(r, false, x, y)) return false;
+        int ri, rj; room_ij(r, ri, rj);
+        const int tx = ri * (S - 1), ty = rj * (S - 1);
+        const int xh = tx + S < cfg.W ? tx + S : cfg.W, yh = ty + S < cfg.H ? ty + S : cfg.H;
+        int pose_tries = 0, tries = 0;
+        agent_set = false;
+        for (;;) {
+            m.topup();
+            if (tries > 1000) return false;      // place_obj's RecursionError
+            ++tries;
+            const int x = rand_int(tx, xh);
+            const int y = rand_int(ty, yh);
+            if (occupied(x, y)) continue;
             ax = x; ay = y; agent_set = true;
             adir = rand_int(0, 4);
             const int fx = ax + (adir == 0) - (adir == 2), fy = ay + (adir == 1) - (adir == 3);
             if (!obj_at(fx, fy)) return true;            // the front cell is empty or a wall
+            if (++pose_tries > 1000) return false;       // (termination guard: bbai_gen.hpp place_agent)
+            agent_set = false;
+            tries = 0;
         }
-        return false;
     }
     BB_HD bool connect_all() {
         const int start = room_of(ax, ay);
@@ -279,6 +384,7 @@ struct GenL {
         for (;;) {
             if (itrs > 5000) return false;
             ++itrs;
+            m.topup();
             if (grew) {
                 const uint32_t d0 = (uint32_t)doors & 0x1FFu, d1 = (uint32_t)(doors >> 16) & 0x1FFu;
                 const uint32_t d2 = (uint32_t)(doors >> 32) & 0x1FFu, d3 = (uint32_t)(doors >> 48) & 0x1FFu;
@@ -301,16 +407,39 @@ struct GenL {
             grew = true;
         }
     }
+    // RoomGrid.add_distractors(i=None, j=None): look, room, then place_obj's rejection loop -- as ONE loop, one placement try per trip
+    // (see place_agent).
     BB_HD bool add_distractors(int num, bool all_unique) {
-        int count = 0;
+        int count = 0, tries = 0, color = 0, type = 0, tx = 0, ty = 0, xh = 0, yh = 0;
+        bool fresh = true;
         while (count < num) {
-            const int color = rand_color();
-            const int type = T_KEY + rand_int(0, 3);
-            if (all_unique && (seen >> ((type - T_KEY) * 6 + color) & 1u)) continue;
-            const int ri = rand_int(0, cols);
-            const int rj = rand_int(0, rows);
-            if (add_object(rj * cols + ri, type, color) < 0) return false;
+            m.topup();
+            if (fresh) {
+                color = rand_color();
+                type = T_KEY + rand_int(0, 3);
+                if (all_unique && (seen >> ((type - T_KEY) * 6 + color) & 1u)) continue;
+                const int ri = rand_int(0, cols);
+                const int rj = rand_int(0, rows);
+                tx = ri * (S - 1); ty = rj * (S - 1);
+                xh = tx + S < cfg.W ? tx + S : cfg.W; yh = ty + S < cfg.H ? ty + S : cfg.H;
+                tries = 0;
+                fresh = false;
+            }
+            if (tries > 1000) return false;
+            ++tries;
+            const int x = rand_int(tx, xh);
+            const int y = rand_int(ty, yh);
+            if (occupied(x, y)) continue;
+            if (agent_set && x == ax && y == ay) continue;
+            if ((x > ax ? x - ax : ax - x) + (y > ay ? y - ay : ay - y) < 2) continue;
+            if (nobj >= cfg.maxo) return false;
+            const int id = nobj++;
+            const int e = e_make(type, color, 0);
+            m.st(L.obj + id, (uint32_t)e | (uint32_t)x << 8 | (uint32_t)y << 16 | (uint32_t)NONE8 << 24);
+            mark(x, y);
+            note_obj(e);
             ++count;
+            fresh = true;
         }
         return true;
     }
@@ -439,12 +568,15 @@ struct GenL {
         for (;;) {
             if (tries > 100) return false;
             ++tries;
+            m.topup();
             const int cv = rand_int(0, 7);
             const int color = cv == 0 ? 7 : color_name_to_idx(cv - 1);
             const int type = types_mode == 0 ? T_BOX - rand_int(0, 4) : types_mode == 1 ? T_BOX - rand_int(0, 3) : T_DOOR;
             int loc = LOC_NONE;
             if (cfg.locations && rand_bool()) loc = 1 + rand_int(0, 4);
             const uint64_t mm = find_matching(type, color, loc);
+            BBAI_GENL_TRACE(m, 40, cv | type << 8 | loc << 16);
+            BBAI_GENL_TRACE(m, 41, (int)(uint32_t)mm);
             if (mm == 0) continue;
             if (!cfg.implicit_unlock && last_locked >= 0) {
                 int li, lj; room_ij(last_locked, li, lj);
@@ -460,11 +592,13 @@ struct GenL {
             }
             p_set(leaf, slot, mm);
             p_desc(leaf, slot, type, color, loc, __builtin_popcountll(mm));
+            BBAI_GENL_TRACE(m, 10 + leaf * 2 + slot, (int)(uint32_t)mm);
             return true;
         }
     }
     BB_HD bool rand_action(int leaf) {
         const int a = cfg.action_kinds[rand_int(0, cfg.n_action_kinds)];
+        BBAI_GENL_TRACE(m, 20 + leaf, a);
         if (a == AK_GOTO) { p_kind(leaf, L_GOTO); return rand_obj(0, leaf, 0); }
         if (a == AK_PICKUP) { p_kind(leaf, L_PICKUP); return rand_obj(1, leaf, 0); }
         if (a == AK_OPEN) { p_kind(leaf, L_OPEN); return rand_obj(2, leaf, 0); }
@@ -553,15 +687,21 @@ struct GenL {
                 break;
             }
         }
+        BBAI_GENL_TRACE(m, 1, nobj);
         if (!connect_all()) return false;
+        BBAI_GENL_TRACE(m, 2, nobj);
         if (!add_distractors(cfg.num_dists, false)) return false;
+        BBAI_GENL_TRACE(m, 3, nobj);
         for (;;) {
             if (!place_agent()) return false;
             if (room_of(ax, ay) == locked_room) continue;
             break;
         }
+        BBAI_GENL_TRACE(m, 4, ax | ay << 8 | adir << 16);
         if (!cfg.unblocking && !objs_reachable()) return false;
-        return rand_instr();
+        const bool ri = rand_instr();
+        BBAI_GENL_TRACE(m, 5, ri);
+        return ri;
     }
 
     BB_HD void set_desc(int leaf, int slot, int o) {
@@ -630,11 +770,14 @@ struct GenL {
     // ONE pass of the rejection loop of RoomGridLevel._gen_grid
     template <int KIND>
     BB_HD bool attempt() {
+        m.topup();
         build_rooms();
         bool ok;
         if constexpr (KIND == K_LEVELGEN) ok = mission_levelgen();
         else ok = mission_goto();
-        return ok && validate();
+        const bool v = ok && validate();
+        BBAI_GENL_TRACE(m, 30, v);
+        return v;
     }
     BB_HD int max_steps() const {
         int navs = 0;

@@ -22,9 +22,11 @@
 #if defined(__HIPCC__)
 #define BB_HD __host__ __device__ __forceinline__
 #define BB_COLD __host__ __device__ __attribute__((noinline))      // rare and large: ONE copy per kernel instead of one per call site
+#define BB_COLD_FN inline __host__ __device__ __attribute__((noinline))     // ... for a plain (non-template) function in a header
 #else
 #define BB_HD inline
 #define BB_COLD inline
+#define BB_COLD_FN inline
 #endif
 
 namespace bbai {

@@ -225,7 +225,10 @@ BB_HD void cpl_from_record(const LevelCfg& c, const uint8_t* rec, uint8_t* row) 
 // Grid.encode of the masked cells: a dword of four appearance bytes e0..e3 becomes the 12 encoding bytes
 // t0 c0 s0 t1 | c1 s1 t2 c2 | s2 t3 c3 s3 (type = e & 7, colour = (e >> 3) & 7, state = e >> 6) with three field extractions on
 // the whole dword and six byte permutes -- 9 instructions per four cells.
-BB_HD void encode_cells(const uint32_t* cp, RowPacker o) {
+template <class Sink> BB_HD void encode_cells_to(const uint32_t* cp, Sink o);
+BB_HD void encode_cells(const uint32_t* cp, RowPacker o) { encode_cells_to(cp, o); }
+// (Sink: put(j, dword j of the 37) in order, then finish() -- RowPacker for k_step's LDS rows, a plain store for the lane generator's first observation)
+template <class Sink> BB_HD void encode_cells_to(const uint32_t* cp, Sink o) {
 #pragma unroll
     for (int k = 0; k < 13; ++k) {
         const uint32_t x = cp[k];

@@ -264,6 +264,12 @@ int bbai_get_done_actions(bbai_env* env);
  *                       launches); a stream that fails runs under the strict rule.  0 = no probe, 2 = every probe fails (tests).  Setting
  *                       it forgets the verdicts so far
  *   "pregen_per_group"  single-room levels: list entries per working lane group of a refill launch (BBAI_PREGEN_PER_GROUP, default 12)
+ *   "pregen_lane"       which kernel generates the look-ahead levels (results identical): 1 = k_pregen_lane, one lane per level (bit boards and an
+ *                       object table instead of planes; every LevelGen parameterisation and the single-instruction levels without a lock-first
+ *                       prologue; default for the single rooms), 0 = k_pregen, one lane group per level (every kind; default elsewhere);
+ *                       BBAI_PREGEN_LANE at bbai_create.  Setting it converts the handle's MT19937 states between the two kernels' forms.
+ *                       BBAI_ERR_ARG when 1 is asked of a kind the lane generator does not cover
+ *   "lane_blocks"       upper bound on k_pregen_lane's waves per launch (BBAI_LANE_BLOCKS, default 16 384)
  *   "gate_fault_inject" tests: raise (1) / clear (0) the sticky word a timed-out window gate leaves behind
  *   "bot_group"         the expert's kernel (bbai_bot_act / bbai_bot_rollout): 0 (default) = one lane per env (k_bot), 16 = one 16-lane
  *                       group per env with the first search in LDS (k_botg: same decisions, measured ~2 x slower -- an experiment

@@ -79,6 +79,8 @@ struct HostLaneMem {
         if (mti >= MT_N) { mt_twist(HostCtx(), mt); mti = 0; }
         return mt_temper(mt[mti++]);
     }
+    uint32_t draw_masked(uint32_t mask, uint32_t rng) { uint32_t v; do { v = next_u32() & mask; } while (v > rng); return v; }
+    void topup() {}
 };
 int hs_generate_lane(const LevelCfg* cfg, uint32_t* mt, int32_t* mti, uint8_t* rec, Hot* hot) {
     if (!lane_gen_ok(*cfg)) return -1;
@@ -96,6 +98,69 @@ int hs_generate_lane(const LevelCfg* cfg, uint32_t* mt, int32_t* mti, uint8_t* r
     }
     *mti = mem.mti;
     memset(rec, 0xEE, cfg->rec_bytes);           // (the record is written completely)
+    alignas(16) static thread_local uint8_t arec[4096];
+    g.write_record(arec, tmpl);
+    memcpy(rec, arec, cfg->rec_bytes);
+    Hot h;
+    memset(&h, 0, sizeof(h));
+    h.ax = g.ax; h.ay = g.ay; h.dir = g.adir; h.carry = NONE8;
+    h.step = 0; h.max_steps = (uint16_t)g.max_steps();
+    h.pre4 = 0xFFFFFFFFu;
+    h.last_locked = g.last_locked < 0 ? NONE8 : (uint8_t)g.last_locked;
+    *hot = h;
+    return g.nobj;
+}
+// ... and with the DEVICE's RNG plumbing emulated: the env's stream as two tempered generations + a signed position (LaneRng), the
+// cooperative twist at the top of every attempt (k_pregen_lane: every lane whose position is >= 0), the lone twist inside a draw.
+// State in: canonical (mt, mti) ; out: canonical again (what k_mt_canon makes of it), so that it compares with hs_generate.
+struct HostLaneMem2 : LaneRng<HostLaneMem2> {
+    uint32_t* w;                                 // (a pointer, as on the device: lane_fill works on a COPY of the policy object)
+    uint32_t ld(int k) const { return w[k]; }
+    void st(int k, uint32_t v) { w[k] = v; }
+    void topup() { if (low()) refill(); }
+};
+// `st` = the env's persistent device-side RNG state between calls: [2 * MT_N] tempered halves, then par, then a "valid" word (0: build it
+// from the canonical (mt, *mti), as k_mt_sync does after a seed / import).  *mti is the SIGNED position on the way out unless `canon`.
+int hs_generate_lane2(const LevelCfg* cfg, uint32_t* mt, int32_t* mti, uint8_t* rec, Hot* hot, int32_t* lone_twists, uint32_t* st, int canon) {
+    if (!lane_gen_ok(*cfg)) return -1;
+    static thread_local HostLaneMem2 mem;
+    static thread_local uint32_t words[160];
+    uint32_t* mtt = st;
+    mem.w = words;
+    memset((void*)words, 0xA5, sizeof(words));
+    if (!st[2 * MT_N + 1]) {
+        for (int k = 0; k < MT_N; ++k) { mtt[k] = mt_temper(mt[k]); mtt[MT_N + k] = 0xDEADBEEFu; }       // k_mt_sync
+        st[2 * MT_N] = 0; st[2 * MT_N + 1] = 1;
+    }
+    mem.mts_env = mt; mem.mtt_env = mtt; mem.fifo0 = lane_layout(*cfg).fifo; mem.start(*mti, (int)st[2 * MT_N]);
+    static thread_local uint8_t tmpl[4096];
+    lane_build_template(*cfg, tmpl);
+    int last_locked = hot->last_locked == NONE8 ? -1 : hot->last_locked;
+    GenL<HostLaneMem2> g(mem, *cfg, last_locked);
+    int coop = 0, total = 0;
+    for (int attempts = 0;; ++attempts) {
+        if (attempts >= Gen<HostCtx>::MAX_ATTEMPTS) return -2;
+        if (mem.position() >= 0) {               // the wave's twist of this lane's env
+            mt_twist(HostCtx(), mt);
+            for (int k = 0; k < MT_N; ++k) mtt[(mem.par ^ 1) * MT_N + k] = mt_temper(mt[k]);
+            mem.twisted(); ++coop;
+        }
+        const int p0 = mem.position(), q0 = mem.par;
+        bool ok = cfg->kind == K_LEVELGEN ? g.attempt<K_LEVELGEN>() : g.attempt<K_GOTO>();
+        (void)p0; if (mem.par != q0) ++total;
+        if (ok) break;
+    }
+    if (lone_twists) *lone_twists = total;
+    // canonical form back (k_mt_canon)
+    int pos = mem.position();
+    if (canon && pos < 0) {
+        const uint32_t* prev = mtt + (mem.par ^ 1) * MT_N;
+        for (int k = 0; k < MT_N; ++k) mt[k] = mt_untemper(prev[k]);
+        pos += MT_N;
+        mem.par ^= 1;
+    }
+    *mti = pos;
+    st[2 * MT_N] = (uint32_t)mem.par;
     alignas(16) static thread_local uint8_t arec[4096];
     g.write_record(arec, tmpl);
     memcpy(rec, arec, cfg->rec_bytes);

@@ -23,6 +23,7 @@ def lib():
         L.hs_seed.argtypes = [ctypes.c_uint64, P]
         L.hs_generate.argtypes = [P, P, P, P, P]
         L.hs_generate_lane.argtypes = [P, P, P, P, P]
+        L.hs_generate_lane2.argtypes = [P, P, P, P, P, P, P, ctypes.c_int]
         L.hs_untemper.argtypes = [ctypes.c_uint32]
         L.hs_untemper.restype = ctypes.c_uint32
         L.hs_temper.argtypes = [ctypes.c_uint32]

@@ -31,7 +31,7 @@ for level, n, b in jobs:
         torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t0)
     levels = n * 2 * b
-    print(json.dumps({"level": level, "envs": n, "levels": levels, "pregen_group": int(os.environ.get("BBAI_PREGEN_GROUP", "32")),
+    print(json.dumps({"level": level, "envs": n, "levels": levels, "pregen_group": int(os.environ.get("BBAI_PREGEN_GROUP", "32")), "pregen_lane": env.get_option("pregen_lane"),
                       "seconds": best, "levels_per_s": levels / best, "ns_per_level": best / levels * 1e9,
                       "generator_failures": env.generator_failures()}), flush=True)
     env.close()

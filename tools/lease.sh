@@ -187,6 +187,12 @@ genrate() {          # bulk level-generation rate (bbai_seed's first fill) per g
         BBAI_PREGEN_GROUP=$g timeout 300 python $REPO/tools/gen_rate.py 2>> $OUT/gen_rate.err | tee -a $OUT/gen_rate_by_group_width.jsonl
     done
 }
+genlane() {          # bulk level-generation rate, lane-group kernel (BBAI_PREGEN_LANE=0) against lane = level (=1): genlane[:<gen_rate.py args>]
+    cd /tmp
+    for l in 0 1; do
+        BBAI_PREGEN_LANE=$l timeout 300 python $REPO/tools/gen_rate.py ${@} 2>> $OUT/gen_rate.err | tee -a $OUT/gen_rate_lane_vs_group.jsonl
+    done
+}
 genpmc() {           # instruction counters of the level generator's bulk fill (tools/gen_rate.py): VALU / SALU / LDS instructions and cycles per level
     cd /tmp
     for pass in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
