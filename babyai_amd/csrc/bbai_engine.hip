@@ -150,6 +150,7 @@ struct bbai_env {
     int pregen_min;       // BBAI_PREGEN_MIN / option "pregen_min": single-room levels: lane groups that work on a refill at least (k_pregen: entries / 32 otherwise); 0 = the whole grid, as mazes always get
     int pregen_group;     // BBAI_PREGEN_GROUP: lanes per env in k_pregen: 32 (default: two envs per wave), 16 or 64
     // the lane = level generator (bbai_genl.hpp, k_pregen_lane): every LevelGen parameterisation and the single-instruction levels without a lock-first prologue
+    unsigned long long* tap_mask; uint32_t* tap_rank0; int32_t* tap_perm; int64_t* tap_ids; int64_t tap_count;     // bbai_step_tap_set: the envs bbai_step_tapped logs
     uint32_t* mtt;        // [n][2][MT_N] tempered outputs of the latest and the previous MT19937 generation of every env (NULL: kind not covered)
     uint8_t* mtpar;       // [n] which half holds the latest generation
     uint8_t* lane_tmpl;   // the kind's record template + C plane (lane_build_template)
@@ -613,6 +614,13 @@ __device__ __forceinline__ void advance_finish(const LevelCfg& c, int64_t n, int
 // FUSE: a wave whose envs finished consumes their look-ahead slots ITSELF (consume_env for every set bit of the wave's ballot,
 // the new episode's first observation straight into the block's LDS rows), instead of listing them for a k_consume launch.
 // `fuse` carries what k_consume's arguments carried.
+// The step's own tap (bbai_step_tapped): the listed envs' outputs of THIS step into caller-owned log rows, written by the stepping lanes
+// themselves -- what a bbai_tap_ids launch behind the step would copy, without the launch (k_tap is 3 us + a dependent-launch gap: a quarter
+// of a 65 536-env step).  mask[block] bit l = env 64 block + l is listed; its log row = perm[rank0[block] + listed envs below it in the block].
+struct TapArgs {
+    const unsigned long long* mask; const uint32_t* rank0; const int32_t* perm;
+    uint8_t* image_out; uint8_t* dir_out; double* rew_out; uint8_t* done_out;
+};
 struct FuseArgs {
     uint8_t* next_recs; const Hot* next_hots; const uint8_t* next_obs; int depth;
     uint8_t* pending; uint8_t* first_slot; uint32_t* win_meta; unsigned long long* totals;
@@ -630,7 +638,7 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
                                                      uint8_t* __restrict__ lsm_arr /* NULL, or the done-action mode's per-env bits */,
                                                      int enum_done /* done-action mode: this step's `done` actions are the enum member (bbai_step.hpp verify_side) */,
                                                      FuseArgs fuse, int64_t block0 /* first 64-env block of this launch (bbai_step_render steps the batch in two halves) */,
-                                                     uint8_t* __restrict__ cplane /* CP: [n][cpl_bytes] */) {
+                                                     uint8_t* __restrict__ cplane /* CP: [n][cpl_bytes] */, TapArgs tap /* mask == NULL: none */) {
     static_assert(!CP || (FUSE == 3 && !VP), "the C plane belongs to the in-place layout");
     // the block's observation rows at the OUTPUT pitch of 147 bytes (bbai_step.hpp RowPacker), 16 bytes of front padding
     __shared__ __attribute__((aligned(16))) uint8_t s_obs[ROWS_FRONT + STEP_BLOCK * OBS_BYTES + 16];
@@ -852,6 +860,22 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
             done_bytes = ndw << 2;
         }
         for (int b = done_bytes + lane; b < total; b += STEP_BLOCK) out[b] = s_rows[b];
+    }
+    // the step's own tap: a listed env's row out of LDS (for an env that finished: already its new episode's first observation), its direction /
+    // reward / done as this wave stored them (agent-scope loads: the direction of a consumed env was stored by another lane)
+    if (tap.mask) {
+        const int64_t blk = (int64_t)blockIdx.x + block0;
+        const unsigned long long tm = tap.mask[blk];
+        if (active && (tm >> lane & 1ull)) {
+            const int64_t row = (int64_t)tap.perm[tap.rank0[blk] + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull))];
+            uint8_t* o = tap.image_out + row * OBS_BYTES;
+            const uint8_t* srow = s_rows + lane * OBS_BYTES;
+            for (int b = 0; b < OBS_BYTES; ++b) o[b] = srow[b];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            tap.dir_out[row] = __hip_atomic_load(dirs + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tap.done_out[row] = __hip_atomic_load(dones + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tap.rew_out[row] = __hip_atomic_load(rewards64 + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -1965,7 +1989,7 @@ void bbai_destroy(bbai_env* e) {
     void* bot_ptrs[] = {e->bot_state, e->bot_work, e->bot_stats, e->bot_rows};
     for (void* p : bot_ptrs) if (p) (void)hipFree(p);
     void* ptrs[] = {e->rec, e->hot, e->stale, e->mt, e->mti, e->vhead, e->vset, e->next_rec, e->next_hot, e->pending, e->first_slot, e->win_meta, e->totals, e->flow, e->gen_list, e->gen_count, e->reset_list, e->counters,
-                    e->atlas, e->lut, e->vplane, e->fcache, e->lsm, e->render_tickets, e->reset_slot, e->next_obs, e->cplane, e->mtt, e->mtpar, e->lane_tmpl};
+                    e->atlas, e->lut, e->vplane, e->fcache, e->lsm, e->render_tickets, e->reset_slot, e->next_obs, e->cplane, e->mtt, e->mtpar, e->lane_tmpl, e->tap_mask, e->tap_rank0, e->tap_perm, e->tap_ids};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (e->host_flags) (void)hipHostFree((void*)e->host_flags);
     delete e;
@@ -2245,7 +2269,7 @@ static bool use_fused_consume(const bbai_env* e) {
 //   step_prepare  the window gate (fused: the slots this step's waves consume must be there) + what the kernel needs to know about the window
 //   step_kernel   k_step over the 64-env blocks [block0, block0 + nblocks) on stream `ks`
 //   step_finish   k_consume (unfused) / mission tokens / the window's close + refill -- on the caller's stream, behind EVERY k_step of the step
-struct StepPlan { FuseArgs fa; bool fused; uint32_t* counter; };
+struct StepPlan { FuseArgs fa; bool fused; uint32_t* counter; TapArgs tap = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; };
 static int step_prepare(bbai_env* e, int auto_reset, hipStream_t s, StepPlan& p) {
     p.fused = auto_reset && (e->inplace || use_fused_consume(e));
     p.counter = e->counters + 16 * e->step_parity;
@@ -2273,9 +2297,9 @@ static int step_kernel(bbai_env* e, const StepPlan& p, const uint8_t* actions, u
                        uint8_t* dones, int auto_reset, hipStream_t ks, int enum_done, int64_t block0, int64_t nblocks) {
     ProfScope prof_(e, 0, ks);
 #define STEP_LAUNCH(VV, FF) hipLaunchKernelGGL((k_step<VV, FF>), dim3((unsigned)nblocks), dim3(STEP_BLOCK), 0, ks, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, \
-                                           image, dirs, rewards, rewards64, dones, auto_reset, e->reset_list, e->reset_slot, p.counter, e->step_prio, e->vplane, e->fcache, e->lsm, enum_done, p.fa, block0, e->cplane)
+                                           image, dirs, rewards, rewards64, dones, auto_reset, e->reset_list, e->reset_slot, p.counter, e->step_prio, e->vplane, e->fcache, e->lsm, enum_done, p.fa, block0, e->cplane, p.tap)
     if (e->inplace && e->cplane) hipLaunchKernelGGL((k_step<false, 3, true>), dim3((unsigned)nblocks), dim3(STEP_BLOCK), 0, ks, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions,
-                                                    image, dirs, rewards, rewards64, dones, auto_reset, e->reset_list, e->reset_slot, p.counter, e->step_prio, e->vplane, e->fcache, e->lsm, enum_done, p.fa, block0, e->cplane);
+                                                    image, dirs, rewards, rewards64, dones, auto_reset, e->reset_list, e->reset_slot, p.counter, e->step_prio, e->vplane, e->fcache, e->lsm, enum_done, p.fa, block0, e->cplane, p.tap);
     else if (e->inplace) STEP_LAUNCH(false, 3);
     else if (p.fused) { if (e->vplane) STEP_LAUNCH(true, 1); else STEP_LAUNCH(false, 1); }
     else { if (e->vplane) STEP_LAUNCH(true, 0); else STEP_LAUNCH(false, 0); }
@@ -2289,12 +2313,23 @@ static int step_finish(bbai_env* e, const StepPlan& p, uint8_t* image, uint8_t* 
     return BBAI_OK;
 }
 static int64_t step_blocks(const bbai_env* e) { return (e->n + STEP_BLOCK - 1) / STEP_BLOCK; }
+struct TapRows { uint8_t* image_out; uint8_t* dir_out; double* rew_out; uint8_t* done_out; };
 static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64,
-                       uint8_t* dones, int auto_reset, hipStream_t s, int enum_done) {
+                       uint8_t* dones, int auto_reset, hipStream_t s, int enum_done, const TapRows* rows = nullptr) {
     StepPlan p;
     { int rc = step_prepare(e, auto_reset, s, p); if (rc != BBAI_OK) return rc; }
+    // Inside the stepping waves wherever the step leaves the final outputs behind (fused consume, in-place layout, no auto-reset);
+    // an unfused auto-resetting step writes the new episodes' first observations in k_consume: the tap is then a launch behind it.
+    const bool in_kernel = rows && (p.fused || e->inplace || !auto_reset);
+    if (in_kernel) p.tap = TapArgs{e->tap_mask, e->tap_rank0, e->tap_perm, rows->image_out, rows->dir_out, rows->rew_out, rows->done_out};
     { int rc = step_kernel(e, p, actions, image, dirs, rewards, rewards64, dones, auto_reset, s, enum_done, 0, step_blocks(e)); if (rc != BBAI_OK) return rc; }
-    return step_finish(e, p, image, dirs, dones, auto_reset, s);
+    { int rc = step_finish(e, p, image, dirs, dones, auto_reset, s); if (rc != BBAI_OK) return rc; }
+    if (rows && !in_kernel) {
+        hipLaunchKernelGGL(k_tap, dim3((unsigned)std::min<int64_t>((e->tap_count * OBS_BYTES + 255) / 256, 2048)), dim3(256), 0, s, e->tap_count, (int64_t)0, e->tap_ids, image, dirs,
+                           rewards64, dones, (const uint8_t*)nullptr, rows->image_out, rows->dir_out, rows->rew_out, rows->done_out, (uint8_t*)nullptr);
+        HIP_TRY(hipGetLastError());
+    }
+    return BBAI_OK;
 }
 
 int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64,
@@ -2310,6 +2345,56 @@ int bbai_step(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs
     CallScope call(e, s);
     if (call.rc != BBAI_OK) return call.rc;
     { int rc = step_launch(e, actions, image, dirs, rewards, rewards64, dones, auto_reset, s, e->done_action_enum); if (rc != BBAI_OK) return rc; }
+    return call.leave();
+}
+
+int bbai_step_tap_set(bbai_env* e, const int64_t* ids, int64_t count) {
+    if (!e || count < 0 || (count && !ids)) ARG_FAIL("null handle or id list");
+    ON_DEVICE(e->device);
+    HIP_TRY(hipDeviceSynchronize());
+    void* old[] = {e->tap_mask, e->tap_rank0, e->tap_perm, e->tap_ids};
+    for (void* q : old) if (q) (void)hipFree(q);
+    e->tap_mask = nullptr; e->tap_rank0 = nullptr; e->tap_perm = nullptr; e->tap_ids = nullptr; e->tap_count = 0;
+    if (count == 0) return BBAI_OK;
+    const int64_t nb = (e->n + STEP_BLOCK - 1) / STEP_BLOCK;
+    std::vector<unsigned long long> mask((size_t)nb, 0ull);
+    std::vector<uint32_t> rank0((size_t)nb, 0u);
+    std::vector<int32_t> perm((size_t)count);
+    std::vector<std::pair<int64_t, int32_t>> order((size_t)count);
+    for (int64_t k = 0; k < count; ++k) {
+        if (ids[k] < 0 || ids[k] >= e->n) ARG_FAIL("env id out of range");
+        if (mask[(size_t)(ids[k] / STEP_BLOCK)] >> (ids[k] % STEP_BLOCK) & 1ull) ARG_FAIL("an env is listed twice");
+        mask[(size_t)(ids[k] / STEP_BLOCK)] |= 1ull << (ids[k] % STEP_BLOCK);
+        order[(size_t)k] = {ids[k], (int32_t)k};
+    }
+    std::sort(order.begin(), order.end());
+    for (int64_t k = 0; k < count; ++k) perm[(size_t)k] = order[(size_t)k].second;      // k-th listed env in ascending order -> its log row
+    uint32_t run = 0;
+    for (int64_t b = 0; b < nb; ++b) { rank0[(size_t)b] = run; run += (uint32_t)__builtin_popcountll(mask[(size_t)b]); }
+    HIP_TRY(hipMalloc((void**)&e->tap_mask, (size_t)nb * 8));
+    HIP_TRY(hipMalloc((void**)&e->tap_rank0, (size_t)nb * 4));
+    HIP_TRY(hipMalloc((void**)&e->tap_perm, (size_t)count * 4));
+    HIP_TRY(hipMalloc((void**)&e->tap_ids, (size_t)count * 8));
+    HIP_TRY(hipMemcpy(e->tap_mask, mask.data(), (size_t)nb * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->tap_rank0, rank0.data(), (size_t)nb * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->tap_perm, perm.data(), (size_t)count * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->tap_ids, ids, (size_t)count * 8, hipMemcpyHostToDevice));
+    e->tap_count = count;
+    return BBAI_OK;
+}
+
+int bbai_step_tapped(bbai_env* e, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64, uint8_t* dones,
+                     int auto_reset, uint8_t* image_out, uint8_t* dir_out, double* reward64_out, uint8_t* done_out, void* stream) {
+    if (!e || !actions || !image || !dirs || !rewards || !rewards64 || !dones || !image_out || !dir_out || !reward64_out || !done_out) ARG_FAIL("null handle or buffer");
+    if (!e->tap_count) { snprintf(g_err, sizeof(g_err), "bbai_step_tapped before bbai_step_tap_set"); return BBAI_ERR_STATE; }
+    if (!e->live) { snprintf(g_err, sizeof(g_err), "step before reset"); return BBAI_ERR_STATE; }
+    if (auto_reset && !e->seeded) { snprintf(g_err, sizeof(g_err), "auto-reset step before seed"); return BBAI_ERR_STATE; }
+    ON_DEVICE(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    CallScope call(e, s);
+    if (call.rc != BBAI_OK) return call.rc;
+    const TapRows rows = {image_out, dir_out, reward64_out, done_out};
+    { int rc = step_launch(e, actions, image, dirs, rewards, rewards64, dones, auto_reset, s, e->done_action_enum, &rows); if (rc != BBAI_OK) return rc; }
     return call.leave();
 }
 

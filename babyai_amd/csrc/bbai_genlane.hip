@@ -10,6 +10,7 @@
 // kernel on every covered level).  The rest of the engine keeps the pass.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "bbai_types.hpp"
 #include "bbai_kernels.hpp"
 #include "bbai_gen.hpp"
@@ -48,9 +49,10 @@ __global__ __launch_bounds__(64, 2) void k_pregen_lane(LevelCfg c, int64_t n, ui
                                                         unsigned long long* __restrict__ gen_failures, uint8_t* __restrict__ next_obs,
                                                         const uint8_t* __restrict__ tmpl, int lane_words) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-    // [lane_words][64] the lanes' words | [MT_N + MT_CH] the cooperative twist's state | (OBS) [64][LANE_PL_PITCH] bytes
+    // [lane_words][64] the lanes' words | one area for the cooperative twist's state ([MT_N + MT_CH] words, top of the main loop) AND, (OBS),
+    // the lanes' 8 x 8 planes ([64][LANE_PL_PITCH] bytes, write-out): never live together
     uint32_t* const s_tw = s_dyn + lane_words * 64;
-    uint8_t* const s_pl = (uint8_t*)(s_tw + MT_N + MT_CH);
+    uint8_t* const s_pl = (uint8_t*)s_tw;
     __shared__ uint32_t s_start[SHARDS + 1];
     const int lane = (int)threadIdx.x;
     const GroupCtx<64> wave;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(64, 2) void k_pregen_lane(LevelCfg c, int64_t n, ui
 // host side of the launch (bbai_engine.hip launch_pregen_lane fills the arguments)
 void bbai::bbai_lane_launch(const LaneLaunch& a) {
     const dim3 g(a.blocks), b(64);
-    const size_t lds = ((size_t)a.lane_words * 64 + MT_N + MT_CH) * 4 + (a.next_obs ? 64 * LANE_PL_PITCH : 0);
+    const size_t lds = (size_t)a.lane_words * 64 * 4 + std::max<size_t>((MT_N + MT_CH) * 4, a.next_obs ? 64 * LANE_PL_PITCH : 0);
 #define LANE_LAUNCH(KK, OO) hipLaunchKernelGGL((k_pregen_lane<KK, OO>), g, b, lds, a.stream, a.cfg, a.n, a.next_rec, a.next_hot, a.mt, a.mtt, a.mtpar, a.mti, \
                                               a.gen_list, a.gen_count, a.depth, a.pending, a.first_slot, a.fails, a.next_obs, a.tmpl, a.lane_words)
     if (a.cfg.kind == K_LEVELGEN) { if (a.next_obs) LANE_LAUNCH(K_LEVELGEN, true); else LANE_LAUNCH(K_LEVELGEN, false); }

@@ -67,6 +67,9 @@ def load_library():
     lib.bbai_get_programs.argtypes = [P, I64, I64, P]
     lib.bbai_tap.argtypes = [I64, I64, P, P, P, P, P, P, P, P, P, P, P]
     lib.bbai_tap_ids.argtypes = [I64, I64, P, P, P, P, P, P, P, P, P, P, P, P]
+    if hasattr(lib, "bbai_step_tapped"):
+        lib.bbai_step_tap_set.argtypes = [P, P, I64]
+        lib.bbai_step_tapped.argtypes = [P, P, P, P, P, P, P, I32, P, P, P, P, P]
     lib.bbai_gae.argtypes = [I64, I32, P, P, P, P, P, ctypes.c_double, ctypes.c_double, P, P, P]
     lib.bbai_set_call_events.argtypes = [P, I32]
     lib.bbai_profile.argtypes = [P, I32]
@@ -95,7 +98,7 @@ EXPORTED_SYMBOLS = (
     "bbai_get_programs", "bbai_reset_count", "bbai_generator_failures", "bbai_bot_act", "bbai_bot_stats",
     "bbai_checkpoint_bytes", "bbai_checkpoint_save", "bbai_checkpoint_load", "bbai_profile", "bbai_profile_read", "bbai_gae", "bbai_tap",
     "bbai_tap_ids", "bbai_set_call_events", "bbai_bot_rollout", "bbai_set_done_actions", "bbai_get_done_actions",
-    "bbai_set_option", "bbai_get_option", "bbai_rollout", "bbai_step_render",
+    "bbai_set_option", "bbai_get_option", "bbai_rollout", "bbai_step_render", "bbai_step_tap_set", "bbai_step_tapped",
 )
 
 
@@ -495,6 +498,28 @@ class BatchedBabyAIEnv(object):
             if ids.dtype != self.torch.int64 or ids.device != self.device or ids.numel() != count or not ids.is_contiguous():
                 raise ValueError("ids: contiguous int64[%d] on %s" % (count, self.device))
             _check(self.lib, self.lib.bbai_tap_ids(count, pp, ids.data_ptr(), *src, *dst), "bbai_tap_ids")
+
+    def set_step_tap(self, ids):
+        """The envs step_tapped() logs (include/bbai.h bbai_step_tap_set): any order, no duplicates; log row k = env ids[k].  None / empty clears."""
+        ids = np.ascontiguousarray(np.asarray([] if ids is None else ids, dtype=np.int64))
+        _check(self.lib, self.lib.bbai_step_tap_set(self.handle, ids.ctypes.data if len(ids) else None, len(ids)), "bbai_step_tap_set")
+        self._step_tap = len(ids)
+
+    def step_tapped(self, actions, image_out, dir_out, reward64_out, done_out):
+        """step(actions) + the listed envs' outputs of this step into the given log rows (uint8[count, 7, 7, 3], uint8[count], float64[count],
+        uint8[count] on the device) -- written by the stepping lanes themselves, no launch behind the step (include/bbai.h bbai_step_tapped).
+        `actions`: uint8[num_envs] on the device."""
+        if actions.dtype != self.torch.uint8 or actions.device != self.device or not actions.is_contiguous() or actions.numel() != self.num_envs:
+            raise ValueError("actions: contiguous uint8[%d] on %s" % (self.num_envs, self.device))
+        if int(done_out.shape[0]) != getattr(self, "_step_tap", 0):
+            raise ValueError("log rows for %d envs, set_step_tap() listed %d" % (int(done_out.shape[0]), getattr(self, "_step_tap", 0)))
+        self._actions = actions
+        _check(self.lib, self.lib.bbai_step_tapped(self.handle, actions.data_ptr(), self.image.data_ptr(), self.direction.data_ptr(),
+                                                    self.reward.data_ptr(), self.reward64.data_ptr(), self.done.data_ptr(),
+                                                    1 if self.auto_reset else 0, image_out.data_ptr(), dir_out.data_ptr(),
+                                                    reward64_out.data_ptr(), done_out.data_ptr(), self._stream()), "bbai_step_tapped")
+        self._obs_version += 1
+        return self.reward, self.done
 
     def set_call_events(self, enable=True):
         """Record the handle's completion event at the end of every call, so that a caller may destroy a stream it used

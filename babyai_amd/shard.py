@@ -170,7 +170,7 @@ def gather_to_rank0(tensor, dist, via_all_gather=False):
 
 
 def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None, after_block=None, before_block=None, local_out=None,
-                 barrier_out=None, run_steps=None):
+                 barrier_out=None, run_steps=None, step_fn=None):
     """The measured loop.  `actions`: uint8[warmup + blocks*steps, E] resident on the env's device.  `warmup` untimed
     steps, then `blocks` timed blocks of EXACTLY `steps` steps.  Every block is bracketed by ranks.barrier() (device idle,
     barrier, device idle) on both sides; a rank's clock runs from the end of the opening barrier until ITS OWN device is
@@ -181,7 +181,8 @@ def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None, af
     `after_step(t)` (t = index into `actions`) runs inside the timed region (parity tap, digests), `before_block(i)` /
     `after_block(i)` between blocks (untimed).  `run_steps(t0, k)`, when given, REPLACES the per-step loop and `after_step`: it
     enqueues steps t0 .. t0 + k - 1 (tap included) in one call -- the engine's open-loop rollout entry (include/bbai.h
-    bbai_rollout; bench.py --rollout-entry).  Returns the list of per-block seconds (max over ranks); `local_out`
+    bbai_rollout; bench.py --rollout-entry).  `step_fn(t)`, when given, is called instead of env.step(actions[t]) (the step that logs its
+    own tap rows: include/bbai.h bbai_step_tapped); `after_step` still follows it.  Returns the list of per-block seconds (max over ranks); `local_out`
     (a list) receives this rank's own per-block seconds.  The cyclic garbage collector is off for the length of the loop (as
     `timeit` does): a generation-2 pass between two launches is a multi-millisecond host stall that no kernel caused."""
     import gc
@@ -190,13 +191,14 @@ def timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step=None, af
     gc.collect()
     gc.disable()
     try:
-        return _timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step, after_block, before_block, local_out, barrier_out, run_steps, time)
+        return _timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step, after_block, before_block, local_out, barrier_out, run_steps, time, step_fn)
     finally:
         if gc_was_on:
             gc.enable()
 
 
-def _timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step, after_block, before_block, local_out, barrier_out, run_steps, time):
+def _timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step, after_block, before_block, local_out, barrier_out, run_steps, time, step_fn=None):
+    do_step = step_fn if step_fn is not None else (lambda t: env.step(actions[t]))
     t = 0
     if run_steps is not None:
         if warmup:
@@ -204,7 +206,7 @@ def _timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step, after_
         t = warmup
     else:
         for _ in range(warmup):
-            env.step(actions[t])
+            do_step(t)
             if after_step:
                 after_step(t)
             t += 1
@@ -219,7 +221,7 @@ def _timed_blocks(env, actions, warmup, steps, blocks, ranks, after_step, after_
             t += steps
         else:
             for _ in range(steps):
-                env.step(actions[t])
+                do_step(t)
                 if after_step:
                     after_step(t)
                 t += 1

@@ -438,8 +438,19 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
         if PP1:
             log1["pixels"][0].copy_(env.pixels[log1["ids"][:PP1]])
 
+    # Encoded observations: the step logs its own tap rows (include/bbai.h bbai_step_tapped: the stepping lanes write the listed envs' outputs,
+    # no launch behind the step -- k_tap and its dependent-launch gap were 6 of a 65 536-env step's 21 us).  Pixel batches keep the tap launch
+    # behind the render (BBAI_BENCH_TAP=launch: everywhere, as rounds 1-5 measured).
+    step_tap = (not pixel) and os.environ.get("BBAI_BENCH_TAP", "step") == "step" and hasattr(env.lib, "bbai_step_tapped")
+
+    def step1(t):
+        env.step_tapped(actions1[t], log1["image"][t + 1], log1["direction"][t + 1], log1["reward64"][t], log1["done"][t])
+
+    if step_tap and log1 is not None:
+        env.set_step_tap(ids1)
+
     def after1(t):
-        if log1 is not None:
+        if log1 is not None and not step_tap:
             tap(log1, t + 1, t)
         if digest is not None:
             digest.update(env.image, env.direction, env.reward64, env.done)
@@ -453,7 +464,7 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
         env.rollout(actions1[t0:t0 + k], tap=log1, obs_row0=t0 + 1, row0=t0)
 
     torch.cuda.synchronize()
-    blocks = shard.timed_blocks(env, actions1, W, K, 1, ranks, after1, run_steps=run1 if fast else None)
+    blocks = shard.timed_blocks(env, actions1, W, K, 1, ranks, after1, run_steps=run1 if fast else None, step_fn=step1 if (step_tap and log1 is not None) else None)
     want = int(min(max_blocks, max(0, -(-min_seconds // blocks[0]))))
     want = int(ranks.max(want))
     if want == 1:
@@ -484,8 +495,14 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
         actions2 = actions_torch(args.action_seed, S1, S1 + S2, first, E, dev)
         log2 = make_log(S2, False, ids2, PP2)
 
+        def step2(t):
+            env.step_tapped(actions2[t], log2["image"][t], log2["direction"][t], log2["reward64"][t], log2["done"][t])
+
+        if step_tap and log2 is not None:
+            env.set_step_tap(ids2)
+
         def after2(t):
-            if log2 is not None:
+            if log2 is not None and not step_tap:
                 tap(log2, t, t)
             if digest is not None:
                 digest.update(env.image, env.direction, env.reward64, env.done)
@@ -501,7 +518,7 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
 
         torch.cuda.synchronize()
         all_blocks = shard.timed_blocks(env, actions2, 0, K, want, ranks, after2, before_block=before_block, local_out=local_blocks,
-                                        barrier_out=barrier_s, run_steps=run2 if fast else None)
+                                        barrier_out=barrier_s, run_steps=run2 if fast else None, step_fn=step2 if (step_tap and log2 is not None) else None)
         env.profile_pause()
         blocks = [b for i, b in enumerate(all_blocks) if not is_prof(i)]
         profiled = [b for i, b in enumerate(all_blocks) if is_prof(i)]
@@ -744,7 +761,9 @@ def main():
                    "max_over_median": st["max_over_median"], "value_at_min": K * E * world / bs[0],
                    "value_at_max": K * E * world / bs[-1],
                    "loop": "one bbai_rollout call per block: the engine enqueues K x (step [+ render] + tap)" if (args.rollout_entry and not args.dump_digest) else
-                           "per-step calls from Python: bbai_step (pixel batches: bbai_step_render = the same step + render as one call) + bbai_tap_ids",
+                           ("per-step calls from Python: bbai_step_render (the step + the render as one call) + bbai_tap_ids" if pixel else
+                            "per-step calls from Python: bbai_step_tapped (the step; the parity tap's rows are written by the stepping lanes)" if os.environ.get("BBAI_BENCH_TAP", "step") == "step" else
+                            "per-step calls from Python: bbai_step + bbai_tap_ids"),
                    "clock": "per block: opening barrier -> K steps -> this rank's device idle; the block = max over ranks; the closing barrier "
                             "and the max-reduce run after every rank's clock has stopped (barrier_ms); Python's cyclic garbage collector is off inside the loop (as timeit does)",
                    "barrier_ms": {"median": median(m["barrier_s"]) * 1e3, "max": max(m["barrier_s"]) * 1e3} if m["barrier_s"] else None,

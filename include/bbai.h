@@ -187,6 +187,18 @@ int bbai_tap_ids(int64_t count, int64_t pix_count, const int64_t* ids_dev, const
                  const double* reward64_dev, const uint8_t* done_dev, const uint8_t* pixels_dev, uint8_t* image_out, uint8_t* dir_out,
                  double* reward64_out, uint8_t* done_out, uint8_t* pixels_out, void* stream);
 
+/* A step that logs its own tap rows.  bbai_step_tap_set lists the envs (host array, any order, no duplicates; count 0 clears); then
+ * bbai_step_tapped = bbai_step + "bbai_tap_ids of the listed envs into these rows" (image_out uint8[count][147], dir_out uint8[count],
+ * reward64_out double[count], done_out uint8[count]; log row k = env ids[k]) -- with the rows written by the stepping lanes themselves
+ * wherever the step kernel leaves the final outputs behind (fused consume, in-place layout, auto_reset 0): no launch behind the step.  A
+ * tap launch is 3 us + a dependent-launch gap, a quarter of a 65 536-env step; a logger that follows a few envs through every step
+ * (bench.py's in-run parity check, a monitor) should not cost that.  Unfused auto-resetting steps (option consume_fused 0) get the
+ * launch behind k_consume: same bytes either way (tests/test_gpu_parity.py::test_step_tapped_equals_step_plus_tap).  reward64 must not
+ * be NULL here.  BBAI_ERR_STATE before bbai_step_tap_set. */
+int bbai_step_tap_set(bbai_env* env, const int64_t* ids_host, int64_t count);
+int bbai_step_tapped(bbai_env* env, const uint8_t* actions_dev, uint8_t* image_dev, uint8_t* dir_dev, float* reward_dev, double* reward64_dev,
+                     uint8_t* done_dev, int auto_reset, uint8_t* image_out, uint8_t* dir_out, double* reward64_out, uint8_t* done_out, void* stream);
+
 /* An open-loop rollout: T steps with NO host round trip in between.  actions_dev[T][n_envs] are resident on the device -- the
  * random-action rollouts the reference's own level test plays (babyai/levels/levelgen.py:522-527), a replayed demonstration, a
  * benchmark's pre-drawn action stream.  For t = 0 .. T-1 exactly what a caller's loop would enqueue:

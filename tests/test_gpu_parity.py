@@ -1822,3 +1822,53 @@ def test_rollout_entry_equals_per_step_calls(gpu, level, n, pixel):
     assert a.reset_count() == b.reset_count() and obs["mission"][0] == a.missions()[0]
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level,n,opts", [("GoToLocal", 3000, {}), ("PickupLoc", 700, {}), ("BossLevel", 1500, {}), ("GoTo", 1300, {"consume_fused": 0}),
+                                          ("GoToLocal", 1000, {"auto_reset": False}), ("PutNextS5N2Carrying", 900, {})])
+def test_step_tapped_equals_step_plus_tap(gpu, level, n, opts):
+    """bbai_step_tapped (the stepping lanes write the listed envs' log rows; bench.py's timed loop) against bbai_step + bbai_tap_ids: every
+    logged byte of every step -- through resets (the new episode's first observation is what the row must hold), in both state layouts,
+    with the unfused consume (there the tap stays a launch behind k_consume) and without auto-reset (frozen envs re-emit)."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from babyai_amd.action_stream import actions_torch
+    from babyai_amd.shard import scattered_ids
+    T, P = 90, 96
+    auto = opts.get("auto_reset", True)
+    a = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=21, auto_reset=auto)
+    b = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=21, auto_reset=auto)
+    for env in (a, b):
+        for k, v in opts.items():
+            if k != "auto_reset":
+                env.set_option(k, v)
+        env.reset()
+    acts = actions_torch(5, 0, T, 0, n, gpu)
+    idl = list(scattered_ids(n, P))
+    idl = idl[1::2] + idl[0::2]                # (not ascending: log row k = env ids[k] whatever the order)
+    ids = torch.as_tensor(idl, dtype=torch.int64, device=gpu)
+
+    def mklog():
+        return {"image": torch.zeros((T, P, 7, 7, 3), dtype=torch.uint8, device=gpu), "direction": torch.zeros((T, P), dtype=torch.uint8, device=gpu),
+                "reward64": torch.zeros((T, P), dtype=torch.float64, device=gpu), "done": torch.zeros((T, P), dtype=torch.uint8, device=gpu)}
+
+    la, lb = mklog(), mklog()
+    b.set_step_tap(idl)
+    for t in range(T):
+        a.step(acts[t])
+        a.tap(la["image"][t], la["direction"][t], la["reward64"][t], la["done"][t], None, ids=ids)
+        b.step_tapped(acts[t], lb["image"][t], lb["direction"][t], lb["reward64"][t], lb["done"][t])
+    for k in la:
+        assert torch.equal(la[k], lb[k]), k
+    assert torch.equal(a.image, b.image) and torch.equal(a.direction, b.direction) and torch.equal(a.reward64, b.reward64) and torch.equal(a.done, b.done)
+    assert a.reset_count() == b.reset_count()
+    if auto and level in ("GoToLocal", "PickupLoc"):
+        assert a.reset_count() > n + 100       # (episodes ended under the tap)
+    with pytest.raises(Exception):
+        b.set_step_tap([0, 0])
+    b.set_step_tap(None)
+    with pytest.raises(Exception):
+        b.step_tapped(acts[0], lb["image"][0], lb["direction"][0], lb["reward64"][0], lb["done"][0])
+    a.close()
+    b.close()
