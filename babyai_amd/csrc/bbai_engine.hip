@@ -1923,7 +1923,9 @@ static int create_finish(bbai_env* e) {
         // The look-ahead stream.  (Confining it to a subset of the CUs with a CU mask was measured in round 3 --
         // profiles/r03/pregen_cus_ab.jsonl: 32 / 64 / 96 / 128 CUs change no step time by more than 1 %, and a masked stream is a
         // BLOCKING stream: with a caller on the NULL stream it serialises generation and stepping, 46 -> 72 us per step at
-        // 65 536 GoToLocal envs.  Not kept.)
+        // 65 536 GoToLocal envs.  Not kept.  Round 6 tried again for callers on their own stream: on this pool's runtime
+        // hipExtStreamCreateWithCUMask changes NOTHING -- a bulk fill confined to 32 of 256 CUs runs at the unconfined rate
+        // (profiles/r06/NOTES.md section 6).)
         int lo = 0, hi = 0;     // look-ahead generation should get wave slots as soon as any free up
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         const char* pv = getenv("BBAI_PREGEN_PRIORITY");     // 1 (default): highest priority, 0: default priority
