@@ -164,6 +164,8 @@ struct bbai_env {
     int prof_pos[3];
     double prof_ms[3];
     int64_t prof_n[3];
+    int64_t prof_step_ticks;   // steps the bracketed k_step launches took (a bbai_rollout launch takes up to a window's worth): option "profile_step_ticks"
+    int rollout_multi;    // BBAI_ROLLOUT_MULTI / option "rollout_multi": bbai_rollout steps up to a look-ahead window per k_step launch (1, default) or one step per launch (0)
     int64_t tick;         // number of consume_and_refill calls so far
     uint8_t* vplane;      // [n][v_bytes] window plane (bbai_types.hpp): one 128-byte line per window-origin class; BBAI_VPLANE=0: none
     uint16_t* fcache;     // [n] appearance of the front cell (low byte) and of the carried object (high byte) after the last step
@@ -218,8 +220,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 //     UNDER the following windows instead of stopping the step stream, as long as no env finishes B more times meanwhile.
 //   * NWIN window buffers (pending / first_slot / meta) so that up to B + 1 refills can be outstanding.
 // tests/test_ring_protocol.py models the rule (sufficient, and the ring depths stay tight).
-__device__ __forceinline__ void count_resets(unsigned long long* __restrict__ totals, unsigned int k) {
-    atomicAdd(&totals[(blockIdx.x & (SHARDS - 1)) * SHARD_U64], (unsigned long long)k);        // (result unused: a no-return atomic)
+__device__ __forceinline__ void count_resets(unsigned long long* __restrict__ totals, unsigned int k, unsigned int blk) {
+    atomicAdd(&totals[(blk & (SHARDS - 1)) * SHARD_U64], (unsigned long long)k);        // (result unused: a no-return atomic)
 }
 // envs (= threads) per k_step block.  The kernel is bound by its chain of dependent memory round trips, not by bytes or
 // instructions, and a block is what waits at its barriers for its slowest wave: ONE wave per block (64) measured against
@@ -620,14 +622,16 @@ __device__ __forceinline__ void advance_finish(const LevelCfg& c, int64_t n, int
 struct TapArgs {
     const unsigned long long* mask; const uint32_t* rank0; const int32_t* perm;
     uint8_t* image_out; uint8_t* dir_out; double* rew_out; uint8_t* done_out;
+    int64_t count;        // listed envs = log rows per tick (a launch of several ticks moves on by one row set per tick)
 };
 struct FuseArgs {
     uint8_t* next_recs; const Hot* next_hots; const uint8_t* next_obs; int depth;
     uint8_t* pending; uint8_t* first_slot; uint32_t* win_meta; unsigned long long* totals;
 };
+// step_body: ONE tick of a 64-env block (the whole of k_step; k_step_ticks calls it once per tick).  `s_obs`: the block's LDS rows.
 template <bool VP, int FUSE /* 0: finished envs listed for k_consume; 1: consumed by the stepping wave (consume_env); 3: in-place layout (advance_load / advance_finish) */,
           bool CP = false /* in-place small single rooms: pose-independent C plane row instead of the record's planes (bbai_types.hpp) */>
-__global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c, int64_t n, uint8_t* __restrict__ recs,
+__device__ __forceinline__ void step_body(const LevelCfg& c, int64_t n, uint8_t* __restrict__ recs,
                                                      Hot* __restrict__ hots, uint64_t* __restrict__ stales,
                                                      uint32_t* vheads, uint64_t* vsets /* read by every lane, WRITTEN for the envs the wave moves on (FUSE): no restrict */,
                                                      const uint8_t* __restrict__ actions, uint8_t* image /* read (frozen envs re-emit) AND written: no restrict */,
@@ -638,14 +642,12 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
                                                      uint8_t* __restrict__ lsm_arr /* NULL, or the done-action mode's per-env bits */,
                                                      int enum_done /* done-action mode: this step's `done` actions are the enum member (bbai_step.hpp verify_side) */,
                                                      FuseArgs fuse, int64_t block0 /* first 64-env block of this launch (bbai_step_render steps the batch in two halves) */,
-                                                     uint8_t* __restrict__ cplane /* CP: [n][cpl_bytes] */, TapArgs tap /* mask == NULL: none */) {
+                                                     uint8_t* __restrict__ cplane /* CP: [n][cpl_bytes] */, const TapArgs& tap /* mask == NULL: none */,
+                                                     uint8_t* const s_obs, const int lane /* threadIdx.x */, const int blk_x /* blockIdx.x */) {
     static_assert(!CP || (FUSE == 3 && !VP), "the C plane belongs to the in-place layout");
-    // the block's observation rows at the OUTPUT pitch of 147 bytes (bbai_step.hpp RowPacker), 16 bytes of front padding
-    __shared__ __attribute__((aligned(16))) uint8_t s_obs[ROWS_FRONT + STEP_BLOCK * OBS_BYTES + 16];
     uint8_t* const s_rows = s_obs + ROWS_FRONT;
     if (prio) __builtin_amdgcn_s_setprio(3);            // the look-ahead generator's waves share the CUs: issue ours first
-    const int lane = (int)threadIdx.x;
-    const int64_t env0 = ((int64_t)blockIdx.x + block0) * STEP_BLOCK;
+    const int64_t env0 = ((int64_t)blk_x + block0) * STEP_BLOCK;
     const int64_t env = env0 + lane;
     const bool active = env < n;
     bool want_reset = false;
@@ -817,7 +819,7 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
                 }
             } else if constexpr (FUSE == 3) {
                 // in-place layout: every finished lane moves its own env on (its stores to its own SoA entries stay in program order)
-                if (lane == leader) count_resets(fuse.totals, (unsigned int)__popcll(bal));
+                if (lane == leader) count_resets(fuse.totals, (unsigned int)__popcll(bal), (unsigned int)blk_x);
                 if (want_reset)
                     advance_finish<CP>(c, n, env, lane, my_slot, fuse.depth, fuse.next_recs, adv, hots, stales, vheads, vsets, fuse.pending, fuse.first_slot,
                                        fuse.win_meta, s_rows, dirs, lsm_arr, cplane, fcache);
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
                 // Everything this wave stored to the records, window planes and SoA entries of these envs must have landed
                 // before other lanes overwrite them (a terminal pickup patches the record the consume is about to replace).
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == leader) count_resets(fuse.totals, (unsigned int)__popcll(bal));
+                if (lane == leader) count_resets(fuse.totals, (unsigned int)__popcll(bal), (unsigned int)blk_x);
                 while (bal) {
                     const int src = __ffsll((long long)bal) - 1;
                     bal &= bal - 1;
@@ -864,7 +866,7 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
     // the step's own tap: a listed env's row out of LDS (for an env that finished: already its new episode's first observation), its direction /
     // reward / done as this wave stored them (agent-scope loads: the direction of a consumed env was stored by another lane)
     if (tap.mask) {
-        const int64_t blk = (int64_t)blockIdx.x + block0;
+        const int64_t blk = (int64_t)blk_x + block0;
         const unsigned long long tm = tap.mask[blk];
         if (active && (tm >> lane & 1ull)) {
             const int64_t row = (int64_t)tap.perm[tap.rank0[blk] + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull))];
@@ -876,6 +878,46 @@ __global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(LevelCfg c
             tap.done_out[row] = __hip_atomic_load(dones + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             tap.rew_out[row] = __hip_atomic_load(rewards64 + env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+}
+// What a step launch is given: the kernels' one argument (the kernarg segment IS this struct).
+struct StepArgs {
+    LevelCfg c; int64_t n; uint8_t* recs; Hot* hots; uint64_t* stales; uint32_t* vheads; uint64_t* vsets; const uint8_t* actions; uint8_t* image; uint8_t* dirs;
+    float* rewards; double* rewards64; uint8_t* dones; int auto_reset; int32_t* reset_list; uint8_t* reset_slot; uint32_t* counters; int prio; uint8_t* vplane;
+    uint16_t* fcache; uint8_t* lsm_arr; int enum_done; FuseArgs fuse; int64_t block0; uint8_t* cplane; TapArgs tap;
+    int ticks;            // k_step_ticks: steps this launch takes; tick t reads actions + t n and logs into the tap rows t * tap.count further on
+};
+template <bool VP, int FUSE, bool CP = false>
+__global__ __launch_bounds__(STEP_BLOCK, BBAI_STEP_WAVES) void k_step(StepArgs a) {
+    // the block's observation rows at the OUTPUT pitch of 147 bytes (bbai_step.hpp RowPacker), 16 bytes of front padding
+    __shared__ __attribute__((aligned(16))) uint8_t s_obs[ROWS_FRONT + STEP_BLOCK * OBS_BYTES + 16];
+    step_body<VP, FUSE, CP>(a.c, a.n, a.recs, a.hots, a.stales, a.vheads, a.vsets, a.actions, a.image, a.dirs, a.rewards, a.rewards64, a.dones, a.auto_reset, a.reset_list,
+                            a.reset_slot, a.counters, a.prio, a.vplane, a.fcache, a.lsm_arr, a.enum_done, a.fuse, a.block0, a.cplane, a.tap, s_obs, (int)threadIdx.x, (int)blockIdx.x);
+}
+// Several ticks in one launch (bbai_rollout, open-loop actions): an env's step touches only its own state, its block's LDS rows and -- for a
+// finished env -- look-ahead slots the window gate in front of the launch has vouched for, so a block walks through its ticks on its own, with
+// no launch boundary (and no dependent-launch gap: 4-5 us, a third of a 65 536-env step) in between.  Everything a tick reads of the previous one
+// was stored by THIS wave: its vector-memory operations stay in program order.
+// Every tick reads its arguments from the kernarg segment AGAIN, through a pointer the compiler cannot see through: left to itself it hoists
+// what the ticks share (fifty LevelCfg words, thirty pointers and all that derives from them) out of the loop and keeps it in registers across
+// the body -- 251 VGPRs against 93, two waves per SIMD against five.
+typedef const StepArgs __attribute__((address_space(4))) * StepArgsPtr;
+// ... and the register budget is the four waves per SIMD the one-tick kernels of the default paths have (115-117 VGPRs): the constants the
+// loop optimiser still parks in registers in front of the loop are rematerialised or, a handful, spilled (2-7 VGPRs: kernel_resources.json).
+template <bool VP, int FUSE, bool CP = false>
+__global__ __launch_bounds__(STEP_BLOCK, 4) void k_step_ticks(StepArgs a_) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_obs[ROWS_FRONT + STEP_BLOCK * OBS_BYTES + 16];
+    const int ticks = a_.ticks;
+    for (int tick = 0; tick < ticks; ++tick) {
+        StepArgsPtr ap = (StepArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        int t = tick, lane = (int)threadIdx.x, blk_x = (int)blockIdx.x;        // (the lane and block arithmetic likewise: re-derived per tick)
+        asm volatile("" : "+s"(ap), "+s"(t), "+v"(lane), "+s"(blk_x));
+        const StepArgs a = *(const StepArgs*)ap;          // (InferAddressSpaces turns these back into scalar loads of the constant segment)
+        TapArgs tap = a.tap;
+        tap.image_out += (int64_t)t * tap.count * OBS_BYTES; tap.dir_out += (int64_t)t * tap.count; tap.rew_out += (int64_t)t * tap.count; tap.done_out += (int64_t)t * tap.count;
+        step_body<VP, FUSE, CP>(a.c, a.n, a.recs, a.hots, a.stales, a.vheads, a.vsets, a.actions + (int64_t)t * a.n, a.image, a.dirs, a.rewards, a.rewards64, a.dones, a.auto_reset,
+                                a.reset_list, a.reset_slot, a.counters, a.prio, a.vplane, a.fcache, a.lsm_arr, a.enum_done, a.fuse, a.block0, a.cplane, tap, s_obs, lane, blk_x);
+        __syncthreads();        // (one wave per block: orders this tick's LDS reads before the next one's writes for the compiler)
     }
 }
 
@@ -1962,6 +2004,8 @@ static int create_finish(bbai_env* e) {
         e->render_pace = pv2 ? std::max(0, atoi(pv2)) : 0;
         const char* ss = getenv("BBAI_STEP_RENDER_SPLIT");
         e->step_render_split = ss ? atoi(ss) : -1;
+        const char* rm = getenv("BBAI_ROLLOUT_MULTI");
+        e->rollout_multi = rm ? atoi(rm) : 1;
         const char* gs = getenv("BBAI_GATE_STRICT");
         e->gate_strict = gs ? atoi(gs) != 0 : 0;
         const char* gp = getenv("BBAI_GATE_PROBE");
@@ -2157,10 +2201,11 @@ static int window_begin(bbai_env* e, hipStream_t s) {
     }
     return BBAI_OK;
 }
-static int window_end(bbai_env* e, hipStream_t s, int tokens_mode /* k_tokens: 0 list, 1 every env, 2 by `dones` */, const uint8_t* dones) {
+static int window_end(bbai_env* e, hipStream_t s, int tokens_mode /* k_tokens: 0 list, 1 every env, 2 by `dones` */, const uint8_t* dones,
+                      int ticks = 1 /* consume-ticks the launch in front took (bbai_rollout: up to the window's last; no token buffer then) */) {
     const int B = e->period;
     const TickPos tp = tick_pos(e);
-    const int wb = tp.wb, pos = tp.pos;
+    const int wb = tp.wb, pos = tp.pos + ticks - 1;         // (the launch's LAST tick: all of them lie in this window)
     if (e->tokens) {
         const int64_t hint = tokens_mode ? e->n : std::max<int64_t>(e->n / 64, 64);
         hipLaunchKernelGGL(k_tokens, dim3((unsigned)std::min<int64_t>((hint + 63) / 64, 4096)), dim3(64), 0, s, e->cfg, e->n, e->rec, e->inplace ? e->next_rec : nullptr, e->depth, e->hot,
@@ -2184,7 +2229,7 @@ static int window_end(bbai_env* e, hipStream_t s, int tokens_mode /* k_tokens: 0
         HIP_TRY(hipEventRecord(e->ev_refill[wb], e->side));
         HIP_TRY(hipGetLastError());
     }
-    e->tick++;
+    e->tick += ticks;
     return BBAI_OK;
 }
 // main stream: slots -> live state (+ first obs) by k_consume; side stream: refill the consumed slots.
@@ -2271,7 +2316,7 @@ static bool use_fused_consume(const bbai_env* e) {
 //   step_prepare  the window gate (fused: the slots this step's waves consume must be there) + what the kernel needs to know about the window
 //   step_kernel   k_step over the 64-env blocks [block0, block0 + nblocks) on stream `ks`
 //   step_finish   k_consume (unfused) / mission tokens / the window's close + refill -- on the caller's stream, behind EVERY k_step of the step
-struct StepPlan { FuseArgs fa; bool fused; uint32_t* counter; TapArgs tap = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; };
+struct StepPlan { FuseArgs fa; bool fused; uint32_t* counter; TapArgs tap = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0}; };
 static int step_prepare(bbai_env* e, int auto_reset, hipStream_t s, StepPlan& p) {
     p.fused = auto_reset && (e->inplace || use_fused_consume(e));
     p.counter = e->counters + 16 * e->step_parity;
@@ -2296,15 +2341,20 @@ static int step_prepare(bbai_env* e, int auto_reset, hipStream_t s, StepPlan& p)
     return BBAI_OK;
 }
 static int step_kernel(bbai_env* e, const StepPlan& p, const uint8_t* actions, uint8_t* image, uint8_t* dirs, float* rewards, double* rewards64,
-                       uint8_t* dones, int auto_reset, hipStream_t ks, int enum_done, int64_t block0, int64_t nblocks) {
+                       uint8_t* dones, int auto_reset, hipStream_t ks, int enum_done, int64_t block0, int64_t nblocks, int ticks = 1) {
     ProfScope prof_(e, 0, ks);
-#define STEP_LAUNCH(VV, FF) hipLaunchKernelGGL((k_step<VV, FF>), dim3((unsigned)nblocks), dim3(STEP_BLOCK), 0, ks, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions, \
-                                           image, dirs, rewards, rewards64, dones, auto_reset, e->reset_list, e->reset_slot, p.counter, e->step_prio, e->vplane, e->fcache, e->lsm, enum_done, p.fa, block0, e->cplane, p.tap)
-    if (e->inplace && e->cplane) hipLaunchKernelGGL((k_step<false, 3, true>), dim3((unsigned)nblocks), dim3(STEP_BLOCK), 0, ks, e->cfg, e->n, e->rec, e->hot, e->stale, e->vhead, e->vset, actions,
-                                                    image, dirs, rewards, rewards64, dones, auto_reset, e->reset_list, e->reset_slot, p.counter, e->step_prio, e->vplane, e->fcache, e->lsm, enum_done, p.fa, block0, e->cplane, p.tap);
-    else if (e->inplace) STEP_LAUNCH(false, 3);
-    else if (p.fused) { if (e->vplane) STEP_LAUNCH(true, 1); else STEP_LAUNCH(false, 1); }
-    else { if (e->vplane) STEP_LAUNCH(true, 0); else STEP_LAUNCH(false, 0); }
+    if (e->prof_on) e->prof_step_ticks += ticks;
+    StepArgs a;
+    a.c = e->cfg; a.n = e->n; a.recs = e->rec; a.hots = e->hot; a.stales = e->stale; a.vheads = e->vhead; a.vsets = e->vset; a.actions = actions; a.image = image; a.dirs = dirs;
+    a.rewards = rewards; a.rewards64 = rewards64; a.dones = dones; a.auto_reset = auto_reset; a.reset_list = e->reset_list; a.reset_slot = e->reset_slot; a.counters = p.counter;
+    a.prio = e->step_prio; a.vplane = e->vplane; a.fcache = e->fcache; a.lsm_arr = e->lsm; a.enum_done = enum_done; a.fuse = p.fa; a.block0 = block0; a.cplane = e->cplane;
+    a.tap = p.tap; a.ticks = ticks;
+#define STEP_LAUNCH(VV, FF, CC) do { if (ticks > 1) hipLaunchKernelGGL((k_step_ticks<VV, FF, CC>), dim3((unsigned)nblocks), dim3(STEP_BLOCK), 0, ks, a); \
+                                     else hipLaunchKernelGGL((k_step<VV, FF, CC>), dim3((unsigned)nblocks), dim3(STEP_BLOCK), 0, ks, a); } while (0)
+    if (e->inplace && e->cplane) STEP_LAUNCH(false, 3, true);
+    else if (e->inplace) STEP_LAUNCH(false, 3, false);
+    else if (p.fused) { if (e->vplane) STEP_LAUNCH(true, 1, false); else STEP_LAUNCH(false, 1, false); }
+    else { if (e->vplane) STEP_LAUNCH(true, 0, false); else STEP_LAUNCH(false, 0, false); }
 #undef STEP_LAUNCH
     HIP_TRY(hipGetLastError());
     return BBAI_OK;
@@ -2323,7 +2373,7 @@ static int step_launch(bbai_env* e, const uint8_t* actions, uint8_t* image, uint
     // Inside the stepping waves wherever the step leaves the final outputs behind (fused consume, in-place layout, no auto-reset);
     // an unfused auto-resetting step writes the new episodes' first observations in k_consume: the tap is then a launch behind it.
     const bool in_kernel = rows && (p.fused || e->inplace || !auto_reset);
-    if (in_kernel) p.tap = TapArgs{e->tap_mask, e->tap_rank0, e->tap_perm, rows->image_out, rows->dir_out, rows->rew_out, rows->done_out};
+    if (in_kernel) p.tap = TapArgs{e->tap_mask, e->tap_rank0, e->tap_perm, rows->image_out, rows->dir_out, rows->rew_out, rows->done_out, e->tap_count};
     { int rc = step_kernel(e, p, actions, image, dirs, rewards, rewards64, dones, auto_reset, s, enum_done, 0, step_blocks(e)); if (rc != BBAI_OK) return rc; }
     { int rc = step_finish(e, p, image, dirs, dones, auto_reset, s); if (rc != BBAI_OK) return rc; }
     if (rows && !in_kernel) {
@@ -2967,13 +3017,52 @@ int bbai_rollout(bbai_env* e, int T, const uint8_t* actions, uint8_t* image, uin
     if (!e->live) { snprintf(g_err, sizeof(g_err), "rollout before reset"); return BBAI_ERR_STATE; }
     if (auto_reset && !e->seeded) { snprintf(g_err, sizeof(g_err), "auto-reset rollout before seed"); return BBAI_ERR_STATE; }
     if (pixels && e->n_tiles <= 0) { snprintf(g_err, sizeof(g_err), "rollout with pixels before set_atlas"); return BBAI_ERR_STATE; }
-    if (tap && (!rewards64 || tap->count <= 0 || tap->pix_count < 0 || tap->pix_count > tap->count || !tap->ids_dev || !tap->image_out || !tap->dir_out ||
+    if (tap && (!rewards64 || tap->count <= 0 || tap->pix_count < 0 || tap->pix_count > tap->count || !tap->image_out || !tap->dir_out ||
                 !tap->reward64_out || !tap->done_out || (tap->pix_count && (!pixels || !tap->pixels_out))))
         ARG_FAIL("tap log incomplete (it needs reward64_dev, and pixels_dev for its pixel rows)");
     ON_DEVICE(e->device);
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)e->n;
+    const bool own_tap = tap && !tap->ids_dev;          // the envs of bbai_step_tap_set, logged by the stepping lanes
+    if (own_tap && (tap->count != e->tap_count || tap->pix_count != 0)) {
+        snprintf(g_err, sizeof(g_err), "rollout: a tap log without ids_dev follows bbai_step_tap_set's list (%lld envs, no pixel rows)", (long long)e->tap_count);
+        return BBAI_ERR_ARG;
+    }
+    // Encoded observations, the finished envs moved on inside k_step (or nobody resets): the launches carry as many ticks as the look-ahead
+    // window has left -- the same bytes as tick-by-tick launches (tests/test_gpu_parity.py::test_rollout_*), without their boundaries.
+    // An unfused auto-reset (k_consume between the steps), a token buffer (k_tokens reads every step's dones) or a tap that is a launch
+    // keep one step per launch.
+    const bool fused = auto_reset && (e->inplace || use_fused_consume(e));
+    if (!pixels && (fused || !auto_reset) && !e->tokens && (!tap || own_tap) && (e->rollout_multi || own_tap)) {
+        CallScope call(e, s);
+        if (call.rc != BBAI_OK) return call.rc;
+        for (int t = 0; t < T;) {
+            StepPlan p;
+            { int rc = step_prepare(e, auto_reset, s, p); if (rc != BBAI_OK) return rc; }
+            int ticks = e->rollout_multi ? T - t : 1;
+            if (fused) ticks = std::min(ticks, e->period - tick_pos(e).pos);
+            if (own_tap) {
+                const size_t c = (size_t)tap->count, orow = (size_t)(tap->obs_row0 + t), row = (size_t)(tap->row0 + t);
+                p.tap = TapArgs{e->tap_mask, e->tap_rank0, e->tap_perm, tap->image_out + orow * c * OBS_BYTES, tap->dir_out + orow * c,
+                                tap->reward64_out + row * c, tap->done_out + row * c, tap->count};
+            }
+            { int rc = step_kernel(e, p, actions + (size_t)t * n, image, dirs, rewards, rewards64, dones, auto_reset, s, e->done_action_enum, 0, step_blocks(e), ticks); if (rc != BBAI_OK) return rc; }
+            if (fused) { int rc = window_end(e, s, 2, dones, ticks); if (rc != BBAI_OK) return rc; }
+            t += ticks;
+        }
+        return call.leave();
+    }
+    if (own_tap && pixels) { snprintf(g_err, sizeof(g_err), "rollout: a tap log without ids_dev has no pixel rows (encoded observations only)"); return BBAI_ERR_ARG; }
     for (int t = 0; t < T; ++t) {
+        if (own_tap) {          // (unfused auto-reset / a token buffer: one bbai_step_tapped per step)
+            CallScope call(e, s);
+            if (call.rc != BBAI_OK) return call.rc;
+            const size_t c = (size_t)tap->count, orow = (size_t)(tap->obs_row0 + t), row = (size_t)(tap->row0 + t);
+            const TapRows rows = {tap->image_out + orow * c * OBS_BYTES, tap->dir_out + orow * c, tap->reward64_out + row * c, tap->done_out + row * c};
+            { int rc = step_launch(e, actions + (size_t)t * n, image, dirs, rewards, rewards64, dones, auto_reset, s, e->done_action_enum, &rows); if (rc != BBAI_OK) return rc; }
+            { int rc = call.leave(); if (rc != BBAI_OK) return rc; }
+            continue;
+        }
         { int rc = step_render_launch(e, actions + (size_t)t * n, image, dirs, rewards, rewards64, dones, auto_reset, pixels, s, e->done_action_enum); if (rc != BBAI_OK) return rc; }
         if (tap) {
             const size_t c = (size_t)tap->count, orow = (size_t)(tap->obs_row0 + t), row = (size_t)(tap->row0 + t);
@@ -3056,6 +3145,7 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     else if (!strcmp(name, "gate_fault_inject")) e->host_flags[0] = v != 0;       // tests: what a timed-out gate leaves behind
     else if (!strcmp(name, "bot_group")) e->bot_group = v;
     else if (!strcmp(name, "step_render_split")) e->step_render_split = v;
+    else if (!strcmp(name, "rollout_multi")) e->rollout_multi = v;
     else if (!strcmp(name, "done_action_enum")) e->done_action_enum = v != 0;       // (the one SEMANTIC switch in this list: include/bbai.h bbai_set_done_actions)
     else {
         snprintf(g_err, sizeof(g_err), "set_option: unknown option '%s'", name);
@@ -3093,6 +3183,8 @@ int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     else if (!strcmp(name, "gate_fault")) *out = e->host_flags ? (int64_t)e->host_flags[0] : 0;     // sticky; no synchronisation
     else if (!strcmp(name, "bot_group")) *out = e->bot_group;
     else if (!strcmp(name, "step_render_split")) *out = e->step_render_split;
+    else if (!strcmp(name, "rollout_multi")) *out = e->rollout_multi;
+    else if (!strcmp(name, "profile_step_ticks")) *out = e->prof_step_ticks;
     else if (!strcmp(name, "inplace")) *out = e->inplace;
     else if (!strcmp(name, "cplane")) *out = e->cplane ? 1 : 0;
     else if (!strcmp(name, "done_action_enum")) *out = e->done_action_enum;
@@ -3116,6 +3208,7 @@ int bbai_profile(bbai_env* e, int enable) {
     if (!e) ARG_FAIL("null handle");
     e->prof_on = enable != 0;
     // 1: start from zero; 2: resume (totals kept: callers that bracket every other block of a run); 0: pause, totals readable
+    if (enable == 1) e->prof_step_ticks = 0;
     if (enable == 1) for (int k = 0; k < 3; ++k) { e->prof_ms[k] = 0; e->prof_n[k] = 0; for (int i = 0; i < PROF_RING; ++i) e->prof[k][i].used = false; }
     return BBAI_OK;
 }

@@ -327,13 +327,15 @@ class BatchedBabyAIEnv(object):
         self._ev_end("step", ev)
         return self._obs(), self.reward, self.done, {}
 
-    def rollout(self, actions, tap=None, obs_row0=0, row0=0):
+    def rollout(self, actions, tap=None, obs_row0=0, row0=0, step_tap=False):
         """An open-loop rollout (include/bbai.h bbai_rollout): `actions` uint8[T, N] on the device; T steps (+ the pixel render
         in pixel mode) are enqueued by ONE call, exactly what T calls of step() enqueue.  `tap`: a log dict as bench.py builds
         it -- device tensors "image" [rows, P, 7, 7, 3], "direction" [rows, P], "reward64" [rows, P], "done" [rows, P],
         optionally "pixels" [rows, PP, 56, 56, 3], and "ids" int64[P]: step t logs the listed envs' outputs into obs row
         obs_row0 + t / result row row0 + t.  Afterwards image / direction / reward / done (/ pixels) hold the last step's
-        outputs; returns the observation dict of that step."""
+        outputs; returns the observation dict of that step.  step_tap=True: the log's rows are written by the stepping lanes for the envs
+        listed with set_step_tap() (log row k = listed env k; no "ids" needed, no pixel rows) -- with encoded observations one k_step launch then
+        takes every step the look-ahead window has left (include/bbai.h bbai_rollout)."""
         torch = self.torch
         if actions.dtype != torch.uint8 or actions.device != self.device or not actions.is_contiguous() or actions.dim() != 2 \
                 or actions.shape[1] != self.num_envs:
@@ -346,7 +348,9 @@ class BatchedBabyAIEnv(object):
             for k in ("image", "direction", "reward64", "done"):
                 if not tap[k].is_contiguous():
                     raise ValueError("tap log tensors must be contiguous")
-            log = TapLog(P_, int(pix.shape[1]) if pix is not None else 0, tap["ids"].data_ptr(), tap["image"].data_ptr(), tap["direction"].data_ptr(),
+            if step_tap:
+                pix = None
+            log = TapLog(P_, int(pix.shape[1]) if pix is not None else 0, None if step_tap else tap["ids"].data_ptr(), tap["image"].data_ptr(), tap["direction"].data_ptr(),
                          tap["reward64"].data_ptr(), tap["done"].data_ptr(), pix.data_ptr() if pix is not None else None, int(obs_row0), int(row0))
             if tap["image"].shape[0] < obs_row0 + T or tap["done"].shape[0] < row0 + T:
                 raise ValueError("tap log has too few rows for %d steps" % T)

@@ -163,6 +163,9 @@ def parse_args(argv=None):
     ap.add_argument("--extra-cpu-seconds", type=float, default=1.0, help="CPU baseline (the oracle port on the host cores) per extra workload; 0 = only the ratio on file")
     ap.add_argument("--extra-parity-horizon", type=int, default=1024, help="steps over which ALL --extra-parity-envs are followed (then a spread of them)")
     ap.add_argument("--profile-tail", action="store_true", help="all plain blocks first (one contiguous rollout), the profiled blocks behind them (default: alternating; the extra configs always run this way)")
+    ap.add_argument("--loop", choices=("auto", "step", "rollout"), default=os.environ.get("BBAI_BENCH_LOOP", "auto"),
+                    help="auto (default): encoded observations through bbai_rollout (one k_step launch per look-ahead window's steps, the tap rows written by the "
+                         "stepping lanes), pixel observations through per-step calls; step: per-step calls everywhere (rounds 1-5's loop); rollout: bbai_rollout everywhere")
     ap.add_argument("--rollout-entry", action="store_true", help="one bbai_rollout call per block instead of one bbai_step / bbai_render / bbai_tap_ids call per step from Python (the same launches)")
     ap.add_argument("--full-out", default=None, help="where the FULL record goes (default <repo>/gpurun_out/bench_full.json); stdout carries the compact judged line only")
     ap.add_argument("--dump-digest", default=None, help="write per-env output digests of this rank to <prefix>.rank<r>.npy")
@@ -349,7 +352,8 @@ def traffic_of(level, E, pixel, dom):
         kk = wl["kernels"][key]
         fetch = kk.get("FETCH_SIZE_corrected", 2 * kk["FETCH_SIZE"])      # gfx950: FETCH_SIZE tallies 128-B requests as 64 B
         t = {"bytes": fetch + kk["WRITE_SIZE"], "fetch_corrected": fetch, "fetch_raw": kk["FETCH_SIZE"], "write": kk["WRITE_SIZE"],
-             "kernel": key, "correction": "FETCH_SIZE x 2 (MI355X_MICROARCH.md, calibrated on k_render's known byte counts)",
+             "kernel": key, "steps_per_launch": float(wl.get("k_step_steps_per_launch", 1.0)) if dom == "k_step" else 1.0,
+             "correction": "FETCH_SIZE x 2 (MI355X_MICROARCH.md, calibrated on k_render's known byte counts)",
              "source": "profiles/pmc_latest.json", "commit": pmc.get("commit"), "csrc_sha": pmc.get("csrc_sha"),
              "current": pmc.get("csrc_sha") == csrc_sha()}
         if not t["current"]:
@@ -390,6 +394,14 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
 
     P = min(P, E)
     PP = min(PP, P) if pixel else 0
+    # Which loop.  Encoded observations: ONE bbai_rollout call per block (include/bbai.h: a k_step launch takes every step the look-ahead window has
+    # left; the actions of a block are resident, as they always were) -- the warm-up is then rounded UP to the next window boundary (the reset is a
+    # window tick itself), so that every timed launch is a whole window and "per launch" means one thing.  Pixels: per-step calls (the render sits
+    # between the steps).  --loop step: per-step calls everywhere, as rounds 1-5 measured.
+    fast = digest is None and (args.rollout_entry or args.loop == "rollout" or (args.loop == "auto" and not pixel))
+    period = int(env.get_option("lookahead_period"))
+    if fast and not pixel and env.get_option("rollout_multi"):
+        W = W + (-(1 + W)) % period
 
     # the tapped envs: scattered over the shard; the ones whose pixels are checked too come first in the log rows and
     # are themselves a spread (both ends included)
@@ -458,10 +470,8 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
     # --rollout-entry: one call per block (include/bbai.h bbai_rollout: K x (step [+ render] + tap) enqueued by the engine) instead of
     # the per-step calls -- the same launches; measured equal on every config (profiles/r04/bench_loop_rollout_entry_vs_python_ab.jsonl:
     # the GPU, not the interpreter, sets the pace even of a 40-us step), so the default stays what a caller's loop looks like
-    fast = digest is None and args.rollout_entry
-
     def run1(t0, k):
-        env.rollout(actions1[t0:t0 + k], tap=log1, obs_row0=t0 + 1, row0=t0)
+        env.rollout(actions1[t0:t0 + k], tap=log1, obs_row0=t0 + 1, row0=t0, step_tap=step_tap and log1 is not None)
 
     torch.cuda.synchronize()
     blocks = shard.timed_blocks(env, actions1, W, K, 1, ranks, after1, run_steps=run1 if fast else None, step_fn=step1 if (step_tap and log1 is not None) else None)
@@ -514,7 +524,7 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
                 env.profile_pause()
 
         def run2(t0, k):
-            env.rollout(actions2[t0:t0 + k], tap=log2, obs_row0=t0, row0=t0)
+            env.rollout(actions2[t0:t0 + k], tap=log2, obs_row0=t0, row0=t0, step_tap=step_tap and log2 is not None)
 
         torch.cuda.synchronize()
         all_blocks = shard.timed_blocks(env, actions2, 0, K, want, ranks, after2, before_block=before_block, local_out=local_blocks,
@@ -531,6 +541,7 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
             env.step(actions1[t])
         torch.cuda.synchronize()
     prof = env.profile_read()
+    step_ticks = int(env.get_option("profile_step_ticks"))      # steps the bracketed k_step launches took (several per launch under bbai_rollout)
     env.profile(False)
     gate_timeouts = int(ranks.sum(env.gate_timeouts()))      # (synchronises; outside the timed blocks) a window gate that gave up = a void run
     m = {"level": level, "pixel": pixel, "E": E, "total_envs": total_envs, "first": first, "K": K, "W": W, "S1": S1, "S2": S2, "want": want,
@@ -538,6 +549,12 @@ def measure(ctx, level, pixel, E, total_envs, K, W, min_seconds, max_blocks, P, 
          "kernel_ms": {k: v[0] for k, v in prof.items() if v[0] is not None},
          "kernel_launches": {k: v[1] for k, v in prof.items() if v[0] is not None},
          "resets": resets, "setup_ms": setup_ms, "gate_timeouts": gate_timeouts,
+         "steps_per_k_step_launch": (step_ticks / float(prof["k_step"][1])) if prof["k_step"][1] else 1.0,
+         "loop": ("one bbai_rollout call per block: ONE k_step launch per look-ahead window (%d steps), the parity tap's rows written by the stepping lanes" % period) if (fast and not pixel and env.get_option("rollout_multi")) else
+                 "one bbai_rollout call per block: the engine enqueues K x (step [+ render] + tap)" if fast else
+                 ("per-step calls from Python: bbai_step_render (the step + the render as one call) + bbai_tap_ids" if pixel else
+                  "per-step calls from Python: bbai_step_tapped (the step; the parity tap's rows are written by the stepping lanes)" if step_tap else
+                  "per-step calls from Python: bbai_step + bbai_tap_ids"),
          "state_layout": "in-place (the look-ahead slot is the live record)" if env.get_option("inplace") else "classic (live record per env, k_consume / in-wave copy on reset)",
          "lookahead_period": env.get_option("lookahead_period"),
          "log1": log1, "log2": log2, "ids2": ids2, "PP1": PP1, "PP2": PP2, "sel2": sel2, "env": env}
@@ -595,7 +612,8 @@ def roofline_of(m):
     if m["pixel"]:
         dom, alg_bytes, bps, key = "k_render", E * (147 + 9408), 9496, "fill_GBs"        # reads the encoding, writes the pixels: a pure store stream
     else:
-        dom, alg_bytes, bps, key = "k_step", E * 235, 235, "copy_GBs"                    # reads and writes mixed
+        # (reads and writes mixed; a bbai_rollout launch takes steps_per_k_step_launch steps: its algorithmic bytes are that many steps')
+        dom, alg_bytes, bps, key = "k_step", E * 235 * m.get("steps_per_k_step_launch", 1.0), 235, "copy_GBs"
     dom_ms = m["kernel_ms"][dom]
     return dom, alg_bytes, bps, dom_ms, alg_bytes / (dom_ms * 1e-3) / 1e9, key
 
@@ -739,7 +757,7 @@ def main():
     traffic = traffic_of(level, E, pixel, dom)
     prof_med = median(profiled) if profiled else None
     out = {
-        "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": m["W"],
         "ms_per_step": st["mean"] / K * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": "BabyAI-%s-v0 %s obs, %d envs in total = %d per GPU x %d, random actions, auto-reset" % (
@@ -760,10 +778,7 @@ def main():
                    "value_mean": st["value_mean"], "value_median": st["value_median"], "mean_over_median": st["mean_over_median"],
                    "max_over_median": st["max_over_median"], "value_at_min": K * E * world / bs[0],
                    "value_at_max": K * E * world / bs[-1],
-                   "loop": "one bbai_rollout call per block: the engine enqueues K x (step [+ render] + tap)" if (args.rollout_entry and not args.dump_digest) else
-                           ("per-step calls from Python: bbai_step_render (the step + the render as one call) + bbai_tap_ids" if pixel else
-                            "per-step calls from Python: bbai_step_tapped (the step; the parity tap's rows are written by the stepping lanes)" if os.environ.get("BBAI_BENCH_TAP", "step") == "step" else
-                            "per-step calls from Python: bbai_step + bbai_tap_ids"),
+                   "loop": m["loop"],
                    "clock": "per block: opening barrier -> K steps -> this rank's device idle; the block = max over ranks; the closing barrier "
                             "and the max-reduce run after every rank's clock has stopped (barrier_ms); Python's cyclic garbage collector is off inside the loop (as timeit does)",
                    "barrier_ms": {"median": median(m["barrier_s"]) * 1e3, "max": max(m["barrier_s"]) * 1e3} if m["barrier_s"] else None,
@@ -780,7 +795,7 @@ def main():
                      "traffic": traffic["bytes"] if traffic else None, "traffic_provenance": traffic,
                      "achievable": achievable, "frac_of_achievable": (achieved / achievable[ceiling_key]) if achievable else None,
                      "achievable_ceiling": ceiling_key,
-                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
+                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms, "steps_per_launch": 1.0 if pixel else m["steps_per_k_step_launch"],
                      "whole_step_alg_GBs": value / world * bytes_per_step / 1e9,
                      "kernel_avg_ms": kernel_ms, "kernel_launches": kernel_launches, "measured_on": "rank 0"},
         "parity": None, "cpu_baseline": None, "configs": None, "gate_timeouts": m["gate_timeouts"],
@@ -879,7 +894,9 @@ def main():
                 "block_ms": {"min": cst["min"] * 1e3, "median": cst["median"] * 1e3, "mean": cst["mean"] * 1e3, "p90": cst["p90"] * 1e3, "max": cst["max"] * 1e3},
                 "block_ms_list": [round(b * 1e3, 4) for b in mc["blocks"]],
                 "kernel_avg_ms": mc["kernel_ms"], "state_layout": mc["state_layout"], "lookahead_period": mc["lookahead_period"],
-                "roofline": {"bound": "hbm", "kernel": cdom, "alg_bytes_per_launch": calg, "avg_launch_ms": cdom_ms, "achieved": cach, "unit": "GB/s",
+                "loop": mc["loop"],
+                "roofline": {"bound": "hbm", "kernel": cdom, "alg_bytes_per_launch": calg, "avg_launch_ms": cdom_ms, "steps_per_launch": 1.0 if c["pixel"] else mc["steps_per_k_step_launch"],
+                             "achieved": cach, "unit": "GB/s",
                              "peak": HBM_PEAK_GBS, "frac": cach / HBM_PEAK_GBS,
                              "frac_of_achievable": (cach / achievable[ckey]) if achievable else None, "achievable_ceiling": ckey,
                              "traffic": ctraffic["bytes"] if ctraffic else None, "traffic_provenance": ctraffic,

@@ -208,11 +208,18 @@ int bbai_step_tapped(bbai_env* env, const uint8_t* actions_dev, uint8_t* image_d
  * image / dir / reward / reward64 / done (/ pixels) hold the LAST step's outputs on return; the tap log keeps every step of the listed
  * envs: image_out [rows][count][147], dir_out [rows][count], pixels_out [rows][pix_count][9408] indexed by obs_row0 + t (a caller
  * that stored the reset()'s observation in row 0 passes obs_row0 = 1), reward64_out / done_out [rows][count] indexed by row0 + t.
- * The per-step calls give the same bytes (tests/test_gpu_parity.py::test_rollout_entry_*) and, measured, the same speed even on 65 536-env
- * shards (bench.py --rollout-entry; profiles/r04/bench_loop_rollout_entry_vs_python_ab.jsonl): the entry is a convenience, not a fast path. */
+ * The per-step calls give the same bytes (tests/test_gpu_parity.py::test_rollout_entry_*).
+ * Since round 6 the entry is also the fast path of open-loop stepping: with encoded observations (pixels_dev NULL), no token buffer,
+ * and steps that move their finished envs on themselves (the default: fused consume / in-place layout; or auto_reset 0), ONE k_step
+ * launch takes every step the current look-ahead window has left (up to 32) -- an env's step touches only its own state, so a 64-env
+ * block walks through the ticks on its own, no launch boundary and no dependent-launch gap (4-5 us: a third of a 65 536-env step) in
+ * between; tick t reads actions_dev + t * n_envs.  A tap log is then written by the stepping lanes (bbai_step_tapped's mechanism): pass
+ * ids_dev = NULL and count = the number of envs listed by bbai_step_tap_set (log row k = env ids[k]; pix_count 0).  A tap log WITH
+ * ids_dev is a bbai_tap_ids launch behind every step and keeps one step per launch.  Option "rollout_multi" 0 (BBAI_ROLLOUT_MULTI=0):
+ * one step per launch everywhere. */
 typedef struct bbai_tap_log {
     int64_t count, pix_count;           /* envs listed / how many of the first listed ones also log pixels */
-    const int64_t* ids_dev;             /* int64[count] env indices */
+    const int64_t* ids_dev;             /* int64[count] env indices; NULL: the envs of bbai_step_tap_set (count must match) */
     uint8_t* image_out; uint8_t* dir_out; double* reward64_out; uint8_t* done_out; uint8_t* pixels_out;
     int64_t obs_row0, row0;
 } bbai_tap_log;
@@ -231,7 +238,8 @@ int bbai_gae(int64_t num_envs, int num_frames, const float* rewards_dev, const f
 /* Per-kernel timing for measurements (bench.py's roofline): while enabled, every k_step / k_consume / k_render launch is
  * bracketed by a HIP event pair ON THE STREAM IT IS LAUNCHED ON; bbai_profile_read returns the summed milliseconds and the
  * launch counts in that order.  enable: 1 = start from zero, 2 = resume (totals kept), 0 = pause (totals stay readable).
- * Costs two event records per launch. */
+ * Costs two event records per launch.  A bbai_rollout launch of k_step takes several steps: bbai_get_option "profile_step_ticks" =
+ * the steps the bracketed k_step launches took. */
 int bbai_profile(bbai_env* env, int enable);
 int bbai_profile_read(bbai_env* env, double* ms_total /* [3] */, int64_t* launches /* [3] */);
 
@@ -282,6 +290,8 @@ int bbai_get_done_actions(bbai_env* env);
  *                       BBAI_PREGEN_LANE at bbai_create.  Setting it converts the handle's MT19937 states between the two kernels' forms.
  *                       BBAI_ERR_ARG when 1 is asked of a kind the lane generator does not cover
  *   "lane_blocks"       upper bound on k_pregen_lane's waves per launch (BBAI_LANE_BLOCKS, default 16 384)
+ *   "rollout_multi"     bbai_rollout with encoded observations: 1 (default; BBAI_ROLLOUT_MULTI) = one k_step launch per look-ahead window's remaining steps,
+ *                       0 = one launch per step
  *   "gate_fault_inject" tests: raise (1) / clear (0) the sticky word a timed-out window gate leaves behind
  *   "bot_group"         the expert's kernel (bbai_bot_act / bbai_bot_rollout): 0 (default) = one lane per env (k_bot), 16 = one 16-lane
  *                       group per env with the first search in LDS (k_botg: same decisions, measured ~2 x slower -- an experiment

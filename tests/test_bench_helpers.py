@@ -26,7 +26,7 @@ def test_every_benched_workload_has_counters_of_the_committed_sources():
         dom = "k_render" if pixel else "k_step"
         t = bench.traffic_of(level, envs, pixel, dom)
         assert t is not None and t["current"] and t["bytes"] > 0, (level, envs, pixel)
-        alg = envs * (147 + 9408) if pixel else envs * 235
+        alg = envs * (147 + 9408) if pixel else envs * 235 * t["steps_per_launch"]        # (bbai_rollout: a k_step launch takes a look-ahead window's steps)
         assert 0.99 < t["bytes"] / alg < 3.0, (level, envs, pixel, t["bytes"] / alg)       # the render writes every byte once; k_step's gathers cost whole lines
 
 

@@ -1825,6 +1825,79 @@ def test_rollout_entry_equals_per_step_calls(gpu, level, n, pixel):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("level,n,opts", [("GoToLocal", 3000, {}), ("PickupLoc", 700, {}), ("BossLevel", 1500, {}), ("GoTo", 1300, {}), ("GoTo", 1100, {"consume_fused": 0}),
+                                          ("GoToLocal", 1000, {"auto_reset": False}), ("PutNextS5N2Carrying", 900, {}), ("KeyInBox", 800, {}),
+                                          ("GoToLocal", 2500, {"inplace_off": True}), ("SynthS5R2", 1000, {}), ("GoToRedBallGrey", 700, {"done_actions": True})])
+def test_rollout_steps_many_ticks_per_launch(gpu, level, n, opts):
+    """bbai_rollout's fast path -- ONE k_step launch per look-ahead window's remaining ticks, log rows written by the stepping lanes -- against
+    one bbai_step + bbai_tap_ids per step: every logged byte of every step (through resets, window boundaries inside a call, calls that start
+    in mid-window), the final outputs of every env, the reset count, and the state the run leaves behind (both continue per step and must stay
+    equal).  Shapes where the fast path does not apply (unfused consume) take the same entry and must give the same bytes."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from babyai_amd.action_stream import actions_torch
+    from babyai_amd.shard import scattered_ids
+    T, T2, P = 117, 40, 96
+    auto = opts.get("auto_reset", True)
+    env_kw = {}
+    if opts.get("inplace_off"):
+        os.environ["BBAI_INPLACE"] = "0"
+    if opts.get("done_actions"):
+        env_kw["done_actions"] = True
+    try:
+        a = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=33, auto_reset=auto, **env_kw)
+        b = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=33, auto_reset=auto, **env_kw)
+        c = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=33, auto_reset=auto, **env_kw)
+    finally:
+        os.environ.pop("BBAI_INPLACE", None)
+    for env in (a, b, c):
+        for k, v in opts.items():
+            if k not in ("auto_reset", "inplace_off", "done_actions"):
+                env.set_option(k, v)
+        env.reset()
+    assert b.get_option("rollout_multi") == 1
+    acts = actions_torch(9, 0, T + T2, 0, n, gpu)
+    idl = list(scattered_ids(n, P))
+    idl = idl[1::2] + idl[0::2]
+    ids = torch.as_tensor(idl, dtype=torch.int64, device=gpu)
+
+    def mklog():
+        return {"image": torch.zeros((T, P, 7, 7, 3), dtype=torch.uint8, device=gpu), "direction": torch.zeros((T, P), dtype=torch.uint8, device=gpu),
+                "reward64": torch.zeros((T, P), dtype=torch.float64, device=gpu), "done": torch.zeros((T, P), dtype=torch.uint8, device=gpu)}
+
+    la, lb = mklog(), mklog()
+    for t in range(T):
+        a.step(acts[t])
+        a.tap(la["image"][t], la["direction"][t], la["reward64"][t], la["done"][t], None, ids=ids)
+    b.set_step_tap(idl)
+    cuts = [0, 5, 6, 45, 110, T]                # calls that end and start in mid-window, one that spans three windows, a one-step call
+    for t0, t1 in zip(cuts, cuts[1:]):
+        b.rollout(acts[t0:t1], tap=lb, obs_row0=t0, row0=t0, step_tap=True)
+    c.rollout(acts[:T])                         # no log at all
+    for k in la:
+        assert torch.equal(la[k], lb[k]), k
+    for other in (b, c):
+        assert torch.equal(a.image, other.image) and torch.equal(a.direction, other.direction) and torch.equal(a.reward64, other.reward64)
+        assert torch.equal(a.done, other.done) and torch.equal(a.reward, other.reward)
+        assert a.reset_count() == other.reset_count()
+    if auto and level in ("GoToLocal", "PickupLoc"):
+        assert a.reset_count() > n + 100
+    # the states are equal too: the three go on, step by step / in one more rollout, and stay together
+    for t in range(T, T + T2):
+        a.step(acts[t])
+        b.step(acts[t])
+    c.rollout(acts[T:])
+    for other in (b, c):
+        assert torch.equal(a.image, other.image) and torch.equal(a.direction, other.direction) and torch.equal(a.reward64, other.reward64) and torch.equal(a.done, other.done)
+        assert a.reset_count() == other.reset_count()
+    assert a.missions()[:50] == b.missions()[:50] == c.missions()[:50]
+    with pytest.raises(Exception):              # the log must match the listed envs
+        b.rollout(acts[:2], tap={k: v[:, :P - 1].contiguous() for k, v in lb.items()}, step_tap=True)
+    for env in (a, b, c):
+        env.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("level,n,opts", [("GoToLocal", 3000, {}), ("PickupLoc", 700, {}), ("BossLevel", 1500, {}), ("GoTo", 1300, {"consume_fused": 0}),
                                           ("GoToLocal", 1000, {"auto_reset": False}), ("PutNextS5N2Carrying", 900, {})])
 def test_step_tapped_equals_step_plus_tap(gpu, level, n, opts):

@@ -129,8 +129,10 @@ def main():
             if f.endswith(".json") and f.startswith("bench_"):
                 shutil.copy(os.path.join(src, f), dst)
     level, envs, pixel, what = "BossLevel", 1048576, True, "python bench.py --steps 20 --warmup 5"
+    steps_per_launch = 1.0        # steps a k_step launch of this workload's loop takes (bbai_rollout: a look-ahead window's worth)
     try:
         d = json.loads(open(bench_json).read().strip().splitlines()[-1])
+        steps_per_launch = float((d.get("roofline") or {}).get("steps_per_launch") or 1.0)
         shutil.copy(bench_json, os.path.join(dst, "bench_%s_under_rocprof.json" % name))
         w = d["config"]["workload"]
         level = w.split("-")[1]
@@ -201,7 +203,7 @@ def main():
     latest["commit"] = git_head()
     latest["profile_tag"] = tag
     if kernels:
-        latest["workloads"][key] = {"what": what, "kernels": kernels}
+        latest["workloads"][key] = {"what": what, "kernels": kernels, "k_step_steps_per_launch": steps_per_launch}
         json.dump(latest, open(latest_path, "w"), indent=1, sort_keys=True)
     print("workload", key)
     print("\n".join(lines))
