@@ -82,8 +82,12 @@ struct DeviceGuard {
     HIP_TRY((hipError_t)guard_.err)
 
 constexpr int PROF_RING = 256;          // event pairs per profiled kernel (bbai_profile)
-constexpr int MAX_PERIOD = 32;          // refill period B (ticks per look-ahead refill); ring depth D = 2B
-constexpr int NWIN = MAX_PERIOD + 2;    // window buffers (see "the windows' bookkeeping" below)
+constexpr int MAX_SIDES = 8;            // look-ahead streams a window's refill can be split over
+#ifndef LOOKAHEAD_STREAMS_DEFAULT
+#define LOOKAHEAD_STREAMS_DEFAULT 1
+#endif
+constexpr int MAX_PERIOD = 64;          // refill period B (ticks per look-ahead refill); ring depth D = 2B (+ 1 in place: slot numbers stay bytes)
+constexpr int NWIN = 34;                // window buffers (see "the windows' bookkeeping" below): at most 33 refills outstanding, whatever B
 
 struct bbai_env {
     LevelCfg cfg;
@@ -118,7 +122,18 @@ struct bbai_env {
     int step_parity;
     bool next_counter_clean;
     uint8_t* tokens;      // optional caller-owned [n][72] mission token buffer kept current on resets
-    hipStream_t side;     // look-ahead generation stream
+    hipStream_t side;     // look-ahead generation stream (= sides[0]: bbai_seed's first fill, the probe)
+    // Round 6: a window's refill is split over n_sides look-ahead streams, each with a CONTIGUOUS range of 64-env blocks and a work list of its own.
+    // An env's levels are generated in stream order on ITS stream (its MT19937 state never has two writers); the streams run side by side, so
+    // refill w + 1 of one range starts while refill w of another is still at its slowest level.  k_mark runs on a stream of its own behind an
+    // event of every part (`refilled` stays "every env of windows < r has its levels").
+    hipStream_t sides[MAX_SIDES];
+    hipStream_t mark_stream;
+    hipEvent_t ev_part[MAX_SIDES];
+    int side_prio;
+    int n_sides;          // BBAI_LOOKAHEAD_STREAMS / option "lookahead_streams"
+    int32_t* gen_lists[MAX_SIDES];      // sides >= 1 (side 0: gen_list / gen_count below)
+    uint32_t* gen_counts[MAX_SIDES];
     hipStream_t split;    // bbai_step_render: the second half-batch's k_step runs here, under the first half's render
     hipEvent_t ev_split0, ev_splitB;
     int step_render_split;   // BBAI_STEP_RENDER_SPLIT / option "step_render_split": 1 = split (from STEP_RENDER_SPLIT_MIN envs), 0 = never, -1 = default
@@ -218,7 +233,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 //     at most B) -- k_gate, one wave on the step stream at every window start, waits for exactly that instead of for "refill
 //     w - 2 has landed".  A reset storm (a million maze envs timing out on the same tick: 37 ms of generator time) then runs
 //     UNDER the following windows instead of stopping the step stream, as long as no env finishes B more times meanwhile.
-//   * NWIN window buffers (pending / first_slot / meta) so that up to B + 1 refills can be outstanding.
+//   * NWIN = 34 window buffers (pending / first_slot / meta): up to 33 refills can be outstanding (B + 1 of them for B <= 32).
 // tests/test_ring_protocol.py models the rule (sufficient, and the ring depths stay tight).
 __device__ __forceinline__ void count_resets(unsigned long long* __restrict__ totals, unsigned int k, unsigned int blk) {
     atomicAdd(&totals[(blk & (SHARDS - 1)) * SHARD_U64], (unsigned long long)k);        // (result unused: a no-return atomic)
@@ -1230,11 +1245,12 @@ __global__ __launch_bounds__(256) void k_consume(LevelCfg c, int64_t n, uint8_t*
 // k_compact, look-ahead stream, in front of the window's k_pregen: the envs whose `pending` byte is set, as SHARDS dense sub-lists.  Wave
 // w covers envs [64 w, 64 w + 64) and appends to sub-list w % SHARDS: one returning atomic per wave that found any, spread over SHARDS
 // counters (1 048 576 envs, every one pending: 256 per counter) -- off the step path, a few microseconds per window.
-__global__ __launch_bounds__(256) void k_compact(int64_t n, const uint8_t* __restrict__ pending, int32_t* __restrict__ gen_list, uint32_t* __restrict__ gen_count) {
+__global__ __launch_bounds__(256) void k_compact(int64_t n, const uint8_t* __restrict__ pending, int32_t* __restrict__ gen_list, uint32_t* __restrict__ gen_count,
+                                                 int64_t wave0, int64_t waves /* this look-ahead stream's 64-env blocks: [wave0, wave0 + waves) */) {
     const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t wave = wave0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t env = wave * 64 + lane;
-    const bool mine = env < n && pending[env] != 0;
+    const bool mine = wave < wave0 + waves && env < n && pending[env] != 0;
     const unsigned long long bal = __ballot(mine);
     if (!bal) return;
     const int j = (int)(wave % SHARDS);
@@ -1823,6 +1839,7 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
     alloc((void**)&e->flow, FLOW_WORDS * 8);
     alloc((void**)&e->gen_list, (size_t)SHARDS * (size_t)gen_sublist_cap(n_envs) * 4);
     alloc((void**)&e->gen_count, SHARDS * GEN_COUNT_U32 * 4);
+    e->gen_lists[0] = e->gen_list; e->gen_counts[0] = e->gen_count;         // (further look-ahead streams' lists: set_sides)
     {
         // BBAI_INPLACE: 1 / 0 force the in-place layout (live_slot above) on / off; default: by level family and batch size
         const char* iv = getenv("BBAI_INPLACE");
@@ -1864,7 +1881,9 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
         // Refill period B (ticks per look-ahead refill, BBAI_LOOKAHEAD); ring depth D = 2B.  One k_pregen launch per
         // window lasts as long as its slowest level (hundreds of microseconds to milliseconds: rejection sampling has a
         // heavy tail) and has to land within one window, so B ticks of the step path must outlast it or the step stream
-        // waits: default = the longest period of 32, 16, 8, 4, 2 whose ring fits the cap.  The cap is BBAI_RING_GIB
+        // waits: default = the longest period of 64, 32, 16, 8, 4, 2 whose ring fits the cap.  (64 since round 6: a refill launch lasts as long
+        // as its slowest WAVE -- 0.4 ms for 64 single-room levels per lane-generator wave, 0.6-0.9 ms for a lane group's maze -- almost whatever its
+        // size, and bbai_rollout's k_step takes 8 us per tick at 65 536 envs: 32 ticks no longer outlast a refill, 64 nearly do.)  The cap is BBAI_RING_GIB
         // (default 64 GiB -- the part has 288 GB; round 4: 1 048 576 GoTo envs waited for refills at period 4, the 16-GiB cap of
         // rounds 1-3) but never more than a quarter of the memory that is FREE right now (several handles or ranks
         // on one device, smaller parts), and an allocation that fails all the same is retried with half the period: a
@@ -1930,6 +1949,26 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
 
 }  // extern "C"
 
+// The look-ahead streams beyond the first, and the stream k_mark needs once there are several, exist only while asked for: every HIP stream
+// is a hardware queue, and a dozen of them made EVERY dispatch of a handle that used two wait its turn (k_step 10 -> 50 us whenever a refill ran,
+// profiles/r06/NOTES.md section 9).
+static int set_sides(bbai_env* e, int want) {
+    want = std::max(1, std::min(MAX_SIDES, want));
+    for (int k = 1; k < want; ++k) {
+        if (!e->sides[k]) HIP_TRY(hipStreamCreateWithPriority(&e->sides[k], hipStreamNonBlocking, e->side_prio));
+        if (!e->gen_lists[k]) HIP_TRY(hipMalloc((void**)&e->gen_lists[k], (size_t)SHARDS * (size_t)gen_sublist_cap(e->n) * 4));
+        if (!e->gen_counts[k]) HIP_TRY(hipMalloc((void**)&e->gen_counts[k], SHARDS * GEN_COUNT_U32 * 4));
+    }
+    if (want > 1) {
+        if (!e->mark_stream) HIP_TRY(hipStreamCreateWithPriority(&e->mark_stream, hipStreamNonBlocking, e->side_prio));
+        for (int k = 0; k < want; ++k) if (!e->ev_part[k]) HIP_TRY(hipEventCreateWithFlags(&e->ev_part[k], hipEventDisableTiming));
+    }
+    for (int k = want; k < MAX_SIDES; ++k) if (k >= 1 && e->sides[k]) { HIP_TRY(hipStreamDestroy(e->sides[k])); e->sides[k] = nullptr; }
+    if (want == 1 && e->mark_stream) { HIP_TRY(hipStreamDestroy(e->mark_stream)); e->mark_stream = nullptr; }
+    e->n_sides = want;
+    e->n_probed = 0;
+    return BBAI_OK;
+}
 static int create_finish(bbai_env* e) {
     const LevelCfg& c = e->cfg;
     const int64_t n_envs = e->n;
@@ -1971,7 +2010,11 @@ static int create_finish(bbai_env* e) {
         int lo = 0, hi = 0;     // look-ahead generation should get wave slots as soon as any free up
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         const char* pv = getenv("BBAI_PREGEN_PRIORITY");     // 1 (default): highest priority, 0: default priority
-        HIP_TRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, (pv && atoi(pv) == 0) ? lo : hi));
+        e->side_prio = (pv && atoi(pv) == 0) ? lo : hi;
+        HIP_TRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, e->side_prio));
+        e->sides[0] = e->side;
+        const char* ls = getenv("BBAI_LOOKAHEAD_STREAMS");
+        { int rc = set_sides(e, ls ? atoi(ls) : LOOKAHEAD_STREAMS_DEFAULT); if (rc != BBAI_OK) return rc; }
         HIP_TRY(hipEventCreateWithFlags(&e->ev_consumed, hipEventDisableTiming));
         HIP_TRY(hipStreamCreateWithFlags(&e->split, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_split0, hipEventDisableTiming));
@@ -2025,6 +2068,10 @@ void bbai_destroy(bbai_env* e) {
     DeviceGuard guard_(e->device);
     (void)hipDeviceSynchronize();
     if (e->side) (void)hipStreamDestroy(e->side);
+    for (int k = 1; k < MAX_SIDES; ++k) if (e->sides[k]) (void)hipStreamDestroy(e->sides[k]);
+    if (e->mark_stream) (void)hipStreamDestroy(e->mark_stream);
+    for (int k = 0; k < MAX_SIDES; ++k) if (e->ev_part[k]) (void)hipEventDestroy(e->ev_part[k]);
+    for (int k = 1; k < MAX_SIDES; ++k) { if (e->gen_lists[k]) (void)hipFree(e->gen_lists[k]); if (e->gen_counts[k]) (void)hipFree(e->gen_counts[k]); }
     if (e->split) (void)hipStreamDestroy(e->split);
     if (e->ev_split0) (void)hipEventDestroy(e->ev_split0);
     if (e->ev_splitB) (void)hipEventDestroy(e->ev_splitB);
@@ -2046,40 +2093,40 @@ void bbai_destroy(bbai_env* e) {
 // k_pregen is instantiated per level family so that a launch carries only that family's mission code, and per group
 // width G (envs per wave = 64 / G; BBAI_PREGEN_GROUP, default 32: two envs per wave)
 template <int G>
-static void launch_pregen_g(const bbai_env* e, unsigned groups, bool listed /* false: dense -- every env, the whole grid works */, uint8_t* pending, const uint8_t* first_slot) {
+static void launch_pregen_g(const bbai_env* e, unsigned groups, bool listed /* false: dense -- every env, the whole grid works */, uint8_t* pending, const uint8_t* first_slot, int side) {
     unsigned long long* fails = e->flow + FLOW_GEN_FAILURES;
     const dim3 g((groups + 64 / G - 1) / (64 / G)), b(64);
     // Demand-sized groups only where a level is cheap (single rooms, <= 60 us per group): a maze level costs a group ~300 us,
     // and GoTo at 131 072 envs stalls the step stream with 4 entries per group (0.0534 vs 0.0385 ms per step,
     // profiles/r04/pregen_min_ab.jsonl) -- mazes keep the whole grid.
     const int min_groups = e->cfg.num_rows * e->cfg.num_cols > 1 ? 0 : e->pregen_min;
-#define PREGEN_LAUNCH(KK, OO) hipLaunchKernelGGL((k_pregen<KK, G, OO>), g, b, 0, e->side, e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, e->gen_list, \
-                                                listed ? e->gen_count : nullptr, e->depth, pending, first_slot, fails, min_groups, e->pregen_per_group, e->next_obs)
+#define PREGEN_LAUNCH(KK, OO) hipLaunchKernelGGL((k_pregen<KK, G, OO>), g, b, 0, e->sides[side], e->cfg, e->n, e->next_rec, e->next_hot, e->mt, e->mti, e->gen_lists[side], \
+                                                listed ? e->gen_counts[side] : nullptr, e->depth, pending, first_slot, fails, min_groups, e->pregen_per_group, e->next_obs)
     if (e->cfg.kind == K_LEVELGEN) { if (e->next_obs) PREGEN_LAUNCH(K_LEVELGEN, true); else PREGEN_LAUNCH(K_LEVELGEN, false); }
     else if (e->cfg.kind == K_BONUS) { if (e->next_obs) PREGEN_LAUNCH(K_BONUS, true); else PREGEN_LAUNCH(K_BONUS, false); }
     else { if (e->next_obs) PREGEN_LAUNCH(K_GOTO, true); else PREGEN_LAUNCH(K_GOTO, false); }
 #undef PREGEN_LAUNCH
 }
 // k_pregen_lane lives in a translation unit of its own (bbai_genlane.hip: compiled without machine-CSE, see there)
-static void launch_pregen_lane(const bbai_env* e, int64_t entries_hint, bool listed, uint8_t* pending, const uint8_t* first_slot) {
+static void launch_pregen_lane(const bbai_env* e, int64_t entries_hint, bool listed, uint8_t* pending, const uint8_t* first_slot, int side) {
     LaneLaunch a;
     a.cfg = e->cfg; a.n = e->n; a.next_rec = e->next_rec; a.next_hot = e->next_hot; a.mt = e->mt; a.mtt = e->mtt; a.mtpar = e->mtpar; a.mti = e->mti;
-    a.gen_list = e->gen_list; a.gen_count = listed ? e->gen_count : nullptr; a.depth = e->depth; a.pending = pending; a.first_slot = first_slot;
+    a.gen_list = e->gen_lists[side]; a.gen_count = listed ? e->gen_counts[side] : nullptr; a.depth = e->depth; a.pending = pending; a.first_slot = first_slot;
     a.fails = e->flow + FLOW_GEN_FAILURES; a.next_obs = e->next_obs; a.tmpl = e->lane_tmpl; a.lane_words = e->lane_words;
     a.blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((entries_hint + 63) / 64, e->lane_blocks));
-    a.stream = e->side;
+    a.stream = e->sides[side];
     bbai_lane_launch(a);
 }
-static void launch_pregen(const bbai_env* e, unsigned groups, bool listed, uint8_t* pending, const uint8_t* first_slot, int64_t entries_hint) {
-    if (e->pregen_lane) { launch_pregen_lane(e, entries_hint, listed, pending, first_slot); return; }
+static void launch_pregen(const bbai_env* e, unsigned groups, bool listed, uint8_t* pending, const uint8_t* first_slot, int64_t entries_hint, int side = 0) {
+    if (e->pregen_lane) { launch_pregen_lane(e, entries_hint, listed, pending, first_slot, side); return; }
     // Measured (profiles/r03/gen_rate_by_group_width.jsonl, pregen_group_width_in_bench.jsonl): levels per second of a bulk
     // fill 64 -> 32 -> 16 lanes per env: BossLevel 1 : 1.16 : 1.18, GoTo 1 : 1.13 : 1.17, PickupLoc 1 : 1.20 : 1.27,
     // GoToLocal 1 : 1.25 : 1.36; inside the step loop 32 is never behind 64 (GoToLocal 65 536 envs -3 %, PickupLoc 262 144
     // -6 %, GoTo 131 072 +-0) while 16 costs the step kernels of GoTo 131 072 9 % (fewer, fatter generator waves next to
     // them: 200 VGPRs and 20 KB of LDS each).
-    if (e->pregen_group == 64) launch_pregen_g<64>(e, groups, listed, pending, first_slot);
-    else if (e->pregen_group == 16) launch_pregen_g<16>(e, groups, listed, pending, first_slot);
-    else launch_pregen_g<32>(e, groups, listed, pending, first_slot);
+    if (e->pregen_group == 64) launch_pregen_g<64>(e, groups, listed, pending, first_slot, side);
+    else if (e->pregen_group == 16) launch_pregen_g<16>(e, groups, listed, pending, first_slot, side);
+    else launch_pregen_g<32>(e, groups, listed, pending, first_slot, side);
 }
 
 extern "C" {
@@ -2175,7 +2222,13 @@ static int probe_stream(bbai_env* e, hipStream_t s, bool* ok) {
         e->host_flags[1] = 0;
         hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, s, e->flow, 0ull);
         hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, s, e->flow, e->host_flags_dev + 1);
-        hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, e->side, e->flow, 1ull);
+        // (the releasing kernel sits behind an event of EVERY look-ahead stream, on the stream k_mark uses: all of them have to run beside the caller's)
+        for (int k = 0; k < e->n_sides && e->n_sides > 1; ++k) {
+            hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, e->sides[k], e->flow, 0ull);
+            HIP_TRY(hipEventRecord(e->ev_part[k], e->sides[k]));
+            HIP_TRY(hipStreamWaitEvent(e->mark_stream, e->ev_part[k], 0));
+        }
+        hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, e->n_sides > 1 ? e->mark_stream : e->side, e->flow, 1ull);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(s));
         verdict = e->host_flags[1] == 1;
@@ -2220,13 +2273,25 @@ static int window_end(bbai_env* e, hipStream_t s, int tokens_mode /* k_tokens: 0
         // Window end, on the look-ahead stream: the window's work list (k_compact), one refill launch for everything consumed in it, the mark behind it.
         const int64_t w = e->tick / B;
         HIP_TRY(hipEventRecord(e->ev_consumed, s));
-        HIP_TRY(hipStreamWaitEvent(e->side, e->ev_consumed, 0));
-        HIP_TRY(hipMemsetAsync(e->gen_count, 0, SHARDS * GEN_COUNT_U32 * 4, e->side));
-        hipLaunchKernelGGL(k_compact, dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->side, e->n, e->pending + (size_t)wb * e->n, e->gen_list, e->gen_count);
-        const int64_t rh = std::max<int64_t>((int64_t)B * (e->n / 64), 64);
-        launch_pregen(e, pregen_grid(e, rh), true, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n, std::min<int64_t>(e->n, 2 * rh));
-        hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, e->side, e->flow, (unsigned long long)(w + 1));
-        HIP_TRY(hipEventRecord(e->ev_refill[wb], e->side));
+        const int64_t nb = (e->n + 63) / 64;
+        const int S = (int)std::max<int64_t>(1, std::min<int64_t>(e->n_sides, nb / 4));          // (a stream's range: at least 256 envs; the streams beyond S idle)
+        for (int k = 0; k < S; ++k) {
+            const int64_t w0 = nb * k / S, w1 = nb * (k + 1) / S, ne = std::min<int64_t>(e->n, w1 * 64) - w0 * 64;
+            hipStream_t ss = e->sides[k];
+            HIP_TRY(hipStreamWaitEvent(ss, e->ev_consumed, 0));
+            HIP_TRY(hipMemsetAsync(e->gen_counts[k], 0, SHARDS * GEN_COUNT_U32 * 4, ss));
+            hipLaunchKernelGGL(k_compact, dim3((unsigned)((w1 - w0 + 3) / 4)), dim3(256), 0, ss, e->n, e->pending + (size_t)wb * e->n, e->gen_lists[k], e->gen_counts[k], w0, w1 - w0);
+            const int64_t rh = std::max<int64_t>((int64_t)B * (ne / 64), 64);
+            launch_pregen(e, (unsigned)std::max<int64_t>(1, std::min<int64_t>(rh, e->pregen_cap / S)), true, e->pending + (size_t)wb * e->n, e->first_slot + (size_t)wb * e->n,
+                          std::min<int64_t>(ne, 2 * rh), k);
+            if (e->n_sides > 1) {
+                HIP_TRY(hipEventRecord(e->ev_part[k], ss));
+                HIP_TRY(hipStreamWaitEvent(e->mark_stream, e->ev_part[k], 0));
+            }
+        }
+        hipStream_t ms = e->n_sides > 1 ? e->mark_stream : e->side;
+        hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, ms, e->flow, (unsigned long long)(w + 1));
+        HIP_TRY(hipEventRecord(e->ev_refill[wb], ms));
         HIP_TRY(hipGetLastError());
     }
     e->tick += ticks;
@@ -3146,6 +3211,7 @@ int bbai_set_option(bbai_env* e, const char* name, int64_t value) {
     else if (!strcmp(name, "bot_group")) e->bot_group = v;
     else if (!strcmp(name, "step_render_split")) e->step_render_split = v;
     else if (!strcmp(name, "rollout_multi")) e->rollout_multi = v;
+    else if (!strcmp(name, "lookahead_streams")) { int rc = set_sides(e, v); if (rc != BBAI_OK) return rc; }
     else if (!strcmp(name, "done_action_enum")) e->done_action_enum = v != 0;       // (the one SEMANTIC switch in this list: include/bbai.h bbai_set_done_actions)
     else {
         snprintf(g_err, sizeof(g_err), "set_option: unknown option '%s'", name);
@@ -3184,6 +3250,7 @@ int bbai_get_option(bbai_env* e, const char* name, int64_t* out) {
     else if (!strcmp(name, "bot_group")) *out = e->bot_group;
     else if (!strcmp(name, "step_render_split")) *out = e->step_render_split;
     else if (!strcmp(name, "rollout_multi")) *out = e->rollout_multi;
+    else if (!strcmp(name, "lookahead_streams")) *out = e->n_sides;
     else if (!strcmp(name, "profile_step_ticks")) *out = e->prof_step_ticks;
     else if (!strcmp(name, "inplace")) *out = e->inplace;
     else if (!strcmp(name, "cplane")) *out = e->cplane ? 1 : 0;

@@ -619,14 +619,15 @@ def roofline_of(m):
 
 
 # what the one JSON line carries next to the headline: every other BASELINE.json config on this GPU (world == 1), measured by
-# the same loop.  steps = steps per block (a block must last milliseconds for a host clock); C4 is quoted on 8 GPUs --
+# the same loop.  steps = steps per block (a block must last milliseconds for a host clock, and many look-ahead windows: it ends with the
+# device idle, i.e. with its last refills drained -- 0.4-0.9 ms that a run in progress never waits for); C4 is quoted on 8 GPUs --
 # its total fits one, so the single-GPU line runs the total, and the per-GPU shard of the 8-GPU job next to it.
 EXTRA_CONFIGS = [
-    ("C2", dict(level="GoToLocal", total=65536, pixel=False, steps=256, ref="BASELINE.json configs[1]; babyai/levels/iclr19_levels.py:105-124")),
-    ("C3", dict(level="PickupLoc", total=262144, pixel=False, steps=128, ref="BASELINE.json configs[2]; iclr19_levels.py:494-515")),
-    ("C4", dict(level="GoTo", total=1048576, pixel=False, steps=32, ref="BASELINE.json configs[3] (1 048 576 envs, here on ONE GPU); iclr19_levels.py:224-257")),
-    ("C4-shard", dict(level="GoTo", total=131072, pixel=False, steps=128, ref="one GPU's share of configs[3] on 8 GPUs")),
-    ("C5-encoded", dict(level="BossLevel", total=1048576, pixel=False, steps=32, ref="the headline's level with 7x7x3 encoded observations (k_step's own roofline)")),
+    ("C2", dict(level="GoToLocal", total=65536, pixel=False, steps=1024, ref="BASELINE.json configs[1]; babyai/levels/iclr19_levels.py:105-124")),
+    ("C3", dict(level="PickupLoc", total=262144, pixel=False, steps=512, ref="BASELINE.json configs[2]; iclr19_levels.py:494-515")),
+    ("C4", dict(level="GoTo", total=1048576, pixel=False, steps=128, ref="BASELINE.json configs[3] (1 048 576 envs, here on ONE GPU); iclr19_levels.py:224-257")),
+    ("C4-shard", dict(level="GoTo", total=131072, pixel=False, steps=512, ref="one GPU's share of configs[3] on 8 GPUs")),
+    ("C5-encoded", dict(level="BossLevel", total=1048576, pixel=False, steps=128, ref="the headline's level with 7x7x3 encoded observations (k_step's own roofline)")),
     # the headline's own per-GPU workloads on 8 / 4 / 2 GPUs (`scaling: "strong"`: 1 048 576 envs in total), on this ONE GPU: the only
     # driver-timed evidence a scaling claim can have while no multi-GPU node runs the bench (`scaling_implied` in the line)
     ("C5-shard-131072", dict(level="BossLevel", total=131072, pixel=True, steps=64, horizon=384, of_gpus=8, ref="one GPU's share of configs[4] (the headline) on 8 GPUs")),

@@ -290,6 +290,8 @@ int bbai_get_done_actions(bbai_env* env);
  *                       BBAI_PREGEN_LANE at bbai_create.  Setting it converts the handle's MT19937 states between the two kernels' forms.
  *                       BBAI_ERR_ARG when 1 is asked of a kind the lane generator does not cover
  *   "lane_blocks"       upper bound on k_pregen_lane's waves per launch (BBAI_LANE_BLOCKS, default 16 384)
+ *   "lookahead_streams" look-ahead streams a window's refill is split over (1 .. 8; BBAI_LOOKAHEAD_STREAMS): each takes a contiguous range of 64-env
+ *                       blocks, so an env's levels stay in stream order on ONE stream while the ranges' refills overlap
  *   "rollout_multi"     bbai_rollout with encoded observations: 1 (default; BBAI_ROLLOUT_MULTI) = one k_step launch per look-ahead window's remaining steps,
  *                       0 = one launch per step
  *   "gate_fault_inject" tests: raise (1) / clear (0) the sticky word a timed-out window gate leaves behind

@@ -1526,7 +1526,8 @@ def test_options_do_not_change_results(gpu):
     settings = [("step_prio", 0), ("pregen_group", 64), ("pregen_blocks", 64), ("render_group", 4), ("render_tpb", 256),
                 ("consume_fused", 1), ("pregen_group", 16), ("render_queue", 1), ("consume_fused", 0),
                 ("render_queue", 6), ("pregen_group", 32), ("step_prio", 1), ("consume_fused", 1), ("consume_fused", -1), ("pregen_min", 0),
-                ("pregen_min", 7), ("pregen_group", 64), ("pregen_min", 2048), ("gate_strict", 1), ("pregen_blocks", 64), ("gate_strict", 0)]
+                ("pregen_min", 7), ("pregen_group", 64), ("pregen_min", 2048), ("gate_strict", 1), ("pregen_blocks", 64), ("gate_strict", 0),
+                ("lookahead_streams", 3), ("lookahead_streams", 8), ("gate_strict", 1), ("lookahead_streams", 2), ("gate_strict", 0), ("lookahead_streams", 1)]
     for t in range(20 * len(settings)):
         assert torch.equal(oa["image"], ob["image"]) and torch.equal(a.image, b.image) and torch.equal(a.direction, b.direction), t
         if t % 20 == 0:
@@ -1827,12 +1828,14 @@ def test_rollout_entry_equals_per_step_calls(gpu, level, n, pixel):
 @pytest.mark.gpu
 @pytest.mark.parametrize("level,n,opts", [("GoToLocal", 3000, {}), ("PickupLoc", 700, {}), ("BossLevel", 1500, {}), ("GoTo", 1300, {}), ("GoTo", 1100, {"consume_fused": 0}),
                                           ("GoToLocal", 1000, {"auto_reset": False}), ("PutNextS5N2Carrying", 900, {}), ("KeyInBox", 800, {}),
-                                          ("GoToLocal", 2500, {"inplace_off": True}), ("SynthS5R2", 1000, {}), ("GoToRedBallGrey", 700, {"done_actions": True})])
+                                          ("GoToLocal", 2500, {"inplace_off": True}), ("SynthS5R2", 1000, {}), ("GoToRedBallGrey", 700, {"done_actions": True}),
+                                          ("GoToLocal", 9000, {"streams": 3}), ("GoTo", 5000, {"streams": 5}), ("BossLevel", 4000, {"streams": 2}), ("PickupLoc", 2000, {"streams": 8})])
 def test_rollout_steps_many_ticks_per_launch(gpu, level, n, opts):
     """bbai_rollout's fast path -- ONE k_step launch per look-ahead window's remaining ticks, log rows written by the stepping lanes -- against
     one bbai_step + bbai_tap_ids per step: every logged byte of every step (through resets, window boundaries inside a call, calls that start
     in mid-window), the final outputs of every env, the reset count, and the state the run leaves behind (both continue per step and must stay
-    equal).  Shapes where the fast path does not apply (unfused consume) take the same entry and must give the same bytes."""
+    equal).  Shapes where the fast path does not apply (unfused consume) take the same entry and must give the same bytes.  `streams`: the
+    refills of the two rollout batches are split over that many look-ahead streams (option "lookahead_streams"), the per-step batch keeps one."""
     import torch
     from babyai_amd.engine import BatchedBabyAIEnv
     from babyai_amd.action_stream import actions_torch
@@ -1852,8 +1855,11 @@ def test_rollout_steps_many_ticks_per_launch(gpu, level, n, opts):
         os.environ.pop("BBAI_INPLACE", None)
     for env in (a, b, c):
         for k, v in opts.items():
-            if k not in ("auto_reset", "inplace_off", "done_actions"):
+            if k not in ("auto_reset", "inplace_off", "done_actions", "streams"):
                 env.set_option(k, v)
+        if "streams" in opts and env is not a:          # the window refills split over several look-ahead streams (the reference batch: one)
+            env.set_option("lookahead_streams", opts["streams"])
+            assert env.get_option("lookahead_streams") == opts["streams"]
         env.reset()
     assert b.get_option("rollout_multi") == 1
     acts = actions_torch(9, 0, T + T2, 0, n, gpu)

@@ -25,7 +25,7 @@ and that a ring ONE slot shallower, or a gate that admits a sum of B + 1, breaks
 import numpy as np
 import pytest
 
-NWIN = 34            # bbai_engine.hip NWIN = MAX_PERIOD + 2
+NWIN = 34            # bbai_engine.hip NWIN (MAX_PERIOD = 64 since round 6: at most 33 refills outstanding whatever B)
 
 
 class Env:

@@ -62,13 +62,14 @@ bench() {            # one BASELINE config as its own line: bench:C2 [extra args
 }
 benchenv() {         # one BASELINE config under an environment setting: benchenv:BBAI_GATE_STRICT=1:C4[:extra bench args]
     local kv=$1 cfg=$2; shift 2
-    cd /tmp && env "$kv" timeout 600 python $REPO/bench.py --config $cfg --no-extra-configs --no-cpu-baseline ${@} > $OUT/bench_${cfg}_$kv.json 2>> $OUT/bench.err
+    cd /tmp && env ${kv//,/ } timeout 600 python $REPO/bench.py --config $cfg --no-extra-configs --no-cpu-baseline ${@} > $OUT/bench_${cfg}_$kv.json 2>> $OUT/bench.err      # (several settings: A=1,B=2)
     python - <<PY
 import json
 d = json.loads(open("$OUT/bench_${cfg}_$kv.json").read().strip().splitlines()[-1])
 t = d["timing"]
-print("$kv $cfg ms/step mean %.4f median %.4f max/med %.2f blocks %s parity %s" % (d["ms_per_step"], t["block_ms"]["median"] / d["steps"], t["max_over_median"],
-      [round(b, 1) for b in t["block_ms_list"]], (d.get("parity") or {}).get("mismatches_all_ranks")))
+r = d["roofline"]
+print("$kv $cfg ms/step mean %.4f median %.4f max/med %.2f k_step per step %.4f parity %s gate_timeouts %s" % (d["ms_per_step"], t["block_ms"]["median"] / d["steps"], t["max_over_median"],
+      r["kernel_avg_ms"].get("k_step", 0) / (r.get("steps_per_launch") or 1.0), (d.get("parity") or {}).get("mismatches_all_ranks"), d.get("gate_timeouts")))
 PY
 }
 ab() {               # tools/ab.py presets
@@ -311,6 +312,28 @@ steps = [r for r in main if r[2].startswith("k_step")]
 if len(steps) > 2: print("step period median %.2f us" % med([(b[0] - a[0]) / 1e3 for a, b in zip(steps, steps[1:])]))
 PY
     find $OUT -name "*.csv" -size +20M -delete
+}
+timeline() {         # timeline:<config>:<A=1,B=2 settings or ->[:<bench args>] -- every kernel of ~3 windows in the middle of the run, start / end in us, with its queue
+    local cfg=$1 kv=$2; shift 2
+    local name=timeline_${cfg}_${kv}
+    cd /tmp && rm -rf $OUT/$name
+    env ${kv//,/ } DUMMY=1 timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/$name -o t -- python $REPO/bench.py --config $cfg --no-extra-configs --no-cpu-baseline --parity-envs 0 --min-seconds 0.2 --max-blocks 6 $@ > $OUT/$name.json 2> $OUT/$name.log
+    python - <<PY | tee $OUT/$name.txt
+import csv, glob
+rows = []
+for path in glob.glob("$OUT/$name/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(path)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", ""), r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
+rows.sort()
+steps = [i for i, r in enumerate(rows) if r[2].startswith("k_step")]
+if steps:
+    mid = steps[len(steps) * 2 // 3]
+    t0 = rows[mid][0]
+    sel = [r for r in rows if t0 <= r[0] <= t0 + 2500000][:140]
+    for a, b, k, q, st in sel:
+        print("%9.1f %9.1f  dur %8.1f us  q%-3s s%-3s %s" % ((a - t0) / 1e3, (b - t0) / 1e3, (b - a) / 1e3, q, st, k))
+PY
+    rm -rf $OUT/$name
 }
 run() { cd $REPO && timeout 900 "$@"; }          # run:python:tools/x.py:arg ...
 
