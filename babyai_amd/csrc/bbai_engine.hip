@@ -86,7 +86,7 @@ constexpr int MAX_SIDES = 8;            // look-ahead streams a window's refill 
 #ifndef LOOKAHEAD_STREAMS_DEFAULT
 #define LOOKAHEAD_STREAMS_DEFAULT 1
 #endif
-constexpr int MAX_PERIOD = 64;          // refill period B (ticks per look-ahead refill); ring depth D = 2B (+ 1 in place: slot numbers stay bytes)
+constexpr int MAX_PERIOD = 96;          // refill period B (ticks per look-ahead refill); ring depth D = 2B (+ 1 in place): slot numbers and per-window counts stay bytes
 constexpr int NWIN = 34;                // window buffers (see "the windows' bookkeeping" below): at most 33 refills outstanding, whatever B
 
 struct bbai_env {
@@ -1881,9 +1881,10 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
         // Refill period B (ticks per look-ahead refill, BBAI_LOOKAHEAD); ring depth D = 2B.  One k_pregen launch per
         // window lasts as long as its slowest level (hundreds of microseconds to milliseconds: rejection sampling has a
         // heavy tail) and has to land within one window, so B ticks of the step path must outlast it or the step stream
-        // waits: default = the longest period of 64, 32, 16, 8, 4, 2 whose ring fits the cap.  (64 since round 6: a refill launch lasts as long
-        // as its slowest WAVE -- 0.4 ms for 64 single-room levels per lane-generator wave, 0.6-0.9 ms for a lane group's maze -- almost whatever its
-        // size, and bbai_rollout's k_step takes 8 us per tick at 65 536 envs: 32 ticks no longer outlast a refill, 64 nearly do.)  The cap is BBAI_RING_GIB
+        // waits: default = the longest period of 96 (mazes), 64, 32, 16, 8, 4, 2 whose ring fits the cap.  (Up to 32 until round 6.  A refill launch lasts as
+        // long as its slowest WAVE -- 0.4 ms for 64 single-room levels per lane-generator wave, 0.6-0.9 ms for a lane group's maze -- almost whatever its
+        // size, and bbai_rollout's k_step takes 8 us per tick at 65 536 envs: 32 ticks no longer outlast a refill.  GoToLocal 65 536 envs 0.0146 -> 0.0103 ms
+        // per step at 64, GoTo 131 072 0.0344 -> 0.0244 at 64 -> 0.0214 at 96: profiles/r06/NOTES.md section 9.)  The cap is BBAI_RING_GIB
         // (default 64 GiB -- the part has 288 GB; round 4: 1 048 576 GoTo envs waited for refills at period 4, the 16-GiB cap of
         // rounds 1-3) but never more than a quarter of the memory that is FREE right now (several handles or ranks
         // on one device, smaller parts), and an allocation that fails all the same is retried with half the period: a
@@ -1896,7 +1897,8 @@ int bbai_create(const bbai_level_cfg* cfg, int64_t n_envs, int device, bbai_env*
         const size_t cap = std::min((size_t)(gv ? std::max(1, atoi(gv)) : 64) << 30, free_b / 4);
         int b = 2;
         if (ev) b = atoi(ev);
-        else for (int cand = MAX_PERIOD; cand >= 2; cand >>= 1) if (slot_bytes * (2 * (size_t)cand + (size_t)e->inplace) <= cap) { b = cand; break; }
+        else for (int cand : {96, 64, 32, 16, 8, 4, 2}) if (cand <= (c.num_rows * c.num_cols > 1 ? 96 : 64))      // (single rooms: 96 measured equal to 64)
+             if (slot_bytes * (2 * (size_t)cand + (size_t)e->inplace) <= cap) { b = cand; break; }
         b = b < 1 ? 1 : (b > MAX_PERIOD ? MAX_PERIOD : b);
         for (; err == hipSuccess; b >>= 1) {
             e->period = b;

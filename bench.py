@@ -626,7 +626,7 @@ EXTRA_CONFIGS = [
     ("C2", dict(level="GoToLocal", total=65536, pixel=False, steps=1024, ref="BASELINE.json configs[1]; babyai/levels/iclr19_levels.py:105-124")),
     ("C3", dict(level="PickupLoc", total=262144, pixel=False, steps=512, ref="BASELINE.json configs[2]; iclr19_levels.py:494-515")),
     ("C4", dict(level="GoTo", total=1048576, pixel=False, steps=128, ref="BASELINE.json configs[3] (1 048 576 envs, here on ONE GPU); iclr19_levels.py:224-257")),
-    ("C4-shard", dict(level="GoTo", total=131072, pixel=False, steps=512, ref="one GPU's share of configs[3] on 8 GPUs")),
+    ("C4-shard", dict(level="GoTo", total=131072, pixel=False, steps=576, ref="one GPU's share of configs[3] on 8 GPUs")),
     ("C5-encoded", dict(level="BossLevel", total=1048576, pixel=False, steps=128, ref="the headline's level with 7x7x3 encoded observations (k_step's own roofline)")),
     # the headline's own per-GPU workloads on 8 / 4 / 2 GPUs (`scaling: "strong"`: 1 048 576 envs in total), on this ONE GPU: the only
     # driver-timed evidence a scaling claim can have while no multi-GPU node runs the bench (`scaling_implied` in the line)

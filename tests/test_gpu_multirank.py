@@ -123,7 +123,9 @@ def test_self_launch_spawns_n_ranks():
     p, line = _run([sys.executable, "bench.py", "--gpus", "2", "--parity-envs", "0", "--no-cpu-baseline"], timeout=300)
     assert p.returncode != 0 and line is None
     assert "launching 2 ranks" in p.stderr
-    assert p.stderr.count("bench.py needs a ROCm GPU") >= 2
+    # (both ranks say so unless the elastic agent ends the second one the moment the first has failed -- seen on a loaded box: then its
+    #  failure report still names two local ranks)
+    assert p.stderr.count("bench.py needs a ROCm GPU") >= 2 or (p.stderr.count("bench.py needs a ROCm GPU") == 1 and "local_rank: 1" in p.stderr or "rank      : 1" in p.stderr)
 
 
 def test_default_workload_is_the_metric_configuration():
