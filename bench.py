@@ -345,7 +345,7 @@ def traffic_of(level, E, pixel, dom):
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
         wl = pmc["workloads"]["%s:%d:%s" % (level, E, "pixel" if pixel else "encoded")]
-        cands = [k for k in wl["kernels"] if k == dom or k.startswith(dom + "<") or k.startswith(dom + "_q<")]      # k_render / k_render_q are templates
+        cands = [k for k in wl["kernels"] if k == dom or k.startswith(dom + "<") or k.startswith(dom + "_q<") or k.startswith(dom + "_ticks<")]      # k_render / k_render_q, k_step / k_step_ticks: templates
         if not cands:
             return None
         key = max(cands, key=lambda k: wl["kernels"][k].get("launches", 0))        # (the instantiation the step loop runs)

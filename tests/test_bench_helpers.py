@@ -27,7 +27,9 @@ def test_every_benched_workload_has_counters_of_the_committed_sources():
         t = bench.traffic_of(level, envs, pixel, dom)
         assert t is not None and t["current"] and t["bytes"] > 0, (level, envs, pixel)
         alg = envs * (147 + 9408) if pixel else envs * 235 * t["steps_per_launch"]        # (bbai_rollout: a k_step launch takes a look-ahead window's steps)
-        assert 0.99 < t["bytes"] / alg < 3.0, (level, envs, pixel, t["bytes"] / alg)       # the render writes every byte once; k_step's gathers cost whole lines
+        # the render writes every byte once; k_step's gathers cost whole lines -- and a k_step_ticks launch that rewrites a small batch's outputs tick after
+        # tick keeps part of them in the memory-side cache (GoToLocal 65 536: below its algorithmic bytes)
+        assert (0.99 if pixel else 0.5) < t["bytes"] / alg < 3.0, (level, envs, pixel, t["bytes"] / alg)
 
 
 def test_extra_configs_cover_baseline_json():

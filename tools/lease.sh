@@ -265,7 +265,7 @@ profcfg() {          # profcfg:<config>[:<bench args>] -- the evidence set of ON
                      # FETCH_SIZE and WRITE_SIZE passes (each on its own: gpurun refuses counter + trace-domain mixes), and the SQ pass; condensed by
                      # tools/summarize_profile.py into profiles/<tag>/ and profiles/pmc_latest.json (one entry per workload)
     local cfg=$1; shift
-    local B1="python $REPO/bench.py --config $cfg --no-extra-configs --no-cpu-baseline --parity-envs 0 --min-seconds 0.25 --max-blocks 8 $@"
+    local B1="python $REPO/bench.py --config $cfg --no-extra-configs --no-cpu-baseline --parity-envs 0 --min-seconds 0.25 --max-blocks 8 --steps 192 $@"      # (192: whole look-ahead windows of 16 / 64 / 96 ticks -- every k_step_ticks launch of a block takes the same number of steps)
     cd /tmp && rm -rf $OUT/stats_$cfg $OUT/pmc_fetch_$cfg $OUT/pmc_write_$cfg $OUT/pmc_sq_$cfg
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$cfg -o t -- $B1 > $OUT/bench_${cfg}_under_rocprof.json 2> $OUT/rocprof_stats_$cfg.log
     timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$cfg -o t -- $B1 > /dev/null 2> $OUT/rocprof_fetch_$cfg.log
