@@ -211,7 +211,7 @@ int bbai_step_tapped(bbai_env* env, const uint8_t* actions_dev, uint8_t* image_d
  * The per-step calls give the same bytes (tests/test_gpu_parity.py::test_rollout_entry_*).
  * Since round 6 the entry is also the fast path of open-loop stepping: with encoded observations (pixels_dev NULL), no token buffer,
  * and steps that move their finished envs on themselves (the default: fused consume / in-place layout; or auto_reset 0), ONE k_step
- * launch takes every step the current look-ahead window has left (up to 32) -- an env's step touches only its own state, so a 64-env
+ * launch takes every step the current look-ahead window has left (up to 64 single-room / 96 maze ticks) -- an env's step touches only its own state, so a 64-env
  * block walks through the ticks on its own, no launch boundary and no dependent-launch gap (4-5 us: a third of a 65 536-env step) in
  * between; tick t reads actions_dev + t * n_envs.  A tap log is then written by the stepping lanes (bbai_step_tapped's mechanism): pass
  * ids_dev = NULL and count = the number of envs listed by bbai_step_tap_set (log row k = env ids[k]; pix_count 0).  A tap log WITH
@@ -290,8 +290,10 @@ int bbai_get_done_actions(bbai_env* env);
  *                       BBAI_PREGEN_LANE at bbai_create.  Setting it converts the handle's MT19937 states between the two kernels' forms.
  *                       BBAI_ERR_ARG when 1 is asked of a kind the lane generator does not cover
  *   "lane_blocks"       upper bound on k_pregen_lane's waves per launch (BBAI_LANE_BLOCKS, default 16 384)
- *   "lookahead_streams" look-ahead streams a window's refill is split over (1 .. 8; BBAI_LOOKAHEAD_STREAMS): each takes a contiguous range of 64-env
- *                       blocks, so an env's levels stay in stream order on ONE stream while the ranges' refills overlap
+ *   "lookahead_streams" look-ahead streams a window's refill is split over (1 .. 8, default 1; BBAI_LOOKAHEAD_STREAMS): each takes a contiguous range of
+ *                       64-env blocks, so an env's levels stay in stream order on ONE stream while the ranges' refills run side by side.  Measured: no gain
+ *                       (a refill launch lasts as long as its slowest wave whatever its size) -- and the extra streams are created only while asked
+ *                       for: every HIP stream is a hardware queue, a dozen per handle slow EVERY dispatch down
  *   "rollout_multi"     bbai_rollout with encoded observations: 1 (default; BBAI_ROLLOUT_MULTI) = one k_step launch per look-ahead window's remaining steps,
  *                       0 = one launch per step
  *   "gate_fault_inject" tests: raise (1) / clear (0) the sticky word a timed-out window gate leaves behind
