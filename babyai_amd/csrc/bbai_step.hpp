@@ -120,42 +120,71 @@ BB_HD int verify_leaf(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale
 // reference's own bot returns the member (bot.py:593, fed to env.step by scripts/make_agent_demos.py:93-107).  `enum_done`
 // says which kind this step's `done` actions are: bbai_bot_rollout (the expert's own actions) and the "done_action_enum"
 // option set it.  A lone ActionInstr passes its failure through.
-BB_HD int verify_side(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int base, int n, int bit_a, int action, int fe2, Lsm& lsm, int idf,
-                      bool enum_done = false) {
-    if (n == 1) return verify_leaf(c, r, h, stale, base, action, fe2, lsm, idf);
-    int sa = V_SUCCESS, sb = V_SUCCESS;              // (a side that succeeded earlier is not verified again: a_done stays 'success')
-    if (!(h.vstate >> bit_a & 1)) {
-        sa = verify_leaf(c, r, h, stale, base, action, fe2, lsm, idf);
-        if (sa == V_SUCCESS) h.vstate |= 1 << bit_a;
-    }
-    if (!(h.vstate >> (bit_a + 1) & 1)) {
-        sb = verify_leaf(c, r, h, stale, base + 1, action, fe2, lsm, idf);
-        if (sb == V_SUCCESS) h.vstate |= 1 << (bit_a + 1);
-    }
-    if (lsm.on && enum_done && action == A_DONE && sa == V_FAILURE && sb == V_FAILURE) return V_FAILURE;
+//
+// The tree is walked as ONE loop over at most four leaf evaluations -- the first side's one or two leaves, then the second side's -- around a
+// single copy of verify_leaf (round 6).  Written as the reference writes it (verify_root -> verify_side -> verify_leaf, everything inlined) the
+// kernel held up to twelve copies of verify_leaf_action, and a wave whose envs carry different program shapes (BossLevel) walked through most of
+// them on every step: 630 vector + 400 scalar instructions per wave-step more than GoTo's single leaf (profiles/r06/k_step_ticks_instruction_mix.txt).
+// Which leaves are evaluated, in which order, and with which side effects (preCarrying, And progress bits, lastStepMatch) is unchanged:
+//   * a side's leaf is evaluated unless the side is an And and the leaf's progress bit is already set (verifier.py:536-550);
+//   * Before: a then b; After: b then a.  The second part is verified with the SAME action in the step the first part completes
+//     (verifier.py:463-464,504-505); a failure of either part fails; while the first part is pending, a strict Seq PROBES the second part -- a
+//     verify() with its side effects -- and fails if it succeeds (verifier.py:466-469,507-510).
+BB_HD int side_status(const Hot& h, int n, int bit_a, int sa, int sb, bool and_fails) {
+    if (n == 1) return sa;
+    if (and_fails && sa == V_FAILURE && sb == V_FAILURE) return V_FAILURE;
     return (h.vstate >> bit_a & 3) == 3 ? V_SUCCESS : V_CONTINUE;
 }
-
 BB_HD int verify_root(const LevelCfg& c, const EnvRef& r, Hot& h, uint64_t stale, int action, int fe2, Lsm& lsm, int idf, bool enum_done = false) {
     const VProg* p = &r.prog;
-    if (p->root() == R_ACTION || p->root() == R_AND) return verify_side(c, r, h, stale, 0, p->n_a(), 1, action, fe2, lsm, idf, enum_done);
-    // Before: a then b; After: b then a.  The second part is verified with the SAME action in
-    // the step the first part completes (verifier.py:463-464,504-505); a failure of either part fails.
-    const bool before = p->root() == R_BEFORE;
-    const int b1 = before ? 0 : 2, n1 = before ? p->n_a() : p->n_b(), s1 = before ? 1 : 3;
-    const int b2 = before ? 2 : 0, n2 = before ? p->n_b() : p->n_a(), s2 = before ? 3 : 1;
-    if (!(h.vstate & 1)) {
-        int st = verify_side(c, r, h, stale, b1, n1, s1, action, fe2, lsm, idf, enum_done);
-        if (st == V_FAILURE) return st;
-        if (st != V_SUCCESS) {
-            // strict Seq: completing the second part first fails (verifier.py:466-469,507-510); the probe IS a verify()
-            // of the second part, with its side effects (preCarrying, And progress bits, lastStepMatch)
-            if (p->strict_seq() && verify_side(c, r, h, stale, b2, n2, s2, action, fe2, lsm, idf, enum_done) == V_SUCCESS) return V_FAILURE;
-            return st;
+    const int root = p->root();
+    // a lone ActionInstr (every single-instruction level; a fifth of BossLevel's missions): leaf 0, with everything that depends on the leaf
+    // number folded -- the loop's copy of verify_leaf indexes the program by a variable (150 vector instructions per wave-step more on GoToLocal
+    // when it was the only copy)
+    if (root == R_ACTION) return verify_leaf(c, r, h, stale, 0, action, fe2, lsm, idf);
+    const bool seq = root != R_AND;
+    const bool before = root == R_BEFORE;
+    const int na = p->n_a(), nb = p->n_b();
+    // first side / second side: base leaf, leaf count, first And progress bit
+    const int b1 = (seq && !before) ? 2 : 0, n1 = (seq && !before) ? nb : na, s1 = (seq && !before) ? 3 : 1;
+    const int b2 = before ? 2 : 0, n2 = before ? nb : na, s2 = before ? 3 : 1;
+    const bool first_done = seq && (h.vstate & 1);
+    const bool and_fails = lsm.on && enum_done && action == A_DONE;
+    int ra = V_SUCCESS, rb = V_SUCCESS;     // the current side's leaf results (a leaf that succeeded earlier is not verified again: it stays 'success')
+    bool second = first_done;               // is the second side evaluated on this step?  (decided after the first side's leaves)
+    int st1 = V_SUCCESS;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+    for (int trip = 0; trip < 4; ++trip) {
+        const int k = trip & 1;
+        if (trip == 2) {
+            if (!seq) break;
+            if (!first_done) {
+                st1 = side_status(h, n1, s1, ra, rb, and_fails);
+                second = st1 == V_SUCCESS || (st1 != V_FAILURE && p->strict_seq());
+            }
+            ra = V_SUCCESS; rb = V_SUCCESS;
         }
-        h.vstate |= 1;
+        const bool side2 = trip >= 2;
+        const int base = side2 ? b2 : b1, n = side2 ? n2 : n1, bit = (side2 ? s2 : s1) + k;
+        const bool live = (side2 ? second : !first_done) && k < n && (n == 1 || !(h.vstate >> bit & 1));
+        if (live) {
+            const int v = verify_leaf(c, r, h, stale, base + k, action, fe2, lsm, idf);
+            if (n == 2 && v == V_SUCCESS) h.vstate |= 1 << bit;
+            if (k == 0) ra = v; else rb = v;
+        }
     }
-    return verify_side(c, r, h, stale, b2, n2, s2, action, fe2, lsm, idf, enum_done);
+    if (!seq) return side_status(h, n1, s1, ra, rb, and_fails);
+    const int st2 = side_status(h, n2, s2, ra, rb, and_fails);       // (meaningful where the second side was evaluated)
+    if (first_done) return st2;
+    if (st1 == V_FAILURE) return st1;
+    if (st1 != V_SUCCESS) {             // the first part is still pending: a strict Seq has probed the second
+        if (p->strict_seq() && st2 == V_SUCCESS) return V_FAILURE;
+        return st1;
+    }
+    h.vstate |= 1;
+    return st2;
 }
 
 // reward = 1 - 0.9 * (step_count / max_steps) in float64 (MiniGridEnv._reward, returned as a Python float at
