@@ -1904,6 +1904,60 @@ def test_rollout_steps_many_ticks_per_launch(gpu, level, n, opts):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("level,n", [("GoToLocal", 2000), ("BossLevel", 1200)])
+def test_rollout_with_a_token_buffer_keeps_one_step_per_launch(gpu, level, n):
+    """A registered mission-token buffer has to follow every step's resets (k_tokens reads each step's `done` bytes), so bbai_rollout keeps one
+    step per launch then -- through the same entry, with the same bytes, the token rows included; the stepping lanes' tap rows still work there;
+    option rollout_multi 0 does the same without a token buffer."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from babyai_amd.action_stream import actions_torch
+    from babyai_amd.shard import scattered_ids
+    T, P = 100, 64
+    envs = [BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=77) for _ in range(3)]
+    a, b, c = envs
+    for env in (a, b):
+        env.enable_instr_tokens()
+    c.set_option("rollout_multi", 0)
+    for env in envs:
+        env.reset()
+    acts = actions_torch(13, 0, T, 0, n, gpu)
+    idl = list(scattered_ids(n, P))
+
+    def mklog():
+        return {"image": torch.zeros((T, P, 7, 7, 3), dtype=torch.uint8, device=gpu), "direction": torch.zeros((T, P), dtype=torch.uint8, device=gpu),
+                "reward64": torch.zeros((T, P), dtype=torch.float64, device=gpu), "done": torch.zeros((T, P), dtype=torch.uint8, device=gpu)}
+
+    la, lb, lc = mklog(), mklog(), mklog()
+    a.set_step_tap(idl)
+    for t in range(T):
+        a.step_tapped(acts[t], la["image"][t], la["direction"][t], la["reward64"][t], la["done"][t])
+    b.set_step_tap(idl)
+    b.rollout(acts[:37], tap=lb, obs_row0=0, row0=0, step_tap=True)
+    b.rollout(acts[37:], tap=lb, obs_row0=37, row0=37, step_tap=True)
+    c.set_step_tap(idl)
+    c.rollout(acts, tap=lc, obs_row0=0, row0=0, step_tap=True)
+    for k in la:
+        assert torch.equal(la[k], lb[k]) and torch.equal(la[k], lc[k]), k
+    assert torch.equal(a.instr, b.instr)
+    for other in (b, c):
+        assert torch.equal(a.image, other.image) and torch.equal(a.reward64, other.reward64) and torch.equal(a.done, other.done)
+        assert a.reset_count() == other.reset_count()
+    if level == "GoToLocal":
+        assert a.reset_count() > n + 100
+    with pytest.raises(Exception):              # a tap log of the stepping lanes has no pixel rows; rollouts of a pixel batch keep the launch (ids)
+        p = BatchedBabyAIEnv("BabyAI-%s-v0" % level, 256, device=gpu, seeds=1, pixel=True)
+        try:
+            p.reset()
+            p.set_step_tap([0, 1])
+            p.rollout(acts[:2, :256].contiguous(), tap={k: v[:, :2].contiguous() for k, v in mklog().items()}, step_tap=True)
+        finally:
+            p.close()
+    for env in envs:
+        env.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("level,n,opts", [("GoToLocal", 3000, {}), ("PickupLoc", 700, {}), ("BossLevel", 1500, {}), ("GoTo", 1300, {"consume_fused": 0}),
                                           ("GoToLocal", 1000, {"auto_reset": False}), ("PutNextS5N2Carrying", 900, {})])
 def test_step_tapped_equals_step_plus_tap(gpu, level, n, opts):
