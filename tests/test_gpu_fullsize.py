@@ -212,3 +212,38 @@ def test_baseline_configs_1024_scattered_envs_vs_oracle(gpu, level, n, pixel, st
         assert finished >= 2 * 1024 and resets >= 2 * n          # everybody crossed auto-resets, twice on average
     else:
         assert finished >= 1024 // 2 if level == "GoTo" else finished > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level,n,T", [("BossLevel", N_FULL, 72), ("GoTo", 131072, 230), ("PickupLoc", 262144, 150), ("GoToLocal", 65536, 150)])
+def test_rollout_full_size_equals_per_step_calls(gpu, level, n, T):
+    """bbai_rollout's window-per-launch path at the BASELINE.json batch sizes (the sizes bench.py runs it at) against per-step calls: every output byte of
+    EVERY env after T steps -- several look-ahead windows, thousands to millions of resets -- the reset totals, and the states the runs leave behind
+    (both go on per step and must stay equal)."""
+    import torch
+    from babyai_amd.engine import BatchedBabyAIEnv
+    from babyai_amd.action_stream import actions_torch
+    a = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=5)
+    b = BatchedBabyAIEnv("BabyAI-%s-v0" % level, n, device=gpu, seeds=5)
+    a.reset()
+    b.reset()
+    chunk = 24                                    # (the action stream of a million envs, a few steps at a time)
+    t = 0
+    while t < T:
+        k = min(chunk, T - t)
+        acts = actions_torch(3, t, t + k, 0, n, gpu)
+        for j in range(k):
+            a.step(acts[j])
+        b.rollout(acts)
+        t += k
+        assert torch.equal(a.image, b.image) and torch.equal(a.direction, b.direction), t
+        assert torch.equal(a.reward64, b.reward64) and torch.equal(a.done, b.done), t
+    assert a.reset_count() == b.reset_count() and a.reset_count() > n
+    acts = actions_torch(3, T, T + 8, 0, n, gpu)
+    for j in range(8):
+        a.step(acts[j])
+        b.step(acts[j])
+    assert torch.equal(a.image, b.image) and torch.equal(a.reward64, b.reward64) and torch.equal(a.done, b.done)
+    assert a.gate_timeouts() == 0 and b.gate_timeouts() == 0
+    a.close()
+    b.close()
