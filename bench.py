@@ -277,7 +277,8 @@ def compact_line(out, full_path=None):
             cr = c.get("roofline") or {}
             cfgs[name] = {"envs": c.get("envs"), "ms_per_step": c.get("ms_per_step"), "ms_median": c.get("ms_per_step_median"),
                           "max_over_median": c.get("max_over_median"),
-                          "kernel": cr.get("kernel"), "kernel_ms": cr.get("avg_launch_ms"), "frac": cr.get("frac"),
+                          "loop": ("rollout" if str(c.get("loop", "")).startswith("one bbai_rollout") else "step"),      # (bbai_rollout: a window's steps per launch / per-step calls)
+                          "kernel": cr.get("kernel"), "kernel_ms": cr.get("avg_launch_ms"), "steps_per_launch": cr.get("steps_per_launch"), "frac": cr.get("frac"),
                           "step_frac": (cr["whole_step_alg_GBs"] / cr["peak"]) if cr.get("whole_step_alg_GBs") and cr.get("peak") else None,
                           "traffic_ratio": (cr["traffic"] / cr["alg_bytes_per_launch"]) if cr.get("traffic") and cr.get("alg_bytes_per_launch") else None,
                           "mismatches": (c.get("parity") or {}).get("mismatches"),
@@ -297,7 +298,8 @@ def compact_line(out, full_path=None):
     line["parity"] = par
     line["timing"] = {"blocks": t.get("blocks"), "ms_median": (bm.get("median") / K) if bm.get("median") else None,
                       "ms_max": (bm.get("max") / K) if bm.get("max") else None, "mean_over_median": t.get("mean_over_median"),
-                      "timed_seconds": t.get("timed_seconds"), "profiled_ms_per_step": t.get("profiled_ms_per_step")}
+                      "timed_seconds": t.get("timed_seconds"), "profiled_ms_per_step": t.get("profiled_ms_per_step"),
+                      "loop": ("rollout" if str(t.get("loop", "")).startswith("one bbai_rollout") else "step")}
     line["kernel_avg_ms"] = r.get("kernel_avg_ms")
     rc = out.get("rccl") or {}
     line["rccl"] = pick(rc, ("world", "backend", "allreduce_of_ones", "distinct_devices", "per_rank_ms_per_step_min", "per_rank_ms_per_step_max", "launched_by"))
