@@ -51,7 +51,10 @@ def _run(name, n, steps, gpu, switch=False):
     if not a.get_option("inplace") == b.get_option("inplace"):
         pytest.skip("layouts differ")
     if a.get_option("pregen_lane") != 1:
+        uncovered = a.get_option("inplace") == 1 and a.get_option("cplane") == 0
         a.close(); b.close()
+        if uncovered:       # (BBAI_INPLACE=1 forced on a kind whose default is the classic layout: in place, the lane generator needs the C plane row of the
+            pytest.skip("%s in the in-place layout without a C plane: not covered by the lane generator (bbai_create)" % name)      # small single rooms)
         raise AssertionError("%s: BBAI_PREGEN_LANE=1 did not select the lane generator" % name)
     assert b.get_option("pregen_lane") == 0
     rng = np.random.RandomState(11)
