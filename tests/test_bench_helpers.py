@@ -46,7 +46,8 @@ def _synthetic_record(n_configs=9):
         "envs": 1048576, "gate_timeouts": 0, "workload": "BabyAI-BossLevel-v0 56x56x3 pixel (RGBImgPartialObsWrapper) obs, 1048576 envs in total" * 2,
         "reference": "x" * 200, "value": 6.5e8, "ms_per_step": 0.123456789, "ms_per_step_median": 0.12, "mean_over_median": 1.01, "max_over_median": 6.5,
         "block_ms_list": [1.2345] * 64, "kernel_avg_ms": {"k_step": 0.1, "k_render": 1.5},
-        "roofline": {"bound": "hbm", "kernel": "k_render", "alg_bytes_per_launch": 10019143680, "avg_launch_ms": 1.5, "achieved": 6646.7, "unit": "GB/s",
+        "loop": "one bbai_rollout call per block: ONE k_step launch per look-ahead window (64 steps), the parity tap's rows written by the stepping lanes",
+        "roofline": {"bound": "hbm", "kernel": "k_render", "alg_bytes_per_launch": 10019143680, "avg_launch_ms": 1.5, "steps_per_launch": 64.0, "achieved": 6646.7, "unit": "GB/s",
                      "peak": 8000.0, "frac": 0.83, "traffic": 10038800000.0, "traffic_provenance": {"source": "y" * 300}, "whole_step_alg_GBs": 6197.3},
         "parity": {"envs": 256, "steps": 3584, "mismatches": 0, "env_selection": "z" * 100},
         "cpu_baseline": {"value": 58149.6, "sample": "s" * 400}, "cpu_reference_over_port": {"provenance": "p" * 600},
@@ -94,6 +95,7 @@ def test_judged_line_is_small():
         assert k in line["cpu_baseline"], k
     assert line["parity"]["mismatches"] == 0 and line["build"]["csrc_sha"] == "0123456789abcdef"
     assert len(line["configs"]) == 9 and all("ms_per_step" in c and "frac" in c and "traffic_ratio" in c and "mismatches" in c for c in line["configs"].values())
+    assert all(c["loop"] == "rollout" and c["steps_per_launch"] == 64.0 for c in line["configs"].values()) and line["timing"]["loop"] in ("step", "rollout")
     assert set(line["scaling_implied"]["gpus"]) == {"8", "4", "2"} and line["scaling_implied"]["C4"]["gpus"] == 8
     assert abs(line["value"] - rec["value"]) / rec["value"] < 1e-6 and abs(line["ms_per_step"] - rec["ms_per_step"]) / rec["ms_per_step"] < 1e-6
     # a run with far more configs than any real one still fits: the optional parts are shed, the required ones stay
